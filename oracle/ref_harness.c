@@ -1,0 +1,276 @@
+/* ref_harness.c — drives the REFERENCE's own hot-path objects (convert.c, crc.c,
+ * demod_2400.c, mode_s.c, icao_filter.c, comm_b.c, mode_ac.c, ais_charset.c,
+ * compiled from /root/reference where they lie; see oracle/Makefile) through the
+ * same buffer grid sdr_ifile.c produces, and records every message that reaches
+ * netUseMessage().  TEST INFRASTRUCTURE ONLY (see oracle_io.h).
+ *
+ * What it reproduces (reference file:line):
+ *   - ifileRun's buffer model: 131072-sample blocks, 326-sample overlap copied from
+ *     the previous block, sampleTimestamp = sampleCounter*5, sysTimestamp =
+ *     sampleTimestamp/12000 + startup_time, short final block, and one extra
+ *     zero-length block when the file is an exact multiple (sdr_ifile.c:194-241)
+ *   - decodeEntryPoint's per-buffer sequence: demodulate2400(buf) then
+ *     backgroundTasks(now = mstime()) which flips the ICAO filter every 60 s of
+ *     synthetic time, starting with next_flip = 0 (readsb.c:869-902, 1227-1231)
+ *   - modesInit's order: modesChecksumInit(nfix), icaoFilterInit(),
+ *     icaoFilterAdd(show_only = BADDR) (readsb.c:306-310)
+ *
+ * It supplies the eight symbols those objects leave undefined: Modes, setExit,
+ * netGetMM, netUseMessage, netDrainMessageBuffers, receiveclock_ms_elapsed
+ * (util.c:149), printACASInfoShort, sprint_uuid1.
+ *
+ * The reference keeps per-process static state (valid_df bitsets are initialised
+ * once, demod_2400.c:276), so ONE configuration per process: use the CLI
+ * (`ref_demod`), one process per run.
+ */
+#include "readsb.h"
+#include "oracle_io.h"
+
+struct _Modes Modes;
+
+static struct modesMessage g_slot;
+static struct messageBuffer g_mb;
+
+static struct oracle_msg *g_out;
+static uint64_t g_nout, g_capout;
+
+void setExit(int arg) { Modes.exit = arg; }
+
+int64_t receiveclock_ms_elapsed(int64_t t1, int64_t t2) { return (t2 - t1) / 12000U; }
+
+void printACASInfoShort(uint32_t addr, unsigned char *MV, struct aircraft *a, struct modesMessage *mm, int64_t now) {
+    (void) addr; (void) MV; (void) a; (void) mm; (void) now;
+}
+
+char *sprint_uuid1(uint64_t id1, char *p) { (void) id1; *p = 0; return p; }
+
+struct modesMessage *netGetMM(struct messageBuffer *buf) {
+    memset(&g_slot, 0, sizeof(g_slot));
+    g_slot.messageBuffer = buf;
+    return &g_slot;
+}
+
+void netUseMessage(struct modesMessage *mm) {
+    if (g_nout == g_capout) {
+        g_capout = g_capout ? g_capout * 2 : 65536;
+        g_out = realloc(g_out, g_capout * sizeof(*g_out));
+        if (!g_out) { fprintf(stderr, "ref_harness: out of memory\n"); exit(1); }
+    }
+    struct oracle_msg *o = &g_out[g_nout++];
+    memset(o, 0, sizeof(*o));
+    o->timestamp = mm->timestamp;
+    o->sys_rel_ms = mm->sysTimestamp - Modes.startup_time;
+    o->score = mm->score;
+    o->correctedbits = mm->correctedbits;
+    o->msgbits = mm->msgbits;
+    o->msgtype = mm->msgtype;
+    /* low 24 bits: the CRC/address stage's value; the later ES field decode may OR in
+     * MODES_NON_ICAO_ADDRESS for some DF18 formats, which is outside the hot path */
+    o->addr = mm->addr & 0xffffff;
+    /* demodulate2400 memcpy's all 14 bytes of its scratch buffer (demod_2400.c:420); for a
+     * 56-bit frame bytes 7..13 are leftovers of earlier slices, so only msgbits/8 bytes are kept */
+    memcpy(o->msg, mm->msg, mm->msgbits / 8);
+    memcpy(o->raw, mm->verbatim, mm->msgbits / 8);
+    o->signalLevel = mm->signalLevel;
+}
+
+void netDrainMessageBuffers(void) { }
+
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + ts.tv_nsec * 1e-9;
+}
+
+static struct converter_state *g_cstate;
+static iq_convert_fn g_conv;
+static int g_configured;
+
+static int ref_configure(int format, int nfix, int fixdf, int thr) {
+    if (g_configured) {
+        fprintf(stderr, "ref_harness: one configuration per process\n");
+        return -1;
+    }
+    g_configured = 1;
+    memset(&Modes, 0, sizeof(Modes));
+    Modes.nfix_crc = nfix;
+    Modes.fixDF = fixdf;
+    Modes.preambleThreshold = thr;
+    Modes.sample_rate = 2400000.0;
+    Modes.sdr_buf_size = 256 * 1024;
+    Modes.sdr_buf_samples = Modes.sdr_buf_size / 2;
+    Modes.trailing_samples = (unsigned) ((MODES_PREAMBLE_US + MODES_LONG_MSG_BITS + 16) * 1e-6 * Modes.sample_rate);
+    Modes.sdr_type = SDR_IFILE;
+    Modes.decodeThreads = 1;
+    Modes.decode_all = 0;
+    Modes.net_verbatim = 1;  /* keep the uncorrected bytes in mm->verbatim (mode_s.c:444) */
+    Modes.show_only = BADDR;
+    Modes.startup_time = ORACLE_STARTUP_MS;
+    Modes.synthetic_now = Modes.startup_time;
+    g_mb.msg = &g_slot; g_mb.len = 0; g_mb.alloc = 1 << 30;
+    Modes.netMessageBuffer = &g_mb;
+
+    modesChecksumInit(Modes.nfix_crc);
+    icaoFilterInit();
+    icaoFilterAdd(Modes.show_only);
+
+    g_conv = init_converter((input_format_t) format, Modes.sample_rate, 0, &g_cstate);
+    return g_conv ? 0 : -1;
+}
+
+/* Converter only: iq -> mag, as one call of the reference iq_convert_fn. */
+int ref_convert(int format, const void *iq, uint16_t *mag, unsigned n, double *mean_level, double *mean_power) {
+    static int conv_format = -1;
+    static iq_convert_fn fn;
+    static struct converter_state *st;
+    if (conv_format != format) {
+        if (g_conv && !fn) { fn = g_conv; st = g_cstate; }
+        else {
+            Modes.sdr_type = SDR_NONE;
+            fn = init_converter((input_format_t) format, 2400000.0, 0, &st);
+        }
+        conv_format = format;
+    }
+    if (!fn) return -1;
+    fn((void *) iq, mag, n, st, mean_level, mean_power);
+    return 0;
+}
+
+/* Whole path on an in-memory capture.  mag_dump (optional) receives the delayed
+ * magnitude stream: mag_dump[0..326) = 0, mag_dump[326+i] = magnitude of sample i.
+ * per-buffer mean_level/mean_power go to ml/mp (optional, nbuffers entries). */
+int ref_demod_run(int format, int nfix, int fixdf, int thr,
+                  const uint8_t *iq, uint64_t nsamples,
+                  struct oracle_msg **out, uint64_t *nout, struct oracle_stats *st,
+                  uint16_t *mag_dump, double *ml, double *mp) {
+    if (ref_configure(format, nfix, fixdf, thr) < 0)
+        return -1;
+    const unsigned B = Modes.sdr_buf_samples, TR = Modes.trailing_samples;
+    const unsigned bps = (format == ORACLE_FMT_UC8) ? 2 : 4;
+    struct mag_buf bufs[2];
+    memset(bufs, 0, sizeof(bufs));
+    for (int i = 0; i < 2; i++)
+        bufs[i].data = calloc(B + TR, sizeof(uint16_t));
+    if (mag_dump) memset(mag_dump, 0, TR * sizeof(uint16_t));
+
+    memset(st, 0, sizeof(*st));
+    int64_t next_flip = 0;
+    uint64_t sampleCounter = 0;
+    uint64_t k = 0;
+    int eof = 0;
+    while (!eof) {
+        struct mag_buf *outbuf = &bufs[k & 1], *lastbuf = &bufs[(k + 1) & 1];
+        uint64_t remain = nsamples - sampleCounter;
+        unsigned slen = remain >= B ? B : (unsigned) remain;
+        if (slen < B) eof = 1;   /* short (possibly zero-length) read ends the file, sdr_ifile.c:223-237 */
+
+        outbuf->sampleTimestamp = sampleCounter * 12e6 / Modes.sample_rate;
+        if (k > 0 && lastbuf->length >= TR)
+            memcpy(outbuf->data, lastbuf->data + lastbuf->length, TR * sizeof(uint16_t));
+        else
+            memset(outbuf->data, 0, TR * sizeof(uint16_t));
+        outbuf->sysTimestamp = outbuf->sampleTimestamp / 12000U + Modes.startup_time;
+        outbuf->sysMicroseconds = outbuf->sampleTimestamp / 12U + Modes.startup_time * 1000;
+        outbuf->length = slen;
+        outbuf->dropped = 0;
+
+        double t0 = now_s();
+        g_conv((void *) (iq + sampleCounter * bps), &outbuf->data[TR], slen, g_cstate, &outbuf->mean_level, &outbuf->mean_power);
+        double t1 = now_s();
+        if (mag_dump) memcpy(mag_dump + TR + sampleCounter, &outbuf->data[TR], slen * sizeof(uint16_t));
+        if (ml) ml[k] = outbuf->mean_level;
+        if (mp) mp[k] = outbuf->mean_power;
+        sampleCounter += slen;
+
+        demodulate2400(outbuf);
+        double t2 = now_s();
+        st->t_convert_s += t1 - t0;
+        st->t_demod_s += t2 - t1;
+        Modes.stats_current.samples_processed += outbuf->length;
+        Modes.stats_current.samples_lost += B - outbuf->length;
+
+        int64_t now = Modes.synthetic_now;      /* mstime() for ifile input, util.c:58-60 */
+        if (now >= next_flip) {                 /* readsb.c:1227-1231 */
+            icaoFilterExpire();
+            next_flip = now + MODES_ICAO_FILTER_TTL;
+            st->nflips++;
+        }
+        k++;
+    }
+    struct stats *s = &Modes.stats_current;
+    st->demod_preambles = s->demod_preambles;
+    st->demod_rejected_bad = s->demod_rejected_bad;
+    st->demod_rejected_unknown_icao = s->demod_rejected_unknown_icao;
+    for (int i = 0; i < 3; i++) st->demod_accepted[i] = s->demod_accepted[i];
+    for (int i = 0; i < 5; i++) { st->demod_preamblePhase[i] = s->demod_preamblePhase[i]; st->demod_bestPhase[i] = s->demod_bestPhase[i]; }
+    st->strong_signal_count = s->strong_signal_count;
+    st->signal_power_count = s->signal_power_count;
+    st->noise_power_count = s->noise_power_count;
+    st->samples_processed = s->samples_processed;
+    st->samples_lost = s->samples_lost;
+    st->nbuffers = k;
+    st->signal_power_sum = s->signal_power_sum;
+    st->noise_power_sum = s->noise_power_sum;
+    st->peak_signal_power = s->peak_signal_power;
+    *out = g_out; *nout = g_nout;
+    for (int i = 0; i < 2; i++) free(bufs[i].data);
+    return 0;
+}
+
+/* CRC KATs (the reference's only pinned numbers for crc.c are the table sizes printed by
+ * `crctests`): expose checksum + diagnose so tests can compare tables. */
+uint32_t ref_modesChecksum(const uint8_t *msg, int bits) { return modesChecksum((uint8_t *) msg, bits); }
+
+/* returns number of error bits (0..2) or -1 when uncorrectable; bit positions in b0/b1 */
+int ref_diagnose(uint32_t syndrome, int bits, int *b0, int *b1) {
+    struct errorinfo *ei = modesChecksumDiagnose(syndrome, bits);
+    if (!ei) return -1;
+    *b0 = ei->errors > 0 ? ei->bit[0] : -1;
+    *b1 = ei->errors > 1 ? ei->bit[1] : -1;
+    return ei->errors;
+}
+
+void ref_crc_init(int nfix) { modesChecksumInit(nfix); }
+
+#ifdef REF_HARNESS_MAIN
+static void *read_file(const char *path, uint64_t *size) {
+    FILE *f = fopen(path, "rb");
+    if (!f) { perror(path); exit(1); }
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    void *p = malloc(sz ? sz : 1);
+    if (fread(p, 1, sz, f) != (size_t) sz) { perror("fread"); exit(1); }
+    fclose(f);
+    *size = sz;
+    return p;
+}
+
+/* ref_demod <UC8|SC16|SC16Q11> <nfix> <fixdf> <thr> <in.iq> <out.msgs> [out.stats] [out.mag]
+ * out.msgs : array of struct oracle_msg;  out.stats : one struct oracle_stats;
+ * out.mag  : u16 delayed magnitude stream (326 zeros + one magnitude per sample) */
+int main(int argc, char **argv) {
+    if (argc < 7) {
+        fprintf(stderr, "usage: %s <UC8|SC16|SC16Q11> <nfix> <fixdf> <thr> <in.iq> <out.msgs> [out.stats] [out.mag]\n", argv[0]);
+        return 2;
+    }
+    int format = !strcmp(argv[1], "UC8") ? ORACLE_FMT_UC8 : !strcmp(argv[1], "SC16") ? ORACLE_FMT_SC16 : ORACLE_FMT_SC16Q11;
+    int nfix = atoi(argv[2]), fixdf = atoi(argv[3]), thr = atoi(argv[4]);
+    uint64_t size;
+    uint8_t *iq = read_file(argv[5], &size);
+    uint64_t n = size / (format == ORACLE_FMT_UC8 ? 2 : 4);
+    struct oracle_msg *out; uint64_t nout; struct oracle_stats st;
+    uint16_t *mag = argc > 8 ? malloc((n + 326) * sizeof(uint16_t)) : NULL;
+    if (ref_demod_run(format, nfix, fixdf, thr, iq, n, &out, &nout, &st, mag, NULL, NULL) < 0)
+        return 1;
+    FILE *f = fopen(argv[6], "wb");
+    if (!f) { perror(argv[6]); return 1; }
+    fwrite(out, sizeof(*out), nout, f);
+    fclose(f);
+    if (argc > 7) { f = fopen(argv[7], "wb"); fwrite(&st, sizeof(st), 1, f); fclose(f); }
+    if (argc > 8) { f = fopen(argv[8], "wb"); fwrite(mag, sizeof(uint16_t), n + 326, f); fclose(f); }
+    fprintf(stderr, "ref_demod: %llu samples, %llu msgs, convert %.3f s, demod %.3f s\n",
+            (unsigned long long) n, (unsigned long long) nout, st.t_convert_s, st.t_demod_s);
+    return 0;
+}
+#endif

@@ -1,0 +1,194 @@
+/* modes_gpu.h — C ABI of libmodes_gpu.so, the MI355X (gfx950) implementation of readsb's
+ * Mode-S demodulator hot path:
+ *
+ *     IQ bytes -> magnitude (convert.c) -> 2.4 MSps preamble sweep + PPM bit slicer
+ *     (demod_2400.c demodulate2400) -> CRC-24 + 1/2-bit repair (crc.c) -> scored, ordered
+ *     message records ready for decodeModesMessage()/track.c.
+ *
+ * Everything here is `extern "C"`, plain pointers and sizes; the caller owns all host
+ * memory, the library owns all device memory.  One context = one SDR stream on one GPU;
+ * a context is not thread-safe (the reference calls demodulate2400 from one decode thread
+ * only, readsb.c:871).  Each entry point names the reference interface it replaces
+ * (file:line under the reference tree).
+ *
+ * The reference-side binding a maintainer would add is shown in INTEGRATION.md.
+ */
+#ifndef MODES_GPU_H
+#define MODES_GPU_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* input_format_t, convert.h:28-31 (same numeric values) */
+#define MGPU_FMT_UC8     0
+#define MGPU_FMT_SC16    1
+#define MGPU_FMT_SC16Q11 2
+
+/* status codes (0 = ok, negative = error; text via mgpu_strerror) */
+#define MGPU_OK              0
+#define MGPU_E_INVAL        -1   /* bad argument / bad state */
+#define MGPU_E_NODEVICE     -2   /* no usable HIP device: the library never falls back to the CPU */
+#define MGPU_E_HIP          -3   /* a HIP runtime call failed (message via mgpu_last_error) */
+#define MGPU_E_NOMEM        -4
+#define MGPU_E_OVERFLOW     -5   /* a device-side pool was too small; recreate with a larger pool */
+#define MGPU_E_CAPACITY     -6   /* more samples than cfg.max_samples in one call */
+#define MGPU_E_EOF          -7   /* stream already ended on a short buffer (sdr_ifile.c:223-237) */
+
+typedef struct mgpu_ctx mgpu_ctx;
+
+/* Options of the hot path, named after the struct _Modes fields they mirror. */
+struct mgpu_config {
+    int32_t  device;              /* HIP device ordinal */
+    int32_t  format;              /* MGPU_FMT_*: --iformat (sdr_ifile.c:82-108) */
+    int32_t  nfix_crc;            /* Modes.nfix_crc: 0 --no-fix, 1 --fix (default, readsb.c:150), 2 --aggressive */
+    int32_t  fixDF;               /* Modes.fixDF (readsb.c:194), 0 with --no-fix-df */
+    int32_t  preamble_threshold;  /* Modes.preambleThreshold, default 58 (readsb.c:2268) */
+    uint32_t buf_samples;         /* Modes.sdr_buf_samples, default 131072 (readsb.c:2212); multiple of 4096 */
+    uint32_t trailing_samples;    /* Modes.trailing_samples = 326 (readsb.c:288); must be 326 */
+    uint32_t reserved0;
+    uint64_t max_samples;         /* largest number of new samples one mgpu_feed_* call may carry */
+    int64_t  startup_time_ms;     /* Modes.startup_time: wall clock (ms) the 12 MHz sample clock is anchored to */
+    uint64_t record_pool_records; /* device pool for per-phase candidate records; 0 = max_samples/16 + 65536 */
+    uint64_t max_messages;        /* cap on accepted messages kept per feed; 0 = max_samples/64 + 65536 */
+};
+
+/* Fills cfg with the reference defaults (configSetDefaults, readsb.c:150-228). */
+void mgpu_config_defaults(struct mgpu_config *cfg);
+
+/* One accepted message, in stream order: everything demodulate2400 hands to
+ * decodeModesMessage()/netUseMessage() (demod_2400.c:401-471).  64 bytes. */
+struct mgpu_msg {
+    int64_t  timestamp;       /* mm->timestamp, 12 MHz ticks, end of bit 56 (demod_2400.c:406) */
+    int64_t  sysTimestamp;    /* mm->sysTimestamp, ms (demod_2400.c:409) */
+    uint64_t sig_sumsq;       /* sum of mag^2 over the signal window (demod_2400.c:442-445) */
+    uint16_t sig_len;         /* samples in that window: msglen*12/5 = 268 or 134 */
+    int16_t  score;           /* mm->score (scoreModesMessage, mode_s.c:309) */
+    uint8_t  phase;           /* bestphase 4..8 */
+    uint8_t  correctedbits;   /* mm->correctedbits after decodeModesMessage */
+    uint8_t  msgtype;         /* DF after DF repair (mm->msgtype) */
+    uint8_t  msgbits;         /* 56 or 112 after DF repair (mm->msgbits) */
+    uint32_t addr;            /* address the CRC stage settled on (AA, or the AP syndrome) */
+    uint8_t  msg[14];         /* corrected frame = mm->msg after decodeModesMessage */
+    uint8_t  raw[14];         /* frame as sliced = what demodulate2400 copies into mm->msg (:420) */
+};
+/* signalLevel exactly as demod_2400.c:447-448 */
+static inline double mgpu_msg_signal_level(const struct mgpu_msg *m) {
+    return (double) m->sig_sumsq / 65535.0 / 65535.0 / (double) m->sig_len;
+}
+
+/* struct stats demod counters the reference updates inside demodulate2400
+ * (stats.h:62-82; demod_2400.c:216,387-456,474-479), accumulated since create/reset. */
+struct mgpu_counters {
+    uint64_t demod_preambles;
+    uint64_t demod_rejected_bad;
+    uint64_t demod_rejected_unknown_icao;
+    uint64_t demod_accepted[3];
+    uint64_t demod_preamblePhase[5];
+    uint64_t demod_bestPhase[5];
+    uint64_t strong_signal_count;
+    uint64_t signal_power_count;
+    uint64_t noise_power_count;
+    uint64_t samples_processed;
+    uint64_t samples_lost;
+    uint64_t nbuffers;
+    uint64_t nflips;             /* icaoFilterExpire() calls made by the filter clock */
+    double   signal_power_sum;
+    double   noise_power_sum;
+    double   peak_signal_power;
+};
+
+/* Device time of the last feed, from HIP events on the context's stream (ms). */
+struct mgpu_timing {
+    float h2d_ms;        /* host->device copy of the IQ block (0 for resident input) */
+    float convert_ms;    /* k_convert_* */
+    float sweep_ms;      /* k_sweep_slice: preamble sweep + bit slicer + CRC, the roofline kernel */
+    float prescreen_ms;  /* record pre-screen + compaction */
+    float resolve_ms;    /* ordered accept / skip-ahead / ICAO filter walk (host wall time) */
+    float sigpower_ms;   /* k_signal_power + stats window fix-up */
+    float d2h_ms;        /* record / message copies back */
+    float total_ms;      /* wall time of the whole call */
+    uint64_t n_candidates;   /* positions that passed a preamble threshold */
+    uint64_t n_records;      /* per-phase records the slicer emitted */
+    uint64_t n_live_records; /* records that survived the pre-screen (reach the ordered walk) */
+    uint64_t n_messages;     /* accepted messages */
+};
+
+/* ---- lifecycle -------------------------------------------------------------------- */
+
+/* Replaces modesInit()'s hot-path part: modesChecksumInit(nfix_crc), icaoFilterInit(),
+ * icaoFilterAdd(show_only), init_converter() (readsb.c:306-310, sdr_ifile.c:156). */
+int  mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out);
+void mgpu_destroy(mgpu_ctx *ctx);
+/* Back to the state right after mgpu_create (sample clock 0, filter = {show_only}). */
+int  mgpu_reset(mgpu_ctx *ctx);
+const char *mgpu_strerror(int code);
+const char *mgpu_last_error(mgpu_ctx *ctx);
+/* 1 when a gfx950-class HIP device is visible, 0 otherwise (never throws). */
+int  mgpu_device_count(void);
+
+/* ---- whole hot path: what sdr_ifile.c's reader + the decode thread do per block ------ */
+
+/* ifileRun's read+convert (sdr_ifile.c:194-259) followed by demodulate2400() per
+ * 131072-sample buffer (readsb.c:871) and the per-buffer filter clock (readsb.c:1227-1231),
+ * for `nsamples` new IQ samples continuing the stream.  nsamples need not be a multiple of
+ * buf_samples; a short last buffer ends the stream exactly like a short read() does.
+ * Synchronous: on return the accepted messages are available to mgpu_collect(). */
+int mgpu_feed_iq(mgpu_ctx *ctx, const void *iq_host, uint64_t nsamples);
+
+/* Same, for IQ already resident in device memory (HBM): d_iq is a device pointer to
+ * nsamples samples of cfg.format.  This is the entry the benchmark times. */
+int mgpu_feed_iq_device(mgpu_ctx *ctx, const void *d_iq, uint64_t nsamples);
+
+/* Host -> HBM copy only (no processing): stages nsamples IQ samples in the context's device
+ * input buffer, whose address mgpu_device_iq_buffer() returns; follow with
+ * mgpu_feed_iq_device(ctx, mgpu_device_iq_buffer(ctx), nsamples) to demodulate them in place. */
+int   mgpu_upload_iq(mgpu_ctx *ctx, const void *iq_host, uint64_t nsamples);
+void *mgpu_device_iq_buffer(mgpu_ctx *ctx);
+
+/* EOF handling of ifileRun: when the stream length is an exact multiple of buf_samples the
+ * reference pushes one more zero-length buffer (sdr_ifile.c:223-237).  Call once at end. */
+int mgpu_finish(mgpu_ctx *ctx);
+
+/* Messages of the calls since the last collect, in stream order (netUseMessage order,
+ * demod_2400.c:471).  Copies up to `cap` messages, *n = number copied; remaining count
+ * via mgpu_pending_messages().  counters may be NULL. */
+int mgpu_collect(mgpu_ctx *ctx, struct mgpu_msg *out, uint64_t cap, uint64_t *n,
+                 struct mgpu_counters *counters);
+uint64_t mgpu_pending_messages(mgpu_ctx *ctx);
+int mgpu_last_timing(mgpu_ctx *ctx, struct mgpu_timing *t);
+
+/* ---- the two plugin-surface pieces on their own ----------------------------------- */
+
+/* iq_convert_fn (convert.h:34-39) for the non-DC-filter converters convert_uc8_nodc,
+ * convert_sc16_nodc, convert_sc16q11_nodc (convert.c:64,212,329): nsamples IQ samples in
+ * host memory -> nsamples u16 magnitudes in host memory; out_mean_* may be NULL. */
+int mgpu_convert(mgpu_ctx *ctx, const void *iq_host, uint16_t *mag_host, uint32_t nsamples,
+                 double *out_mean_level, double *out_mean_power);
+
+/* demodulate2400(struct mag_buf *) (demod_2400.h:38) on one magnitude buffer laid out as
+ * struct mag_buf.data (readsb.h:450-464): trailing_samples of overlap then `length` new
+ * samples.  The caller passes the struct's scalar fields; messages come back through
+ * mgpu_collect().  The stream position / filter clock advance exactly as for mgpu_feed_iq. */
+int mgpu_demod_mag_buf(mgpu_ctx *ctx, const uint16_t *data, uint32_t length,
+                       int64_t sampleTimestamp, int64_t sysTimestamp,
+                       double mean_power, uint32_t dropped);
+
+/* ---- tables, for known-answer tests against crc.c --------------------------------- */
+
+/* These run on the host (they are how the device tables are built) and need no context. */
+uint32_t mgpu_crc_checksum(const uint8_t *msg, int bits);                 /* modesChecksum, crc.c:67 */
+/* modesChecksumDiagnose (crc.c:383) for the tables modesChecksumInit(nfix_crc) builds:
+ * returns #error bits 0..2 (positions in *bit0,*bit1, -1 = unused), or -1 if uncorrectable */
+int mgpu_crc_diagnose(int nfix_crc, uint32_t syndrome, int bits, int *bit0, int *bit1);
+int mgpu_crc_table_size(int nfix_crc, int bits);                           /* crctests' table sizes */
+/* the 65536-entry UC8 magnitude table (init_uc8_lookup, convert.c:35-62), index I | Q<<8 */
+const uint16_t *mgpu_uc8_table(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

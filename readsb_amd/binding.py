@@ -1,0 +1,218 @@
+"""ctypes binding of libmodes_gpu.so (include/modes_gpu.h).
+
+Mirrors the reference's interface for this path: a converter (`iq_convert_fn`, convert.h:34-39),
+`demodulate2400(struct mag_buf *)` (demod_2400.h:38) and the ifile reader's feed loop
+(sdr_ifile.c:169-270).  There is no CPU fallback: if the HIP library or a GPU is missing the
+constructor raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+FMT_UC8, FMT_SC16, FMT_SC16Q11 = 0, 1, 2
+_FMT_BYTES = {FMT_UC8: 2, FMT_SC16: 4, FMT_SC16Q11: 4}
+
+# struct mgpu_msg (64 bytes)
+MSG_DTYPE = np.dtype([
+    ("timestamp", "<i8"), ("sysTimestamp", "<i8"), ("sig_sumsq", "<u8"), ("sig_len", "<u2"),
+    ("score", "<i2"), ("phase", "u1"), ("correctedbits", "u1"), ("msgtype", "u1"), ("msgbits", "u1"),
+    ("addr", "<u4"), ("msg", "u1", 14), ("raw", "u1", 14),
+])
+assert MSG_DTYPE.itemsize == 64
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("device", C.c_int32), ("format", C.c_int32), ("nfix_crc", C.c_int32), ("fixDF", C.c_int32),
+        ("preamble_threshold", C.c_int32), ("buf_samples", C.c_uint32), ("trailing_samples", C.c_uint32),
+        ("reserved0", C.c_uint32), ("max_samples", C.c_uint64), ("startup_time_ms", C.c_int64),
+        ("record_pool_records", C.c_uint64), ("max_messages", C.c_uint64),
+    ]
+
+
+class Counters(C.Structure):
+    _fields_ = [
+        ("demod_preambles", C.c_uint64), ("demod_rejected_bad", C.c_uint64),
+        ("demod_rejected_unknown_icao", C.c_uint64), ("demod_accepted", C.c_uint64 * 3),
+        ("demod_preamblePhase", C.c_uint64 * 5), ("demod_bestPhase", C.c_uint64 * 5),
+        ("strong_signal_count", C.c_uint64), ("signal_power_count", C.c_uint64),
+        ("noise_power_count", C.c_uint64), ("samples_processed", C.c_uint64), ("samples_lost", C.c_uint64),
+        ("nbuffers", C.c_uint64), ("nflips", C.c_uint64), ("signal_power_sum", C.c_double),
+        ("noise_power_sum", C.c_double), ("peak_signal_power", C.c_double),
+    ]
+
+    def as_dict(self):
+        out = {}
+        for name, _ in self._fields_:
+            v = getattr(self, name)
+            out[name] = list(v) if hasattr(v, "__len__") else v
+        return out
+
+
+class Timing(C.Structure):
+    _fields_ = [
+        ("h2d_ms", C.c_float), ("convert_ms", C.c_float), ("sweep_ms", C.c_float), ("prescreen_ms", C.c_float),
+        ("resolve_ms", C.c_float), ("sigpower_ms", C.c_float), ("d2h_ms", C.c_float), ("total_ms", C.c_float),
+        ("n_candidates", C.c_uint64), ("n_records", C.c_uint64), ("n_live_records", C.c_uint64),
+        ("n_messages", C.c_uint64),
+    ]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+class MgpuError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmodes_gpu.so")
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libmodes_gpu.so (built in-tree by __graft_entry__.build()).  Raises if missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise MgpuError(f"{path} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = C.CDLL(path)
+    vp, u64, u32, i32, i64 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_int64
+    lib.mgpu_config_defaults.argtypes = [C.POINTER(Config)]
+    lib.mgpu_config_defaults.restype = None
+    lib.mgpu_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    lib.mgpu_destroy.argtypes = [vp]
+    lib.mgpu_destroy.restype = None
+    lib.mgpu_reset.argtypes = [vp]
+    lib.mgpu_strerror.argtypes = [i32]
+    lib.mgpu_strerror.restype = C.c_char_p
+    lib.mgpu_last_error.argtypes = [vp]
+    lib.mgpu_last_error.restype = C.c_char_p
+    lib.mgpu_device_count.restype = i32
+    lib.mgpu_feed_iq.argtypes = [vp, vp, u64]
+    lib.mgpu_feed_iq_device.argtypes = [vp, vp, u64]
+    lib.mgpu_upload_iq.argtypes = [vp, vp, u64]
+    lib.mgpu_device_iq_buffer.argtypes = [vp]
+    lib.mgpu_device_iq_buffer.restype = vp
+    lib.mgpu_finish.argtypes = [vp]
+    lib.mgpu_collect.argtypes = [vp, vp, u64, C.POINTER(u64), C.POINTER(Counters)]
+    lib.mgpu_pending_messages.argtypes = [vp]
+    lib.mgpu_pending_messages.restype = u64
+    lib.mgpu_last_timing.argtypes = [vp, C.POINTER(Timing)]
+    lib.mgpu_convert.argtypes = [vp, vp, vp, u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.mgpu_demod_mag_buf.argtypes = [vp, vp, u32, i64, i64, C.c_double, u32]
+    lib.mgpu_crc_checksum.argtypes = [vp, i32]
+    lib.mgpu_crc_checksum.restype = u32
+    lib.mgpu_crc_diagnose.argtypes = [i32, u32, i32, C.POINTER(i32), C.POINTER(i32)]
+    lib.mgpu_crc_table_size.argtypes = [i32, i32]
+    lib.mgpu_uc8_table.restype = C.POINTER(C.c_uint16)
+    _lib = lib
+    return lib
+
+
+class Demodulator:
+    """One SDR stream on one GPU (struct mgpu_ctx)."""
+
+    def __init__(self, fmt=FMT_UC8, nfix_crc=1, fix_df=1, preamble_threshold=58, max_samples=64 * 131072,
+                 device=0, startup_time_ms=0, record_pool_records=0, max_messages=0, buf_samples=131072):
+        self.lib = load_library()
+        cfg = Config()
+        self.lib.mgpu_config_defaults(C.byref(cfg))
+        cfg.device, cfg.format, cfg.nfix_crc, cfg.fixDF = device, fmt, nfix_crc, fix_df
+        cfg.preamble_threshold, cfg.max_samples, cfg.startup_time_ms = preamble_threshold, max_samples, startup_time_ms
+        cfg.record_pool_records, cfg.max_messages, cfg.buf_samples = record_pool_records, max_messages, buf_samples
+        self.cfg = cfg
+        self.fmt = fmt
+        self.ctx = C.c_void_p()
+        rc = self.lib.mgpu_create(C.byref(cfg), C.byref(self.ctx))
+        if rc != 0:
+            raise MgpuError(f"mgpu_create: {self.lib.mgpu_strerror(rc).decode()}")
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.mgpu_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise MgpuError(f"{what}: {self.lib.mgpu_strerror(rc).decode()} ({self.lib.mgpu_last_error(self.ctx).decode()})")
+
+    def _nsamples(self, iq):
+        iq = np.ascontiguousarray(iq).view(np.uint8).reshape(-1)
+        return iq, iq.size // _FMT_BYTES[self.fmt]
+
+    def reset(self):
+        self._chk(self.lib.mgpu_reset(self.ctx), "mgpu_reset")
+
+    def feed_iq(self, iq):
+        iq, n = self._nsamples(iq)
+        self._chk(self.lib.mgpu_feed_iq(self.ctx, iq.ctypes.data, n), "mgpu_feed_iq")
+
+    def upload_iq(self, iq):
+        iq, n = self._nsamples(iq)
+        self._chk(self.lib.mgpu_upload_iq(self.ctx, iq.ctypes.data, n), "mgpu_upload_iq")
+        return n
+
+    def device_iq_buffer(self):
+        return self.lib.mgpu_device_iq_buffer(self.ctx)
+
+    def feed_resident(self, nsamples, dptr=None):
+        self._chk(self.lib.mgpu_feed_iq_device(self.ctx, dptr if dptr is not None else self.device_iq_buffer(), nsamples),
+                  "mgpu_feed_iq_device")
+
+    def finish(self):
+        self._chk(self.lib.mgpu_finish(self.ctx), "mgpu_finish")
+
+    def collect(self):
+        n = int(self.lib.mgpu_pending_messages(self.ctx))
+        out = np.zeros(n, dtype=MSG_DTYPE)
+        got = C.c_uint64(0)
+        cnt = Counters()
+        self._chk(self.lib.mgpu_collect(self.ctx, out.ctypes.data, n, C.byref(got), C.byref(cnt)), "mgpu_collect")
+        return out[: got.value], cnt.as_dict()
+
+    def timing(self):
+        t = Timing()
+        self._chk(self.lib.mgpu_last_timing(self.ctx, C.byref(t)), "mgpu_last_timing")
+        return t.as_dict()
+
+    def convert(self, iq):
+        """iq_convert_fn: returns (mag u16[n], mean_level, mean_power)."""
+        iq, n = self._nsamples(iq)
+        mag = np.empty(n, dtype=np.uint16)
+        ml, mp = C.c_double(), C.c_double()
+        self._chk(self.lib.mgpu_convert(self.ctx, iq.ctypes.data, mag.ctypes.data, n, C.byref(ml), C.byref(mp)), "mgpu_convert")
+        return mag, ml.value, mp.value
+
+    def demod_mag_buf(self, data, length, sample_timestamp, sys_timestamp, mean_power, dropped=0):
+        """demodulate2400(struct mag_buf *): data = u16[326 + length]."""
+        data = np.ascontiguousarray(data, dtype=np.uint16)
+        assert data.size >= 326 + length
+        self._chk(self.lib.mgpu_demod_mag_buf(self.ctx, data.ctypes.data, length, sample_timestamp, sys_timestamp,
+                                              float(mean_power), dropped), "mgpu_demod_mag_buf")
+
+    def demodulate_capture(self, iq, chunk_samples=None):
+        """Whole capture: feed in chunks that are multiples of the buffer size, finish, collect."""
+        iq, n = self._nsamples(iq)
+        bps = _FMT_BYTES[self.fmt]
+        chunk = chunk_samples or int(self.cfg.max_samples)
+        chunk -= chunk % int(self.cfg.buf_samples)
+        assert chunk > 0
+        off = 0
+        while off < n:
+            k = min(chunk, n - off)
+            self.feed_iq(iq[off * bps:(off + k) * bps])
+            off += k
+        self.finish()
+        return self.collect()

@@ -1,0 +1,117 @@
+// kernels.h — device data layout and kernel launchers of the Mode-S hot path (gfx950).
+//
+// HBM layout of one feed of n new samples (one context = one stream):
+//   d_iq   : raw IQ, n * {2,4} bytes (UC8 / SC16, SC16Q11)
+//   d_mag  : u16 magnitudes, the reference's "delayed stream": d_mag[0..326) = the 326
+//            samples that preceded this feed (zeros at stream start), d_mag[326 + i] =
+//            magnitude of new sample i.  Index D of d_mag is exactly the scan position
+//            `pa - m` of demodulate2400 summed over the 131072-sample buffers
+//            (demod_2400.c:287-290, sdr_ifile.c:209-213), so D in [0, n) are the preamble
+//            start positions and a position reads d_mag[D .. D+289].
+//   pool   : PhaseRec[], per-unit chains of segments written by k_sweep_slice
+//   live   : PhaseRec[], records surviving the pre-screen, globally ordered by (pos, phase)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace mgpu {
+
+constexpr int kTrailing = 326;          // Modes.trailing_samples (readsb.c:288)
+constexpr int kTile = 4096;             // scan positions per LDS tile
+constexpr int kHalo = 304;              // >= 290 samples of look-ahead (demod reads pa[0..289]), multiple of 8
+constexpr int kTilesPerUnit = 8;
+constexpr int kUnit = kTile * kTilesPerUnit;   // positions per unit (one record chain per unit)
+constexpr int kBlock = 256;
+constexpr int kBatch = 64;              // candidates sliced per batch (4 waves x 16)
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+
+// flags of a PhaseRec
+enum : uint8_t {
+    REC_ACCEPT_IF_UNKNOWN = 1,   // decodeModesMessage accepts it even when the address is not in the ICAO filter
+    REC_ADDER = 2,               // a clean DF17 / DF11 IID 0: accepted => icaoFilterAdd(addr) (mode_s.c:766-779)
+    REC_DFFIX = 4,               // DF repaired to 17 (fixDF17msgtype, mode_s.c:276-301); fixbit0 = DF bit index
+    REC_LONG = 8,                // 14 bytes were sliced (else 7)
+    REC_CORR_SHIFT = 4,          // bits 4-5: mm->correctedbits decodeModesMessage will report
+    REC_COND = 64,               // score_unknown < 0: only alive if the address is (or may become) known
+};
+
+// One scored (candidate position, phase) pair whose score is not -2: the filter-independent
+// part of score_phase()+scoreModesMessage() (demod_2400.c:215-258, mode_s.c:309-419).
+// A record with phase == 0xFF is a segment header: pos = record count, addr = index of the
+// next segment header of the same unit (kNone = last).
+struct PhaseRec {
+    uint32_t pos;            // scan position D within the feed
+    uint8_t phase;           // try-phase 4..8
+    uint8_t flags;
+    int16_t score_known;     // score if `addr` is in the ICAO filter
+    int16_t score_unknown;   // score if it is not (-1 = rejected as unknown ICAO)
+    uint8_t fixbit0, fixbit1;  // frame bits decodeModesMessage flips (0xFF = none)
+    uint32_t addr;           // address the filter is asked about (AA after repair, or the AP syndrome)
+    uint8_t msg[14];         // frame as sliced
+    uint16_t pad;
+};
+static_assert(sizeof(PhaseRec) == 32, "PhaseRec must be 32 bytes");
+
+// counters produced on the device (indices into a u64 array)
+enum {
+    CNT_CANDIDATES = 0,      // positions with >= 1 phase tried, before any skip-ahead
+    CNT_PHASE0 = 1,          // .. CNT_PHASE0+4: score_phase calls per try-phase 4..8, before skip-ahead
+    CNT_RECORDS = 6,
+    CNT_POOL_OVERFLOW = 7,
+    CNT_CLASS_COND = 8,      // candidates whose records are all conditional (REC_COND)
+    CNT_CLASS_UNCOND = 9,    // candidates with >= 1 unconditional record
+    CNT_NUM = 16,
+};
+
+struct SweepParams {
+    const uint16_t *mag;      // d_mag
+    uint64_t n;               // number of scan positions (= new samples)
+    int32_t thr;              // preamble threshold (demod_2400.c:335-338)
+    uint32_t valid_long;      // valid_df_long_bitset  (demod_2400.c:112-128)
+    uint32_t valid_short;     // valid_df_short_bitset
+    int32_t fix_df;           // Modes.fixDF && Modes.nfix_crc
+    const uint32_t *bit_syndrome;   // [112]
+    const uint64_t *parity;         // PH[24], PL[24], PS[24]
+    const uint64_t *tab_long;       // packed syndrome table for 112-bit frames
+    const uint64_t *tab_short;      // packed syndrome table for 56-bit frames
+    int32_t n_long, n_short;
+    PhaseRec *pool;
+    uint32_t pool_cap;
+    uint32_t *pool_used;      // device counter (records incl. headers)
+    uint32_t *unit_first;     // [nunits] index of the unit's first segment header, kNone if empty
+    uint32_t *unit_count;     // [nunits] records of the unit (without headers)
+    uint32_t nunits;
+    uint32_t *adder_bitmap;   // 2^24 bits: addresses some clean DF17 / DF11 IID 0 frame carries
+    uint32_t *class_bitmap;   // 1 bit per scan position: candidate whose records are all conditional
+    unsigned long long *counters;   // [CNT_NUM]
+};
+
+struct ConvertParams {
+    const uint8_t *iq;
+    uint16_t *mag;            // d_mag (written from index kTrailing on)
+    uint64_t n;
+    uint32_t buf_samples;
+    uint64_t first_buffer_offset;   // always 0: feeds start on the buffer grid
+    const uint16_t *uc8_folded;     // device copy of the folded UC8 table
+    unsigned long long *sum_level;  // [nbuffers] UC8: exact integer sum of mag
+    unsigned long long *sum_power;  // [nbuffers] UC8: exact integer sum of mag^2
+    double *fsum_level;             // [nbuffers] SC16*: sum of mag (0..1), double accumulation
+    double *fsum_power;             // [nbuffers] SC16*: sum of magsq
+};
+
+void launch_convert(int format, const ConvertParams &p, hipStream_t s);
+void launch_sweep_slice(const SweepParams &p, hipStream_t s);
+// pre-screen: count / write the records whose address may matter to the ordered walk
+void launch_prescreen(const PhaseRec *pool, const uint32_t *unit_first, uint32_t nunits,
+                      const uint32_t *adder_bitmap, uint32_t *unit_live /*[nunits+1]*/,
+                      PhaseRec *live, unsigned long long *counters, hipStream_t s);
+// signal power of accepted messages: sum of mag^2 over d_mag[pos+19 .. pos+19+len)
+void launch_signal_power(const uint16_t *mag, const uint32_t *pos, const uint16_t *len, uint32_t nmsg,
+                         unsigned long long *out, hipStream_t s);
+// candidates / tried phases / conditional-class candidates inside the skip-ahead window of
+// each accepted message (positions pos+1 .. pos+skip, clipped to `limit`), for the stats fix-up
+void launch_window_stats(const uint16_t *mag, uint64_t n, int thr, const uint32_t *class_bitmap,
+                         const uint32_t *pos, const uint16_t *skip, const uint32_t *limit, uint32_t nmsg,
+                         unsigned long long *out /*[8]: cand, ph0..4, cond*/, hipStream_t s);
+
+}  // namespace mgpu

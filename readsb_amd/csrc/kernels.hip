@@ -1,0 +1,781 @@
+// kernels.hip — hand-written HIP kernels (gfx950 / CDNA4, wave64) for readsb's Mode-S hot path.
+//
+//   k_convert_*      IQ -> u16 magnitude                   (convert.c:64-108, 212-250, 329-367)
+//   k_sweep_slice    preamble sweep over every sample position, wave-ballot/prefix compaction of
+//                    the candidates, PPM bit slicing of each tried phase straight from the
+//                    LDS-staged sample window, wave-parallel CRC-24, syndrome lookup and the
+//                    filter-independent half of scoreModesMessage
+//                                                          (demod_2400.c:74-93,133-258,290-378;
+//                                                           mode_s.c:276-419; crc.c:67-82,383-406)
+//   k_prescreen_*    drops records that can only ever score "unknown ICAO"
+//   k_signal_power   sum of mag^2 over an accepted frame  (demod_2400.c:436-457)
+//   k_window_stats   what the skip-ahead hid from the counters (demod_2400.c:468)
+//
+// No MFMA anywhere: this is HBM-bound integer/byte streaming work.  All arithmetic on the
+// message path is integer and bit-exact with the reference; the SC16 converters use IEEE float
+// ops with contraction disabled and a correctly rounded sqrt.
+#include "kernels.h"
+#include "tables.h"
+
+namespace mgpu {
+
+#define WAVE 64
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
+
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int src) {
+    uint32_t lo = __builtin_amdgcn_readlane((uint32_t) v, src);
+    uint32_t hi = __builtin_amdgcn_readlane((uint32_t) (v >> 32), src);
+    return ((uint64_t) hi << 32) | lo;
+}
+
+// inclusive->exclusive wave prefix sum; total = sum over the wave
+__device__ __forceinline__ int wave_excl_scan(int v, int &total) {
+    const int lane = lane_id();
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        int y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    total = __shfl(x, WAVE - 1);
+    return x - v;
+}
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+// =============================================================================================
+// IQ -> magnitude
+// =============================================================================================
+
+// Per-thread running (level, power) sums for the buffer the thread is currently inside; flushed
+// with two atomics whenever the thread crosses a 131072-sample buffer boundary.
+struct BufSums {
+    unsigned long long level, power;
+    uint64_t next_boundary;   // first sample index of the next buffer
+    uint32_t cur;             // current buffer index
+    __device__ void init(uint64_t sample, uint32_t B) {
+        cur = (uint32_t) (sample / B);
+        next_boundary = (uint64_t) (cur + 1) * B;
+        level = power = 0;
+    }
+    __device__ void flush(const ConvertParams &p) {
+        if (level | power) {
+            atomicAdd(&p.sum_level[cur], level);
+            atomicAdd(&p.sum_power[cur], power);
+        }
+        level = power = 0;
+    }
+    __device__ void advance_to(uint64_t sample, const ConvertParams &p) {
+        while (sample >= next_boundary) {
+            flush(p);
+            ++cur;
+            next_boundary += p.buf_samples;
+        }
+    }
+};
+
+// UC8: magnitude = table[I | Q<<8] (convert.c:64-108).  The 65536-entry table has two mirror
+// symmetries (I -> 255-I, Q -> 255-Q) so a 128x128 quadrant, padded to an odd-ish row stride,
+// is staged in LDS (33 KB) and every sample is one ds_read_u16.
+// Thread work item: one 16-byte-aligned chunk of 8 output magnitudes d_mag[8c .. 8c+8) =
+// samples 8c-326 .. 8c-319; the 16 IQ bytes are one (4-byte aligned) global_load_dwordx4.
+__global__ __launch_bounds__(kBlock) void k_convert_uc8(ConvertParams p) {
+    __shared__ uint16_t s_lut[128 * UC8_FOLD_STRIDE];
+    for (int i = threadIdx.x; i < 128 * UC8_FOLD_STRIDE / 2; i += kBlock)
+        ((uint32_t *) s_lut)[i] = ((const uint32_t *) p.uc8_folded)[i];
+    __syncthreads();
+
+    const uint64_t c_first = kTrailing / 8;                       // chunk holding d_mag[326]
+    const uint64_t c_end = (kTrailing + p.n + 7) / 8;
+    const uint64_t nchunks = c_end - c_first;
+    uint64_t per_block = (nchunks + gridDim.x - 1) / gridDim.x;
+    per_block = (per_block + kBlock - 1) / kBlock * kBlock;
+    const uint64_t blk_lo = c_first + (uint64_t) blockIdx.x * per_block;
+    const uint64_t blk_hi = blk_lo + per_block < c_end ? blk_lo + per_block : c_end;
+    if (blk_lo >= c_end) return;
+
+    BufSums sums;
+    {
+        int64_t s0 = (int64_t) (blk_lo + threadIdx.x) * 8 - kTrailing;
+        sums.init(s0 < 0 ? 0 : (uint64_t) s0, p.buf_samples);
+    }
+    for (uint64_t c = blk_lo + threadIdx.x; c < blk_hi; c += kBlock) {
+        const int64_t i0 = (int64_t) c * 8 - kTrailing;   // sample index of element 0
+        uint32_t w[4];
+        const bool full = i0 >= 0 && (uint64_t) i0 + 8 <= p.n;
+        if (full) {
+            u32x4_a4 v = *(const u32x4_a4 *) (p.iq + 2 * i0);
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        } else {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                uint32_t x = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    int64_t byte = 2 * i0 + 4 * d + b;
+                    if (byte >= 0 && (uint64_t) byte < 2 * p.n) x |= (uint32_t) p.iq[byte] << (8 * b);
+                }
+                w[d] = x;
+            }
+        }
+        uint32_t out[4];
+        uint32_t lvl = 0;
+        unsigned long long pw = 0;
+        uint16_t m[8];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            // fold all four bytes: v >= 128 ? v - 128 : 127 - v
+            const uint32_t hi = (w[d] >> 7) & 0x01010101u;
+            const uint32_t f = (w[d] ^ 0x7F7F7F7Fu ^ (hi * 0x7Fu)) & 0x7F7F7F7Fu;
+            const uint32_t a0 = f & 0xff, b0 = (f >> 8) & 0xff, a1 = (f >> 16) & 0xff, b1 = f >> 24;
+            m[2 * d] = s_lut[a0 * UC8_FOLD_STRIDE + b0];
+            m[2 * d + 1] = s_lut[a1 * UC8_FOLD_STRIDE + b1];
+            out[d] = (uint32_t) m[2 * d] | ((uint32_t) m[2 * d + 1] << 16);
+        }
+        if (full) {
+            if ((uint64_t) i0 + 7 >= sums.next_boundary || (uint64_t) i0 < sums.next_boundary - p.buf_samples) {
+                // chunk straddles (or jumps) a buffer boundary: element-wise
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    sums.advance_to((uint64_t) i0 + e, p);
+                    sums.level += m[e];
+                    sums.power += (unsigned long long) m[e] * m[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { lvl += m[e]; pw += (unsigned long long) ((uint32_t) m[e] * (uint32_t) m[e]); }
+                sums.level += lvl;
+                sums.power += pw;
+            }
+            u32x4 o = {out[0], out[1], out[2], out[3]};
+            *(u32x4 *) (p.mag + c * 8) = o;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int64_t i = i0 + e;
+                if (i >= 0 && (uint64_t) i < p.n) {
+                    sums.advance_to((uint64_t) i, p);
+                    sums.level += m[e];
+                    sums.power += (unsigned long long) m[e] * m[e];
+                    p.mag[c * 8 + e] = m[e];
+                }
+            }
+        }
+    }
+    sums.flush(p);
+}
+
+// SC16 / SC16Q11: mag = sqrtf(min(1, fI*fI + fQ*fQ)), fI = I/scale, u16 = (uint16_t)(mag*65535+0.5)
+// (convert.c:212-250, 329-367).  Every float operation is rounded on its own (the reference is
+// scalar SSE built with -std=c11, i.e. no FMA contraction); sqrtf is the correctly rounded one.
+template <int SCALE_SHIFT>
+__global__ __launch_bounds__(kBlock) void k_convert_sc16(ConvertParams p) {
+#pragma clang fp contract(off)
+    const uint64_t c_first = kTrailing / 8;
+    const uint64_t c_end = (kTrailing + p.n + 7) / 8;
+    const uint64_t nchunks = c_end - c_first;
+    uint64_t per_block = (nchunks + gridDim.x - 1) / gridDim.x;
+    per_block = (per_block + kBlock - 1) / kBlock * kBlock;
+    const uint64_t blk_lo = c_first + (uint64_t) blockIdx.x * per_block;
+    const uint64_t blk_hi = blk_lo + per_block < c_end ? blk_lo + per_block : c_end;
+    if (blk_lo >= c_end) return;
+    const float inv = 1.0f / (float) (1 << SCALE_SHIFT);   // power of two: I * inv == I / scale exactly
+
+    double lvl = 0.0, pw = 0.0;
+    uint32_t cur = 0xFFFFFFFFu;
+    for (uint64_t c = blk_lo + threadIdx.x; c < blk_hi; c += kBlock) {
+        const int64_t i0 = (int64_t) c * 8 - kTrailing;
+        uint16_t m[8];
+        const bool full = i0 >= 0 && (uint64_t) i0 + 8 <= p.n;
+        uint32_t w[8];
+        if (full) {
+            u32x4_a8 v0 = *(const u32x4_a8 *) (p.iq + 4 * i0);
+            u32x4_a8 v1 = *(const u32x4_a8 *) (p.iq + 4 * i0 + 16);
+            w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w;
+            w[4] = v1.x; w[5] = v1.y; w[6] = v1.z; w[7] = v1.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int64_t i = i0 + e;
+                w[e] = (i >= 0 && (uint64_t) i < p.n) ? *(const uint32_t *) (p.iq + 4 * i) : 0u;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int64_t i = i0 + e;
+            const float fI = (float) (int16_t) (w[e] & 0xffff) * inv;
+            const float fQ = (float) (int16_t) (w[e] >> 16) * inv;
+            const float a = fI * fI;
+            const float b = fQ * fQ;
+            float magsq = a + b;
+            if (magsq > 1.0f) magsq = 1.0f;
+            const float mag = sqrtf(magsq);
+            const float sc = mag * 65535.0f;
+            const float rd = sc + 0.5f;
+            m[e] = (uint16_t) rd;
+            if (i >= 0 && (uint64_t) i < p.n) {
+                const uint32_t b_e = (uint32_t) ((uint64_t) i / p.buf_samples);
+                if (b_e != cur) {
+                    if (cur != 0xFFFFFFFFu) { atomicAdd(&p.fsum_level[cur], lvl); atomicAdd(&p.fsum_power[cur], pw); }
+                    cur = b_e; lvl = pw = 0.0;
+                }
+                lvl += (double) mag;
+                pw += (double) magsq;
+            }
+        }
+        if (full) {
+            u32x4 o = {(uint32_t) m[0] | ((uint32_t) m[1] << 16), (uint32_t) m[2] | ((uint32_t) m[3] << 16),
+                       (uint32_t) m[4] | ((uint32_t) m[5] << 16), (uint32_t) m[6] | ((uint32_t) m[7] << 16)};
+            *(u32x4 *) (p.mag + c * 8) = o;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int64_t i = i0 + e;
+                if (i >= 0 && (uint64_t) i < p.n) p.mag[c * 8 + e] = m[e];
+            }
+        }
+    }
+    if (cur != 0xFFFFFFFFu) { atomicAdd(&p.fsum_level[cur], lvl); atomicAdd(&p.fsum_power[cur], pw); }
+}
+
+void launch_convert(int format, const ConvertParams &p, hipStream_t s) {
+    if (p.n == 0) return;
+    const uint64_t nchunks = (kTrailing + p.n + 7) / 8 - kTrailing / 8;
+    uint64_t blocks = (nchunks + kBlock * 8 - 1) / (kBlock * 8);   // >= 8 chunks per thread
+    if (blocks < 1) blocks = 1;
+    if (blocks > 1024) blocks = 1024;                                // 4 x 33 KB LDS per CU
+    if (format == 0) hipLaunchKernelGGL(k_convert_uc8, dim3((unsigned) blocks), dim3(kBlock), 0, s, p);
+    else if (format == 1) hipLaunchKernelGGL(k_convert_sc16<15>, dim3((unsigned) blocks * 2), dim3(kBlock), 0, s, p);
+    else hipLaunchKernelGGL(k_convert_sc16<11>, dim3((unsigned) blocks * 2), dim3(kBlock), 0, s, p);
+}
+
+// =============================================================================================
+// preamble sweep + bit slicer + CRC/score
+// =============================================================================================
+
+// slice_phase0..4 (demod_2400.c:74-93) as rows of a 5x4 table
+__constant__ int c_slice_coef[5][4] = {{18, -15, -3, 0}, {14, -5, -9, 0}, {16, 5, -20, 0}, {7, 11, -18, 0}, {4, 15, -20, 1}};
+
+struct LaneConst {
+    uint64_t PH, PL, PS;   // CRC parity masks of syndrome bit `lane` (lanes >= 24: zero)
+};
+
+// modesChecksumDiagnose (crc.c:383-406) as a wave-cooperative two-level search of the sorted,
+// packed table: 64 pivots, then the <=64 entries of the pivot's bucket.  All arguments and
+// results are wave-uniform.
+__device__ __forceinline__ int wave_diagnose(const uint64_t *tab, int n, uint32_t synd, int &b0, int &b1) {
+    if (n <= 0) return -1;
+    const int lane = lane_id();
+    const int stride = (n + WAVE - 1) / WAVE;
+    const int i1 = lane * stride;
+    const uint64_t v = i1 < n ? tab[i1] : ~0ull;
+    const uint64_t le = __ballot((uint32_t) (v >> 16) <= synd && i1 < n);
+    if (le == 0) return -1;
+    const int base = (__popcll(le) - 1) * stride;
+    const int i2 = base + lane;
+    const uint64_t w = (lane < stride && i2 < n) ? tab[i2] : ~0ull;
+    const uint64_t hit = __ballot((uint32_t) (w >> 16) == synd && lane < stride && i2 < n);
+    if (hit == 0) return -1;
+    const uint64_t e = readlane64(w, __ffsll((unsigned long long) hit) - 1);
+    b0 = (int) ((e >> 8) & 0xff);
+    b1 = (int) (e & 0xff);
+    return b1 == 0xff ? 1 : 2;
+}
+
+// correct_aa_field (mode_s.c:230-245)
+__device__ __forceinline__ uint32_t fix_aa(uint32_t aa, int bit) {
+    return (bit >= 8 && bit <= 31) ? aa ^ (1u << (31 - bit)) : aa;
+}
+
+// One try-phase of one candidate, executed by a whole wave: slice (lane = frame bit), CRC,
+// syndrome lookup, score.  Writes the record into *slot (LDS) and returns its flags | 0x100,
+// or returns 0 when the phase scores -2 whatever the ICAO filter holds.
+__device__ __forceinline__ uint32_t slice_and_score(const SweepParams &p, const LaneConst &lc, const uint16_t *s_mag,
+                                                    const int (*s_coef)[4], int pos_local, uint32_t pos, int t,
+                                                    PhaseRec *slot) {
+    const int lane = lane_id();
+    // ---- bits 0..63 (slice_byte's closed form) ----
+    uint64_t hi, lo = 0;
+    {
+        const int u = (t % 5) + 12 * lane;
+        const int q = u / 5, sub = u - 5 * q;
+        const uint16_t *s = s_mag + pos_local + 19 + t / 5 + q;
+        const int corr = s_coef[sub][0] * s[0] + s_coef[sub][1] * s[1] + s_coef[sub][2] * s[2] + s_coef[sub][3] * s[3];
+        hi = __brevll(__ballot(corr > 0));
+    }
+    const uint32_t df = (uint32_t) (hi >> 59);
+    const bool is_long = (p.valid_long >> df) & 1;
+    if (!is_long && !((p.valid_short >> df) & 1)) return 0;   // score_phase: invalid DF -> -2
+    if (is_long) {
+        const int k = 64 + lane;
+        const int u = (t % 5) + 12 * k;
+        const int q = u / 5, sub = u - 5 * q;
+        const uint16_t *s = s_mag + pos_local + 19 + t / 5 + q;
+        int corr = 0;
+        if (lane < 48) corr = s_coef[sub][0] * s[0] + s_coef[sub][1] * s[1] + s_coef[sub][2] * s[2] + s_coef[sub][3] * s[3];
+        lo = __brevll(__ballot(corr > 0 && lane < 48)) >> 16;
+    }
+    const uint32_t aa = (uint32_t) (hi >> 32) & 0xffffffu;   // getbits(msg, 9, 32)
+
+    int sk = -2, su = -2, fb0 = 0xff, fb1 = 0xff;
+    uint32_t addr = 0, flags = is_long ? REC_LONG : 0;
+    bool emit = false;
+
+    if (is_long) {
+        // CRC-24 syndrome of the 112-bit frame: lane j < 24 owns syndrome bit j
+        const int par = __popcll(hi & lc.PH) + __popcll(lo & lc.PL);
+        const uint32_t synd = (uint32_t) __ballot(par & 1) & 0xffffffu;
+        bool handled = false;
+        // fixDF17msgtype (mode_s.c:276-301): DF one bit away from 17 and the frame is clean once DF := 17
+        if (p.fix_df && (df == 1 || df == 16 || df == 19 || df == 21 || df == 25)) {
+            const int j = 4 - (__ffs(df ^ 17u) - 1);   // frame bit that differs
+            if (synd == p.bit_syndrome[j]) {
+                sk = 1800 / 2; su = 1400 / 2; addr = aa;
+                flags |= REC_ACCEPT_IF_UNKNOWN | REC_DFFIX | (1u << REC_CORR_SHIFT);
+                fb0 = j;
+                emit = handled = true;
+            }
+        }
+        if (!handled) {
+            if ((hi >> 8) == 0) {
+                // first 7 bytes all zero -> -2 (mode_s.c:337-338)
+            } else if (df == 16 || df == 20 || df == 21) {
+                sk = 1000; su = -1; addr = synd; flags |= REC_COND; emit = true;      // Address/Parity
+            } else if (df == 17 || df == 18) {
+                int b0 = 0xff, b1 = 0xff;
+                const int nerr = synd == 0 ? 0 : wave_diagnose(p.tab_long, p.n_long, synd, b0, b1);
+                if (nerr >= 0) {
+                    uint32_t a2 = aa;
+                    if (nerr >= 1) a2 = fix_aa(a2, b0);
+                    if (nerr >= 2) a2 = fix_aa(a2, b1);
+                    sk = 1800 / (nerr + 1); su = 1400 / (nerr + 1); addr = a2;
+                    flags |= (uint32_t) nerr << REC_CORR_SHIFT;
+                    if (a2 == aa) flags |= REC_ACCEPT_IF_UNKNOWN;   // mode_s.c:560: only a changed AA needs the filter
+                    if (nerr == 0 && df == 17) flags |= REC_ADDER;
+                    if (nerr >= 1) fb0 = b0;
+                    if (nerr >= 2) fb1 = b1;
+                    emit = true;
+                }
+            }
+            // unrepaired DF 1, 19, 25: scoreModesMessage's default case -> -2
+        }
+    } else {
+        if ((hi >> 8) == 0) return 0;
+        const int par = __popcll(hi & lc.PS);
+        const uint32_t synd = (uint32_t) __ballot(par & 1) & 0xffffffu;
+        if (df == 11) {
+            if (synd & 0xffff80u) {
+                int b0 = 0xff, b1 = 0xff;
+                const int nerr = wave_diagnose(p.tab_short, p.n_short, synd, b0, b1);
+                if (nerr == 1) {                                  // 2-bit errors are ambiguous in DF11
+                    sk = 800; su = -1; addr = fix_aa(aa, b0);
+                    flags |= REC_COND | (1u << REC_CORR_SHIFT);
+                    fb0 = b0;
+                    emit = true;
+                }
+            } else if ((synd & 0x7f) == 0) {
+                sk = 1600; su = 750; addr = aa; flags |= REC_ACCEPT_IF_UNKNOWN | REC_ADDER; emit = true;
+            } else {
+                sk = 1000; su = -1; addr = aa; flags |= REC_COND; emit = true;
+            }
+        } else {   // DF 0, 4, 5
+            sk = 1000; su = -1; addr = synd; flags |= REC_COND; emit = true;
+        }
+    }
+    if (!emit) return 0;
+    if (lane == 0) {
+        u32x4 a, b;
+        a.x = pos;
+        a.y = (uint32_t) t | (flags << 8) | ((uint32_t) (uint16_t) sk << 16);
+        a.z = (uint32_t) (uint16_t) su | ((uint32_t) fb0 << 16) | ((uint32_t) fb1 << 24);
+        a.w = addr;
+        // msg bytes 0..13: byte b = frame bits 8b..8b+7; memory order = byte 0 first
+        const uint64_t h = __builtin_bswap64(hi);
+        const uint64_t l = __builtin_bswap64(lo << 16);
+        b.x = (uint32_t) h;
+        b.y = (uint32_t) (h >> 32);
+        b.z = (uint32_t) l;
+        b.w = (uint32_t) (l >> 32) & 0xffffu;
+        u32x4 *d = (u32x4 *) slot;
+        d[0] = a;
+        d[1] = b;
+        if (flags & REC_ADDER) atomicOr(&p.adder_bitmap[addr >> 5], 1u << (addr & 31));
+    }
+    return flags | 0x100u;
+}
+
+// Workgroup = one unit of kTilesPerUnit tiles, processed tile after tile:
+//   1. stage kTile + kHalo magnitudes in LDS (coalesced 16-byte loads)
+//   2. sweep: every thread evaluates 8 consecutive positions from a 26-sample register window
+//      (pre-check + the three threshold tests of demod_2400.c:311-378) -> 3-bit phase mask
+//   3. compact the candidates, in position order, into an LDS queue (wave prefix sums)
+//   4. slice + score: one wave per candidate, records of a 64-candidate batch are gathered in
+//      LDS in (position, phase) order and flushed to the global pool as one segment
+__global__ __launch_bounds__(kBlock) void k_sweep_slice(SweepParams p) {
+    __shared__ __attribute__((aligned(16))) uint16_t s_mag[kTile + kHalo + 8];
+    __shared__ uint16_t s_queue[kTile];
+    __shared__ __attribute__((aligned(16))) PhaseRec s_slots[kBatch * 5];
+    __shared__ uint32_t s_cls[kTile / 32];
+    __shared__ int s_segcount[8];
+    __shared__ int s_coef[5][4];
+    __shared__ unsigned long long s_cnt[CNT_NUM];
+
+    const int tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    if (tid < 20) s_coef[tid >> 2][tid & 3] = c_slice_coef[tid >> 2][tid & 3];
+    if (tid < CNT_NUM) s_cnt[tid] = 0;
+    LaneConst lc;
+    lc.PH = lane < 24 ? p.parity[lane] : 0;
+    lc.PL = lane < 24 ? p.parity[24 + lane] : 0;
+    lc.PS = lane < 24 ? p.parity[48 + lane] : 0;
+
+    uint32_t n_cand = 0, n_ph[3] = {0, 0, 0};     // per-thread sweep counters
+    uint32_t n_cond = 0, n_uncond = 0, n_rec = 0;  // wave-uniform (counted by lane 0)
+
+    for (uint32_t unit = blockIdx.x; unit < p.nunits; unit += gridDim.x) {
+        uint32_t prev_hdr = kNone, unit_records = 0;   // meaningful in wave 0 only
+        if (tid == 0) p.unit_first[unit] = kNone;
+        for (int tile = 0; tile < kTilesPerUnit; ++tile) {
+            const uint64_t D0 = ((uint64_t) unit * kTilesPerUnit + tile) * kTile;
+            if (D0 >= p.n) break;
+            __syncthreads();   // previous tile fully consumed
+            // ---- 1. stage ----
+            for (int i = tid; i < (kTile + kHalo) / 8; i += kBlock)
+                *(u32x4 *) &s_mag[8 * i] = *(const u32x4 *) &p.mag[D0 + 8 * i];
+            if (tid < kTile / 32) s_cls[tid] = 0;
+            __syncthreads();
+            // ---- 2. sweep ----
+            uint32_t fl[2];
+            int pre[2];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int p0 = it * (kTile / 2) + tid * 8;
+                uint32_t w[13];
+                {
+                    const u32x4 a = *(const u32x4 *) &s_mag[p0], b = *(const u32x4 *) &s_mag[p0 + 8],
+                                c = *(const u32x4 *) &s_mag[p0 + 16];
+                    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+                    w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+                    w[8] = c.x; w[9] = c.y; w[10] = c.z; w[11] = c.w;
+                    w[12] = *(const uint32_t *) &s_mag[p0 + 24];
+                }
+                uint32_t f = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+#define SM(i) ((int) ((w[((e) + (i)) >> 1] >> ((((e) + (i)) & 1) * 16)) & 0xffffu))
+                    const bool pc = SM(1) > SM(7) && SM(12) > SM(14) && SM(12) > SM(15);
+                    const int base_noise = SM(5) + SM(8) + SM(16) + SM(17) + SM(18);
+                    const int ref = (base_noise * p.thr) >> 5;
+                    const int d23 = SM(2) - SM(3), s14 = SM(1) + SM(4), d1011 = SM(10) - SM(11);
+                    const int common = s14 - d23 + SM(9) + SM(12);
+                    uint32_t m = 0;
+                    if (common - d1011 >= ref) m |= 1;
+                    if (common + d1011 >= ref) m |= 2;
+                    if (s14 + 2 * d23 + d1011 + SM(12) >= ref) m |= 4;
+#undef SM
+                    if (!pc || D0 + p0 + e >= p.n) m = 0;
+                    f |= m << (3 * e);
+                }
+                fl[it] = f;
+                const uint32_t nz = (f | (f >> 1) | (f >> 2)) & 0x249249u;
+                const int cnt = __popc(nz);
+                n_cand += cnt;
+                n_ph[0] += __popc(f & 0x249249u);
+                n_ph[1] += __popc((f >> 1) & 0x249249u);
+                n_ph[2] += __popc((f >> 2) & 0x249249u);
+                int total;
+                pre[it] = wave_excl_scan(cnt, total);
+                if (lane == 0) s_segcount[it * 4 + wv] = total;
+            }
+            __syncthreads();
+            // ---- 3. ordered compaction ----
+            int ncand = 0;
+            {
+                int segbase[8];
+#pragma unroll
+                for (int sgi = 0; sgi < 8; ++sgi) { segbase[sgi] = ncand; ncand += s_segcount[sgi]; }
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    int dst = segbase[it * 4 + wv] + pre[it];
+                    const int p0 = it * (kTile / 2) + tid * 8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const uint32_t m = (fl[it] >> (3 * e)) & 7u;
+                        if (m) s_queue[dst++] = (uint16_t) (((p0 + e) << 3) | m);
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- 4. slice + score, 64 candidates per batch ----
+            for (int b0 = 0; b0 < ncand; b0 += kBatch) {
+                for (int i = tid; i < kBatch * 5; i += kBlock) s_slots[i].phase = 0;
+                __syncthreads();
+                for (int j = 0; j < kBatch / 4; ++j) {
+                    const int ci = b0 + wv * (kBatch / 4) + j;
+                    if (ci >= ncand) break;
+                    const uint32_t q = s_queue[ci];
+                    const int pos_local = q >> 3;
+                    const uint32_t mask = q & 7u;
+                    const uint32_t pos = (uint32_t) (D0 + pos_local);
+                    PhaseRec *slots = &s_slots[(wv * (kBatch / 4) + j) * 5];
+                    uint32_t any_uncond = 0, any_cond = 0, nrec = 0;
+#pragma unroll
+                    for (int t = 4; t <= 8; ++t) {
+                        const uint32_t need = t <= 5 ? (mask & 1u) : t <= 7 ? (mask & 2u) : (mask & 4u);
+                        if (!need) continue;
+                        const uint32_t r = slice_and_score(p, lc, s_mag, s_coef, pos_local, pos, t, &slots[t - 4]);
+                        if (r) {
+                            ++nrec;
+                            if (r & REC_COND) any_cond = 1; else any_uncond = 1;
+                        }
+                    }
+                    n_rec += nrec;
+                    if (any_uncond) ++n_uncond;
+                    else if (any_cond) {
+                        ++n_cond;
+                        if (lane == 0) atomicOr(&s_cls[pos_local >> 5], 1u << (pos_local & 31));
+                    }
+                }
+                __syncthreads();
+                if (wv == 0) {
+                    // flush the batch's records, in slot order, as one segment of the unit's chain
+                    uint64_t valid[5];
+                    int cnt = 0;
+#pragma unroll
+                    for (int r = 0; r < 5; ++r) {
+                        valid[r] = __ballot(s_slots[r * WAVE + lane].phase != 0);
+                        cnt += __popcll(valid[r]);
+                    }
+                    if (cnt > 0) {
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(p.pool_used, (uint32_t) cnt + 1u);
+                        base = rfl(base);
+                        if ((uint64_t) base + cnt + 1 > p.pool_cap) {
+                            if (lane == 0) atomicAdd(&p.counters[CNT_POOL_OVERFLOW], 1ull);
+                        } else {
+                            if (lane == 0) {
+                                u32x4 h0 = {(uint32_t) cnt, 0xFFu, 0u, kNone}, h1 = {0, 0, 0, 0};
+                                u32x4 *hd = (u32x4 *) &p.pool[base];
+                                hd[0] = h0; hd[1] = h1;
+                                if (prev_hdr == kNone) p.unit_first[unit] = base;
+                                else p.pool[prev_hdr].addr = base;
+                            }
+                            prev_hdr = base;
+                            uint32_t run = base + 1;
+#pragma unroll
+                            for (int r = 0; r < 5; ++r) {
+                                if ((valid[r] >> lane) & 1) {
+                                    const uint32_t dst = run + __popcll(valid[r] & ((1ull << lane) - 1));
+                                    const u32x4 *src = (const u32x4 *) &s_slots[r * WAVE + lane];
+                                    u32x4 *d = (u32x4 *) &p.pool[dst];
+                                    d[0] = src[0]; d[1] = src[1];
+                                }
+                                run += __popcll(valid[r]);
+                            }
+                            unit_records += cnt;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            // ---- class bitmap of this tile (all words, so the bitmap needs no clearing) ----
+            if (tid < kTile / 32) p.class_bitmap[(D0 >> 5) + tid] = s_cls[tid];
+        }
+        if (tid == 0) p.unit_count[unit] = unit_records;
+    }
+    // ---- counters: one set of atomics per workgroup ----
+    atomicAdd(&s_cnt[CNT_CANDIDATES], (unsigned long long) n_cand);
+    atomicAdd(&s_cnt[CNT_PHASE0 + 0], (unsigned long long) n_ph[0]);
+    atomicAdd(&s_cnt[CNT_PHASE0 + 2], (unsigned long long) n_ph[1]);
+    atomicAdd(&s_cnt[CNT_PHASE0 + 4], (unsigned long long) n_ph[2]);
+    if (lane == 0) {
+        atomicAdd(&s_cnt[CNT_RECORDS], (unsigned long long) n_rec);
+        atomicAdd(&s_cnt[CNT_CLASS_COND], (unsigned long long) n_cond);
+        atomicAdd(&s_cnt[CNT_CLASS_UNCOND], (unsigned long long) n_uncond);
+    }
+    __syncthreads();
+    if (tid < CNT_NUM && s_cnt[tid]) {
+        unsigned long long v = s_cnt[tid];
+        if (tid == CNT_PHASE0 + 0) { atomicAdd(&p.counters[CNT_PHASE0 + 0], v); atomicAdd(&p.counters[CNT_PHASE0 + 1], v); }
+        else if (tid == CNT_PHASE0 + 2) { atomicAdd(&p.counters[CNT_PHASE0 + 2], v); atomicAdd(&p.counters[CNT_PHASE0 + 3], v); }
+        else atomicAdd(&p.counters[tid], v);
+    }
+}
+
+void launch_sweep_slice(const SweepParams &p, hipStream_t s) {
+    if (p.nunits == 0) return;
+    unsigned blocks = p.nunits < 256u * 5u ? p.nunits : 256u * 5u;
+    hipLaunchKernelGGL(k_sweep_slice, dim3(blocks), dim3(kBlock), 0, s, p);
+}
+
+// =============================================================================================
+// pre-screen: a conditional record (score_unknown < 0) can only matter if its address is one
+// that some clean DF17 / DF11-IID0 frame of this stream carries (the only frames that ever add
+// to the ICAO filter, mode_s.c:766-779).  Everything else is "rejected_unknown_icao" for sure.
+// =============================================================================================
+
+__device__ __forceinline__ bool rec_live(const PhaseRec &r, const uint32_t *bitmap) {
+    if (!(r.flags & REC_COND)) return true;
+    const uint32_t a = r.addr & 0xffffffu;
+    return (bitmap[a >> 5] >> (a & 31)) & 1;
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(kBlock) void k_prescreen(const PhaseRec *pool, const uint32_t *unit_first, uint32_t nunits,
+                                                      const uint32_t *bitmap, uint32_t *unit_live, PhaseRec *live) {
+    const int lane = lane_id();
+    const uint32_t u = blockIdx.x * (kBlock / WAVE) + (threadIdx.x >> 6);
+    if (u >= nunits) return;
+    uint32_t h = unit_first[u];
+    uint32_t nlive = 0;
+    const uint32_t dst0 = WRITE ? unit_live[u] : 0;
+    while (h != kNone) {
+        const uint32_t cnt = pool[h].pos, next = pool[h].addr;
+        for (uint32_t i0 = 0; i0 < cnt; i0 += WAVE) {
+            const uint32_t i = i0 + lane;
+            bool ok = false;
+            if (i < cnt) ok = rec_live(pool[h + 1 + i], bitmap);
+            const uint64_t m = __ballot(ok);
+            if (WRITE && ok) {
+                const uint32_t d = dst0 + nlive + __popcll(m & ((1ull << lane) - 1));
+                const u32x4 *src = (const u32x4 *) &pool[h + 1 + i];
+                u32x4 *dd = (u32x4 *) &live[d];
+                dd[0] = src[0]; dd[1] = src[1];
+            }
+            nlive += __popcll(m);
+        }
+        h = next;
+    }
+    if (!WRITE && lane == 0) unit_live[u] = nlive;
+}
+
+// exclusive scan of unit_live[0..n) in place; unit_live[n] = total.  One workgroup.
+__global__ __launch_bounds__(1024) void k_scan_units(uint32_t *unit_live, uint32_t n, unsigned long long *counters) {
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const int v = i < n ? (int) unit_live[i] : 0;
+        int total;
+        const int ex = wave_excl_scan(v, total);
+        if (lane == 0) s_wave[wv] = total;
+        __syncthreads();
+        uint32_t off = s_carry;
+        for (int k = 0; k < wv; ++k) off += s_wave[k];
+        if (i < n) unit_live[i] = off + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t t = 0;
+            for (int k = 0; k < 16; ++k) t += s_wave[k];
+            s_carry += t;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { unit_live[n] = s_carry; (void) counters; }
+}
+
+void launch_prescreen(const PhaseRec *pool, const uint32_t *unit_first, uint32_t nunits, const uint32_t *adder_bitmap,
+                      uint32_t *unit_live, PhaseRec *live, unsigned long long *counters, hipStream_t s) {
+    if (nunits == 0) return;
+    const unsigned blocks = (nunits + 3) / 4;
+    hipLaunchKernelGGL(k_prescreen<false>, dim3(blocks), dim3(kBlock), 0, s, pool, unit_first, nunits, adder_bitmap, unit_live, live);
+    hipLaunchKernelGGL(k_scan_units, dim3(1), dim3(1024), 0, s, unit_live, nunits, counters);
+    hipLaunchKernelGGL(k_prescreen<true>, dim3(blocks), dim3(kBlock), 0, s, pool, unit_first, nunits, adder_bitmap, unit_live, live);
+}
+
+// =============================================================================================
+// per accepted message: signal power, and what its skip-ahead window hid from the counters
+// =============================================================================================
+
+__global__ __launch_bounds__(kBlock) void k_signal_power(const uint16_t *mag, const uint32_t *pos, const uint16_t *len,
+                                                         uint32_t nmsg, unsigned long long *out) {
+    const int lane = lane_id();
+    const uint32_t wave_global = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * kBlock) >> 6;
+    for (uint32_t i = wave_global; i < nmsg; i += nwaves) {
+        const uint16_t *s = mag + pos[i] + 19;
+        const int n = len[i];
+        unsigned long long acc = 0;
+        for (int k = lane; k < n; k += WAVE) { const uint32_t v = s[k]; acc += (unsigned long long) (v * v); }
+        acc = wave_sum_u64(acc);
+        if (lane == 0) out[i] = acc;
+    }
+}
+
+void launch_signal_power(const uint16_t *mag, const uint32_t *pos, const uint16_t *len, uint32_t nmsg,
+                         unsigned long long *out, hipStream_t s) {
+    if (nmsg == 0) return;
+    unsigned blocks = (nmsg + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_signal_power, dim3(blocks), dim3(kBlock), 0, s, mag, pos, len, nmsg, out);
+}
+
+// The reference never looks at the `skip` positions after an accepted frame (pa += msglen*2,
+// demod_2400.c:468), so candidates there count neither as preambles nor as rejects.  The sweep
+// counted every candidate; this kernel re-evaluates the threshold tests on each window
+// (<= 224 positions) and totals what has to be subtracted.
+__global__ __launch_bounds__(kBlock) void k_window_stats(const uint16_t *mag, uint64_t n, int thr, const uint32_t *class_bitmap,
+                                                         const uint32_t *pos, const uint16_t *skip, const uint32_t *limit,
+                                                         uint32_t nmsg, unsigned long long *out) {
+    __shared__ unsigned long long s_acc[8];
+    if (threadIdx.x < 8) s_acc[threadIdx.x] = 0;
+    __syncthreads();
+    const int lane = lane_id();
+    const uint32_t wave_global = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * kBlock) >> 6;
+    uint32_t c_cand = 0, c_a = 0, c_b = 0, c_c = 0, c_cond = 0;
+    for (uint32_t i = wave_global; i < nmsg; i += nwaves) {
+        const uint32_t first = pos[i] + 1;
+        uint32_t last = pos[i] + skip[i];            // inclusive
+        if (last >= limit[i]) last = limit[i] - 1;   // the walk restarts at every buffer boundary
+        for (uint32_t q = first + lane; q <= last; q += WAVE) {
+            if (q >= n) break;
+            const uint16_t *pa = mag + q;
+            uint32_t m = 0;
+            if (pa[1] > pa[7] && pa[12] > pa[14] && pa[12] > pa[15]) {
+                const int base_noise = pa[5] + pa[8] + pa[16] + pa[17] + pa[18];
+                const int ref = (base_noise * thr) >> 5;
+                const int d23 = pa[2] - pa[3], s14 = pa[1] + pa[4], d1011 = pa[10] - pa[11];
+                const int common = s14 - d23 + pa[9] + pa[12];
+                if (common - d1011 >= ref) m |= 1;
+                if (common + d1011 >= ref) m |= 2;
+                if (s14 + 2 * d23 + d1011 + pa[12] >= ref) m |= 4;
+            }
+            if (m) {
+                ++c_cand;
+                c_a += m & 1; c_b += (m >> 1) & 1; c_c += (m >> 2) & 1;
+                c_cond += (class_bitmap[q >> 5] >> (q & 31)) & 1;
+            }
+        }
+    }
+    atomicAdd(&s_acc[0], (unsigned long long) c_cand);
+    atomicAdd(&s_acc[1], (unsigned long long) c_a);
+    atomicAdd(&s_acc[2], (unsigned long long) c_b);
+    atomicAdd(&s_acc[3], (unsigned long long) c_c);
+    atomicAdd(&s_acc[4], (unsigned long long) c_cond);
+    __syncthreads();
+    if (threadIdx.x < 5 && s_acc[threadIdx.x]) atomicAdd(&out[threadIdx.x], s_acc[threadIdx.x]);
+}
+
+void launch_window_stats(const uint16_t *mag, uint64_t n, int thr, const uint32_t *class_bitmap, const uint32_t *pos,
+                         const uint16_t *skip, const uint32_t *limit, uint32_t nmsg, unsigned long long *out, hipStream_t s) {
+    if (nmsg == 0) return;
+    unsigned blocks = (nmsg + 3) / 4;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_window_stats, dim3(blocks), dim3(kBlock), 0, s, mag, n, thr, class_bitmap, pos, skip, limit, nmsg, out);
+}
+
+}  // namespace mgpu

@@ -1,0 +1,83 @@
+// resolve.h — the ordered half of demodulate2400: best-phase selection, acceptance, skip-ahead
+// and the ICAO address filter (demod_2400.c:381-472, mode_s.c:443-606/766-779, icao_filter.c).
+//
+// The kernels emit, for every candidate position and tried phase, a record whose score is known
+// up to one question: "is this address in the ICAO filter right now?".  Answering it needs the
+// exact serial order of the reference (accepted frames add addresses, accepted frames hide the
+// next 112/224 positions, the filter forgets on a 60 s clock), so this walk is sequential per
+// stream.  It touches only the records that survived the pre-screen (about one per real frame).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "../../include/modes_gpu.h"
+#include "kernels.h"
+
+namespace mgpu {
+
+// Exact model of icao_filter.c: two generations, `occupied`, table size.  Bucket placement never
+// shows in results; membership, the occupied count and the grow/shrink thresholds do, because
+// growing re-inserts only the active generation (icaoFilterResize, icao_filter.c:65-93).
+class IcaoFilter {
+  public:
+    IcaoFilter();
+    void init();                       // icaoFilterInit (:47-59)
+    void add(uint32_t addr);           // icaoFilterAdd (:112-130)
+    bool test(uint32_t addr) const {   // icaoFilterTest (:132-154)
+        return addr < (1u << 24) ? (((bits_[0][addr >> 6] | bits_[1][addr >> 6]) >> (addr & 63)) & 1) : big_test(addr);
+    }
+    void expire();                     // icaoFilterExpire (:96-110)
+    uint32_t occupied() const { return occupied_; }
+    uint32_t table_bits() const { return filter_bits_; }
+
+  private:
+    void resize(uint32_t bits);
+    bool big_test(uint32_t addr) const;
+    void clear_gen(int g);
+    std::vector<uint64_t> bits_[2];       // 2^24-bit membership bitmap per generation
+    std::vector<uint32_t> members_[2];    // for O(members) clearing
+    std::vector<uint32_t> big_[2];        // addresses >= 2^24 (only Modes.show_only's default)
+    int active_ = 0;
+    uint32_t occupied_ = 0, filter_bits_ = 8;
+};
+
+struct BufferClock {
+    int64_t sampleTimestamp;   // mag_buf.sampleTimestamp (12 MHz ticks)
+    int64_t sysTimestamp;      // mag_buf.sysTimestamp (ms)
+    uint32_t first, length;    // scan positions [first, first+length) of the feed
+};
+
+struct ResolveCounts {
+    uint64_t visited_groups = 0;        // candidate groups the walk looked at
+    uint64_t rejected_unknown = 0;      // visited, best == -1 or decode stage -1
+    uint64_t rejected_bad = 0;          // visited, decode stage -2 (not produced) / best == -2
+    uint64_t accepted[3] = {0, 0, 0};
+    uint64_t best_phase[5] = {0, 0, 0, 0, 0};
+    uint64_t skipped_uncond_groups = 0; // live groups hidden by a skip window, >= 1 unconditional record
+    uint64_t skipped_cond_groups = 0;   // live groups hidden by a skip window, conditional records only
+    uint64_t visited_cond_groups = 0;   // visited groups with conditional records only
+    uint64_t visited_uncond_groups = 0;
+};
+
+class Resolver {
+  public:
+    void reset(int64_t startup_ms);
+    // Walk the ordered live records of one feed.  `base_pos` = stream position of the feed's
+    // scan position 0.  Appends accepted messages (sig_* left 0) and their feed-relative
+    // positions / skip lengths / buffer limits.
+    void walk(const PhaseRec *recs, uint64_t nrecs, const std::vector<BufferClock> &buffers,
+              std::vector<mgpu_msg> &out, std::vector<uint32_t> &out_pos, std::vector<uint16_t> &out_skip,
+              std::vector<uint32_t> &out_limit, ResolveCounts &counts);
+    // the per-buffer filter clock for a buffer that produced no walk (zero-length EOF buffer)
+    void tick_empty(int64_t sysTimestamp);
+    IcaoFilter &filter() { return filter_; }
+    uint64_t nflips() const { return nflips_; }
+
+  private:
+    void after_buffer();
+    IcaoFilter filter_;
+    int64_t synthetic_now_ = 0, next_flip_ = 0;
+    uint64_t nflips_ = 0;
+};
+
+}  // namespace mgpu

@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py — whole-job throughput of the Mode-S demodulator hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--samples S]
+
+A "step" = one pass of the hot path (IQ -> magnitude -> preamble sweep + bit slicer + CRC ->
+ordered accept walk -> signal power) over one synthetic UC8 2.4 MSps stream that is already
+resident in HBM when the timed region starts (BASELINE.json configs[1]: single UC8 stream,
+--fix).  With N > 1 every rank demodulates its own independent stream (configs[3]) and the
+decoded message counts/records are gathered over RCCL inside the timed step.
+
+Prints ONE JSON line (rank 0): metric/value/unit as BASELINE.json, plus
+  roofline     — k_sweep_slice: algorithmic bytes (2 B per magnitude sample) / its HIP-event time
+  cpu_baseline — the reference's own C files (oracle/_ref) timed on this host on the same stream,
+                 whose message list must be bit-identical to the GPU's (checked in the same run).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+BUF = 131072
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+SWEEP_BYTES_PER_SAMPLE = 2.0   # k_preamble_sweep reads one u16 magnitude per position
+
+
+def cpu_reference(iq, nsamples):
+    """oracle/_ref (the reference's own convert.c + demodulate2400 + ...) on the host, 1 core."""
+    import helpers
+    so = os.path.join(ROOT, "oracle", "_ref", "libreadsb_ref.so")
+    if os.path.exists(so):
+        lib = C.CDLL(so)
+        lib.ref_demod_run.argtypes = [C.c_int] * 4 + [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
+                                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        out, nout = C.c_void_p(), C.c_uint64()
+        st = np.zeros(1, dtype=helpers.ORACLE_STATS)
+        devnull = os.open(os.devnull, os.O_WRONLY)
+        saved = os.dup(2)
+        os.dup2(devnull, 2)   # init_converter prints to stderr
+        try:
+            rc = lib.ref_demod_run(0, 1, 1, 58, iq.ctypes.data, nsamples, C.byref(out), C.byref(nout), st.ctypes.data,
+                                   None, None, None)
+        finally:
+            os.dup2(saved, 2)
+            os.close(devnull)
+        assert rc == 0
+        msgs = np.zeros(nout.value, dtype=helpers.ORACLE_MSG)
+        C.memmove(msgs.ctypes.data, out.value, nout.value * helpers.ORACLE_MSG.itemsize)
+        return "reference", msgs, st[0]
+    msgs, st = helpers.oracle_run(iq[: nsamples * 2])
+    return "port", msgs, st
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--samples", type=int, default=4096 * BUF, help="samples per stream per step (multiple of 131072)")
+    ap.add_argument("--msgs-per-sec", type=float, default=2000.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    n = args.samples - args.samples % BUF
+    assert n > 0
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libmodes_gpu has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import helpers
+    import readsb_amd
+    helpers.ensure_built()
+
+    # ---- synthetic input: one independent stream per rank, generated on the host, staged in HBM ----
+    t0 = time.time()
+    threads = max(1, (os.cpu_count() or 8) // max(1, world))
+    iq = helpers.synth(nsamples=n, seed=88172645463325252 + rank, rate=args.msgs_per_sec, threads=min(threads, 64))
+    t_gen = time.time() - t0
+    d = readsb_amd.Demodulator(max_samples=n, device=local_rank, startup_time_ms=helpers.STARTUP_MS)
+    d.upload_iq(iq)
+
+    def step():
+        d.reset()
+        d.feed_resident(n)                      # timed: everything from HBM-resident IQ to ordered messages
+        d.finish()                              # ifile EOF bookkeeping (zero-length buffer on exact multiples)
+        msgs, counters = d.collect()
+        if world > 1:                           # aggregator role: counts + records to rank 0 over RCCL
+            cnt = torch.tensor([len(msgs)], dtype=torch.int64, device="cuda")
+            counts = [torch.zeros_like(cnt) for _ in range(world)]
+            dist.all_gather(counts, cnt)
+            cap = int(max(int(c.item()) for c in counts))
+            buf = torch.zeros(cap * 64, dtype=torch.uint8, device="cuda")
+            buf[: len(msgs) * 64] = torch.from_numpy(msgs.view(np.uint8).reshape(-1)).cuda()
+            gathered = [torch.zeros_like(buf) for _ in range(world)] if rank == 0 else None
+            dist.gather(buf, gathered, dst=0)
+        return msgs, counters
+
+    for _ in range(args.warmup):
+        step()
+    sweep_ms, conv_ms, resolve_ms, total_ms = [], [], [], []
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        msgs, counters = step()
+        tm = d.timing()
+        sweep_ms.append(tm["sweep_ms"]); conv_ms.append(tm["convert_ms"]); resolve_ms.append(tm["resolve_ms"]); total_ms.append(tm["total_ms"])
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        nm = torch.tensor([len(msgs)], dtype=torch.int64, device="cuda")
+        dist.all_reduce(nm)
+        total_msgs = int(nm.item())
+    else:
+        total_msgs = len(msgs)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = n * world * args.steps / elapsed / 1e6
+        sweep = float(np.mean(sweep_ms))
+        achieved = n * SWEEP_BYTES_PER_SAMPLE / (sweep * 1e-3) / 1e9
+        out = {
+            "metric": "IQ Msamples/s demodulated (UC8 2.4 MSps stream, --fix), whole job",
+            "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u16", "data": "synthetic",
+            "config": {"workload": "configs[1]: single 2.4 MSps UC8 stream per GPU, --fix (nfix_crc=1, fixDF=1, thr=58), "
+                                   f"{n} samples = {n / 2.4e6:.1f} s of signal per stream, {args.msgs_per_sec:.0f} frames/s, HBM-resident IQ",
+                       "samples_per_stream": n, "streams": world, "parallelism": f"1 stream per GPU x{world}"},
+            "x_realtime_per_gpu": round(value / world / 2.4, 1),
+            "msgs_per_s": round(total_msgs * args.steps / elapsed, 1),
+            "messages_per_step": total_msgs,
+            "stage_ms": {"convert": round(float(np.mean(conv_ms)), 3), "sweep_slice": round(sweep, 3),
+                         "prescreen": round(tm["prescreen_ms"], 3), "d2h": round(tm["d2h_ms"], 3),
+                         "resolve_host": round(float(np.mean(resolve_ms)), 3), "sigpower": round(tm["sigpower_ms"], 3),
+                         "feed_total": round(float(np.mean(total_ms)), 3)},
+            "roofline": {"kernel": "k_sweep_slice", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(n * SWEEP_BYTES_PER_SAMPLE), "avg_launch_ms": round(sweep, 4)},
+            "synth_gen_s": round(t_gen, 2),
+        }
+        if not args.no_cpu_baseline:
+            t0 = time.time()
+            kind, ref_msgs, st = cpu_reference(iq, n)
+            cpu_s = float(st["t_convert_s"] + st["t_demod_s"])
+            helpers.assert_same_messages(msgs, ref_msgs)      # bit-identical decoded message set, same run
+            helpers.assert_same_counters(counters, st)
+            out["cpu_baseline"] = {"value": round(n / cpu_s / 1e6, 1), "unit": "Msamples/s", "cores": 1, "kind": kind,
+                                   "sample": f"the whole rank-0 stream ({n} samples): convert {st['t_convert_s']:.2f} s + "
+                                             f"demodulate2400 {st['t_demod_s']:.2f} s on one host core "
+                                             f"({os.cpu_count()} cores present)",
+                                   "messages": int(len(ref_msgs)), "bit_identical_to_gpu": True}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -85,6 +85,7 @@ def main():
 
     import helpers
     import readsb_amd
+    from readsb_amd.gather import gather_messages
     helpers.ensure_built()
 
     # ---- synthetic input: one independent stream per rank, generated on the host, staged in HBM ----
@@ -101,14 +102,7 @@ def main():
         d.finish()                              # ifile EOF bookkeeping (zero-length buffer on exact multiples)
         msgs, counters = d.collect()
         if world > 1:                           # aggregator role: counts + records to rank 0 over RCCL
-            cnt = torch.tensor([len(msgs)], dtype=torch.int64, device="cuda")
-            counts = [torch.zeros_like(cnt) for _ in range(world)]
-            dist.all_gather(counts, cnt)
-            cap = int(max(int(c.item()) for c in counts))
-            buf = torch.zeros(cap * 64, dtype=torch.uint8, device="cuda")
-            buf[: len(msgs) * 64] = torch.from_numpy(msgs.view(np.uint8).reshape(-1)).cuda()
-            gathered = [torch.zeros_like(buf) for _ in range(world)] if rank == 0 else None
-            dist.gather(buf, gathered, dst=0)
+            gather_messages(msgs, torch.device("cuda", local_rank))
         return msgs, counters
 
     for _ in range(args.warmup):

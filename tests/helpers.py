@@ -38,6 +38,9 @@ COUNTER_FIELDS = ["demod_preambles", "demod_rejected_bad", "demod_rejected_unkno
 
 def ensure_built():
     """Build whatever is missing (everything is normally built by __graft_entry__.build())."""
+    import sys
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
     import __graft_entry__ as g
     g.build(quiet=True)
 

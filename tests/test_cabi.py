@@ -1,0 +1,93 @@
+"""CPU tests of the product library: it loads without a GPU, exports every symbol the header
+declares, refuses to run without a device (no CPU fallback), and its host-built tables equal
+the reference's."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import helpers
+
+TABLES = np.load(os.path.join(helpers.GOLDEN_DIR, "tables.npz"))
+
+
+def _header_functions():
+    text = open(os.path.join(helpers.ROOT, "include", "modes_gpu.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b(mgpu_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(n for n in names if n != "mgpu_msg_signal_level"))
+
+
+def test_library_exports_every_declared_symbol(built):
+    import readsb_amd
+    lib = C.CDLL(readsb_amd.lib_path())
+    names = _header_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/modes_gpu.h but not exported"
+
+
+def test_struct_sizes_match_the_c_header(built, tmp_path):
+    """The ctypes mirrors must have exactly the layout a C caller sees (compiled with plain gcc -std=c11,
+    which also proves the header is C, not C++)."""
+    import subprocess
+    import readsb_amd
+    from readsb_amd import binding
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "modes_gpu.h"\nint main(void){printf("%zu %zu %zu %zu\\n",'
+                   'sizeof(struct mgpu_config),sizeof(struct mgpu_msg),sizeof(struct mgpu_counters),sizeof(struct mgpu_timing));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(helpers.ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    sizes = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert sizes == [C.sizeof(binding.Config), readsb_amd.MSG_DTYPE.itemsize, C.sizeof(binding.Counters), C.sizeof(binding.Timing)]
+    assert sizes[1] == 64
+
+
+def test_no_cpu_fallback(built):
+    """Without a GPU the product must fail loudly, never compute on the CPU."""
+    import readsb_amd
+    lib = readsb_amd.load_library()
+    if lib.mgpu_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(readsb_amd.MgpuError, match="no usable HIP device"):
+        readsb_amd.Demodulator()
+
+
+def test_host_crc_matches_reference_tables(built):
+    import readsb_amd
+    lib = readsb_amd.load_library()
+    assert (lib.mgpu_crc_table_size(1, 56), lib.mgpu_crc_table_size(1, 112)) == (51, 107)
+    assert (lib.mgpu_crc_table_size(2, 56), lib.mgpu_crc_table_size(2, 112)) == (1326, 3831)
+    assert (lib.mgpu_crc_table_size(0, 56), lib.mgpu_crc_table_size(0, 112)) == (0, 0)
+    for nfix in (1, 2):
+        for bits in (56, 112):
+            gold = TABLES[f"nfix{nfix}_{bits}"]
+            for syn, n, b0, b1 in gold:
+                x, y = C.c_int(), C.c_int()
+                assert lib.mgpu_crc_diagnose(nfix, int(syn), bits, C.byref(x), C.byref(y)) == n
+                assert (x.value, y.value) == (b0, b1)
+    rng = np.random.default_rng(0)
+    olib = helpers.oracle_lib()
+    olib.modes_oracle_crc_init(2)
+    for _ in range(2000):
+        syn = int(rng.integers(1, 1 << 24))
+        x, y, u, v = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        assert lib.mgpu_crc_diagnose(2, syn, 112, C.byref(x), C.byref(y)) == olib.modes_oracle_diagnose(syn, 112, C.byref(u), C.byref(v))
+    single = TABLES["single_bit_syndrome_112"]
+    for k in range(112):
+        m = np.zeros(14, dtype=np.uint8)
+        m[k >> 3] = 0x80 >> (k & 7)
+        assert lib.mgpu_crc_checksum(m.ctypes.data, 112) == single[k]
+    for _ in range(200):
+        m = rng.integers(0, 256, size=14, dtype=np.uint8)
+        for bits in (56, 112):
+            assert lib.mgpu_crc_checksum(m.ctypes.data, bits) == olib.modes_oracle_checksum(m.ctypes.data, bits)
+
+
+def test_host_uc8_table_matches_reference(built):
+    import readsb_amd
+    lib = readsb_amd.load_library()
+    tab = np.ctypeslib.as_array(lib.mgpu_uc8_table(), shape=(65536,))
+    assert np.array_equal(tab.reshape(256, 256), TABLES["uc8_mag_by_i_q"])

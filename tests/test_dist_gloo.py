@@ -1,0 +1,57 @@
+"""CPU test of the N>1 path: world_size-2 `gloo` run of the aggregator gather bench.py uses
+over RCCL (readsb_amd/gather.py)."""
+import os
+import sys
+
+import numpy as np
+import torch.multiprocessing as mp
+
+import helpers
+
+
+def _worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, helpers.ROOT)
+    from readsb_amd.binding import MSG_DTYPE
+    from readsb_amd.gather import gather_messages, merge_by_timestamp
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(100 + rank)
+    n = [700, 123][rank]                                  # ragged counts
+    msgs = np.zeros(n, dtype=MSG_DTYPE)
+    msgs["timestamp"] = np.sort(rng.integers(0, 10**9, size=n))
+    msgs["addr"] = rank
+    msgs["msg"] = rng.integers(0, 256, size=(n, 14), dtype=np.uint8)
+    counts, per_rank = gather_messages(msgs, torch.device("cpu"))
+    ok = counts == [700, 123]
+    if rank == 0:
+        ok = ok and len(per_rank) == 2 and per_rank[0].tobytes() == msgs.tobytes() and len(per_rank[1]) == 123
+        ok = ok and bool((per_rank[1]["addr"] == 1).all())
+        merged = merge_by_timestamp(per_rank)
+        ok = ok and len(merged) == 823 and bool((np.diff(merged["timestamp"]) >= 0).all())
+    else:
+        ok = ok and per_rank is None
+    # empty rank edge case
+    counts2, per2 = gather_messages(msgs[:0] if rank == 1 else msgs[:5], torch.device("cpu"))
+    ok = ok and counts2 == [5, 0]
+    if rank == 0:
+        ok = ok and len(per2[1]) == 0 and len(per2[0]) == 5
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_two_ranks_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results == {0: True, 1: True}

@@ -1,0 +1,103 @@
+"""CPU tests: the plain-C restatement (oracle/modes_oracle.c) is pinned against
+  (1) the golden fixtures in tests/golden/, produced by the reference's own C files, and
+  (2) the reference itself (oracle/_ref), live, wherever it has been built (dev container and,
+      because the binaries travel, the GPU box)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+
+INDEX = json.load(open(os.path.join(helpers.GOLDEN_DIR, "index.json")))
+TABLES = np.load(os.path.join(helpers.GOLDEN_DIR, "tables.npz"))
+
+
+def _stats_match(st, want):
+    for f in helpers.COUNTER_FIELDS:
+        assert np.asarray(st[f]).tolist() == want[f], f
+    for f in ("signal_power_sum", "peak_signal_power", "noise_power_sum"):
+        a, b = float(st[f]), float.fromhex(want[f])
+        assert (np.isnan(a) and np.isnan(b)) or a == b, f
+
+
+@pytest.mark.parametrize("name", sorted(INDEX))
+def test_restatement_matches_golden(built, name):
+    c = INDEX[name]
+    iq = helpers.synth(**c["synth"])
+    assert hashlib.sha256(iq.tobytes()).hexdigest() == c["iq_sha256"], "synthetic generator drifted: regenerate goldens"
+    msgs, st = helpers.oracle_run(iq, c["fmt"], c["nfix"], c["fixdf"], c["thr"])
+    gold = np.load(os.path.join(helpers.GOLDEN_DIR, name + ".msgs.npy"))
+    assert len(msgs) == c["nmsgs"] == len(gold)
+    assert msgs.tobytes() == gold.tobytes()
+    _stats_match(st, c["stats"])
+
+
+@pytest.mark.skipif(not helpers.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("fmt,nfix,fixdf,thr,skw", [
+    (0, 1, 1, 58, dict(seconds=2.0, seed=31)),
+    (0, 2, 1, 58, dict(seconds=2.0, seed=32, rate=6000.0)),
+    (0, 1, 0, 40, dict(seconds=1.0, seed=33)),
+    (2, 2, 1, 58, dict(seconds=1.0, seed=34, fmt=2)),
+    (1, 1, 1, 58, dict(seconds=1.0, seed=35, fmt=1)),
+    (0, 1, 1, 58, dict(nsamples=131072, seed=36)),          # exact multiple: zero-length EOF buffer
+    (0, 1, 1, 58, dict(nsamples=1000, seed=37)),
+])
+def test_restatement_matches_reference_live(built, fmt, nfix, fixdf, thr, skw):
+    iq = helpers.synth(**skw)
+    a, sa, ma = helpers.oracle_run(iq, fmt, nfix, fixdf, thr, want_mag=True)
+    b, sb, mb = helpers.ref_run(iq, fmt, nfix, fixdf, thr, want_mag=True)
+    assert a.tobytes() == b.tobytes()
+    assert np.array_equal(ma, mb)
+    for f in helpers.COUNTER_FIELDS:
+        assert np.array_equal(np.asarray(sa[f]), np.asarray(sb[f])), f
+    for f in ("signal_power_sum", "peak_signal_power", "noise_power_sum"):
+        x, y = float(sa[f]), float(sb[f])
+        assert (np.isnan(x) and np.isnan(y)) or x == y
+
+
+@pytest.mark.skipif(not helpers.have_ref(), reason="oracle/_ref not built")
+def test_filter_expiry_two_minutes(built):
+    """130 s stream: three filter flips, aircraft fall silent and are forgotten."""
+    iq = helpers.synth(seconds=130.0, seed=11, rate=1500.0, naircraft=300)
+    a, sa = helpers.oracle_run(iq)
+    b, sb = helpers.ref_run(iq)
+    assert sa["nflips"] >= 3
+    assert a.tobytes() == b.tobytes()
+    for f in helpers.COUNTER_FIELDS:
+        assert np.array_equal(np.asarray(sa[f]), np.asarray(sb[f])), f
+
+
+def test_crc_table_sizes_are_crctests_numbers(built):
+    """The only KATs the reference has for crc.c: `crctests 1 1` -> 51/107, `crctests 2 4` -> 1326/3831."""
+    lib = helpers.oracle_lib()
+    lib.modes_oracle_crc_init(1)
+    assert (lib.modes_oracle_table_size(56), lib.modes_oracle_table_size(112)) == (51, 107)
+    lib.modes_oracle_crc_init(2)
+    assert (lib.modes_oracle_table_size(56), lib.modes_oracle_table_size(112)) == (1326, 3831)
+
+
+@pytest.mark.parametrize("nfix", [1, 2])
+def test_crc_tables_match_reference_dump(built, nfix):
+    import ctypes as C
+    lib = helpers.oracle_lib()
+    lib.modes_oracle_crc_init(nfix)
+    for bits in (56, 112):
+        gold = TABLES[f"nfix{nfix}_{bits}"]
+        assert lib.modes_oracle_table_size(bits) == len(gold)
+        for syn, n, b0, b1 in gold[:: max(1, len(gold) // 400)]:
+            x, y = C.c_int(), C.c_int()
+            assert lib.modes_oracle_diagnose(int(syn), bits, C.byref(x), C.byref(y)) == n
+            assert (x.value, y.value) == (b0, b1)
+    x, y = C.c_int(), C.c_int()
+    assert lib.modes_oracle_diagnose(0x123457, 112, C.byref(x), C.byref(y)) in (-1, 1, 2)
+
+
+def test_uc8_table_matches_reference(built):
+    lut = np.ctypeslib.as_array(helpers.oracle_lib().modes_oracle_uc8_lut(), shape=(65536,))
+    gold = TABLES["uc8_mag_by_i_q"]     # [I][Q] from the reference converter
+    # table index = I | Q<<8
+    assert np.array_equal(lut.reshape(256, 256).T, gold)
+    assert np.array_equal(gold, gold.T)  # symmetric

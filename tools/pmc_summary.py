@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc CSVs (one counter per pass, as MI355X_MICROARCH.md prescribes) into
+per-kernel HBM traffic.  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly
+half of a wide coalesced streaming read, so reads are doubled (guide, section HBM).
+
+usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> [out.json]"""
+import collections
+import csv
+import json
+import sys
+
+
+def per_kernel(path, counter):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+def main():
+    fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+    write = per_kernel(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for k in sorted(set(fetch) | set(write)):
+        if not k.startswith("mgpu::") and "mgpu::" not in k:
+            continue
+        rd = 2.0 * fetch.get(k, 0.0) * 1024.0      # gfx950 correction: x2
+        wr = write.get(k, 0.0) * 1024.0
+        out[k] = {"fetch_size_kib_raw": fetch.get(k, 0.0), "write_size_kib_raw": write.get(k, 0.0),
+                  "hbm_read_bytes_corrected": rd, "hbm_write_bytes": wr, "hbm_bytes": rd + wr}
+    text = json.dumps(out, indent=1)
+    if len(sys.argv) > 3:
+        open(sys.argv[3], "w").write(text + "\n")
+    print(text)
+
+
+if __name__ == "__main__":
+    main()

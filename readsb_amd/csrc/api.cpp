@@ -7,8 +7,13 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -29,36 +34,48 @@ double wall_ms() {
 }
 }  // namespace
 
-struct mgpu_ctx {
-    mgpu_config cfg{};
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[8] = {};
-    std::string err;
-
-    // capacities
-    uint64_t cap_samples = 0, cap_units = 0, cap_buffers = 0, cap_pool = 0, cap_msgs = 0;
-
+// One pipeline stage's worth of buffers: a chunk of the stream is converted, swept and pre-screened
+// into a slot on the GPU while the worker thread walks the previous chunk's records on the host.
+struct Slot {
     // device
-    uint8_t *d_iq = nullptr;
-    uint16_t *d_mag = nullptr, *d_tail = nullptr;
-    PhaseRec *d_pool = nullptr, *d_live = nullptr;
-    uint32_t *d_pool_used = nullptr, *d_unit_first = nullptr, *d_unit_count = nullptr, *d_unit_live = nullptr;
-    uint32_t *d_adder_bitmap = nullptr, *d_class_bitmap = nullptr;
-    unsigned long long *d_counters = nullptr, *d_sum_level = nullptr, *d_sum_power = nullptr, *d_win = nullptr;
+    uint16_t *d_mag = nullptr;
+    PhaseRec *d_pool = nullptr;
+    uint32_t *d_pool_used = nullptr, *d_unit_first = nullptr, *d_unit_count = nullptr, *d_unit_live = nullptr, *d_class_bitmap = nullptr;
+    unsigned long long *d_counters = nullptr, *d_sum_level = nullptr, *d_sum_power = nullptr, *d_win = nullptr, *d_msg_sig = nullptr;
     double *d_fsum_level = nullptr, *d_fsum_power = nullptr;
-    uint32_t *d_bit_syndrome = nullptr;
-    uint64_t *d_parity = nullptr, *d_tab_long = nullptr, *d_tab_short = nullptr;
-    uint16_t *d_uc8_folded = nullptr;
     uint32_t *d_msg_pos = nullptr, *d_msg_limit = nullptr;
     uint16_t *d_msg_len = nullptr, *d_msg_skip = nullptr;
-    unsigned long long *d_msg_sig = nullptr;
-    int n_long = 0, n_short = 0;
-
     // pinned host
-    PhaseRec *h_live = nullptr;
+    PhaseRec *h_live = nullptr;          // k_prescreen<write> stores the surviving records straight into host memory
     unsigned long long *h_counters = nullptr, *h_sums = nullptr, *h_win = nullptr, *h_sig = nullptr;
     double *h_fsums = nullptr;
-    uint32_t *h_total = nullptr;
+    uint32_t *h_total = nullptr, *h_msg_pos = nullptr, *h_msg_limit = nullptr;
+    uint16_t *h_msg_len = nullptr, *h_msg_skip = nullptr;
+    hipEvent_t ev[4] = {};
+    // the job
+    uint64_t n = 0;
+    bool have_mag = false, busy = false;
+    std::vector<BufferClock> buffers;
+    std::vector<double> given_mean_power;
+};
+
+struct mgpu_ctx {
+    mgpu_config cfg{};
+    hipStream_t stream = nullptr, stream2 = nullptr;
+    std::string err;
+
+    uint64_t cap_samples = 0;      // per feed call (cfg.max_samples)
+    uint64_t chunk_samples = 0;    // per pipeline slot
+    uint64_t cap_units = 0, cap_buffers = 0, cap_pool = 0, cap_msgs = 0;   // per slot
+
+    uint8_t *d_iq = nullptr;
+    uint16_t *d_tail = nullptr;
+    uint32_t *d_adder_bitmap = nullptr;
+    uint32_t *d_bit_syndrome = nullptr, *d_group_syndrome = nullptr;
+    uint64_t *d_parity = nullptr, *d_tab_long = nullptr, *d_tab_short = nullptr;
+    uint16_t *d_uc8_folded = nullptr;
+    int n_long = 0, n_short = 0;
+    Slot slot[2];
 
     std::vector<SyndromeEntry> tab_long, tab_short;
     uint32_t valid_long = 0, valid_short = 0;
@@ -66,9 +83,18 @@ struct mgpu_ctx {
     Resolver resolver;
     std::vector<mgpu_msg> pending;
     mgpu_counters counters{};
-    mgpu_timing timing{};
-    uint64_t stream_pos = 0;   // samples consumed so far
+    mgpu_timing timing{}, acc{};
+    uint64_t stream_pos = 0;
     bool eof = false, have_tail = false;
+    bool use_v1 = false;       // MGPU_SWEEP_V1=1: first-generation slicer (kept for A/B measurements)
+
+    // worker thread: ordered walk + signal power of the slots, in submission order
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<int> queue;
+    bool stop = false;
+    int worker_rc = MGPU_OK;
 };
 
 #define HIPCHK(ctx, call)                                                                          \
@@ -79,6 +105,9 @@ struct mgpu_ctx {
             return e_ == hipErrorOutOfMemory ? MGPU_E_NOMEM : MGPU_E_HIP;                          \
         }                                                                                          \
     } while (0)
+
+static int finish_slot(mgpu_ctx *c, Slot &sl);
+static void worker_main(mgpu_ctx *c);
 
 extern "C" {
 
@@ -117,55 +146,95 @@ int mgpu_device_count(void) {
     return n;
 }
 
+static int alloc_slot(mgpu_ctx *c, Slot &sl) {
+    const uint64_t n = c->chunk_samples;
+    const uint64_t mag_len = (n + kTile - 1) / kTile * kTile + kTile + kHalo + 64;
+    HIPCHK(c, hipMalloc(&sl.d_mag, mag_len * sizeof(uint16_t)));
+    HIPCHK(c, hipMemsetAsync(sl.d_mag, 0, mag_len * sizeof(uint16_t), c->stream));
+    HIPCHK(c, hipMalloc(&sl.d_pool, c->cap_pool * sizeof(PhaseRec)));
+    HIPCHK(c, hipMalloc(&sl.d_pool_used, 64));
+    HIPCHK(c, hipMalloc(&sl.d_unit_first, (c->cap_units + 1) * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(&sl.d_unit_count, (c->cap_units + 1) * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(&sl.d_unit_live, (c->cap_units + 2) * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(&sl.d_class_bitmap, (mag_len / 32 + 64) * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(&sl.d_counters, CNT_NUM * sizeof(unsigned long long)));
+    HIPCHK(c, hipMalloc(&sl.d_sum_level, c->cap_buffers * sizeof(unsigned long long)));
+    HIPCHK(c, hipMalloc(&sl.d_sum_power, c->cap_buffers * sizeof(unsigned long long)));
+    HIPCHK(c, hipMalloc(&sl.d_fsum_level, c->cap_buffers * sizeof(double)));
+    HIPCHK(c, hipMalloc(&sl.d_fsum_power, c->cap_buffers * sizeof(double)));
+    HIPCHK(c, hipMalloc(&sl.d_win, 8 * sizeof(unsigned long long)));
+    HIPCHK(c, hipMalloc(&sl.d_msg_pos, c->cap_msgs * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(&sl.d_msg_limit, c->cap_msgs * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(&sl.d_msg_len, c->cap_msgs * sizeof(uint16_t)));
+    HIPCHK(c, hipMalloc(&sl.d_msg_skip, c->cap_msgs * sizeof(uint16_t)));
+    HIPCHK(c, hipMalloc(&sl.d_msg_sig, c->cap_msgs * sizeof(unsigned long long)));
+    HIPCHK(c, hipHostMalloc(&sl.h_live, c->cap_pool * sizeof(PhaseRec)));
+    HIPCHK(c, hipHostMalloc(&sl.h_counters, CNT_NUM * sizeof(unsigned long long)));
+    HIPCHK(c, hipHostMalloc(&sl.h_sums, 2 * c->cap_buffers * sizeof(unsigned long long)));
+    HIPCHK(c, hipHostMalloc(&sl.h_fsums, 2 * c->cap_buffers * sizeof(double)));
+    HIPCHK(c, hipHostMalloc(&sl.h_win, 8 * sizeof(unsigned long long)));
+    HIPCHK(c, hipHostMalloc(&sl.h_sig, c->cap_msgs * sizeof(unsigned long long)));
+    HIPCHK(c, hipHostMalloc(&sl.h_total, 64));
+    HIPCHK(c, hipHostMalloc(&sl.h_msg_pos, c->cap_msgs * sizeof(uint32_t)));
+    HIPCHK(c, hipHostMalloc(&sl.h_msg_limit, c->cap_msgs * sizeof(uint32_t)));
+    HIPCHK(c, hipHostMalloc(&sl.h_msg_len, c->cap_msgs * sizeof(uint16_t)));
+    HIPCHK(c, hipHostMalloc(&sl.h_msg_skip, c->cap_msgs * sizeof(uint16_t)));
+    for (auto &e : sl.ev) HIPCHK(c, hipEventCreate(&e));
+    return MGPU_OK;
+}
+
+static void free_slot(Slot &sl) {
+    void *dev[] = {sl.d_mag, sl.d_pool, sl.d_pool_used, sl.d_unit_first, sl.d_unit_count, sl.d_unit_live, sl.d_class_bitmap,
+                   sl.d_counters, sl.d_sum_level, sl.d_sum_power, sl.d_fsum_level, sl.d_fsum_power, sl.d_win, sl.d_msg_pos,
+                   sl.d_msg_limit, sl.d_msg_len, sl.d_msg_skip, sl.d_msg_sig};
+    for (void *p : dev)
+        if (p) (void) hipFree(p);
+    void *host[] = {sl.h_live, sl.h_counters, sl.h_sums, sl.h_fsums, sl.h_win, sl.h_sig, sl.h_total, sl.h_msg_pos,
+                    sl.h_msg_limit, sl.h_msg_len, sl.h_msg_skip};
+    for (void *p : host)
+        if (p) (void) hipHostFree(p);
+    for (auto &e : sl.ev)
+        if (e) (void) hipEventDestroy(e);
+}
+
 static int alloc_all(mgpu_ctx *c) {
     const mgpu_config &cfg = c->cfg;
     const uint64_t n = cfg.max_samples;
     c->cap_samples = n;
-    c->cap_units = (n + kUnit - 1) / kUnit;
-    c->cap_buffers = (n + cfg.buf_samples - 1) / cfg.buf_samples + 1;
-    c->cap_pool = cfg.record_pool_records ? cfg.record_pool_records : n / 16 + 65536;
+    // pipeline chunk: a whole number of 131072-sample buffers; MGPU_CHUNK_BUFFERS overrides (experiments)
+    uint64_t chunk_buffers = 512;
+    if (const char *e = getenv("MGPU_CHUNK_BUFFERS")) { long v = atol(e); if (v >= 1) chunk_buffers = (uint64_t) v; }
+    c->chunk_samples = chunk_buffers * cfg.buf_samples;
+    const uint64_t nmax_buffers = (n + cfg.buf_samples - 1) / cfg.buf_samples;
+    if (c->chunk_samples > nmax_buffers * cfg.buf_samples) c->chunk_samples = nmax_buffers * cfg.buf_samples;
+    const uint64_t cs = c->chunk_samples;
+    c->cap_units = (cs + kUnit - 1) / kUnit;
+    c->cap_buffers = (cs + cfg.buf_samples - 1) / cfg.buf_samples + 1;
+    // default pool: 1 record per 16 samples (8x the density of busy synthetic traffic) + what the
+    // workgroups reserve but may leave unused (one chunk each)
+    const uint64_t reserve = (uint64_t) kPoolChunkRecords * (c->cap_units < (uint64_t) kSweepMaxBlocks ? c->cap_units : (uint64_t) kSweepMaxBlocks);
+    uint64_t pool = cfg.record_pool_records ? cfg.record_pool_records : cs / 16 + 65536;
+    c->cap_pool = pool + reserve;
     if (c->cap_pool > 0xFFFFFFF0ull) c->cap_pool = 0xFFFFFFF0ull;
-    c->cap_msgs = cfg.max_messages ? cfg.max_messages : n / 64 + 65536;
+    c->cap_msgs = cfg.max_messages ? cfg.max_messages : cs / 64 + 65536;
     const size_t bps = cfg.format == MGPU_FMT_UC8 ? 2 : 4;
-    const uint64_t mag_len = (n + kTile - 1) / kTile * kTile + kTile + kHalo + 64;
 
     HIPCHK(c, hipMalloc(&c->d_iq, n * bps + 64));
-    HIPCHK(c, hipMalloc(&c->d_mag, mag_len * sizeof(uint16_t)));
-    HIPCHK(c, hipMemsetAsync(c->d_mag, 0, mag_len * sizeof(uint16_t), c->stream));
     HIPCHK(c, hipMalloc(&c->d_tail, kTrailing * sizeof(uint16_t)));
-    HIPCHK(c, hipMalloc(&c->d_pool, c->cap_pool * sizeof(PhaseRec)));
-    HIPCHK(c, hipMalloc(&c->d_live, c->cap_pool * sizeof(PhaseRec)));
-    HIPCHK(c, hipMalloc(&c->d_pool_used, 64));
-    HIPCHK(c, hipMalloc(&c->d_unit_first, (c->cap_units + 1) * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc(&c->d_unit_count, (c->cap_units + 1) * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc(&c->d_unit_live, (c->cap_units + 2) * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc(&c->d_adder_bitmap, (1u << 24) / 8));
     HIPCHK(c, hipMemsetAsync(c->d_adder_bitmap, 0, (1u << 24) / 8, c->stream));
-    HIPCHK(c, hipMalloc(&c->d_class_bitmap, (mag_len / 32 + 64) * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc(&c->d_counters, CNT_NUM * sizeof(unsigned long long)));
-    HIPCHK(c, hipMalloc(&c->d_sum_level, c->cap_buffers * sizeof(unsigned long long)));
-    HIPCHK(c, hipMalloc(&c->d_sum_power, c->cap_buffers * sizeof(unsigned long long)));
-    HIPCHK(c, hipMalloc(&c->d_fsum_level, c->cap_buffers * sizeof(double)));
-    HIPCHK(c, hipMalloc(&c->d_fsum_power, c->cap_buffers * sizeof(double)));
-    HIPCHK(c, hipMalloc(&c->d_win, 8 * sizeof(unsigned long long)));
-    HIPCHK(c, hipMalloc(&c->d_msg_pos, c->cap_msgs * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc(&c->d_msg_limit, c->cap_msgs * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc(&c->d_msg_len, c->cap_msgs * sizeof(uint16_t)));
-    HIPCHK(c, hipMalloc(&c->d_msg_skip, c->cap_msgs * sizeof(uint16_t)));
-    HIPCHK(c, hipMalloc(&c->d_msg_sig, c->cap_msgs * sizeof(unsigned long long)));
-
-    HIPCHK(c, hipHostMalloc(&c->h_live, c->cap_pool * sizeof(PhaseRec)));
-    HIPCHK(c, hipHostMalloc(&c->h_counters, CNT_NUM * sizeof(unsigned long long)));
-    HIPCHK(c, hipHostMalloc(&c->h_sums, 2 * c->cap_buffers * sizeof(unsigned long long)));
-    HIPCHK(c, hipHostMalloc(&c->h_fsums, 2 * c->cap_buffers * sizeof(double)));
-    HIPCHK(c, hipHostMalloc(&c->h_win, 8 * sizeof(unsigned long long)));
-    HIPCHK(c, hipHostMalloc(&c->h_sig, c->cap_msgs * sizeof(unsigned long long)));
-    HIPCHK(c, hipHostMalloc(&c->h_total, 64));
+    for (auto &sl : c->slot) {
+        int rc = alloc_slot(c, sl);
+        if (rc != MGPU_OK) return rc;
+    }
 
     // constant tables
     const CrcTables &crc = crc_tables();
     HIPCHK(c, hipMalloc(&c->d_bit_syndrome, 112 * sizeof(uint32_t)));
     HIPCHK(c, hipMemcpy(c->d_bit_syndrome, crc.bit_syndrome, 112 * sizeof(uint32_t), hipMemcpyHostToDevice));
+    const std::vector<uint32_t> gs = build_group_syndromes();
+    HIPCHK(c, hipMalloc(&c->d_group_syndrome, gs.size() * sizeof(uint32_t)));
+    HIPCHK(c, hipMemcpy(c->d_group_syndrome, gs.data(), gs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     const ParityMasks pm = build_parity_masks();
     HIPCHK(c, hipMalloc(&c->d_parity, sizeof(pm)));
     HIPCHK(c, hipMemcpy(c->d_parity, &pm, sizeof(pm), hipMemcpyHostToDevice));
@@ -190,18 +259,17 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     if (!cfg || !out) return MGPU_E_INVAL;
     *out = nullptr;
     if (cfg->trailing_samples != (uint32_t) kTrailing || cfg->buf_samples == 0 || cfg->buf_samples % kTile != 0 ||
-        cfg->max_samples == 0 || cfg->max_samples > 0xF0000000ull || cfg->format < 0 || cfg->format > 2 ||
-        cfg->nfix_crc < 0 || cfg->nfix_crc > 2)
+        cfg->max_samples == 0 || cfg->format < 0 || cfg->format > 2 || cfg->nfix_crc < 0 || cfg->nfix_crc > 2)
         return MGPU_E_INVAL;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device >= ndev) return MGPU_E_NODEVICE;
     mgpu_ctx *c = new (std::nothrow) mgpu_ctx();
     if (!c) return MGPU_E_NOMEM;
     c->cfg = *cfg;
+    { const char *e = getenv("MGPU_SWEEP_V1"); c->use_v1 = e && e[0] == '1'; }
     if (hipSetDevice(cfg->device) != hipSuccess) { delete c; return MGPU_E_NODEVICE; }
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MGPU_E_HIP; }
-    for (auto &e : c->ev)
-        if (hipEventCreate(&e) != hipSuccess) { mgpu_destroy(c); return MGPU_E_HIP; }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { mgpu_destroy(c); return MGPU_E_HIP; }
     // valid_df_*_bitset, init_bitsets() demod_2400.c:112-128 (ENABLE_DF24 off, readsb.h:303)
     c->valid_short = (1u << 0) | (1u << 4) | (1u << 5) | (1u << 11);
     c->valid_long = (1u << 16) | (1u << 17) | (1u << 18) | (1u << 20) | (1u << 21);
@@ -214,26 +282,28 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
         return rc;
     }
     c->resolver.reset(cfg->startup_time_ms);
+    c->worker = std::thread(worker_main, c);
     *out = c;
     return MGPU_OK;
 }
 
 void mgpu_destroy(mgpu_ctx *c) {
     if (!c) return;
-    hipSetDevice(c->cfg.device);
-    if (c->stream) hipStreamSynchronize(c->stream);
-    void *dev[] = {c->d_iq, c->d_mag, c->d_tail, c->d_pool, c->d_live, c->d_pool_used, c->d_unit_first, c->d_unit_count,
-                   c->d_unit_live, c->d_adder_bitmap, c->d_class_bitmap, c->d_counters, c->d_sum_level, c->d_sum_power,
-                   c->d_fsum_level, c->d_fsum_power, c->d_win, c->d_msg_pos, c->d_msg_limit, c->d_msg_len, c->d_msg_skip,
-                   c->d_msg_sig, c->d_bit_syndrome, c->d_parity, c->d_tab_long, c->d_tab_short, c->d_uc8_folded};
+    if (c->worker.joinable()) {
+        { std::lock_guard<std::mutex> lk(c->mu); c->stop = true; }
+        c->cv.notify_all();
+        c->worker.join();
+    }
+    (void) hipSetDevice(c->cfg.device);
+    if (c->stream) (void) hipStreamSynchronize(c->stream);
+    if (c->stream2) (void) hipStreamSynchronize(c->stream2);
+    for (auto &sl : c->slot) free_slot(sl);
+    void *dev[] = {c->d_iq, c->d_tail, c->d_adder_bitmap, c->d_bit_syndrome, c->d_group_syndrome, c->d_parity,
+                   c->d_tab_long, c->d_tab_short, c->d_uc8_folded};
     for (void *p : dev)
-        if (p) hipFree(p);
-    void *host[] = {c->h_live, c->h_counters, c->h_sums, c->h_fsums, c->h_win, c->h_sig, c->h_total};
-    for (void *p : host)
-        if (p) hipHostFree(p);
-    for (auto &e : c->ev)
-        if (e) hipEventDestroy(e);
-    if (c->stream) hipStreamDestroy(c->stream);
+        if (p) (void) hipFree(p);
+    if (c->stream) (void) hipStreamDestroy(c->stream);
+    if (c->stream2) (void) hipStreamDestroy(c->stream2);
     delete c;
 }
 
@@ -247,121 +317,132 @@ int mgpu_reset(mgpu_ctx *c) {
     c->stream_pos = 0;
     c->eof = false;
     c->have_tail = false;
+    c->worker_rc = MGPU_OK;
     HIPCHK(c, hipMemsetAsync(c->d_adder_bitmap, 0, (1u << 24) / 8, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MGPU_OK;
 }
 
-// The pipeline behind every feed.  `have_mag`: d_mag[0 .. 326+n) already holds the buffer
-// (mgpu_demod_mag_buf); otherwise d_iq holds n samples to convert.
-static int run_feed(mgpu_ctx *c, uint64_t n, bool have_mag, const std::vector<BufferClock> &buffers,
-                    const double *given_mean_power, float h2d_ms) {
+// ---- GPU half of a chunk: enqueue convert -> sweep/slice -> pre-screen on the main stream ----------
+// `iq` = device pointer to the chunk's IQ samples (ignored when sl.have_mag: sl.d_mag already holds
+// the magnitudes of one struct mag_buf).
+static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
     const mgpu_config &cfg = c->cfg;
-    const double t_start = wall_ms();
-    const uint32_t nbuf = (uint32_t) buffers.size();
+    const uint64_t n = sl.n;
+    const uint32_t nbuf = (uint32_t) sl.buffers.size();
     const uint32_t nunits = (uint32_t) ((n + kUnit - 1) / kUnit);
     hipStream_t s = c->stream;
-    mgpu_timing tm{};
-    tm.h2d_ms = h2d_ms;
-
-    HIPCHK(c, hipMemsetAsync(c->d_counters, 0, CNT_NUM * sizeof(unsigned long long), s));
-    HIPCHK(c, hipMemsetAsync(c->d_pool_used, 0, sizeof(uint32_t), s));
-    HIPCHK(c, hipMemsetAsync(c->d_win, 0, 8 * sizeof(unsigned long long), s));
-    HIPCHK(c, hipMemsetAsync(c->d_sum_level, 0, nbuf * sizeof(unsigned long long), s));
-    HIPCHK(c, hipMemsetAsync(c->d_sum_power, 0, nbuf * sizeof(unsigned long long), s));
-    HIPCHK(c, hipMemsetAsync(c->d_fsum_level, 0, nbuf * sizeof(double), s));
-    HIPCHK(c, hipMemsetAsync(c->d_fsum_power, 0, nbuf * sizeof(double), s));
-
-    // ---- convert ----
-    HIPCHK(c, hipEventRecord(c->ev[0], s));
-    if (!have_mag) {
-        if (c->have_tail) HIPCHK(c, hipMemcpyAsync(c->d_mag, c->d_tail, kTrailing * sizeof(uint16_t), hipMemcpyDeviceToDevice, s));
-        else HIPCHK(c, hipMemsetAsync(c->d_mag, 0, kTrailing * sizeof(uint16_t), s));
+    HIPCHK(c, hipMemsetAsync(sl.d_counters, 0, CNT_NUM * sizeof(unsigned long long), s));
+    HIPCHK(c, hipMemsetAsync(sl.d_pool_used, 0, sizeof(uint32_t), s));
+    HIPCHK(c, hipMemsetAsync(sl.d_win, 0, 8 * sizeof(unsigned long long), s));
+    HIPCHK(c, hipEventRecord(sl.ev[0], s));
+    if (!sl.have_mag) {
+        HIPCHK(c, hipMemsetAsync(sl.d_sum_level, 0, nbuf * sizeof(unsigned long long), s));
+        HIPCHK(c, hipMemsetAsync(sl.d_sum_power, 0, nbuf * sizeof(unsigned long long), s));
+        HIPCHK(c, hipMemsetAsync(sl.d_fsum_level, 0, nbuf * sizeof(double), s));
+        HIPCHK(c, hipMemsetAsync(sl.d_fsum_power, 0, nbuf * sizeof(double), s));
+        // the 326 magnitudes before this chunk (sdr_ifile.c:209-213)
+        if (c->have_tail) HIPCHK(c, hipMemcpyAsync(sl.d_mag, c->d_tail, kTrailing * sizeof(uint16_t), hipMemcpyDeviceToDevice, s));
+        else HIPCHK(c, hipMemsetAsync(sl.d_mag, 0, kTrailing * sizeof(uint16_t), s));
         ConvertParams cp{};
-        cp.iq = c->d_iq; cp.mag = c->d_mag; cp.n = n; cp.buf_samples = cfg.buf_samples;
+        cp.iq = iq; cp.mag = sl.d_mag; cp.n = n; cp.buf_samples = cfg.buf_samples;
         cp.uc8_folded = c->d_uc8_folded;
-        cp.sum_level = c->d_sum_level; cp.sum_power = c->d_sum_power;
-        cp.fsum_level = c->d_fsum_level; cp.fsum_power = c->d_fsum_power;
+        cp.sum_level = sl.d_sum_level; cp.sum_power = sl.d_sum_power;
+        cp.fsum_level = sl.d_fsum_level; cp.fsum_power = sl.d_fsum_power;
         launch_convert(cfg.format, cp, s);
+        if (n >= (uint64_t) kTrailing) {
+            HIPCHK(c, hipMemcpyAsync(c->d_tail, sl.d_mag + n, kTrailing * sizeof(uint16_t), hipMemcpyDeviceToDevice, s));
+            c->have_tail = true;
+        } else {
+            c->have_tail = false;   // lastbuf->length < trailing_samples -> zeros
+        }
     }
-    HIPCHK(c, hipEventRecord(c->ev[1], s));
-
-    // ---- sweep + slice ----
+    HIPCHK(c, hipEventRecord(sl.ev[1], s));
     SweepParams sp{};
-    sp.mag = c->d_mag; sp.n = n; sp.thr = cfg.preamble_threshold;
+    sp.mag = sl.d_mag; sp.n = n; sp.thr = cfg.preamble_threshold;
     sp.valid_long = c->valid_long; sp.valid_short = c->valid_short;
     sp.fix_df = (cfg.fixDF && cfg.nfix_crc) ? 1 : 0;
-    sp.bit_syndrome = c->d_bit_syndrome; sp.parity = c->d_parity;
+    sp.bit_syndrome = c->d_bit_syndrome; sp.parity = c->d_parity; sp.group_syndrome = c->d_group_syndrome;
     sp.tab_long = c->d_tab_long; sp.tab_short = c->d_tab_short; sp.n_long = c->n_long; sp.n_short = c->n_short;
-    sp.pool = c->d_pool; sp.pool_cap = (uint32_t) c->cap_pool; sp.pool_used = c->d_pool_used;
-    sp.unit_first = c->d_unit_first; sp.unit_count = c->d_unit_count; sp.nunits = nunits;
-    sp.adder_bitmap = c->d_adder_bitmap; sp.class_bitmap = c->d_class_bitmap; sp.counters = c->d_counters;
-    launch_sweep_slice(sp, s);
-    HIPCHK(c, hipEventRecord(c->ev[2], s));
-
-    // ---- pre-screen ----
-    launch_prescreen(c->d_pool, c->d_unit_first, nunits, c->d_adder_bitmap, c->d_unit_live, c->d_live, c->d_counters, s);
-    HIPCHK(c, hipEventRecord(c->ev[3], s));
-    HIPCHK(c, hipMemcpyAsync(c->h_counters, c->d_counters, CNT_NUM * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-    if (nunits) HIPCHK(c, hipMemcpyAsync(c->h_total, c->d_unit_live + nunits, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    else c->h_total[0] = 0;
-    if (!have_mag) {
-        HIPCHK(c, hipMemcpyAsync(c->h_sums, c->d_sum_level, nbuf * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipMemcpyAsync(c->h_sums + nbuf, c->d_sum_power, nbuf * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipMemcpyAsync(c->h_fsums, c->d_fsum_level, nbuf * sizeof(double), hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipMemcpyAsync(c->h_fsums + nbuf, c->d_fsum_power, nbuf * sizeof(double), hipMemcpyDeviceToHost, s));
+    sp.pool = sl.d_pool; sp.pool_cap = (uint32_t) c->cap_pool; sp.pool_used = sl.d_pool_used;
+    sp.unit_first = sl.d_unit_first; sp.unit_count = sl.d_unit_count; sp.nunits = nunits;
+    { const char *e = getenv("MGPU_DEBUG_STAGE"); sp.debug_stage = e ? atoi(e) : 0; }
+    sp.adder_bitmap = c->d_adder_bitmap; sp.class_bitmap = sl.d_class_bitmap; sp.counters = sl.d_counters;
+    if (c->use_v1) launch_sweep_slice_v1(sp, s); else launch_sweep_slice(sp, s);
+    HIPCHK(c, hipEventRecord(sl.ev[2], s));
+    // pre-screen; the surviving records are written by the kernel straight into pinned host memory
+    launch_prescreen(sl.d_pool, sl.d_unit_first, nunits, c->d_adder_bitmap, sl.d_unit_live, sl.h_live, sl.d_counters, s);
+    HIPCHK(c, hipMemcpyAsync(sl.h_counters, sl.d_counters, CNT_NUM * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    if (nunits) HIPCHK(c, hipMemcpyAsync(sl.h_total, sl.d_unit_live + nunits, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    else sl.h_total[0] = 0;
+    if (!sl.have_mag) {
+        HIPCHK(c, hipMemcpyAsync(sl.h_sums, sl.d_sum_level, nbuf * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(sl.h_sums + nbuf, sl.d_sum_power, nbuf * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(sl.h_fsums, sl.d_fsum_level, nbuf * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(sl.h_fsums + nbuf, sl.d_fsum_power, nbuf * sizeof(double), hipMemcpyDeviceToHost, s));
     }
-    HIPCHK(c, hipStreamSynchronize(s));
-    if (c->h_counters[CNT_POOL_OVERFLOW]) {
+    HIPCHK(c, hipEventRecord(sl.ev[3], s));
+    return MGPU_OK;
+}
+
+// ---- host half of a chunk (worker thread): ordered walk, signal power, counters -------------------
+static int finish_slot(mgpu_ctx *c, Slot &sl) {
+    const mgpu_config &cfg = c->cfg;
+    const uint64_t n = sl.n;
+    const uint32_t nbuf = (uint32_t) sl.buffers.size();
+    HIPCHK(c, hipEventSynchronize(sl.ev[3]));
+    if (getenv("MGPU_DEBUG_PRINT")) {
+        const unsigned long long *h = sl.h_counters;
+        fprintf(stderr, "dbg: stage_b cycles %llu calls %llu frames %llu block cycles %llu slice %llu classify %llu records %llu\n",
+                h[10], h[11], h[12], h[13], h[14], h[15], h[CNT_RECORDS]);
+        fprintf(stderr, "dbg: per-tile cycles: stage %llu sweep %llu drainA %llu stageB %llu tail %llu | stage: barrier0 %llu loads %llu\n",
+                h[16], h[17], h[18], h[19], h[20], h[21], h[22]);
+    }
+    if (sl.h_counters[CNT_POOL_OVERFLOW]) {
         c->err = "record pool overflow: recreate the context with a larger record_pool_records";
         return MGPU_E_OVERFLOW;
     }
-    const uint64_t nlive = c->h_total[0];
-    HIPCHK(c, hipEventRecord(c->ev[4], s));
-    if (nlive) HIPCHK(c, hipMemcpyAsync(c->h_live, c->d_live, nlive * sizeof(PhaseRec), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipEventRecord(c->ev[5], s));
-    HIPCHK(c, hipStreamSynchronize(s));
+    float ms;
+    if (hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]) == hipSuccess) c->acc.convert_ms += ms;
+    if (hipEventElapsedTime(&ms, sl.ev[1], sl.ev[2]) == hipSuccess) c->acc.sweep_ms += ms;
+    if (hipEventElapsedTime(&ms, sl.ev[2], sl.ev[3]) == hipSuccess) c->acc.prescreen_ms += ms;
+    const uint64_t nlive = sl.h_total[0];
 
-    // ---- ordered walk (host) ----
     const double t_res0 = wall_ms();
     std::vector<mgpu_msg> msgs;
     std::vector<uint32_t> mpos, mlimit;
     std::vector<uint16_t> mskip;
+    msgs.reserve(nlive / 4 + 16); mpos.reserve(nlive / 4 + 16); mlimit.reserve(nlive / 4 + 16); mskip.reserve(nlive / 4 + 16);
     ResolveCounts rc;
-    c->resolver.walk(c->h_live, nlive, buffers, msgs, mpos, mskip, mlimit, rc);
-    tm.resolve_ms = (float) (wall_ms() - t_res0);
+    c->resolver.walk(sl.h_live, nlive, sl.buffers, msgs, mpos, mskip, mlimit, rc);
+    c->acc.resolve_ms += (float) (wall_ms() - t_res0);
     const uint32_t nmsg = (uint32_t) msgs.size();
     if (nmsg > c->cap_msgs) { c->err = "max_messages exceeded"; return MGPU_E_OVERFLOW; }
 
-    // ---- signal power + window statistics ----
-    HIPCHK(c, hipEventRecord(c->ev[6], s));
+    // signal power + what the skip windows hid from the counters, on the second stream
+    const double t_sig0 = wall_ms();
+    hipStream_t s2 = c->stream2;
     if (nmsg) {
-        std::vector<uint16_t> mlen(nmsg);
-        for (uint32_t i = 0; i < nmsg; ++i) mlen[i] = msgs[i].sig_len;
-        HIPCHK(c, hipMemcpyAsync(c->d_msg_pos, mpos.data(), nmsg * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-        HIPCHK(c, hipMemcpyAsync(c->d_msg_limit, mlimit.data(), nmsg * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-        HIPCHK(c, hipMemcpyAsync(c->d_msg_len, mlen.data(), nmsg * sizeof(uint16_t), hipMemcpyHostToDevice, s));
-        HIPCHK(c, hipMemcpyAsync(c->d_msg_skip, mskip.data(), nmsg * sizeof(uint16_t), hipMemcpyHostToDevice, s));
-        launch_signal_power(c->d_mag, c->d_msg_pos, c->d_msg_len, nmsg, c->d_msg_sig, s);
-        launch_window_stats(c->d_mag, n, cfg.preamble_threshold, c->d_class_bitmap, c->d_msg_pos, c->d_msg_skip,
-                            c->d_msg_limit, nmsg, c->d_win, s);
-        HIPCHK(c, hipMemcpyAsync(c->h_sig, c->d_msg_sig, nmsg * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipStreamSynchronize(s));   // mlen & co. are pageable: keep them alive until copied
+        for (uint32_t i = 0; i < nmsg; ++i) sl.h_msg_len[i] = msgs[i].sig_len;
+        std::memcpy(sl.h_msg_pos, mpos.data(), nmsg * sizeof(uint32_t));
+        std::memcpy(sl.h_msg_limit, mlimit.data(), nmsg * sizeof(uint32_t));
+        std::memcpy(sl.h_msg_skip, mskip.data(), nmsg * sizeof(uint16_t));
+        HIPCHK(c, hipMemcpyAsync(sl.d_msg_pos, sl.h_msg_pos, nmsg * sizeof(uint32_t), hipMemcpyHostToDevice, s2));
+        HIPCHK(c, hipMemcpyAsync(sl.d_msg_limit, sl.h_msg_limit, nmsg * sizeof(uint32_t), hipMemcpyHostToDevice, s2));
+        HIPCHK(c, hipMemcpyAsync(sl.d_msg_len, sl.h_msg_len, nmsg * sizeof(uint16_t), hipMemcpyHostToDevice, s2));
+        HIPCHK(c, hipMemcpyAsync(sl.d_msg_skip, sl.h_msg_skip, nmsg * sizeof(uint16_t), hipMemcpyHostToDevice, s2));
+        launch_signal_power(sl.d_mag, sl.d_msg_pos, sl.d_msg_len, nmsg, sl.d_msg_sig, s2);
+        launch_window_stats(sl.d_mag, n, cfg.preamble_threshold, sl.d_class_bitmap, sl.d_msg_pos, sl.d_msg_skip,
+                            sl.d_msg_limit, nmsg, sl.d_win, s2);
+        HIPCHK(c, hipMemcpyAsync(sl.h_sig, sl.d_msg_sig, nmsg * sizeof(unsigned long long), hipMemcpyDeviceToHost, s2));
     }
-    HIPCHK(c, hipMemcpyAsync(c->h_win, c->d_win, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-    // carry the last 326 magnitudes into the next feed (sdr_ifile.c:209-213)
-    if (n >= (uint64_t) kTrailing || have_mag) {
-        HIPCHK(c, hipMemcpyAsync(c->d_tail, c->d_mag + n, kTrailing * sizeof(uint16_t), hipMemcpyDeviceToDevice, s));
-        c->have_tail = true;
-    } else {
-        c->have_tail = false;   // lastbuf->length < trailing_samples -> zeros
-    }
-    HIPCHK(c, hipEventRecord(c->ev[7], s));
-    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, hipMemcpyAsync(sl.h_win, sl.d_win, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s2));
+    HIPCHK(c, hipStreamSynchronize(s2));
+    c->acc.sigpower_ms += (float) (wall_ms() - t_sig0);
 
     // ---- counters (Modes.stats_current) ----
     mgpu_counters &k = c->counters;
-    const unsigned long long *hc = c->h_counters, *hw = c->h_win;
+    const unsigned long long *hc = sl.h_counters, *hw = sl.h_win;
     const uint64_t C = hc[CNT_CANDIDATES], U = hc[CNT_CLASS_COND], R = hc[CNT_CLASS_UNCOND];
     const uint64_t cW = hw[0], uW = hw[4];
     k.demod_preambles += C - cW;
@@ -380,11 +461,11 @@ static int run_feed(mgpu_ctx *c, uint64_t n, bool have_mag, const std::vector<Bu
     // per-message signal level, per-buffer noise power (demod_2400.c:436-457, 474-479)
     uint32_t mi = 0;
     for (uint32_t b = 0; b < nbuf; ++b) {
-        const BufferClock &bc = buffers[b];
+        const BufferClock &bc = sl.buffers[b];
         uint64_t sum_scaled = 0;
         while (mi < nmsg && mpos[mi] < (uint64_t) bc.first + bc.length) {
             mgpu_msg &m = msgs[mi];
-            m.sig_sumsq = c->h_sig[mi];
+            m.sig_sumsq = sl.h_sig[mi];
             const double signal_power = (double) m.sig_sumsq / 65535.0 / 65535.0;
             const double level = signal_power / m.sig_len;
             k.signal_power_sum += signal_power;
@@ -395,9 +476,9 @@ static int run_feed(mgpu_ctx *c, uint64_t n, bool have_mag, const std::vector<Bu
             ++mi;
         }
         double mean_power;
-        if (given_mean_power) mean_power = given_mean_power[b];
-        else if (cfg.format == MGPU_FMT_UC8) mean_power = (double) c->h_sums[nbuf + b] / 65535.0 / 65535.0 / bc.length;   // convert.c:105-107
-        else mean_power = c->h_fsums[nbuf + b] / bc.length;
+        if (!sl.given_mean_power.empty()) mean_power = sl.given_mean_power[b];
+        else if (cfg.format == MGPU_FMT_UC8) mean_power = (double) sl.h_sums[nbuf + b] / 65535.0 / 65535.0 / bc.length;   // convert.c:105-107
+        else mean_power = sl.h_fsums[nbuf + b] / bc.length;
         const double sum_signal_power = (double) sum_scaled / 65535.0 / 65535.0;
         k.noise_power_sum += (mean_power * bc.length - sum_signal_power);
         k.noise_power_count += bc.length;
@@ -407,24 +488,56 @@ static int run_feed(mgpu_ctx *c, uint64_t n, bool have_mag, const std::vector<Bu
     }
     k.nflips = c->resolver.nflips();
     c->pending.insert(c->pending.end(), msgs.begin(), msgs.end());
-
-    hipEventElapsedTime(&tm.convert_ms, c->ev[0], c->ev[1]);
-    hipEventElapsedTime(&tm.sweep_ms, c->ev[1], c->ev[2]);
-    hipEventElapsedTime(&tm.prescreen_ms, c->ev[2], c->ev[3]);
-    hipEventElapsedTime(&tm.d2h_ms, c->ev[4], c->ev[5]);
-    hipEventElapsedTime(&tm.sigpower_ms, c->ev[6], c->ev[7]);
-    tm.total_ms = (float) (wall_ms() - t_start) + h2d_ms;
-    tm.n_candidates = C;
-    tm.n_records = hc[CNT_RECORDS];
-    tm.n_live_records = nlive;
-    tm.n_messages = nmsg;
-    c->timing = tm;
+    c->acc.n_candidates += C;
+    c->acc.n_records += hc[CNT_RECORDS];
+    c->acc.n_live_records += nlive;
+    c->acc.n_messages += nmsg;
     return MGPU_OK;
 }
 
+static void worker_main(mgpu_ctx *c) {
+    (void) hipSetDevice(c->cfg.device);
+    for (;;) {
+        int idx;
+        {
+            std::unique_lock<std::mutex> lk(c->mu);
+            c->cv.wait(lk, [&] { return c->stop || !c->queue.empty(); });
+            if (c->queue.empty()) return;   // stop requested and nothing left
+            idx = c->queue.front();
+            c->queue.pop_front();
+        }
+        Slot &sl = c->slot[idx];
+        int rc = c->worker_rc == MGPU_OK ? finish_slot(c, sl) : c->worker_rc;   // after an error just drain
+        {
+            std::lock_guard<std::mutex> lk(c->mu);
+            if (rc != MGPU_OK && c->worker_rc == MGPU_OK) c->worker_rc = rc;
+            sl.busy = false;
+        }
+        c->cv.notify_all();
+    }
+}
+
+static Slot &acquire_slot(mgpu_ctx *c, int idx) {
+    std::unique_lock<std::mutex> lk(c->mu);
+    c->cv.wait(lk, [&] { return !c->slot[idx].busy; });
+    c->slot[idx].busy = true;
+    return c->slot[idx];
+}
+
+static void submit_slot(mgpu_ctx *c, int idx) {
+    { std::lock_guard<std::mutex> lk(c->mu); c->queue.push_back(idx); }
+    c->cv.notify_all();
+}
+
+static int wait_all(mgpu_ctx *c) {
+    std::unique_lock<std::mutex> lk(c->mu);
+    c->cv.wait(lk, [&] { return !c->slot[0].busy && !c->slot[1].busy && c->queue.empty(); });
+    return c->worker_rc;
+}
+
 // buffer grid of ifileRun for `n` samples continuing at stream position `pos0` (sdr_ifile.c:194-241)
-static std::vector<BufferClock> ifile_grid(const mgpu_ctx *c, uint64_t pos0, uint64_t n) {
-    std::vector<BufferClock> v;
+static void ifile_grid(const mgpu_ctx *c, uint64_t pos0, uint64_t n, std::vector<BufferClock> &v) {
+    v.clear();
     const uint32_t B = c->cfg.buf_samples;
     for (uint64_t off = 0; off < n; off += B) {
         BufferClock b;
@@ -435,7 +548,6 @@ static std::vector<BufferClock> ifile_grid(const mgpu_ctx *c, uint64_t pos0, uin
         b.sysTimestamp = b.sampleTimestamp / 12000 + c->cfg.startup_time_ms;         // :216
         v.push_back(b);
     }
-    return v;
 }
 
 static int feed_common(mgpu_ctx *c, const void *src, bool src_is_device, uint64_t n) {
@@ -443,22 +555,40 @@ static int feed_common(mgpu_ctx *c, const void *src, bool src_is_device, uint64_
     if (n == 0) return MGPU_OK;
     if (c->eof) return MGPU_E_EOF;
     if (n > c->cap_samples) return MGPU_E_CAPACITY;
+    if (c->worker_rc != MGPU_OK) return c->worker_rc;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const size_t bps = c->cfg.format == MGPU_FMT_UC8 ? 2 : 4;
-    float h2d = 0.f;
-    if (src_is_device) {
-        if (src != c->d_iq) HIPCHK(c, hipMemcpyAsync(c->d_iq, src, n * bps, hipMemcpyDeviceToDevice, c->stream));
-    } else {
+    const double t_start = wall_ms();
+    std::memset(&c->acc, 0, sizeof(c->acc));
+    const uint8_t *iq = (const uint8_t *) src;
+    if (!src_is_device) {
         const double t0 = wall_ms();
         HIPCHK(c, hipMemcpyAsync(c->d_iq, src, n * bps, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        h2d = (float) (wall_ms() - t0);
+        c->acc.h2d_ms = (float) (wall_ms() - t0);
+        iq = c->d_iq;
     }
-    const std::vector<BufferClock> grid = ifile_grid(c, c->stream_pos, n);
-    int rc = run_feed(c, n, false, grid, nullptr, h2d);
+    // software pipeline over chunks: GPU works on chunk i+1 while the worker walks chunk i
+    int rc = MGPU_OK;
+    int k = 0;
+    for (uint64_t off = 0; off < n && rc == MGPU_OK; off += c->chunk_samples, ++k) {
+        const uint64_t len = n - off < c->chunk_samples ? n - off : c->chunk_samples;
+        Slot &sl = acquire_slot(c, k & 1);
+        sl.n = len;
+        sl.have_mag = false;
+        sl.given_mean_power.clear();
+        ifile_grid(c, c->stream_pos + off, len, sl.buffers);
+        rc = enqueue_slot(c, sl, iq + off * bps);
+        submit_slot(c, k & 1);   // even after an enqueue error: the worker releases the slot
+        if (rc != MGPU_OK) { std::lock_guard<std::mutex> lk(c->mu); if (c->worker_rc == MGPU_OK) c->worker_rc = rc; }
+    }
+    const int wrc = wait_all(c);
+    if (rc == MGPU_OK) rc = wrc;
     if (rc != MGPU_OK) return rc;
     c->stream_pos += n;
     if (n % c->cfg.buf_samples) c->eof = true;   // short read = end of file (sdr_ifile.c:223-237)
+    c->acc.total_ms = (float) (wall_ms() - t_start);
+    c->timing = c->acc;
     return MGPU_OK;
 }
 
@@ -512,36 +642,42 @@ int mgpu_last_timing(mgpu_ctx *c, struct mgpu_timing *t) {
 
 int mgpu_convert(mgpu_ctx *c, const void *iq_host, uint16_t *mag_host, uint32_t n, double *out_mean_level, double *out_mean_power) {
     if (!c || !iq_host || !mag_host) return MGPU_E_INVAL;
-    if (n > c->cap_samples) return MGPU_E_CAPACITY;
+    if (n > c->cap_samples || n > 0x7fffffffu) return MGPU_E_CAPACITY;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const size_t bps = c->cfg.format == MGPU_FMT_UC8 ? 2 : 4;
     hipStream_t s = c->stream;
+    Slot &sl = c->slot[0];
     double ml = std::numeric_limits<double>::quiet_NaN(), mp = ml;   // 0/0 for n == 0, as the reference
-    if (n) {
-        HIPCHK(c, hipMemcpyAsync(c->d_iq, iq_host, (size_t) n * bps, hipMemcpyHostToDevice, s));
-        HIPCHK(c, hipMemsetAsync(c->d_sum_level, 0, c->cap_buffers * sizeof(unsigned long long), s));
-        HIPCHK(c, hipMemsetAsync(c->d_sum_power, 0, c->cap_buffers * sizeof(unsigned long long), s));
-        HIPCHK(c, hipMemsetAsync(c->d_fsum_level, 0, c->cap_buffers * sizeof(double), s));
-        HIPCHK(c, hipMemsetAsync(c->d_fsum_power, 0, c->cap_buffers * sizeof(double), s));
+    // chunk by chunk through slot 0's magnitude buffer; one accumulation bucket for the whole call
+    HIPCHK(c, hipMemsetAsync(sl.d_sum_level, 0, sizeof(unsigned long long), s));
+    HIPCHK(c, hipMemsetAsync(sl.d_sum_power, 0, sizeof(unsigned long long), s));
+    HIPCHK(c, hipMemsetAsync(sl.d_fsum_level, 0, sizeof(double), s));
+    HIPCHK(c, hipMemsetAsync(sl.d_fsum_power, 0, sizeof(double), s));
+    for (uint64_t off = 0; off < n; off += c->chunk_samples) {
+        const uint64_t len = n - off < c->chunk_samples ? n - off : c->chunk_samples;
+        HIPCHK(c, hipMemcpyAsync(c->d_iq, (const uint8_t *) iq_host + off * bps, len * bps, hipMemcpyHostToDevice, s));
         ConvertParams cp{};
-        cp.iq = c->d_iq; cp.mag = c->d_mag; cp.n = n;
-        cp.buf_samples = 0x80000000u;   // one accumulation bucket for the whole call
+        cp.iq = c->d_iq; cp.mag = sl.d_mag; cp.n = len;
+        cp.buf_samples = 0x80000000u;
         cp.uc8_folded = c->d_uc8_folded;
-        cp.sum_level = c->d_sum_level; cp.sum_power = c->d_sum_power;
-        cp.fsum_level = c->d_fsum_level; cp.fsum_power = c->d_fsum_power;
+        cp.sum_level = sl.d_sum_level; cp.sum_power = sl.d_sum_power;
+        cp.fsum_level = sl.d_fsum_level; cp.fsum_power = sl.d_fsum_power;
         launch_convert(c->cfg.format, cp, s);
-        HIPCHK(c, hipMemcpyAsync(mag_host, c->d_mag + kTrailing, (size_t) n * sizeof(uint16_t), hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipMemcpyAsync(c->h_sums, c->d_sum_level, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipMemcpyAsync(c->h_sums + 1, c->d_sum_power, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipMemcpyAsync(c->h_fsums, c->d_fsum_level, sizeof(double), hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipMemcpyAsync(c->h_fsums + 1, c->d_fsum_power, sizeof(double), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(mag_host + off, sl.d_mag + kTrailing, len * sizeof(uint16_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+    }
+    if (n) {
+        HIPCHK(c, hipMemcpyAsync(sl.h_sums, sl.d_sum_level, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(sl.h_sums + 1, sl.d_sum_power, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(sl.h_fsums, sl.d_fsum_level, sizeof(double), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(sl.h_fsums + 1, sl.d_fsum_power, sizeof(double), hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
         if (c->cfg.format == MGPU_FMT_UC8) {
-            ml = (double) c->h_sums[0] / 65536.0 / n;              // convert.c:101-103 (sic, 65536)
-            mp = (double) c->h_sums[1] / 65535.0 / 65535.0 / n;    // convert.c:105-107
+            ml = (double) sl.h_sums[0] / 65536.0 / n;              // convert.c:101-103 (sic, 65536)
+            mp = (double) sl.h_sums[1] / 65535.0 / 65535.0 / n;    // convert.c:105-107
         } else {
-            ml = c->h_fsums[0] / n;
-            mp = c->h_fsums[1] / n;
+            ml = sl.h_fsums[0] / n;
+            mp = sl.h_fsums[1] / n;
         }
     }
     if (out_mean_level) *out_mean_level = ml;
@@ -553,11 +689,9 @@ int mgpu_demod_mag_buf(mgpu_ctx *c, const uint16_t *data, uint32_t length, int64
                        double mean_power, uint32_t dropped) {
     if (!c || !data) return MGPU_E_INVAL;
     (void) dropped;   // raising the threshold after drops (demod_2400.c:335-338) is the caller's cfg.preamble_threshold
-    if (length > c->cap_samples) return MGPU_E_CAPACITY;
+    if (length > c->chunk_samples) return MGPU_E_CAPACITY;
+    if (c->worker_rc != MGPU_OK) return c->worker_rc;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    std::vector<BufferClock> grid(1);
-    grid[0].first = 0; grid[0].length = length;
-    grid[0].sampleTimestamp = sampleTimestamp; grid[0].sysTimestamp = sysTimestamp;
     if (length == 0) {
         c->resolver.tick_empty(sysTimestamp);
         c->counters.noise_power_sum += mean_power * 0.0;
@@ -566,12 +700,28 @@ int mgpu_demod_mag_buf(mgpu_ctx *c, const uint16_t *data, uint32_t length, int64
         c->counters.nflips = c->resolver.nflips();
         return MGPU_OK;
     }
-    const double t0 = wall_ms();
-    HIPCHK(c, hipMemcpyAsync(c->d_mag, data, ((size_t) length + kTrailing) * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    const float h2d = (float) (wall_ms() - t0);
-    int rc = run_feed(c, length, true, grid, &mean_power, h2d);
-    if (rc == MGPU_OK) c->stream_pos += length;
+    const double t_start = wall_ms();
+    std::memset(&c->acc, 0, sizeof(c->acc));
+    Slot &sl = acquire_slot(c, 0);
+    sl.n = length;
+    sl.have_mag = true;
+    sl.given_mean_power.assign(1, mean_power);
+    sl.buffers.assign(1, BufferClock{sampleTimestamp, sysTimestamp, 0u, length});
+    int rc = MGPU_OK;
+    {
+        hipError_t e = hipMemcpyAsync(sl.d_mag, data, ((size_t) length + kTrailing) * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) { c->err = std::string("H2D of the magnitude buffer: ") + hipGetErrorString(e); rc = MGPU_E_HIP; }
+    }
+    if (rc == MGPU_OK) rc = enqueue_slot(c, sl, nullptr);
+    submit_slot(c, 0);
+    if (rc != MGPU_OK) { std::lock_guard<std::mutex> lk(c->mu); if (c->worker_rc == MGPU_OK) c->worker_rc = rc; }
+    const int wrc = wait_all(c);
+    if (rc == MGPU_OK) rc = wrc;
+    if (rc == MGPU_OK) {
+        c->stream_pos += length;
+        c->acc.total_ms = (float) (wall_ms() - t_start);
+        c->timing = c->acc;
+    }
     return rc;
 }
 

@@ -21,7 +21,10 @@ constexpr int kTile = 4096;             // scan positions per LDS tile
 constexpr int kHalo = 304;              // >= 290 samples of look-ahead (demod reads pa[0..289]), multiple of 8
 constexpr int kTilesPerUnit = 8;
 constexpr int kUnit = kTile * kTilesPerUnit;   // positions per unit (one record chain per unit)
+constexpr int kTile2 = 4096;            // k_sweep_slice: positions per LDS tile
 constexpr int kBlock = 256;
+constexpr int kSweepMaxBlocks = 256 * 4;  // resident workgroups of k_sweep_slice (4 per CU: 30 KB LDS, <=128 VGPRs)
+constexpr int kPoolChunkRecords = 1024;   // pool records a workgroup reserves per atomic
 constexpr int kBatch = 64;              // candidates sliced per batch (4 waves x 16)
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 
@@ -60,7 +63,8 @@ enum {
     CNT_POOL_OVERFLOW = 7,
     CNT_CLASS_COND = 8,      // candidates whose records are all conditional (REC_COND)
     CNT_CLASS_UNCOND = 9,    // candidates with >= 1 unconditional record
-    CNT_NUM = 16,
+    CNT_DEBUG0 = 16,         // .. 31: cycle counters of k_sweep_slice's stages (thread 0 of every workgroup)
+    CNT_NUM = 32,
 };
 
 struct SweepParams {
@@ -72,6 +76,7 @@ struct SweepParams {
     int32_t fix_df;           // Modes.fixDF && Modes.nfix_crc
     const uint32_t *bit_syndrome;   // [112]
     const uint64_t *parity;         // PH[24], PL[24], PS[24]
+    const uint32_t *group_syndrome;  // [23][32] long + [12][32] short (tables.h build_group_syndromes)
     const uint64_t *tab_long;       // packed syndrome table for 112-bit frames
     const uint64_t *tab_short;      // packed syndrome table for 56-bit frames
     int32_t n_long, n_short;
@@ -84,6 +89,7 @@ struct SweepParams {
     uint32_t *adder_bitmap;   // 2^24 bits: addresses some clean DF17 / DF11 IID 0 frame carries
     uint32_t *class_bitmap;   // 1 bit per scan position: candidate whose records are all conditional
     unsigned long long *counters;   // [CNT_NUM]
+    int32_t debug_stage;      // 0 = full; 1 = sweep only; 2 = sweep + DF stage (timing experiments, MGPU_DEBUG_STAGE)
 };
 
 struct ConvertParams {
@@ -100,7 +106,8 @@ struct ConvertParams {
 };
 
 void launch_convert(int format, const ConvertParams &p, hipStream_t s);
-void launch_sweep_slice(const SweepParams &p, hipStream_t s);
+void launch_sweep_slice(const SweepParams &p, hipStream_t s);      // lane-per-(candidate,phase) slicer
+void launch_sweep_slice_v1(const SweepParams &p, hipStream_t s);   // first version: wave per candidate
 // pre-screen: count / write the records whose address may matter to the ordered walk
 void launch_prescreen(const PhaseRec *pool, const uint32_t *unit_first, uint32_t nunits,
                       const uint32_t *adder_bitmap, uint32_t *unit_live /*[nunits+1]*/,

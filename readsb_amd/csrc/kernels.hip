@@ -17,9 +17,23 @@
 #include "kernels.h"
 #include "tables.h"
 
+#include <cstdlib>
+
 namespace mgpu {
 
 #define WAVE 64
+
+// Per-stage cycle counters of k_sweep_slice (thread 0 of every workgroup, summed into
+// counters[10..22], printed by api.cpp when MGPU_DEBUG_PRINT is set).  Off in production builds:
+// every s_memtime is a scalar-memory round trip.
+#ifndef MGPU_KERNEL_TIMERS
+#define MGPU_KERNEL_TIMERS 0
+#endif
+#if MGPU_KERNEL_TIMERS
+#define DBG_CLOCK() clock64()
+#else
+#define DBG_CLOCK() 0ll
+#endif
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
@@ -422,7 +436,7 @@ __device__ __forceinline__ uint32_t slice_and_score(const SweepParams &p, const 
 //   3. compact the candidates, in position order, into an LDS queue (wave prefix sums)
 //   4. slice + score: one wave per candidate, records of a 64-candidate batch are gathered in
 //      LDS in (position, phase) order and flushed to the global pool as one segment
-__global__ __launch_bounds__(kBlock) void k_sweep_slice(SweepParams p) {
+__global__ __launch_bounds__(kBlock) void k_sweep_slice_v1(SweepParams p) {
     __shared__ __attribute__((aligned(16))) uint16_t s_mag[kTile + kHalo + 8];
     __shared__ uint16_t s_queue[kTile];
     __shared__ __attribute__((aligned(16))) PhaseRec s_slots[kBatch * 5];
@@ -612,10 +626,517 @@ __global__ __launch_bounds__(kBlock) void k_sweep_slice(SweepParams p) {
     }
 }
 
-void launch_sweep_slice(const SweepParams &p, hipStream_t s) {
+void launch_sweep_slice_v1(const SweepParams &p, hipStream_t s) {
     if (p.nunits == 0) return;
     unsigned blocks = p.nunits < 256u * 5u ? p.nunits : 256u * 5u;
-    hipLaunchKernelGGL(k_sweep_slice, dim3(blocks), dim3(kBlock), 0, s, p);
+    hipLaunchKernelGGL(k_sweep_slice_v1, dim3(blocks), dim3(kBlock), 0, s, p);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_sweep_slice (second generation): same sweep, but the slicer runs one LANE per
+// (candidate, phase) pair instead of one wave per candidate, so 64 frames are sliced at once
+// and nothing waits on ballots or scalar branches:
+//
+//   sweep step (2048 positions)  -> ordered candidate queue (u16: pos_local<<3 | phase mask)
+//   drain:  expand 256 candidates into their (position, phase) pairs (block prefix sum)
+//           stage A  lane = pair: slice frame bits 0..4 = the DF field; keep pairs whose DF is in
+//                    valid_df_{long,short}_bitset (demod_2400.c:223-238); ordered append to a ring
+//           stage B  lane = surviving pair, 256 at a time (always full waves): slice the rest of
+//                    the frame five bits at a time, row-major over the five correlators so the
+//                    coefficients are immediates (the phase only changes per-lane sample offsets),
+//                    CRC-24 syndrome by XOR of per-group table entries (GF(2)-linear), score;
+//                    ordered append of the records to an LDS staging area
+//           flush    one atomicAdd per segment, coalesced 32-byte record copies
+//
+// Frame bit k of try-phase t uses correlator row (t + 2k) % 5 at sample pa + 19 + t/5 +
+// (t%5 + 12k)/5 (closed form of slice_byte, demod_2400.c:133-213).  With k = 5g + i the row is
+// (p + 2i) % 5, p = t % 5, so inside every group of five bits each row is used exactly once:
+// iterating rows 0..4 (compile-time coefficients) visits bit i_r = 3(r - p) mod 5 of the group at
+// sample offset 12g + (p + 12 i_r)/5.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSub = kBlock * 8;            // positions per sweep step
+constexpr int kCQCap = kSub + 512;          // candidate queue: a whole worst-case step fits after a drain
+constexpr int kPairCap = kBlock * 5;        // pairs of one 256-candidate expansion
+constexpr int kVCap = 512;                  // ring of valid-DF pairs waiting for stage B (power of two)
+constexpr int kAdderCache = 512;            // direct-mapped LDS cache of adder addresses already published
+constexpr int kPoolChunk = kPoolChunkRecords;  // pool records reserved per returning atomic
+constexpr int kQuadsPerRound = kBlock / 4;  // frames sliced per stage-B round (4 lanes each)
+constexpr int kStageCap = 192;              // staged records; flushed when more than 128 are waiting
+
+struct SliceGeom {          // per lane, derived from the try-phase
+    int wi[5];              // dword index (into the LDS tile viewed as u32) of the even sample at or below row r's first tap
+    int par[5];             // 0 / 16: first tap is the low / high half of that dword
+    int sh[5];              // position (4 - i_r) of row r's bit inside the 5-bit group value
+};
+
+__device__ __forceinline__ void make_geom(int pos_local, int t, SliceGeom &g) {
+    const int p = t % 5;
+    const int base = pos_local + 19 + t / 5;
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        int i = (r - p + 5) * 3;
+        i -= (i / 5) * 5;
+        const int s = base + (p + 12 * i) / 5;
+        g.wi[r] = s >> 1;
+        g.par[r] = (s & 1) * 16;
+        g.sh[r] = 4 - i;
+    }
+}
+
+// Three (four for row 4) consecutive u16 taps starting at a per-lane sample index of either parity,
+// fetched as ALIGNED dwords and funnel-shifted: hipcc otherwise fuses adjacent u16 LDS loads into
+// 2-byte-aligned ds_read_b32, which the LDS replays lane by lane.
+#define TAPS3(R, GW)                                                                   \
+    const uint32_t a_ = w32[g.wi[R] + (GW)], b_ = w32[g.wi[R] + (GW) + 1];             \
+    const uint32_t x_ = __builtin_amdgcn_alignbit(b_, a_, g.par[R]);                   \
+    const int m0 = (int) (x_ & 0xffffu), m1 = (int) (x_ >> 16), m2 = (int) ((b_ >> g.par[R]) & 0xffffu);
+
+// the five correlators (slice_phase0..4, demod_2400.c:74-93); gw = 6 * group (dwords per 12 samples)
+__device__ __forceinline__ uint32_t slice_group(const uint32_t *w32, const SliceGeom &g, int gw) {
+    uint32_t v = 0;
+    { TAPS3(0, gw) v |= (uint32_t) (18 * m0 - 15 * m1 - 3 * m2 > 0) << g.sh[0]; }
+    { TAPS3(1, gw) v |= (uint32_t) (14 * m0 - 5 * m1 - 9 * m2 > 0) << g.sh[1]; }
+    { TAPS3(2, gw) v |= (uint32_t) (16 * m0 + 5 * m1 - 20 * m2 > 0) << g.sh[2]; }
+    { TAPS3(3, gw) v |= (uint32_t) (7 * m0 + 11 * m1 - 18 * m2 > 0) << g.sh[3]; }
+    {
+        TAPS3(4, gw)
+        const uint32_t c_ = w32[g.wi[4] + gw + 2];
+        const int m3 = (int) ((__builtin_amdgcn_alignbit(c_, b_, g.par[4]) >> 16) & 0xffffu);
+        v |= (uint32_t) (4 * m0 + 15 * m1 - 20 * m2 + m3 > 0) << g.sh[4];
+    }
+    return v;
+}
+#undef TAPS3
+
+// per-lane modesChecksumDiagnose (crc.c:383-406): binary search over the sorted syndromes, which
+// are staged in LDS (a miss — the common case for noise — never touches global memory; dependent
+// global loads under a streaming kernel cost thousands of cycles each); a hit fetches the packed
+// entry (syndrome<<16 | bit0<<8 | bit1) from the global table.
+__device__ __forceinline__ int lane_diagnose(const uint32_t *keys, const uint64_t *tab, int n, uint32_t synd, int &b0, int &b1) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (keys[mid] < synd) lo = mid + 1; else hi = mid;
+    }
+    if (lo >= n || keys[lo] != synd) return -1;
+    const uint64_t e = tab[lo];
+    b0 = (int) ((e >> 8) & 0xff);
+    b1 = (int) (e & 0xff);
+    return b1 == 0xff ? 1 : 2;
+}
+
+// Frame bits 5..114 = groups 1..22 of five bits.  FOUR adjacent lanes share one frame: lane j of
+// the quad slices groups 1+6j .. 6+6j (j = 3: groups 19..22) into a 30-bit chunk and a partial
+// syndrome (CRC-24 is GF(2)-linear: the syndrome is the XOR of per-group table entries), so a
+// 256-thread round handles 64 frames with every wave busy and a 6-iteration dependent chain per
+// lane instead of 22.  The loop stays rolled: the unrolled form is ~11 KB of straight-line code
+// per inlined copy.  Lanes of a 56-bit frame stop after group 11 and contribute zeros.
+__device__ __forceinline__ void slice_chunk(const uint32_t *w32, const uint32_t *s_gsyn, const SliceGeom &g, bool is_long,
+                                            int j, uint32_t &chunk, uint32_t &synd) {
+    const uint32_t *gs = s_gsyn + (is_long ? 0 : kGroupsLong * 32);
+    const int g0 = 1 + 6 * j;
+    const int ng = j == 3 ? 4 : 6;
+    chunk = 0;
+#pragma unroll 2
+    for (int k = 0; k < ng; ++k) {
+        const int G = g0 + k;
+        uint32_t grp = 0;
+        if (is_long || G <= 11) {
+            grp = slice_group(w32, g, 6 * G);
+            if (G == 22) grp &= 0x18u;                    // frame bits 110, 111 only
+            if (G == 11 && !is_long) grp &= 0x10u;        // frame bit 55 only
+            synd ^= gs[G * 32 + grp];
+        }
+        chunk = (chunk << 5) | grp;
+    }
+}
+
+// value of `v` in lane k of the caller's quad (DPP quad_perm broadcast, no LDS traffic)
+template <int K>
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
+    return (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, K * 0x55, 0xf, 0xf, false);
+}
+
+struct BlockScan {            // ordered offsets across the 4 waves of the workgroup
+    int *wcount;              // LDS [4]
+    // flag version (1 bit per thread); one __syncthreads inside
+    __device__ __forceinline__ int flags(bool f, int &total) {
+        const uint64_t m = __ballot(f);
+        const int lane = lane_id(), wv = threadIdx.x >> 6;
+        if (lane == 0) wcount[wv] = __popcll(m);
+        __syncthreads();
+        int off = 0, tot = 0;
+#pragma unroll
+        for (int k = 0; k < kBlock / WAVE; ++k) { const int c = wcount[k]; if (k < wv) off += c; tot += c; }
+        total = tot;
+        return off + __popcll(m & ((1ull << lane) - 1));
+    }
+    __device__ __forceinline__ int counts(int v, int &total) {
+        int wt;
+        const int ex = wave_excl_scan(v, wt);
+        const int lane = lane_id(), wv = threadIdx.x >> 6;
+        if (lane == 0) wcount[wv] = wt;
+        __syncthreads();
+        int off = 0, tot = 0;
+#pragma unroll
+        for (int k = 0; k < kBlock / WAVE; ++k) { const int c = wcount[k]; if (k < wv) off += c; tot += c; }
+        total = tot;
+        return off + ex;
+    }
+};
+
+__global__ __launch_bounds__(kBlock) void k_sweep_slice(SweepParams p) {
+    __shared__ __attribute__((aligned(16))) uint16_t s_mag[kTile2 + kHalo + 8];
+    __shared__ __attribute__((aligned(16))) PhaseRec s_stage[kStageCap];
+    __shared__ uint16_t s_cq[kCQCap];
+    __shared__ uint16_t s_pairs[kPairCap];
+    __shared__ uint32_t s_v[kVCap];
+    __shared__ uint32_t s_gsyn[(kGroupsLong + kGroupsShort) * 32];
+    __shared__ uint32_t s_cls_cond[kTile2 / 32], s_cls_uncond[kTile2 / 32];
+    __shared__ int s_wcount[2][kBlock / WAVE];
+    __shared__ uint32_t s_bcast;
+    __shared__ unsigned long long s_cnt[CNT_NUM];
+    __shared__ uint32_t s_acache[kAdderCache];
+    extern __shared__ uint32_t s_keys[];   // n_long + n_short sorted syndromes (dynamic: 0.6 KB for --fix, 20 KB for --aggressive)
+
+    const int tid = threadIdx.x;
+    for (int i = tid; i < (kGroupsLong + kGroupsShort) * 32; i += kBlock) s_gsyn[i] = p.group_syndrome[i];
+    for (int i = tid; i < kAdderCache; i += kBlock) s_acache[i] = 0xFFFFFFFFu;
+    for (int i = tid; i < p.n_long; i += kBlock) s_keys[i] = (uint32_t) (p.tab_long[i] >> 16);
+    for (int i = tid; i < p.n_short; i += kBlock) s_keys[p.n_long + i] = (uint32_t) (p.tab_short[i] >> 16);
+    if (tid < CNT_NUM) s_cnt[tid] = 0;
+    uint32_t n_cand = 0, n_ph[3] = {0, 0, 0}, n_cls_cond = 0, n_cls_uncond = 0, n_rec = 0;
+    uint32_t chunk_base = 0, chunk_left = 0;           // last thread only: reserved pool space
+    long long dbg_b = 0, dbg_nb = 0, dbg_take = 0, dbg_s1 = 0, dbg_s2 = 0, dbg_s3 = 0;
+    long long dbg_tile[6] = {0, 0, 0, 0, 0, 0};
+    const long long dbg_t0 = DBG_CLOCK();
+    int scan_sel = 0;   // alternate between two wave-count arrays so back-to-back scans need no extra barrier
+    auto scan = [&]() __attribute__((always_inline)) { BlockScan b{s_wcount[scan_sel]}; scan_sel ^= 1; return b; };
+
+    for (uint32_t unit = blockIdx.x; unit < p.nunits; unit += gridDim.x) {
+        uint32_t prev_hdr = kNone, unit_records = 0;   // last thread only
+        int scount = 0;                                 // staged records (uniform)
+        if (tid == kBlock - 1) p.unit_first[unit] = kNone;
+
+        // Flush the staged records as one segment of the unit's chain.  Only the LAST wave issues
+        // global stores (records, headers, class bitmap): vector-memory returns are in order on gfx9,
+        // so a wave that has stores in flight waits for their acknowledgements before it sees the
+        // next tile's load data; waves 0..2 do all the tile loads and never store.
+        // Pool space is reserved kPoolChunk records at a time (one returning atomic per chunk, not
+        // per segment: a single hot word is a memory-side atomic every workgroup would queue on).
+        auto flush = [&]() __attribute__((always_inline)) {
+            if (scount == 0) return;
+            if (tid == kBlock - 1) {
+                if (chunk_left < (uint32_t) scount + 1u) {
+                    chunk_base = atomicAdd(p.pool_used, (uint32_t) kPoolChunk);
+                    chunk_left = kPoolChunk;
+                }
+                s_bcast = chunk_base;
+                chunk_base += (uint32_t) scount + 1u;
+                chunk_left -= (uint32_t) scount + 1u;
+            }
+            __syncthreads();
+            const uint32_t base = s_bcast;
+            const bool ok = (uint64_t) base + kPoolChunk <= p.pool_cap;
+            if (tid >= kBlock - WAVE) {
+                if (ok) {
+                    for (int i = tid - (kBlock - WAVE); i < scount; i += WAVE) {
+                        const u32x4 *src = (const u32x4 *) &s_stage[i];
+                        u32x4 *d = (u32x4 *) &p.pool[base + 1 + i];
+                        d[0] = src[0]; d[1] = src[1];
+                    }
+                    if (tid == kBlock - 1) {
+                        u32x4 h0 = {(uint32_t) scount, 0xFFu, 0u, kNone}, h1 = {0, 0, 0, 0};
+                        u32x4 *hd = (u32x4 *) &p.pool[base];
+                        hd[0] = h0; hd[1] = h1;
+                        if (prev_hdr == kNone) p.unit_first[unit] = base; else p.pool[prev_hdr].addr = base;
+                        prev_hdr = base;
+                        unit_records += scount;
+                        n_rec += scount;
+                    }
+                } else if (tid == kBlock - 1) {
+                    atomicAdd(&p.counters[CNT_POOL_OVERFLOW], 1ull);
+                }
+            }
+            scount = 0;
+            __syncthreads();
+        };
+
+        for (int tile = 0; tile < kUnit / kTile2; ++tile) {
+            const uint64_t D0 = (uint64_t) unit * kUnit + (uint64_t) tile * kTile2;
+            if (D0 >= p.n) break;
+            const long long tt0 = DBG_CLOCK();
+            __syncthreads();
+            const long long tta = DBG_CLOCK();
+            if (tid < kBlock - WAVE)
+                for (int i = tid; i < (kTile2 + kHalo) / 8; i += kBlock - WAVE)
+                    *(u32x4 *) &s_mag[8 * i] = *(const u32x4 *) &p.mag[D0 + 8 * i];
+            if (tid < kTile2 / 32) { s_cls_cond[tid] = 0; s_cls_uncond[tid] = 0; }
+#if MGPU_KERNEL_TIMERS
+            __builtin_amdgcn_s_waitcnt(0);
+#endif
+            const long long ttb = DBG_CLOCK();
+            __syncthreads();
+            const long long tt1 = DBG_CLOCK();
+            if (tid == 0) { dbg_tile[5] += tta - tt0; dbg_s3 += ttb - tta; }
+
+            int ccount = 0;            // queued candidates (uniform)
+            int vhead = 0, vcount = 0; // ring of valid pairs (uniform)
+
+            // ---- stage B over the first `take` ring entries ----
+            auto stage_b = [&](int take) __attribute__((always_inline)) {
+                const long long tb0 = DBG_CLOCK();
+                long long tb1 = tb0;
+                bool emit = false;
+                u32x4 ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0};
+                const int quad = tid >> 2, qj = tid & 3;
+                const bool have = quad < take;
+                uint32_t e = 0, chunk = 0, psyn = 0, df = 0;
+                bool is_long = false;
+                int pos_local = 0, t = 4;
+                if (have) {
+                    e = s_v[(vhead + quad) & (kVCap - 1)];
+                    pos_local = (int) ((e & 0xffffu) >> 3);
+                    t = 4 + (int) (e & 7u);
+                    df = e >> 16;
+                    is_long = (p.valid_long >> df) & 1;
+                    if (!(p.debug_stage & 16) && (is_long || qj < 2)) {
+                        SliceGeom g;
+                        make_geom(pos_local, t, g);
+                        slice_chunk((const uint32_t *) s_mag, s_gsyn, g, is_long, qj, chunk, psyn);
+                    }
+                }
+                // gather the quad's chunks / syndrome in every lane (lane 0 of the quad goes on alone)
+                const uint32_t c0 = quad_bcast<0>(chunk), c1 = quad_bcast<1>(chunk), c2 = quad_bcast<2>(chunk), c3 = quad_bcast<3>(chunk);
+                const uint32_t sx = quad_bcast<0>(psyn) ^ quad_bcast<1>(psyn) ^ quad_bcast<2>(psyn) ^ quad_bcast<3>(psyn);
+                if (have && qj == 0) {
+                    uint32_t W[4];
+                    W[0] = (df << 27) | (c0 >> 3);
+                    W[1] = ((c0 & 7u) << 29) | (c1 >> 1);
+                    W[2] = ((c1 & 1u) << 31) | (c2 << 1) | (c3 >> 19);
+                    W[3] = (c3 << 13) & 0xffff0000u;
+                    const uint32_t synd = sx ^ s_gsyn[(is_long ? 0 : kGroupsLong * 32) + df];
+                    tb1 = DBG_CLOCK();
+                    const uint32_t aa = W[0] & 0xffffffu;          // getbits(msg, 9, 32)
+                    int sk = -2, su = -2, fb0 = 0xff, fb1 = 0xff;
+                    uint32_t addr = 0, flags = is_long ? REC_LONG : 0;
+                    if (is_long) {
+                        bool handled = false;
+                        if (p.fix_df && (df == 1 || df == 16 || df == 19 || df == 21 || df == 25)) {
+                            const int j = 4 - (__ffs(df ^ 17u) - 1);
+                            if (synd == s_gsyn[16u >> j]) {             // == bit_syndrome[j]; fixDF17msgtype, mode_s.c:276-301
+                                sk = 900; su = 700; addr = aa;
+                                flags |= REC_ACCEPT_IF_UNKNOWN | REC_DFFIX | (1u << REC_CORR_SHIFT);
+                                fb0 = j; emit = handled = true;
+                            }
+                        }
+                        if (!handled && !(W[0] == 0 && (W[1] >> 8) == 0)) {
+                            if (df == 16 || df == 20 || df == 21) {
+                                sk = 1000; su = -1; addr = synd; flags |= REC_COND; emit = true;
+                            } else if (df == 17 || df == 18) {
+                                int b0 = 0xff, b1 = 0xff;
+                                const int nerr = synd == 0 ? 0 : (p.debug_stage & 4) ? -1 : lane_diagnose(s_keys, p.tab_long, p.n_long, synd, b0, b1);
+                                if (nerr >= 0) {
+                                    uint32_t a2 = aa;
+                                    if (nerr >= 1) a2 = fix_aa(a2, b0);
+                                    if (nerr >= 2) a2 = fix_aa(a2, b1);
+                                    sk = 1800 / (nerr + 1); su = 1400 / (nerr + 1); addr = a2;
+                                    flags |= (uint32_t) nerr << REC_CORR_SHIFT;
+                                    if (a2 == aa) flags |= REC_ACCEPT_IF_UNKNOWN;
+                                    if (nerr == 0 && df == 17) flags |= REC_ADDER;
+                                    if (nerr >= 1) fb0 = b0;
+                                    if (nerr >= 2) fb1 = b1;
+                                    emit = true;
+                                }
+                            }
+                        }
+                    } else if (!(W[0] == 0 && (W[1] >> 8) == 0)) {
+                        if (df == 11) {
+                            if (synd & 0xffff80u) {
+                                int b0 = 0xff, b1 = 0xff;
+                                if (!(p.debug_stage & 4) && lane_diagnose(s_keys + p.n_long, p.tab_short, p.n_short, synd, b0, b1) == 1) {
+                                    sk = 800; su = -1; addr = fix_aa(aa, b0);
+                                    flags |= REC_COND | (1u << REC_CORR_SHIFT);
+                                    fb0 = b0; emit = true;
+                                }
+                            } else if ((synd & 0x7f) == 0) {
+                                sk = 1600; su = 750; addr = aa; flags |= REC_ACCEPT_IF_UNKNOWN | REC_ADDER; emit = true;
+                            } else {
+                                sk = 1000; su = -1; addr = aa; flags |= REC_COND; emit = true;
+                            }
+                        } else {
+                            sk = 1000; su = -1; addr = synd; flags |= REC_COND; emit = true;
+                        }
+                    }
+                    if (emit) {
+                        ra.x = (uint32_t) (D0 + pos_local);
+                        ra.y = (uint32_t) t | (flags << 8) | ((uint32_t) (uint16_t) sk << 16);
+                        ra.z = (uint32_t) (uint16_t) su | ((uint32_t) fb0 << 16) | ((uint32_t) fb1 << 24);
+                        ra.w = addr;
+                        if (!is_long) { W[1] &= 0xffffff00u; W[2] = 0; W[3] = 0; }
+                        rb.x = __builtin_bswap32(W[0]); rb.y = __builtin_bswap32(W[1]);
+                        rb.z = __builtin_bswap32(W[2]); rb.w = __builtin_bswap32(W[3]) & 0xffffu;
+                        if (flags & REC_COND) atomicOr(&s_cls_cond[pos_local >> 5], 1u << (pos_local & 31));
+                        else atomicOr(&s_cls_uncond[pos_local >> 5], 1u << (pos_local & 31));
+                        if (flags & REC_ADDER) {
+                            // Device-scope atomics are executed at the memory side (the 8 XCD L2s are not coherent) and a
+                            // few hundred aircraft addresses are hit millions of times: remember what this workgroup
+                            // already published in a small LDS cache and only send first sightings.
+                            const uint32_t h = (addr ^ (addr >> 8) ^ (addr >> 16)) & (kAdderCache - 1);
+                            if (s_acache[h] != addr) {
+                                s_acache[h] = addr;
+                                atomicOr(&p.adder_bitmap[addr >> 5], 1u << (addr & 31));
+                            }
+                        }
+                    }
+                }
+                const long long tb2 = DBG_CLOCK();
+                int total;
+                const int idx = scan().flags(emit, total);
+                const long long tb3 = DBG_CLOCK();
+                if (emit) {
+                    u32x4 *d = (u32x4 *) &s_stage[scount + idx];
+                    d[0] = ra; d[1] = rb;
+                }
+                __syncthreads();
+                scount += total;
+                vhead += take;
+                vcount -= take;
+                if (p.debug_stage & 8) scount = 0;
+                if (scount > kStageCap - kQuadsPerRound) flush();
+                if (tid == 0) { dbg_b += DBG_CLOCK() - tb0; dbg_nb += 1; dbg_take += take; dbg_s1 += tb1 - tb0; dbg_s2 += tb2 - tb1; }
+            };
+
+            // ---- expand + stage A over all queued candidates, feeding stage B ----
+            auto drain = [&]() __attribute__((always_inline)) {
+                if (p.debug_stage == 1) { ccount = 0; return; }
+                for (int c0 = 0; c0 < ccount; c0 += kBlock) {
+                    const int ci = c0 + tid;
+                    const uint32_t code = ci < ccount ? s_cq[ci] : 0u;
+                    const uint32_t mask = code & 7u;
+                    const int np = 2 * (int) (mask & 1u) + (int) (mask & 2u) + (int) ((mask >> 2) & 1u);
+                    int npairs;
+                    int off = scan().counts(np, npairs);
+                    const uint32_t pl = code & 0xfff8u;
+                    if (mask & 1u) { s_pairs[off++] = (uint16_t) (pl | 0u); s_pairs[off++] = (uint16_t) (pl | 1u); }
+                    if (mask & 2u) { s_pairs[off++] = (uint16_t) (pl | 2u); s_pairs[off++] = (uint16_t) (pl | 3u); }
+                    if (mask & 4u) { s_pairs[off++] = (uint16_t) (pl | 4u); }
+                    __syncthreads();
+                    for (int a0 = 0; a0 < npairs; a0 += kBlock) {
+                        const int j = a0 + tid;
+                        bool valid = false;
+                        uint32_t entry = 0;
+                        if (j < npairs) {
+                            const uint32_t pc = s_pairs[j];
+                            SliceGeom g;
+                            make_geom((int) (pc >> 3), 4 + (int) (pc & 7u), g);
+                            const uint32_t df = slice_group((const uint32_t *) s_mag, g, 0);
+                            valid = ((p.valid_long | p.valid_short) >> df) & 1;
+                            entry = pc | (df << 16);
+                        }
+                        int nvalid;
+                        const int idx = scan().flags(valid, nvalid);
+                        if (valid) s_v[(vhead + vcount + idx) & (kVCap - 1)] = entry;
+                        __syncthreads();
+                        vcount += nvalid;
+                        if (p.debug_stage == 2) { vcount = 0; vhead = 0; }
+                        while (vcount >= kQuadsPerRound) stage_b(kQuadsPerRound);
+                    }
+                }
+                ccount = 0;
+            };
+
+            // ---- sweep, kSub positions per step ----
+            for (int sub = 0; sub < kTile2 / kSub; ++sub) {
+                if (D0 + (uint64_t) sub * kSub >= p.n) break;
+                if (ccount + kSub > kCQCap) drain();
+                const int p0 = sub * kSub + tid * 8;
+                uint32_t w[13];
+                {
+                    const u32x4 a = *(const u32x4 *) &s_mag[p0], b = *(const u32x4 *) &s_mag[p0 + 8],
+                                c = *(const u32x4 *) &s_mag[p0 + 16];
+                    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+                    w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+                    w[8] = c.x; w[9] = c.y; w[10] = c.z; w[11] = c.w;
+                    w[12] = *(const uint32_t *) &s_mag[p0 + 24];
+                }
+                uint32_t f = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+#define SM(i) ((int) ((w[((e) + (i)) >> 1] >> ((((e) + (i)) & 1) * 16)) & 0xffffu))
+                    const bool pc = SM(1) > SM(7) && SM(12) > SM(14) && SM(12) > SM(15);
+                    const int base_noise = SM(5) + SM(8) + SM(16) + SM(17) + SM(18);
+                    const int ref = (base_noise * p.thr) >> 5;
+                    const int d23 = SM(2) - SM(3), s14 = SM(1) + SM(4), d1011 = SM(10) - SM(11);
+                    const int common = s14 - d23 + SM(9) + SM(12);
+                    uint32_t m = 0;
+                    if (common - d1011 >= ref) m |= 1;
+                    if (common + d1011 >= ref) m |= 2;
+                    if (s14 + 2 * d23 + d1011 + SM(12) >= ref) m |= 4;
+#undef SM
+                    if (!pc || D0 + p0 + e >= p.n) m = 0;
+                    f |= m << (3 * e);
+                }
+                const uint32_t nz = (f | (f >> 1) | (f >> 2)) & 0x249249u;
+                const int cnt = __popc(nz);
+                n_cand += cnt;
+                n_ph[0] += __popc(f & 0x249249u);
+                n_ph[1] += __popc((f >> 1) & 0x249249u);
+                n_ph[2] += __popc((f >> 2) & 0x249249u);
+                int total;
+                int dst = ccount + scan().counts(cnt, total);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint32_t m = (f >> (3 * e)) & 7u;
+                    if (m) s_cq[dst++] = (uint16_t) (((p0 + e) << 3) | m);
+                }
+                ccount += total;
+                __syncthreads();
+            }
+            const long long tt2 = DBG_CLOCK();
+            drain();
+            const long long tt3 = DBG_CLOCK();
+            while (vcount > 0) stage_b(vcount < kQuadsPerRound ? vcount : kQuadsPerRound);
+            const long long tt4 = DBG_CLOCK();
+
+            // ---- class bitmap of the tile + candidate class counters ----
+            __syncthreads();
+            if (tid >= kBlock - WAVE) {
+                for (int w = tid - (kBlock - WAVE); w < kTile2 / 32; w += WAVE) {
+                    const uint32_t uc = s_cls_uncond[w], cd = s_cls_cond[w] & ~uc;
+                    p.class_bitmap[(D0 >> 5) + w] = cd;
+                    n_cls_cond += __popc(cd);
+                    n_cls_uncond += __popc(uc);
+                }
+            }
+            if (tid == 0) { dbg_tile[0] += tt1 - tt0; dbg_tile[1] += tt2 - tt1; dbg_tile[2] += tt3 - tt2; dbg_tile[3] += tt4 - tt3; dbg_tile[4] += DBG_CLOCK() - tt4; }
+        }
+        flush();
+        if (tid == kBlock - 1) p.unit_count[unit] = unit_records;
+    }
+    atomicAdd(&s_cnt[CNT_CANDIDATES], (unsigned long long) n_cand);
+    atomicAdd(&s_cnt[CNT_PHASE0 + 0], (unsigned long long) n_ph[0]);
+    atomicAdd(&s_cnt[CNT_PHASE0 + 2], (unsigned long long) n_ph[1]);
+    atomicAdd(&s_cnt[CNT_PHASE0 + 4], (unsigned long long) n_ph[2]);
+    atomicAdd(&s_cnt[CNT_CLASS_COND], (unsigned long long) n_cls_cond);
+    atomicAdd(&s_cnt[CNT_CLASS_UNCOND], (unsigned long long) n_cls_uncond);
+    atomicAdd(&s_cnt[CNT_RECORDS], (unsigned long long) n_rec);
+    if (tid == 0) { s_cnt[10] = dbg_b; s_cnt[11] = dbg_nb; s_cnt[12] = dbg_take; s_cnt[13] = DBG_CLOCK() - dbg_t0; s_cnt[14] = dbg_s1; s_cnt[15] = dbg_s2; for (int k = 0; k < 6; ++k) s_cnt[CNT_DEBUG0 + k] = dbg_tile[k]; s_cnt[CNT_DEBUG0 + 6] = dbg_s3; }
+    __syncthreads();
+    if (tid < CNT_NUM && s_cnt[tid]) {
+        unsigned long long v = s_cnt[tid];
+        if (tid == CNT_PHASE0 + 0) { atomicAdd(&p.counters[CNT_PHASE0 + 0], v); atomicAdd(&p.counters[CNT_PHASE0 + 1], v); }
+        else if (tid == CNT_PHASE0 + 2) { atomicAdd(&p.counters[CNT_PHASE0 + 2], v); atomicAdd(&p.counters[CNT_PHASE0 + 3], v); }
+        else atomicAdd(&p.counters[tid], v);
+    }
+}
+
+void launch_sweep_slice(const SweepParams &p, hipStream_t s) {
+    if (p.nunits == 0) return;
+    unsigned maxb = (unsigned) kSweepMaxBlocks;   // 3 workgroups per CU are resident (LDS, VGPRs)
+    if (const char *e = getenv("MGPU_SWEEP_BLOCKS")) { unsigned v = (unsigned) atoi(e); if (v >= 1 && v < maxb) maxb = v; }
+    unsigned blocks = p.nunits < maxb ? p.nunits : maxb;
+    hipLaunchKernelGGL(k_sweep_slice, dim3(blocks), dim3(kBlock), (size_t) (p.n_long + p.n_short + 4) * sizeof(uint32_t), s, p);
 }
 
 // =============================================================================================

@@ -112,6 +112,30 @@ ParityMasks build_parity_masks() {
     return m;
 }
 
+std::vector<uint32_t> build_group_syndromes() {
+    const CrcTables &crc = crc_tables();
+    std::vector<uint32_t> t((kGroupsLong + kGroupsShort) * 32, 0);
+    for (int g = 0; g < kGroupsLong; ++g)
+        for (int v = 0; v < 32; ++v) {
+            uint32_t s = 0;
+            for (int i = 0; i < 5; ++i) {
+                const int k = 5 * g + i;
+                if (k < 112 && ((v >> (4 - i)) & 1)) s ^= crc.bit_syndrome[k];
+            }
+            t[g * 32 + v] = s;
+        }
+    for (int g = 0; g < kGroupsShort; ++g)
+        for (int v = 0; v < 32; ++v) {
+            uint32_t s = 0;
+            for (int i = 0; i < 5; ++i) {
+                const int k = 5 * g + i;
+                if (k < 56 && ((v >> (4 - i)) & 1)) s ^= crc.bit_syndrome[k + 56];
+            }
+            t[(kGroupsLong + g) * 32 + v] = s;
+        }
+    return t;
+}
+
 const uint16_t *uc8_table() {
     static std::vector<uint16_t> tab;
     static std::once_flag once;

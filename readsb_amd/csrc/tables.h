@@ -42,6 +42,13 @@ std::vector<uint64_t> pack_syndrome_table(const std::vector<SyndromeEntry> &t);
 struct ParityMasks { uint64_t PH[24], PL[24], PS[24]; };
 ParityMasks build_parity_masks();
 
+// Syndrome contribution of each 5-bit group of frame bits: the slicer produces the frame five bits
+// at a time (bits 5g..5g+4, first bit = MSB of the group value), and CRC-24 being GF(2)-linear the
+// syndrome is the XOR over groups of table[g][value].  Bits past the end of the frame contribute 0.
+// Layout: long[23][32] followed by short[12][32].
+constexpr int kGroupsLong = 23, kGroupsShort = 12;
+std::vector<uint32_t> build_group_syndromes();
+
 // UC8 magnitude table, 65536 entries, index = I | Q<<8 (init_uc8_lookup, convert.c:35-62)
 const uint16_t *uc8_table();
 // The same table folded by its two mirror symmetries: entry [a*UC8_FOLD_STRIDE + b] is the

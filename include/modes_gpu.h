@@ -108,13 +108,14 @@ struct mgpu_timing {
     float sweep_ms;      /* k_sweep_slice: preamble sweep + bit slicer + CRC, the roofline kernel */
     float prescreen_ms;  /* record pre-screen + compaction */
     float resolve_ms;    /* ordered accept / skip-ahead / ICAO filter walk (host wall time) */
-    float sigpower_ms;   /* k_signal_power + stats window fix-up */
-    float d2h_ms;        /* record / message copies back */
+    float sigpower_ms;   /* host time spent launching the skip-window statistics kernel */
+    float d2h_ms;        /* explicit record copies back (0: records are written to pinned host memory by the kernel) */
     float total_ms;      /* wall time of the whole call */
     uint64_t n_candidates;   /* positions that passed a preamble threshold */
     uint64_t n_records;      /* per-phase records the slicer emitted */
     uint64_t n_live_records; /* records that survived the pre-screen (reach the ordered walk) */
     uint64_t n_messages;     /* accepted messages */
+    uint64_t n_chunks;       /* pipeline chunks = launches of each kernel; the *_ms fields above are sums over them */
 };
 
 /* ---- lifecycle -------------------------------------------------------------------- */

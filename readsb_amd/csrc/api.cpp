@@ -5,7 +5,10 @@
 // The product has no CPU compute path: without a usable HIP device mgpu_create() fails with
 // MGPU_E_NODEVICE.
 #include <hip/hip_runtime.h>
+#include <pthread.h>
+#include <sched.h>
 
+#include <cctype>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -47,6 +50,9 @@ struct Slot {
     uint16_t *d_msg_len = nullptr, *d_msg_skip = nullptr;
     // pinned host
     PhaseRec *h_live = nullptr;          // k_prescreen<write> stores the surviving records straight into host memory
+    unsigned long long *h_live_sig = nullptr;   // ... and each one's would-be signal power
+    hipEvent_t ev_window = nullptr;       // k_window_stats of this slot's last use has run (stream2)
+    bool window_pending = false;
     unsigned long long *h_counters = nullptr, *h_sums = nullptr, *h_win = nullptr, *h_sig = nullptr;
     double *h_fsums = nullptr;
     uint32_t *h_total = nullptr, *h_msg_pos = nullptr, *h_msg_limit = nullptr;
@@ -76,6 +82,14 @@ struct mgpu_ctx {
     uint16_t *d_uc8_folded = nullptr;
     int n_long = 0, n_short = 0;
     Slot slot[2];
+    unsigned long long *d_win = nullptr, *h_win = nullptr;   // skip-window totals of the current feed
+    uint64_t feed_cand[8] = {0, 0, 0, 0, 0, 0, 0, 0};         // C, phase[5], U, R of the current feed
+    ResolveCounts feed_rc;
+    std::vector<PhaseRec> w_recs;                             // worker scratch (ordinary memory)
+    std::vector<unsigned long long> w_sig;
+    std::vector<uint32_t> w_pos, w_limit;
+    std::vector<uint16_t> w_skip;
+    std::vector<mgpu_msg> w_msgs;
 
     std::vector<SyndromeEntry> tab_long, tab_short;
     uint32_t valid_long = 0, valid_short = 0;
@@ -108,6 +122,34 @@ struct mgpu_ctx {
 
 static int finish_slot(mgpu_ctx *c, Slot &sl);
 static void worker_main(mgpu_ctx *c);
+
+// Run the walk on the CPUs of the GPU's NUMA node: the record buffers are pinned host memory the GPU
+// writes over PCIe (allocated next to the device), and a walk from the other socket reads every
+// record across the inter-socket link.  MGPU_NO_AFFINITY=1 leaves the thread unbound.
+static void bind_near_device(std::thread &th, int device) {
+    if (getenv("MGPU_NO_AFFINITY")) return;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int) sizeof(bus), device) != hipSuccess) return;
+    std::string id(bus);
+    for (auto &ch : id) ch = (char) tolower((unsigned char) ch);
+    FILE *f = fopen(("/sys/bus/pci/devices/" + id + "/local_cpulist").c_str(), "r");
+    if (!f) return;
+    char line[4096] = {0};
+    const bool ok = fgets(line, sizeof(line), f) != nullptr;
+    fclose(f);
+    if (!ok) return;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    int ncpu = 0;
+    for (char *tok = strtok(line, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+        int a = 0, b = 0;
+        const int got = sscanf(tok, "%d-%d", &a, &b);
+        if (got == 1) b = a;
+        if (got >= 1)
+            for (int k = a; k <= b && k < CPU_SETSIZE; ++k) { CPU_SET(k, &set); ++ncpu; }
+    }
+    if (ncpu > 0) (void) pthread_setaffinity_np(th.native_handle(), sizeof(set), &set);
+}
 
 extern "C" {
 
@@ -169,6 +211,8 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
     HIPCHK(c, hipMalloc(&sl.d_msg_skip, c->cap_msgs * sizeof(uint16_t)));
     HIPCHK(c, hipMalloc(&sl.d_msg_sig, c->cap_msgs * sizeof(unsigned long long)));
     HIPCHK(c, hipHostMalloc(&sl.h_live, c->cap_pool * sizeof(PhaseRec)));
+    HIPCHK(c, hipHostMalloc(&sl.h_live_sig, c->cap_pool * sizeof(unsigned long long)));
+    HIPCHK(c, hipEventCreateWithFlags(&sl.ev_window, hipEventDisableTiming));
     HIPCHK(c, hipHostMalloc(&sl.h_counters, CNT_NUM * sizeof(unsigned long long)));
     HIPCHK(c, hipHostMalloc(&sl.h_sums, 2 * c->cap_buffers * sizeof(unsigned long long)));
     HIPCHK(c, hipHostMalloc(&sl.h_fsums, 2 * c->cap_buffers * sizeof(double)));
@@ -189,7 +233,8 @@ static void free_slot(Slot &sl) {
                    sl.d_msg_limit, sl.d_msg_len, sl.d_msg_skip, sl.d_msg_sig};
     for (void *p : dev)
         if (p) (void) hipFree(p);
-    void *host[] = {sl.h_live, sl.h_counters, sl.h_sums, sl.h_fsums, sl.h_win, sl.h_sig, sl.h_total, sl.h_msg_pos,
+    if (sl.ev_window) (void) hipEventDestroy(sl.ev_window);
+    void *host[] = {sl.h_live, sl.h_live_sig, sl.h_counters, sl.h_sums, sl.h_fsums, sl.h_win, sl.h_sig, sl.h_total, sl.h_msg_pos,
                     sl.h_msg_limit, sl.h_msg_len, sl.h_msg_skip};
     for (void *p : host)
         if (p) (void) hipHostFree(p);
@@ -221,6 +266,8 @@ static int alloc_all(mgpu_ctx *c) {
 
     HIPCHK(c, hipMalloc(&c->d_iq, n * bps + 64));
     HIPCHK(c, hipMalloc(&c->d_tail, kTrailing * sizeof(uint16_t)));
+    HIPCHK(c, hipMalloc(&c->d_win, 8 * sizeof(unsigned long long)));
+    HIPCHK(c, hipHostMalloc(&c->h_win, 8 * sizeof(unsigned long long)));
     HIPCHK(c, hipMalloc(&c->d_adder_bitmap, (1u << 24) / 8));
     HIPCHK(c, hipMemsetAsync(c->d_adder_bitmap, 0, (1u << 24) / 8, c->stream));
     for (auto &sl : c->slot) {
@@ -283,6 +330,7 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     }
     c->resolver.reset(cfg->startup_time_ms);
     c->worker = std::thread(worker_main, c);
+    bind_near_device(c->worker, cfg->device);
     *out = c;
     return MGPU_OK;
 }
@@ -298,7 +346,8 @@ void mgpu_destroy(mgpu_ctx *c) {
     if (c->stream) (void) hipStreamSynchronize(c->stream);
     if (c->stream2) (void) hipStreamSynchronize(c->stream2);
     for (auto &sl : c->slot) free_slot(sl);
-    void *dev[] = {c->d_iq, c->d_tail, c->d_adder_bitmap, c->d_bit_syndrome, c->d_group_syndrome, c->d_parity,
+    if (c->h_win) (void) hipHostFree(c->h_win);
+    void *dev[] = {c->d_iq, c->d_tail, c->d_win, c->d_adder_bitmap, c->d_bit_syndrome, c->d_group_syndrome, c->d_parity,
                    c->d_tab_long, c->d_tab_short, c->d_uc8_folded};
     for (void *p : dev)
         if (p) (void) hipFree(p);
@@ -332,9 +381,11 @@ static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
     const uint32_t nbuf = (uint32_t) sl.buffers.size();
     const uint32_t nunits = (uint32_t) ((n + kUnit - 1) / kUnit);
     hipStream_t s = c->stream;
+    // the slot's magnitudes / class bitmap / message lists are still read by the window-statistics
+    // kernel of its previous use (stream2)
+    if (sl.window_pending) { HIPCHK(c, hipStreamWaitEvent(s, sl.ev_window, 0)); sl.window_pending = false; }
     HIPCHK(c, hipMemsetAsync(sl.d_counters, 0, CNT_NUM * sizeof(unsigned long long), s));
     HIPCHK(c, hipMemsetAsync(sl.d_pool_used, 0, sizeof(uint32_t), s));
-    HIPCHK(c, hipMemsetAsync(sl.d_win, 0, 8 * sizeof(unsigned long long), s));
     HIPCHK(c, hipEventRecord(sl.ev[0], s));
     if (!sl.have_mag) {
         HIPCHK(c, hipMemsetAsync(sl.d_sum_level, 0, nbuf * sizeof(unsigned long long), s));
@@ -371,7 +422,8 @@ static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
     if (c->use_v1) launch_sweep_slice_v1(sp, s); else launch_sweep_slice(sp, s);
     HIPCHK(c, hipEventRecord(sl.ev[2], s));
     // pre-screen; the surviving records are written by the kernel straight into pinned host memory
-    launch_prescreen(sl.d_pool, sl.d_unit_first, nunits, c->d_adder_bitmap, sl.d_unit_live, sl.h_live, sl.d_counters, s);
+    launch_prescreen(sl.d_pool, sl.d_unit_first, nunits, c->d_adder_bitmap, sl.d_unit_live, sl.h_live, sl.d_mag, sl.h_live_sig,
+                     sl.d_counters, s);
     HIPCHK(c, hipMemcpyAsync(sl.h_counters, sl.d_counters, CNT_NUM * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     if (nunits) HIPCHK(c, hipMemcpyAsync(sl.h_total, sl.d_unit_live + nunits, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     else sl.h_total[0] = 0;
@@ -408,53 +460,84 @@ static int finish_slot(mgpu_ctx *c, Slot &sl) {
     if (hipEventElapsedTime(&ms, sl.ev[2], sl.ev[3]) == hipSuccess) c->acc.prescreen_ms += ms;
     const uint64_t nlive = sl.h_total[0];
 
+    if (const char *dd = getenv("MGPU_DUMP_DIR")) {   // replay material for tools/walk_replay.cpp
+        static int dumped = 0;
+        if (!dumped++) {
+            std::string base = std::string(dd) + "/walk_";
+            FILE *f = fopen((base + "recs.bin").c_str(), "wb"); fwrite(sl.h_live, sizeof(PhaseRec), nlive, f); fclose(f);
+            f = fopen((base + "sig.bin").c_str(), "wb"); fwrite(sl.h_live_sig, 8, nlive, f); fclose(f);
+            f = fopen((base + "bufs.bin").c_str(), "wb"); fwrite(sl.buffers.data(), sizeof(BufferClock), sl.buffers.size(), f); fclose(f);
+        }
+    }
+    if (getenv("MGPU_DEBUG_WALK2")) {   // experiment: the same walk on a heap copy of the records, with a throw-away filter
+        static Resolver r2; static bool init = false; if (!init) { r2.reset(c->cfg.startup_time_ms); init = true; }
+        const double tc0 = wall_ms();
+        std::vector<PhaseRec> cp(sl.h_live, sl.h_live + nlive);
+        std::vector<unsigned long long> cs(sl.h_live_sig, sl.h_live_sig + nlive);
+        const double tc1 = wall_ms();
+        std::vector<mgpu_msg> o; o.reserve(nlive / 4 + 16);
+        std::vector<uint32_t> a(nlive + 1), b(nlive + 1); std::vector<uint16_t> d(nlive + 1);
+        ResolveCounts rr;
+        r2.walk(cp.data(), cs.data(), nlive, sl.buffers, o, a.data(), d.data(), b.data(), nlive + 1, rr);
+        fprintf(stderr, "dbg: copy of pinned records %.3f ms, walk on heap copy %.3f ms\n", tc1 - tc0, wall_ms() - tc1);
+    }
+    // ordered walk; accepted messages go straight to the pending list, the window-statistics inputs
+    // straight into the slot's pinned staging arrays
     const double t_res0 = wall_ms();
-    std::vector<mgpu_msg> msgs;
-    std::vector<uint32_t> mpos, mlimit;
-    std::vector<uint16_t> mskip;
-    msgs.reserve(nlive / 4 + 16); mpos.reserve(nlive / 4 + 16); mlimit.reserve(nlive / 4 + 16); mskip.reserve(nlive / 4 + 16);
+    const size_t first_msg = c->pending.size();
+    if (c->pending.capacity() - first_msg < nlive / 4 + 16) {   // geometric growth: never re-copy per chunk
+        const size_t want = first_msg + nlive / 4 + 16;
+        c->pending.reserve(want > 2 * c->pending.capacity() ? want : 2 * c->pending.capacity());
+    }
     ResolveCounts rc;
-    c->resolver.walk(sl.h_live, nlive, sl.buffers, msgs, mpos, mskip, mlimit, rc);
+    // The pinned buffers the GPU writes are slow for the CPU's small scattered reads (4x slower walk)
+    // but stream at tens of GB/s: copy the chunk's records into ordinary memory first (0.25 ms for
+    // 180 k records), walk there, and keep the per-message scratch on the heap too.
+    c->w_recs.resize(nlive);
+    c->w_sig.resize(nlive);
+    std::memcpy(c->w_recs.data(), sl.h_live, nlive * sizeof(PhaseRec));
+    std::memcpy(c->w_sig.data(), sl.h_live_sig, nlive * sizeof(unsigned long long));
+    const double t_cp = wall_ms() - t_res0;
+    const uint64_t aux_cap = nlive + 1 < c->cap_msgs ? nlive + 1 : c->cap_msgs;
+    c->w_pos.resize(aux_cap); c->w_limit.resize(aux_cap); c->w_skip.resize(aux_cap);
+    c->w_msgs.clear();
+    const int64_t wn = c->resolver.walk(c->w_recs.data(), c->w_sig.data(), nlive, sl.buffers, c->w_msgs, c->w_pos.data(),
+                                        c->w_skip.data(), c->w_limit.data(), aux_cap, rc);
+    const double t_wk = wall_ms() - t_res0 - t_cp;
+    c->pending.insert(c->pending.end(), c->w_msgs.begin(), c->w_msgs.end());
+    if (wn > 0) {
+        std::memcpy(sl.h_msg_pos, c->w_pos.data(), (size_t) wn * sizeof(uint32_t));
+        std::memcpy(sl.h_msg_limit, c->w_limit.data(), (size_t) wn * sizeof(uint32_t));
+        std::memcpy(sl.h_msg_skip, c->w_skip.data(), (size_t) wn * sizeof(uint16_t));
+    }
     c->acc.resolve_ms += (float) (wall_ms() - t_res0);
-    const uint32_t nmsg = (uint32_t) msgs.size();
-    if (nmsg > c->cap_msgs) { c->err = "max_messages exceeded"; return MGPU_E_OVERFLOW; }
+    if (getenv("MGPU_DEBUG_PRINT")) fprintf(stderr, "dbg: copy %.3f ms + walk %.3f ms for %llu live records -> %lld msgs (pending cap %zu)\n", t_cp, t_wk, (unsigned long long) nlive, (long long) wn, c->pending.capacity());
+    if (wn < 0) { c->err = "max_messages exceeded"; return MGPU_E_OVERFLOW; }
+    const uint32_t nmsg = (uint32_t) wn;
+    c->feed_rc.add(rc);
 
-    // signal power + what the skip windows hid from the counters, on the second stream
+    // what the skip windows hid from the counters: asynchronous on the second stream, totals are
+    // accumulated on the device and read once at the end of the feed
     const double t_sig0 = wall_ms();
-    hipStream_t s2 = c->stream2;
     if (nmsg) {
-        for (uint32_t i = 0; i < nmsg; ++i) sl.h_msg_len[i] = msgs[i].sig_len;
-        std::memcpy(sl.h_msg_pos, mpos.data(), nmsg * sizeof(uint32_t));
-        std::memcpy(sl.h_msg_limit, mlimit.data(), nmsg * sizeof(uint32_t));
-        std::memcpy(sl.h_msg_skip, mskip.data(), nmsg * sizeof(uint16_t));
+        hipStream_t s2 = c->stream2;
         HIPCHK(c, hipMemcpyAsync(sl.d_msg_pos, sl.h_msg_pos, nmsg * sizeof(uint32_t), hipMemcpyHostToDevice, s2));
         HIPCHK(c, hipMemcpyAsync(sl.d_msg_limit, sl.h_msg_limit, nmsg * sizeof(uint32_t), hipMemcpyHostToDevice, s2));
-        HIPCHK(c, hipMemcpyAsync(sl.d_msg_len, sl.h_msg_len, nmsg * sizeof(uint16_t), hipMemcpyHostToDevice, s2));
         HIPCHK(c, hipMemcpyAsync(sl.d_msg_skip, sl.h_msg_skip, nmsg * sizeof(uint16_t), hipMemcpyHostToDevice, s2));
-        launch_signal_power(sl.d_mag, sl.d_msg_pos, sl.d_msg_len, nmsg, sl.d_msg_sig, s2);
         launch_window_stats(sl.d_mag, n, cfg.preamble_threshold, sl.d_class_bitmap, sl.d_msg_pos, sl.d_msg_skip,
-                            sl.d_msg_limit, nmsg, sl.d_win, s2);
-        HIPCHK(c, hipMemcpyAsync(sl.h_sig, sl.d_msg_sig, nmsg * sizeof(unsigned long long), hipMemcpyDeviceToHost, s2));
+                            sl.d_msg_limit, nmsg, c->d_win, s2);
+        HIPCHK(c, hipEventRecord(sl.ev_window, s2));
+        sl.window_pending = true;
     }
-    HIPCHK(c, hipMemcpyAsync(sl.h_win, sl.d_win, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s2));
-    HIPCHK(c, hipStreamSynchronize(s2));
     c->acc.sigpower_ms += (float) (wall_ms() - t_sig0);
 
-    // ---- counters (Modes.stats_current) ----
+    // ---- counters that do not depend on the skip windows ----
     mgpu_counters &k = c->counters;
-    const unsigned long long *hc = sl.h_counters, *hw = sl.h_win;
-    const uint64_t C = hc[CNT_CANDIDATES], U = hc[CNT_CLASS_COND], R = hc[CNT_CLASS_UNCOND];
-    const uint64_t cW = hw[0], uW = hw[4];
-    k.demod_preambles += C - cW;
-    k.demod_preamblePhase[0] += hc[CNT_PHASE0 + 0] - hw[1];
-    k.demod_preamblePhase[1] += hc[CNT_PHASE0 + 1] - hw[1];
-    k.demod_preamblePhase[2] += hc[CNT_PHASE0 + 2] - hw[2];
-    k.demod_preamblePhase[3] += hc[CNT_PHASE0 + 3] - hw[2];
-    k.demod_preamblePhase[4] += hc[CNT_PHASE0 + 4] - hw[3];
-    // candidates without any record score -2 for sure; those hidden inside skip windows are not counted
-    k.demod_rejected_bad += (C - U - R) - (cW - uW - rc.skipped_uncond_groups) + rc.rejected_bad;
-    // conditional-only candidates: dead ones (address can never be known) + the visited live ones the walk rejected
-    k.demod_rejected_unknown_icao += rc.rejected_unknown + (U - rc.visited_cond_groups - uW);
+    const unsigned long long *hc = sl.h_counters;
+    c->feed_cand[0] += hc[CNT_CANDIDATES];
+    for (int i = 0; i < 5; ++i) c->feed_cand[1 + i] += hc[CNT_PHASE0 + i];
+    c->feed_cand[6] += hc[CNT_CLASS_COND];
+    c->feed_cand[7] += hc[CNT_CLASS_UNCOND];
     for (int i = 0; i < 3; ++i) k.demod_accepted[i] += rc.accepted[i];
     for (int i = 0; i < 5; ++i) k.demod_bestPhase[i] += rc.best_phase[i];
 
@@ -463,9 +546,8 @@ static int finish_slot(mgpu_ctx *c, Slot &sl) {
     for (uint32_t b = 0; b < nbuf; ++b) {
         const BufferClock &bc = sl.buffers[b];
         uint64_t sum_scaled = 0;
-        while (mi < nmsg && mpos[mi] < (uint64_t) bc.first + bc.length) {
-            mgpu_msg &m = msgs[mi];
-            m.sig_sumsq = sl.h_sig[mi];
+        while (mi < nmsg && c->w_pos[mi] < (uint64_t) bc.first + bc.length) {
+            const mgpu_msg &m = c->pending[first_msg + mi];
             const double signal_power = (double) m.sig_sumsq / 65535.0 / 65535.0;
             const double level = signal_power / m.sig_len;
             k.signal_power_sum += signal_power;
@@ -487,11 +569,42 @@ static int finish_slot(mgpu_ctx *c, Slot &sl) {
         k.nbuffers++;
     }
     k.nflips = c->resolver.nflips();
-    c->pending.insert(c->pending.end(), msgs.begin(), msgs.end());
-    c->acc.n_candidates += C;
+    c->acc.n_candidates += hc[CNT_CANDIDATES];
     c->acc.n_records += hc[CNT_RECORDS];
     c->acc.n_live_records += nlive;
     c->acc.n_messages += nmsg;
+    c->acc.n_chunks += 1;
+    return MGPU_OK;
+}
+
+// Start / end of one API call that runs chunks: reset and then apply the skip-window corrections of
+// the demod counters (see DESIGN.md §1 "Statistics without a candidate log").
+static int feed_begin(mgpu_ctx *c) {
+    std::memset(&c->acc, 0, sizeof(c->acc));
+    std::memset(c->feed_cand, 0, sizeof(c->feed_cand));
+    c->feed_rc = ResolveCounts();
+    HIPCHK(c, hipMemsetAsync(c->d_win, 0, 8 * sizeof(unsigned long long), c->stream2));
+    return MGPU_OK;
+}
+
+static int feed_end(mgpu_ctx *c) {
+    HIPCHK(c, hipMemcpyAsync(c->h_win, c->d_win, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream2));
+    HIPCHK(c, hipStreamSynchronize(c->stream2));
+    mgpu_counters &k = c->counters;
+    const unsigned long long *hw = c->h_win;
+    const ResolveCounts &rc = c->feed_rc;
+    const uint64_t C = c->feed_cand[0], U = c->feed_cand[6], R = c->feed_cand[7];
+    const uint64_t cW = hw[0], uW = hw[4];
+    k.demod_preambles += C - cW;
+    k.demod_preamblePhase[0] += c->feed_cand[1] - hw[1];
+    k.demod_preamblePhase[1] += c->feed_cand[2] - hw[1];
+    k.demod_preamblePhase[2] += c->feed_cand[3] - hw[2];
+    k.demod_preamblePhase[3] += c->feed_cand[4] - hw[2];
+    k.demod_preamblePhase[4] += c->feed_cand[5] - hw[3];
+    // candidates without any record score -2 for sure; those hidden inside skip windows are not counted
+    k.demod_rejected_bad += (C - U - R) - (cW - uW - rc.skipped_uncond_groups) + rc.rejected_bad;
+    // conditional-only candidates: dead ones (address can never be known) + the visited live ones the walk rejected
+    k.demod_rejected_unknown_icao += rc.rejected_unknown + (U - rc.visited_cond_groups - uW);
     return MGPU_OK;
 }
 
@@ -559,7 +672,7 @@ static int feed_common(mgpu_ctx *c, const void *src, bool src_is_device, uint64_
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const size_t bps = c->cfg.format == MGPU_FMT_UC8 ? 2 : 4;
     const double t_start = wall_ms();
-    std::memset(&c->acc, 0, sizeof(c->acc));
+    { int brc = feed_begin(c); if (brc != MGPU_OK) return brc; }
     const uint8_t *iq = (const uint8_t *) src;
     if (!src_is_device) {
         const double t0 = wall_ms();
@@ -584,6 +697,7 @@ static int feed_common(mgpu_ctx *c, const void *src, bool src_is_device, uint64_
     }
     const int wrc = wait_all(c);
     if (rc == MGPU_OK) rc = wrc;
+    if (rc == MGPU_OK) rc = feed_end(c);
     if (rc != MGPU_OK) return rc;
     c->stream_pos += n;
     if (n % c->cfg.buf_samples) c->eof = true;   // short read = end of file (sdr_ifile.c:223-237)
@@ -701,7 +815,7 @@ int mgpu_demod_mag_buf(mgpu_ctx *c, const uint16_t *data, uint32_t length, int64
         return MGPU_OK;
     }
     const double t_start = wall_ms();
-    std::memset(&c->acc, 0, sizeof(c->acc));
+    { int brc = feed_begin(c); if (brc != MGPU_OK) return brc; }
     Slot &sl = acquire_slot(c, 0);
     sl.n = length;
     sl.have_mag = true;
@@ -717,6 +831,7 @@ int mgpu_demod_mag_buf(mgpu_ctx *c, const uint16_t *data, uint32_t length, int64
     if (rc != MGPU_OK) { std::lock_guard<std::mutex> lk(c->mu); if (c->worker_rc == MGPU_OK) c->worker_rc = rc; }
     const int wrc = wait_all(c);
     if (rc == MGPU_OK) rc = wrc;
+    if (rc == MGPU_OK) rc = feed_end(c);
     if (rc == MGPU_OK) {
         c->stream_pos += length;
         c->acc.total_ms = (float) (wall_ms() - t_start);

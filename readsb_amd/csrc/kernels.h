@@ -109,9 +109,11 @@ void launch_convert(int format, const ConvertParams &p, hipStream_t s);
 void launch_sweep_slice(const SweepParams &p, hipStream_t s);      // lane-per-(candidate,phase) slicer
 void launch_sweep_slice_v1(const SweepParams &p, hipStream_t s);   // first version: wave per candidate
 // pre-screen: count / write the records whose address may matter to the ordered walk
+// (the write pass also stores each live record's would-be signal power: sum of mag^2 over its frame)
 void launch_prescreen(const PhaseRec *pool, const uint32_t *unit_first, uint32_t nunits,
                       const uint32_t *adder_bitmap, uint32_t *unit_live /*[nunits+1]*/,
-                      PhaseRec *live, unsigned long long *counters, hipStream_t s);
+                      PhaseRec *live, const uint16_t *mag, unsigned long long *live_sig,
+                      unsigned long long *counters, hipStream_t s);
 // signal power of accepted messages: sum of mag^2 over d_mag[pos+19 .. pos+19+len)
 void launch_signal_power(const uint16_t *mag, const uint32_t *pos, const uint16_t *len, uint32_t nmsg,
                          unsigned long long *out, hipStream_t s);

@@ -1151,9 +1151,15 @@ __device__ __forceinline__ bool rec_live(const PhaseRec &r, const uint32_t *bitm
     return (bitmap[a >> 5] >> (a & 31)) & 1;
 }
 
+// WRITE pass: besides compacting the live records (straight into pinned host memory) the wave also
+// computes, for every live record, the signal power the reference would report if this record
+// became the accepted frame: sum of mag^2 over d_mag[pos+19 .. pos+19+len), len = 268 / 134 by the
+// DF as sliced (demod_2400.c:399,436-457).  ~5 records per real frame, 5 coalesced loads per lane
+// each — and the ordered walk then needs no second GPU round trip.
 template <bool WRITE>
 __global__ __launch_bounds__(kBlock) void k_prescreen(const PhaseRec *pool, const uint32_t *unit_first, uint32_t nunits,
-                                                      const uint32_t *bitmap, uint32_t *unit_live, PhaseRec *live) {
+                                                      const uint32_t *bitmap, uint32_t *unit_live, PhaseRec *live,
+                                                      const uint16_t *mag, unsigned long long *live_sig) {
     const int lane = lane_id();
     const uint32_t u = blockIdx.x * (kBlock / WAVE) + (threadIdx.x >> 6);
     if (u >= nunits) return;
@@ -1165,13 +1171,35 @@ __global__ __launch_bounds__(kBlock) void k_prescreen(const PhaseRec *pool, cons
         for (uint32_t i0 = 0; i0 < cnt; i0 += WAVE) {
             const uint32_t i = i0 + lane;
             bool ok = false;
-            if (i < cnt) ok = rec_live(pool[h + 1 + i], bitmap);
+            uint32_t pos = 0, len = 0;
+            if (i < cnt) {
+                const PhaseRec &r = pool[h + 1 + i];
+                ok = rec_live(r, bitmap);
+                pos = r.pos;
+                len = (r.msg[0] & 0x80) ? 268u : 134u;
+            }
             const uint64_t m = __ballot(ok);
-            if (WRITE && ok) {
-                const uint32_t d = dst0 + nlive + __popcll(m & ((1ull << lane) - 1));
-                const u32x4 *src = (const u32x4 *) &pool[h + 1 + i];
-                u32x4 *dd = (u32x4 *) &live[d];
-                dd[0] = src[0]; dd[1] = src[1];
+            if (WRITE) {
+                if (ok) {
+                    const uint32_t d = dst0 + nlive + __popcll(m & ((1ull << lane) - 1));
+                    const u32x4 *src = (const u32x4 *) &pool[h + 1 + i];
+                    u32x4 *dd = (u32x4 *) &live[d];
+                    dd[0] = src[0]; dd[1] = src[1];
+                }
+                uint64_t todo = m;
+                uint32_t k = 0;
+                while (todo) {
+                    const int src_lane = __ffsll((unsigned long long) todo) - 1;
+                    todo &= todo - 1;
+                    const uint32_t p0 = __builtin_amdgcn_readlane(pos, src_lane);
+                    const uint32_t n = __builtin_amdgcn_readlane(len, src_lane);
+                    const uint16_t *sm = mag + p0 + 19;
+                    unsigned long long acc = 0;
+                    for (uint32_t q = lane; q < n; q += WAVE) { const uint32_t v = sm[q]; acc += (unsigned long long) (v * v); }
+                    acc = wave_sum_u64(acc);
+                    if (lane == 0) live_sig[dst0 + nlive + k] = acc;
+                    ++k;
+                }
             }
             nlive += __popcll(m);
         }
@@ -1209,12 +1237,13 @@ __global__ __launch_bounds__(1024) void k_scan_units(uint32_t *unit_live, uint32
 }
 
 void launch_prescreen(const PhaseRec *pool, const uint32_t *unit_first, uint32_t nunits, const uint32_t *adder_bitmap,
-                      uint32_t *unit_live, PhaseRec *live, unsigned long long *counters, hipStream_t s) {
+                      uint32_t *unit_live, PhaseRec *live, const uint16_t *mag, unsigned long long *live_sig,
+                      unsigned long long *counters, hipStream_t s) {
     if (nunits == 0) return;
     const unsigned blocks = (nunits + 3) / 4;
-    hipLaunchKernelGGL(k_prescreen<false>, dim3(blocks), dim3(kBlock), 0, s, pool, unit_first, nunits, adder_bitmap, unit_live, live);
+    hipLaunchKernelGGL(k_prescreen<false>, dim3(blocks), dim3(kBlock), 0, s, pool, unit_first, nunits, adder_bitmap, unit_live, live, mag, live_sig);
     hipLaunchKernelGGL(k_scan_units, dim3(1), dim3(1024), 0, s, unit_live, nunits, counters);
-    hipLaunchKernelGGL(k_prescreen<true>, dim3(blocks), dim3(kBlock), 0, s, pool, unit_first, nunits, adder_bitmap, unit_live, live);
+    hipLaunchKernelGGL(k_prescreen<true>, dim3(blocks), dim3(kBlock), 0, s, pool, unit_first, nunits, adder_bitmap, unit_live, live, mag, live_sig);
 }
 
 // =============================================================================================

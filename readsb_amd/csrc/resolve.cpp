@@ -86,10 +86,10 @@ void Resolver::tick_empty(int64_t sysTimestamp) {
 
 static inline void flip_bit(uint8_t *msg, int bit) { msg[bit >> 3] ^= (uint8_t) (0x80u >> (bit & 7)); }
 
-void Resolver::walk(const PhaseRec *recs, uint64_t nrecs, const std::vector<BufferClock> &buffers,
-                    std::vector<mgpu_msg> &out, std::vector<uint32_t> &out_pos, std::vector<uint16_t> &out_skip,
-                    std::vector<uint32_t> &out_limit, ResolveCounts &c) {
-    uint64_t i = 0;
+int64_t Resolver::walk(const PhaseRec *recs, const unsigned long long *sig, uint64_t nrecs,
+                       const std::vector<BufferClock> &buffers, std::vector<mgpu_msg> &out, uint32_t *aux_pos,
+                       uint16_t *aux_skip, uint32_t *aux_limit, uint64_t aux_cap, ResolveCounts &c) {
+    uint64_t i = 0, nout = 0;
     for (const BufferClock &b : buffers) {
         synthetic_now_ = b.sysTimestamp;                       // demod_2400.c:283-285
         const uint64_t end = (uint64_t) b.first + b.length;
@@ -149,17 +149,21 @@ void Resolver::walk(const PhaseRec *recs, uint64_t nrecs, const std::vector<Buff
             if (m.msgbits == 56) { std::memset(m.msg + 7, 0, 7); std::memset(m.raw + 7, 0, 7); }
             m.addr = br->addr & 0xffffffu;
             m.sig_len = (uint16_t) (msglen * 12 / 5);          // :439
+            m.sig_sumsq = sig[br - recs];                      // :442-445, precomputed per record on the GPU
             if (br->flags & REC_ADDER) filter_.add(m.addr);    // mode_s.c:766-779
             ++c.accepted[m.correctedbits];
             ++c.best_phase[br->phase - 4];
+            if (nout >= aux_cap) return -1;
             out.push_back(m);
-            out_pos.push_back(pos);
-            out_skip.push_back((uint16_t) (msglen * 8 / 4));   // :468
-            out_limit.push_back((uint32_t) end);
+            aux_pos[nout] = pos;
+            aux_skip[nout] = (uint16_t) (msglen * 8 / 4);     // :468
+            aux_limit[nout] = (uint32_t) end;
+            ++nout;
             skip_until = (int64_t) pos + msglen * 8 / 4;
         }
         after_buffer();
     }
+    return (int64_t) nout;
 }
 
 }  // namespace mgpu

@@ -48,6 +48,13 @@ struct BufferClock {
 };
 
 struct ResolveCounts {
+    void add(const ResolveCounts &o) {
+        visited_groups += o.visited_groups; rejected_unknown += o.rejected_unknown; rejected_bad += o.rejected_bad;
+        for (int i = 0; i < 3; ++i) accepted[i] += o.accepted[i];
+        for (int i = 0; i < 5; ++i) best_phase[i] += o.best_phase[i];
+        skipped_uncond_groups += o.skipped_uncond_groups; skipped_cond_groups += o.skipped_cond_groups;
+        visited_cond_groups += o.visited_cond_groups; visited_uncond_groups += o.visited_uncond_groups;
+    }
     uint64_t visited_groups = 0;        // candidate groups the walk looked at
     uint64_t rejected_unknown = 0;      // visited, best == -1 or decode stage -1
     uint64_t rejected_bad = 0;          // visited, decode stage -2 (not produced) / best == -2
@@ -62,12 +69,13 @@ struct ResolveCounts {
 class Resolver {
   public:
     void reset(int64_t startup_ms);
-    // Walk the ordered live records of one feed.  `base_pos` = stream position of the feed's
-    // scan position 0.  Appends accepted messages (sig_* left 0) and their feed-relative
-    // positions / skip lengths / buffer limits.
-    void walk(const PhaseRec *recs, uint64_t nrecs, const std::vector<BufferClock> &buffers,
-              std::vector<mgpu_msg> &out, std::vector<uint32_t> &out_pos, std::vector<uint16_t> &out_skip,
-              std::vector<uint32_t> &out_limit, ResolveCounts &counts);
+    // Walk the ordered live records of one chunk.  sig[i] = sum of mag^2 over the frame record i
+    // would occupy.  Appends the accepted messages to `out` and writes their chunk-relative
+    // positions / skip lengths / buffer limits (inputs of k_window_stats) to the aux arrays
+    // (capacity aux_cap); returns the number of messages, or -1 if aux_cap was too small.
+    int64_t walk(const PhaseRec *recs, const unsigned long long *sig, uint64_t nrecs,
+                 const std::vector<BufferClock> &buffers, std::vector<mgpu_msg> &out, uint32_t *aux_pos,
+                 uint16_t *aux_skip, uint32_t *aux_limit, uint64_t aux_cap, ResolveCounts &counts);
     // the per-buffer filter clock for a buffer that produced no walk (zero-length EOF buffer)
     void tick_empty(int64_t sysTimestamp);
     IcaoFilter &filter() { return filter_; }

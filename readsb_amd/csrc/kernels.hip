@@ -807,6 +807,9 @@ __global__ __launch_bounds__(kBlock) void k_sweep_slice(SweepParams p) {
     if (tid < CNT_NUM) s_cnt[tid] = 0;
     uint32_t n_cand = 0, n_ph[3] = {0, 0, 0}, n_cls_cond = 0, n_cls_uncond = 0, n_rec = 0;
     uint32_t chunk_base = 0, chunk_left = 0;           // last thread only: reserved pool space
+    constexpr int kPre = ((kTile2 + kHalo) / 8 + (kBlock - WAVE) - 1) / (kBlock - WAVE);   // 16-byte loads per loading thread and tile
+    u32x4 pre[kPre];
+    bool have_pre = false;
     long long dbg_b = 0, dbg_nb = 0, dbg_take = 0, dbg_s1 = 0, dbg_s2 = 0, dbg_s3 = 0;
     long long dbg_tile[6] = {0, 0, 0, 0, 0, 0};
     const long long dbg_t0 = DBG_CLOCK();
@@ -868,10 +871,34 @@ __global__ __launch_bounds__(kBlock) void k_sweep_slice(SweepParams p) {
             const long long tt0 = DBG_CLOCK();
             __syncthreads();
             const long long tta = DBG_CLOCK();
-            if (tid < kBlock - WAVE)
-                for (int i = tid; i < (kTile2 + kHalo) / 8; i += kBlock - WAVE)
-                    *(u32x4 *) &s_mag[8 * i] = *(const u32x4 *) &p.mag[D0 + 8 * i];
+            // the tile was prefetched into registers while the previous tile was being sliced
+            if (tid < kBlock - WAVE) {
+                if (!have_pre) {
+#pragma unroll
+                    for (int k = 0; k < kPre; ++k) {
+                        const int i = tid + k * (kBlock - WAVE);
+                        if (i < (kTile2 + kHalo) / 8) pre[k] = *(const u32x4 *) &p.mag[D0 + 8 * i];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < kPre; ++k) {
+                    const int i = tid + k * (kBlock - WAVE);
+                    if (i < (kTile2 + kHalo) / 8) *(u32x4 *) &s_mag[8 * i] = pre[k];
+                }
+            }
             if (tid < kTile2 / 32) { s_cls_cond[tid] = 0; s_cls_uncond[tid] = 0; }
+            {   // prefetch the workgroup's next tile (same unit, or the first tile of its next unit)
+                uint64_t Dn = D0 + kTile2;
+                if (tile + 1 >= kUnit / kTile2 || Dn >= p.n) Dn = (uint64_t) (unit + gridDim.x) * kUnit;
+                have_pre = (uint64_t) (unit + gridDim.x) * kUnit == Dn ? (unit + gridDim.x < p.nunits) : true;
+                if (have_pre && tid < kBlock - WAVE) {
+#pragma unroll
+                    for (int k = 0; k < kPre; ++k) {
+                        const int i = tid + k * (kBlock - WAVE);
+                        if (i < (kTile2 + kHalo) / 8) pre[k] = *(const u32x4 *) &p.mag[Dn + 8 * i];
+                    }
+                }
+            }
 #if MGPU_KERNEL_TIMERS
             __builtin_amdgcn_s_waitcnt(0);
 #endif
@@ -1133,7 +1160,19 @@ __global__ __launch_bounds__(kBlock) void k_sweep_slice(SweepParams p) {
 
 void launch_sweep_slice(const SweepParams &p, hipStream_t s) {
     if (p.nunits == 0) return;
-    unsigned maxb = (unsigned) kSweepMaxBlocks;   // 3 workgroups per CU are resident (LDS, VGPRs)
+    // persistent grid = exactly the workgroups that are resident at once (occupancy x CUs): a larger
+    // grid runs a ragged second wave of workgroups, a smaller one leaves CUs idle
+    static int resident = 0;
+    if (!resident) {
+        int per_cu = 0, dev = 0, cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        const size_t dyn = (size_t) (p.n_long + p.n_short + 4) * sizeof(uint32_t);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sweep_slice, kBlock, dyn) != hipSuccess || per_cu < 1) per_cu = 2;
+        resident = per_cu * cus;
+        if (resident > kSweepMaxBlocks) resident = kSweepMaxBlocks;
+    }
+    unsigned maxb = (unsigned) resident;
     if (const char *e = getenv("MGPU_SWEEP_BLOCKS")) { unsigned v = (unsigned) atoi(e); if (v >= 1 && v < maxb) maxb = v; }
     unsigned blocks = p.nunits < maxb ? p.nunits : maxb;
     hipLaunchKernelGGL(k_sweep_slice, dim3(blocks), dim3(kBlock), (size_t) (p.n_long + p.n_short + 4) * sizeof(uint32_t), s, p);

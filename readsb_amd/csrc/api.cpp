@@ -100,7 +100,7 @@ struct mgpu_ctx {
     mgpu_timing timing{}, acc{};
     uint64_t stream_pos = 0;
     bool eof = false, have_tail = false;
-    bool use_v1 = false;       // MGPU_SWEEP_V1=1: first-generation slicer (kept for A/B measurements)
+    int sweep_version = 3;     // MGPU_SWEEP_VERSION=1|2: earlier generations of k_sweep_slice (A/B measurements)
 
     // worker thread: ordered walk + signal power of the slots, in submission order
     std::thread worker;
@@ -257,7 +257,7 @@ static int alloc_all(mgpu_ctx *c) {
     c->cap_buffers = (cs + cfg.buf_samples - 1) / cfg.buf_samples + 1;
     // default pool: 1 record per 16 samples (8x the density of busy synthetic traffic) + what the
     // workgroups reserve but may leave unused (one chunk each)
-    const uint64_t reserve = (uint64_t) kPoolChunkRecords * (c->cap_units < (uint64_t) kSweepMaxBlocks ? c->cap_units : (uint64_t) kSweepMaxBlocks);
+    const uint64_t reserve = 1024ull * (c->cap_units < (uint64_t) kSweepMaxWaves ? c->cap_units : (uint64_t) kSweepMaxWaves);
     uint64_t pool = cfg.record_pool_records ? cfg.record_pool_records : cs / 16 + 65536;
     c->cap_pool = pool + reserve;
     if (c->cap_pool > 0xFFFFFFF0ull) c->cap_pool = 0xFFFFFFF0ull;
@@ -313,7 +313,7 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     mgpu_ctx *c = new (std::nothrow) mgpu_ctx();
     if (!c) return MGPU_E_NOMEM;
     c->cfg = *cfg;
-    { const char *e = getenv("MGPU_SWEEP_V1"); c->use_v1 = e && e[0] == '1'; }
+    if (const char *e = getenv("MGPU_SWEEP_VERSION")) { const int v = atoi(e); if (v >= 1 && v <= 3) c->sweep_version = v; }
     if (hipSetDevice(cfg->device) != hipSuccess) { delete c; return MGPU_E_NODEVICE; }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { mgpu_destroy(c); return MGPU_E_HIP; }
@@ -419,7 +419,9 @@ static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
     sp.unit_first = sl.d_unit_first; sp.unit_count = sl.d_unit_count; sp.nunits = nunits;
     { const char *e = getenv("MGPU_DEBUG_STAGE"); sp.debug_stage = e ? atoi(e) : 0; }
     sp.adder_bitmap = c->d_adder_bitmap; sp.class_bitmap = sl.d_class_bitmap; sp.counters = sl.d_counters;
-    if (c->use_v1) launch_sweep_slice_v1(sp, s); else launch_sweep_slice(sp, s);
+    if (c->sweep_version == 1) launch_sweep_slice_v1(sp, s);
+    else if (c->sweep_version == 2) launch_sweep_slice_v2(sp, s);
+    else launch_sweep_slice(sp, s);
     HIPCHK(c, hipEventRecord(sl.ev[2], s));
     // pre-screen; the surviving records are written by the kernel straight into pinned host memory
     launch_prescreen(sl.d_pool, sl.d_unit_first, nunits, c->d_adder_bitmap, sl.d_unit_live, sl.h_live, sl.d_mag, sl.h_live_sig,

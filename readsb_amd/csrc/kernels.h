@@ -19,12 +19,14 @@ namespace mgpu {
 constexpr int kTrailing = 326;          // Modes.trailing_samples (readsb.c:288)
 constexpr int kTile = 4096;             // scan positions per LDS tile
 constexpr int kHalo = 304;              // >= 290 samples of look-ahead (demod reads pa[0..289]), multiple of 8
-constexpr int kTilesPerUnit = 8;
-constexpr int kUnit = kTile * kTilesPerUnit;   // positions per unit (one record chain per unit)
+constexpr int kTilesPerUnit = 2;
+constexpr int kUnit = kTile * kTilesPerUnit;   // positions per unit (one record chain per unit, one wave's share)
+constexpr int kWaveTile = 2048;         // k_sweep_slice: positions per wave-private LDS tile
 constexpr int kTile2 = 4096;            // k_sweep_slice: positions per LDS tile
 constexpr int kBlock = 256;
-constexpr int kSweepMaxBlocks = 256 * 4;  // resident workgroups of k_sweep_slice (4 per CU: 30 KB LDS, <=128 VGPRs)
-constexpr int kPoolChunkRecords = 1024;   // pool records a workgroup reserves per atomic
+constexpr int kSweepMaxBlocks = 256 * 4;  // resident workgroups of k_sweep_slice (at most 4 per CU)
+constexpr int kPoolChunkRecords = 256;    // pool records a wave reserves per returning atomic
+constexpr int kSweepMaxWaves = kSweepMaxBlocks * (kBlock / 64);
 constexpr int kBatch = 64;              // candidates sliced per batch (4 waves x 16)
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 
@@ -106,7 +108,8 @@ struct ConvertParams {
 };
 
 void launch_convert(int format, const ConvertParams &p, hipStream_t s);
-void launch_sweep_slice(const SweepParams &p, hipStream_t s);      // lane-per-(candidate,phase) slicer
+void launch_sweep_slice(const SweepParams &p, hipStream_t s);      // wave-autonomous sweep + lane-per-frame slicer
+void launch_sweep_slice_v2(const SweepParams &p, hipStream_t s);   // second version: workgroup tiles, block barriers
 void launch_sweep_slice_v1(const SweepParams &p, hipStream_t s);   // first version: wave per candidate
 // pre-screen: count / write the records whose address may matter to the ordered walk
 // (the write pass also stores each live record's would-be signal power: sum of mag^2 over its frame)

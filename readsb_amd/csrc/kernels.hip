@@ -459,8 +459,8 @@ __global__ __launch_bounds__(kBlock) void k_sweep_slice_v1(SweepParams p) {
     for (uint32_t unit = blockIdx.x; unit < p.nunits; unit += gridDim.x) {
         uint32_t prev_hdr = kNone, unit_records = 0;   // meaningful in wave 0 only
         if (tid == 0) p.unit_first[unit] = kNone;
-        for (int tile = 0; tile < kTilesPerUnit; ++tile) {
-            const uint64_t D0 = ((uint64_t) unit * kTilesPerUnit + tile) * kTile;
+        for (int tile = 0; tile < kUnit / kTile; ++tile) {
+            const uint64_t D0 = (uint64_t) unit * kUnit + (uint64_t) tile * kTile;
             if (D0 >= p.n) break;
             __syncthreads();   // previous tile fully consumed
             // ---- 1. stage ----
@@ -659,7 +659,7 @@ constexpr int kCQCap = kSub + 512;          // candidate queue: a whole worst-ca
 constexpr int kPairCap = kBlock * 5;        // pairs of one 256-candidate expansion
 constexpr int kVCap = 512;                  // ring of valid-DF pairs waiting for stage B (power of two)
 constexpr int kAdderCache = 512;            // direct-mapped LDS cache of adder addresses already published
-constexpr int kPoolChunk = kPoolChunkRecords;  // pool records reserved per returning atomic
+constexpr int kPoolChunk = 1024;            // v2: pool records a workgroup reserves per returning atomic
 constexpr int kQuadsPerRound = kBlock / 4;  // frames sliced per stage-B round (4 lanes each)
 constexpr int kStageCap = 192;              // staged records; flushed when more than 128 are waiting
 
@@ -785,7 +785,7 @@ struct BlockScan {            // ordered offsets across the 4 waves of the workg
     }
 };
 
-__global__ __launch_bounds__(kBlock) void k_sweep_slice(SweepParams p) {
+__global__ __launch_bounds__(kBlock) void k_sweep_slice_v2(SweepParams p) {
     __shared__ __attribute__((aligned(16))) uint16_t s_mag[kTile2 + kHalo + 8];
     __shared__ __attribute__((aligned(16))) PhaseRec s_stage[kStageCap];
     __shared__ uint16_t s_cq[kCQCap];
@@ -1158,7 +1158,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_slice(SweepParams p) {
     }
 }
 
-void launch_sweep_slice(const SweepParams &p, hipStream_t s) {
+void launch_sweep_slice_v2(const SweepParams &p, hipStream_t s) {
     if (p.nunits == 0) return;
     // persistent grid = exactly the workgroups that are resident at once (occupancy x CUs): a larger
     // grid runs a ragged second wave of workgroups, a smaller one leaves CUs idle
@@ -1168,14 +1168,395 @@ void launch_sweep_slice(const SweepParams &p, hipStream_t s) {
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
         const size_t dyn = (size_t) (p.n_long + p.n_short + 4) * sizeof(uint32_t);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sweep_slice, kBlock, dyn) != hipSuccess || per_cu < 1) per_cu = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sweep_slice_v2, kBlock, dyn) != hipSuccess || per_cu < 1) per_cu = 2;
         resident = per_cu * cus;
         if (resident > kSweepMaxBlocks) resident = kSweepMaxBlocks;
     }
     unsigned maxb = (unsigned) resident;
     if (const char *e = getenv("MGPU_SWEEP_BLOCKS")) { unsigned v = (unsigned) atoi(e); if (v >= 1 && v < maxb) maxb = v; }
     unsigned blocks = p.nunits < maxb ? p.nunits : maxb;
-    hipLaunchKernelGGL(k_sweep_slice, dim3(blocks), dim3(kBlock), (size_t) (p.n_long + p.n_short + 4) * sizeof(uint32_t), s, p);
+    hipLaunchKernelGGL(k_sweep_slice_v2, dim3(blocks), dim3(kBlock), (size_t) (p.n_long + p.n_short + 4) * sizeof(uint32_t), s, p);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_sweep_slice (third generation): every WAVE is autonomous.  The second generation spent most
+// of its time at workgroup barriers (~20 per tile, with 1-2 of 4 waves working in the slicing
+// stages) — waves that never wait for each other let the CU interleave 16 independent instruction
+// streams instead.  A wave owns a unit of the stream (kUnit positions, one record chain), walks it
+// in wave-private LDS tiles of kWaveTile positions (+304 halo), and does everything itself with
+// wave-level primitives (ballot / prefix sums, no __syncthreads after the table preload):
+//   sweep 4 x 512 positions -> candidate queue -> pairs -> DF stage (lane = pair) -> ring of
+//   valid pairs -> slicing (4 lanes per frame, 16 frames per round) -> CRC/score -> staged records
+//   -> flush into the wave's reserved slice of the pool.  The next tile is prefetched into
+//   registers while the current one is sliced.
+// Shared by the workgroup (read-only after the preload, or benign races): group-syndrome tables,
+// syndrome keys, the adder-address cache.
+// ---------------------------------------------------------------------------------------------
+constexpr int kWT = kWaveTile;
+constexpr int kWTChunks = (kWT + kHalo) / 8;                 // 16-byte chunks per tile (294)
+constexpr int kWPre = (kWTChunks + WAVE - 1) / WAVE;         // 16-byte loads per lane and tile (5)
+constexpr int kWStep = WAVE * 8;                             // positions per sweep step (512)
+constexpr int kWCQCap = kWStep + 64;                         // candidate queue (drained when > 64 wait)
+constexpr int kWVCap = 128;                                  // ring of valid pairs (power of two)
+constexpr int kWFrames = WAVE / 4;                           // frames sliced per round (16)
+constexpr int kWStageCap = 32;                               // staged records per wave
+constexpr int kWAdderCache = 256;
+
+struct WaveLds {                                             // wave-private LDS, 16-byte aligned members first
+    uint16_t mag[kWT + kHalo + 8];                           // 4720 B
+    PhaseRec stage[kWStageCap];                              // 1024 B
+    uint16_t cq[kWCQCap];                                    // 1152 B
+    uint16_t pairs[WAVE * 5];                                //  640 B
+    uint32_t v[kWVCap];                                      //  512 B
+    uint32_t cls_cond[kWT / 32], cls_uncond[kWT / 32];       //  512 B
+};
+
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+__global__ __launch_bounds__(kBlock) void k_sweep_slice(SweepParams p) {
+    __shared__ __attribute__((aligned(16))) WaveLds s_w[kBlock / WAVE];
+    __shared__ uint32_t s_gsyn[(kGroupsLong + kGroupsShort) * 32];
+    __shared__ uint32_t s_acache[kWAdderCache];
+    __shared__ unsigned long long s_cnt[CNT_NUM];
+    extern __shared__ uint32_t s_keys[];   // n_long + n_short sorted syndromes
+
+    const int tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    for (int i = tid; i < (kGroupsLong + kGroupsShort) * 32; i += kBlock) s_gsyn[i] = p.group_syndrome[i];
+    for (int i = tid; i < kWAdderCache; i += kBlock) s_acache[i] = 0xFFFFFFFFu;
+    for (int i = tid; i < p.n_long; i += kBlock) s_keys[i] = (uint32_t) (p.tab_long[i] >> 16);
+    for (int i = tid; i < p.n_short; i += kBlock) s_keys[p.n_long + i] = (uint32_t) (p.tab_short[i] >> 16);
+    if (tid < CNT_NUM) s_cnt[tid] = 0;
+    __syncthreads();   // the only workgroup barrier before the final counter reduction
+
+    WaveLds &L = s_w[wv];
+    const uint32_t *w32 = (const uint32_t *) L.mag;
+    const uint64_t lt_mask = (1ull << lane) - 1;
+    const uint32_t wave_global = blockIdx.x * (kBlock / WAVE) + wv;
+    const uint32_t nwaves = gridDim.x * (kBlock / WAVE);
+
+    uint32_t n_cand = 0, n_ph[3] = {0, 0, 0}, n_cls_cond = 0, n_cls_uncond = 0, n_rec = 0;
+    uint32_t chunk_base = 0, chunk_left = 0;     // wave-uniform: reserved pool space
+    u32x4 pre[kWPre];
+    bool have_pre = false;
+
+    for (uint32_t unit = wave_global; unit < p.nunits; unit += nwaves) {
+        uint32_t prev_hdr = kNone, unit_records = 0;
+        int scount = 0;
+        if (lane == 0) p.unit_first[unit] = kNone;
+
+        auto flush = [&]() __attribute__((always_inline)) {
+            if (scount == 0) return;
+            if (chunk_left < (uint32_t) scount + 1u) {
+                uint32_t b = 0;
+                if (lane == 0) b = atomicAdd(p.pool_used, (uint32_t) kPoolChunkRecords);
+                chunk_base = rfl(b);
+                chunk_left = kPoolChunkRecords;
+            }
+            const uint32_t base = chunk_base;
+            chunk_base += (uint32_t) scount + 1u;
+            chunk_left -= (uint32_t) scount + 1u;
+            if ((uint64_t) base + kPoolChunkRecords <= p.pool_cap) {
+                if (lane < scount) {
+                    const u32x4 *src = (const u32x4 *) &L.stage[lane];
+                    u32x4 *d = (u32x4 *) &p.pool[base + 1 + lane];
+                    d[0] = src[0]; d[1] = src[1];
+                }
+                if (lane == 0) {
+                    u32x4 h0 = {(uint32_t) scount, 0xFFu, 0u, kNone}, h1 = {0, 0, 0, 0};
+                    u32x4 *hd = (u32x4 *) &p.pool[base];
+                    hd[0] = h0; hd[1] = h1;
+                    if (prev_hdr == kNone) p.unit_first[unit] = base; else p.pool[prev_hdr].addr = base;
+                }
+                prev_hdr = base;
+                unit_records += scount;
+                n_rec += scount;
+            } else if (lane == 0) {
+                atomicAdd(&p.counters[CNT_POOL_OVERFLOW], 1ull);
+            }
+            scount = 0;
+            WAVE_SYNC();
+        };
+
+        for (int tile = 0; tile < kUnit / kWT; ++tile) {
+            const uint64_t D0 = (uint64_t) unit * kUnit + (uint64_t) tile * kWT;
+            if (D0 >= p.n) break;
+            // ---- tile into LDS (prefetched while the previous tile was sliced) ----
+            if (!have_pre) {
+#pragma unroll
+                for (int k = 0; k < kWPre; ++k) {
+                    const int i = lane + k * WAVE;
+                    if (i < kWTChunks) pre[k] = *(const u32x4 *) &p.mag[D0 + 8 * i];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < kWPre; ++k) {
+                const int i = lane + k * WAVE;
+                if (i < kWTChunks) *(u32x4 *) &L.mag[8 * i] = pre[k];
+            }
+            L.cls_cond[lane] = 0; L.cls_uncond[lane] = 0;     // kWT / 32 == 64 words each
+            {
+                uint64_t Dn = D0 + kWT;
+                bool next_unit = false;
+                if (tile + 1 >= kUnit / kWT || Dn >= p.n) { Dn = (uint64_t) (unit + nwaves) * kUnit; next_unit = true; }
+                have_pre = next_unit ? (unit + nwaves < p.nunits) : true;
+                if (have_pre) {
+#pragma unroll
+                    for (int k = 0; k < kWPre; ++k) {
+                        const int i = lane + k * WAVE;
+                        if (i < kWTChunks) pre[k] = *(const u32x4 *) &p.mag[Dn + 8 * i];
+                    }
+                }
+            }
+            WAVE_SYNC();
+
+            int ccount = 0, vhead = 0, vcount = 0;
+
+            // ---- slicing: 4 lanes per frame, 16 frames per round ----
+            auto stage_b = [&](int take) __attribute__((always_inline)) {
+                const int quad = lane >> 2, qj = lane & 3;
+                const bool have = quad < take;
+                uint32_t e = 0, chunk = 0, psyn = 0, df = 0;
+                bool is_long = false;
+                int pos_local = 0, t = 4;
+                if (have) {
+                    e = L.v[(vhead + quad) & (kWVCap - 1)];
+                    pos_local = (int) ((e & 0xffffu) >> 3);
+                    t = 4 + (int) (e & 7u);
+                    df = e >> 16;
+                    is_long = (p.valid_long >> df) & 1;
+                    if (is_long || qj < 2) {
+                        SliceGeom g;
+                        make_geom(pos_local, t, g);
+                        slice_chunk(w32, s_gsyn, g, is_long, qj, chunk, psyn);
+                    }
+                }
+                const uint32_t c0 = quad_bcast<0>(chunk), c1 = quad_bcast<1>(chunk), c2 = quad_bcast<2>(chunk), c3 = quad_bcast<3>(chunk);
+                const uint32_t sx = quad_bcast<0>(psyn) ^ quad_bcast<1>(psyn) ^ quad_bcast<2>(psyn) ^ quad_bcast<3>(psyn);
+                bool emit = false;
+                u32x4 ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0};
+                if (have && qj == 0) {
+                    uint32_t W[4];
+                    W[0] = (df << 27) | (c0 >> 3);
+                    W[1] = ((c0 & 7u) << 29) | (c1 >> 1);
+                    W[2] = ((c1 & 1u) << 31) | (c2 << 1) | (c3 >> 19);
+                    W[3] = (c3 << 13) & 0xffff0000u;
+                    const uint32_t synd = sx ^ s_gsyn[(is_long ? 0 : kGroupsLong * 32) + df];
+                    const uint32_t aa = W[0] & 0xffffffu;          // getbits(msg, 9, 32)
+                    int sk = -2, su = -2, fb0 = 0xff, fb1 = 0xff;
+                    uint32_t addr = 0, flags = is_long ? REC_LONG : 0;
+                    if (is_long) {
+                        bool handled = false;
+                        if (p.fix_df && (df == 1 || df == 16 || df == 19 || df == 21 || df == 25)) {
+                            const int j = 4 - (__ffs(df ^ 17u) - 1);
+                            if (synd == s_gsyn[16u >> j]) {             // == bit_syndrome[j]; fixDF17msgtype, mode_s.c:276-301
+                                sk = 900; su = 700; addr = aa;
+                                flags |= REC_ACCEPT_IF_UNKNOWN | REC_DFFIX | (1u << REC_CORR_SHIFT);
+                                fb0 = j; emit = handled = true;
+                            }
+                        }
+                        if (!handled && !(W[0] == 0 && (W[1] >> 8) == 0)) {
+                            if (df == 16 || df == 20 || df == 21) {
+                                sk = 1000; su = -1; addr = synd; flags |= REC_COND; emit = true;
+                            } else if (df == 17 || df == 18) {
+                                int b0 = 0xff, b1 = 0xff;
+                                const int nerr = synd == 0 ? 0 : lane_diagnose(s_keys, p.tab_long, p.n_long, synd, b0, b1);
+                                if (nerr >= 0) {
+                                    uint32_t a2 = aa;
+                                    if (nerr >= 1) a2 = fix_aa(a2, b0);
+                                    if (nerr >= 2) a2 = fix_aa(a2, b1);
+                                    sk = 1800 / (nerr + 1); su = 1400 / (nerr + 1); addr = a2;
+                                    flags |= (uint32_t) nerr << REC_CORR_SHIFT;
+                                    if (a2 == aa) flags |= REC_ACCEPT_IF_UNKNOWN;
+                                    if (nerr == 0 && df == 17) flags |= REC_ADDER;
+                                    if (nerr >= 1) fb0 = b0;
+                                    if (nerr >= 2) fb1 = b1;
+                                    emit = true;
+                                }
+                            }
+                        }
+                    } else if (!(W[0] == 0 && (W[1] >> 8) == 0)) {
+                        if (df == 11) {
+                            if (synd & 0xffff80u) {
+                                int b0 = 0xff, b1 = 0xff;
+                                if (lane_diagnose(s_keys + p.n_long, p.tab_short, p.n_short, synd, b0, b1) == 1) {
+                                    sk = 800; su = -1; addr = fix_aa(aa, b0);
+                                    flags |= REC_COND | (1u << REC_CORR_SHIFT);
+                                    fb0 = b0; emit = true;
+                                }
+                            } else if ((synd & 0x7f) == 0) {
+                                sk = 1600; su = 750; addr = aa; flags |= REC_ACCEPT_IF_UNKNOWN | REC_ADDER; emit = true;
+                            } else {
+                                sk = 1000; su = -1; addr = aa; flags |= REC_COND; emit = true;
+                            }
+                        } else {
+                            sk = 1000; su = -1; addr = synd; flags |= REC_COND; emit = true;
+                        }
+                    }
+                    if (emit) {
+                        ra.x = (uint32_t) (D0 + pos_local);
+                        ra.y = (uint32_t) t | (flags << 8) | ((uint32_t) (uint16_t) sk << 16);
+                        ra.z = (uint32_t) (uint16_t) su | ((uint32_t) fb0 << 16) | ((uint32_t) fb1 << 24);
+                        ra.w = addr;
+                        if (!is_long) { W[1] &= 0xffffff00u; W[2] = 0; W[3] = 0; }
+                        rb.x = __builtin_bswap32(W[0]); rb.y = __builtin_bswap32(W[1]);
+                        rb.z = __builtin_bswap32(W[2]); rb.w = __builtin_bswap32(W[3]) & 0xffffu;
+                        if (flags & REC_COND) atomicOr(&L.cls_cond[pos_local >> 5], 1u << (pos_local & 31));
+                        else atomicOr(&L.cls_uncond[pos_local >> 5], 1u << (pos_local & 31));
+                        if (flags & REC_ADDER) {
+                            const uint32_t h = (addr ^ (addr >> 8) ^ (addr >> 16)) & (kWAdderCache - 1);
+                            if (s_acache[h] != addr) {
+                                s_acache[h] = addr;
+                                atomicOr(&p.adder_bitmap[addr >> 5], 1u << (addr & 31));
+                            }
+                        }
+                    }
+                }
+                const uint64_t em = __ballot(emit);
+                if (emit) {
+                    u32x4 *d = (u32x4 *) &L.stage[scount + __popcll(em & lt_mask)];
+                    d[0] = ra; d[1] = rb;
+                }
+                scount += __popcll(em);
+                vhead += take;
+                vcount -= take;
+                WAVE_SYNC();
+                if (scount > kWStageCap - kWFrames) flush();
+            };
+
+            // ---- candidates -> pairs -> DF stage -> ring ----
+            auto drain = [&]() __attribute__((always_inline)) {
+                for (int c0 = 0; c0 < ccount; c0 += WAVE) {
+                    const int ci = c0 + lane;
+                    const uint32_t code = ci < ccount ? L.cq[ci] : 0u;
+                    const uint32_t mask = code & 7u;
+                    const int np = 2 * (int) (mask & 1u) + (int) (mask & 2u) + (int) ((mask >> 2) & 1u);
+                    int npairs;
+                    int off = wave_excl_scan(np, npairs);
+                    const uint32_t pl = code & 0xfff8u;
+                    if (mask & 1u) { L.pairs[off++] = (uint16_t) (pl | 0u); L.pairs[off++] = (uint16_t) (pl | 1u); }
+                    if (mask & 2u) { L.pairs[off++] = (uint16_t) (pl | 2u); L.pairs[off++] = (uint16_t) (pl | 3u); }
+                    if (mask & 4u) { L.pairs[off++] = (uint16_t) (pl | 4u); }
+                    WAVE_SYNC();
+                    for (int a0 = 0; a0 < npairs; a0 += WAVE) {
+                        const int j = a0 + lane;
+                        bool valid = false;
+                        uint32_t entry = 0;
+                        if (j < npairs) {
+                            const uint32_t pc = L.pairs[j];
+                            SliceGeom g;
+                            make_geom((int) (pc >> 3), 4 + (int) (pc & 7u), g);
+                            const uint32_t df = slice_group(w32, g, 0);
+                            valid = ((p.valid_long | p.valid_short) >> df) & 1;
+                            entry = pc | (df << 16);
+                        }
+                        const uint64_t vm = __ballot(valid);
+                        if (valid) L.v[(vhead + vcount + __popcll(vm & lt_mask)) & (kWVCap - 1)] = entry;
+                        vcount += __popcll(vm);
+                        WAVE_SYNC();
+                        while (vcount >= kWFrames) stage_b(kWFrames);
+                    }
+                }
+                ccount = 0;
+            };
+
+            // ---- sweep, 512 positions per step ----
+            for (int sub = 0; sub < kWT / kWStep; ++sub) {
+                if (D0 + (uint64_t) sub * kWStep >= p.n) break;
+                if (ccount > kWCQCap - kWStep) drain();
+                const int p0 = sub * kWStep + lane * 8;
+                uint32_t w[13];
+                {
+                    const u32x4 a = *(const u32x4 *) &L.mag[p0], b = *(const u32x4 *) &L.mag[p0 + 8],
+                                c = *(const u32x4 *) &L.mag[p0 + 16];
+                    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+                    w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+                    w[8] = c.x; w[9] = c.y; w[10] = c.z; w[11] = c.w;
+                    w[12] = *(const uint32_t *) &L.mag[p0 + 24];
+                }
+                uint32_t f = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+#define SM(i) ((int) ((w[((e) + (i)) >> 1] >> ((((e) + (i)) & 1) * 16)) & 0xffffu))
+                    const bool pc = SM(1) > SM(7) && SM(12) > SM(14) && SM(12) > SM(15);
+                    const int base_noise = SM(5) + SM(8) + SM(16) + SM(17) + SM(18);
+                    const int ref = (base_noise * p.thr) >> 5;
+                    const int d23 = SM(2) - SM(3), s14 = SM(1) + SM(4), d1011 = SM(10) - SM(11);
+                    const int common = s14 - d23 + SM(9) + SM(12);
+                    uint32_t m = 0;
+                    if (common - d1011 >= ref) m |= 1;
+                    if (common + d1011 >= ref) m |= 2;
+                    if (s14 + 2 * d23 + d1011 + SM(12) >= ref) m |= 4;
+#undef SM
+                    if (!pc || D0 + p0 + e >= p.n) m = 0;
+                    f |= m << (3 * e);
+                }
+                const uint32_t nz = (f | (f >> 1) | (f >> 2)) & 0x249249u;
+                const int cnt = __popc(nz);
+                n_cand += cnt;
+                n_ph[0] += __popc(f & 0x249249u);
+                n_ph[1] += __popc((f >> 1) & 0x249249u);
+                n_ph[2] += __popc((f >> 2) & 0x249249u);
+                if (__ballot(cnt != 0)) {
+                    int total;
+                    int dst = ccount + wave_excl_scan(cnt, total);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const uint32_t m = (f >> (3 * e)) & 7u;
+                        if (m) L.cq[dst++] = (uint16_t) (((p0 + e) << 3) | m);
+                    }
+                    ccount += total;
+                    WAVE_SYNC();
+                }
+            }
+            drain();
+            while (vcount > 0) stage_b(vcount < kWFrames ? vcount : kWFrames);
+
+            // ---- class bitmap of the tile (all 64 words: no clearing needed) ----
+            {
+                const uint32_t uc = L.cls_uncond[lane], cd = L.cls_cond[lane] & ~uc;
+                p.class_bitmap[(D0 >> 5) + lane] = cd;
+                n_cls_cond += __popc(cd);
+                n_cls_uncond += __popc(uc);
+            }
+            WAVE_SYNC();
+        }
+        flush();
+        if (lane == 0) p.unit_count[unit] = unit_records;
+    }
+    atomicAdd(&s_cnt[CNT_CANDIDATES], (unsigned long long) n_cand);
+    atomicAdd(&s_cnt[CNT_PHASE0 + 0], (unsigned long long) n_ph[0]);
+    atomicAdd(&s_cnt[CNT_PHASE0 + 2], (unsigned long long) n_ph[1]);
+    atomicAdd(&s_cnt[CNT_PHASE0 + 4], (unsigned long long) n_ph[2]);
+    atomicAdd(&s_cnt[CNT_CLASS_COND], (unsigned long long) n_cls_cond);
+    atomicAdd(&s_cnt[CNT_CLASS_UNCOND], (unsigned long long) n_cls_uncond);
+    if (lane == 0) atomicAdd(&s_cnt[CNT_RECORDS], (unsigned long long) n_rec);
+    __syncthreads();
+    if (tid < CNT_NUM && s_cnt[tid]) {
+        unsigned long long v = s_cnt[tid];
+        if (tid == CNT_PHASE0 + 0) { atomicAdd(&p.counters[CNT_PHASE0 + 0], v); atomicAdd(&p.counters[CNT_PHASE0 + 1], v); }
+        else if (tid == CNT_PHASE0 + 2) { atomicAdd(&p.counters[CNT_PHASE0 + 2], v); atomicAdd(&p.counters[CNT_PHASE0 + 3], v); }
+        else atomicAdd(&p.counters[tid], v);
+    }
+}
+
+void launch_sweep_slice(const SweepParams &p, hipStream_t s) {
+    if (p.nunits == 0) return;
+    // persistent grid = the workgroups resident at once (occupancy x CUs)
+    static int resident = 0;
+    const size_t dyn = (size_t) (p.n_long + p.n_short + 4) * sizeof(uint32_t);
+    if (!resident) {
+        int per_cu = 0, dev = 0, cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sweep_slice, kBlock, dyn) != hipSuccess || per_cu < 1) per_cu = 2;
+        resident = per_cu * cus;
+        if (resident > kSweepMaxBlocks) resident = kSweepMaxBlocks;
+    }
+    unsigned maxb = (unsigned) resident;
+    if (const char *e = getenv("MGPU_SWEEP_BLOCKS")) { unsigned v = (unsigned) atoi(e); if (v >= 1 && v < maxb) maxb = v; }
+    const unsigned want = (p.nunits + (kBlock / WAVE) - 1) / (kBlock / WAVE);
+    const unsigned blocks = want < maxb ? want : maxb;
+    hipLaunchKernelGGL(k_sweep_slice, dim3(blocks), dim3(kBlock), dyn, s, p);
 }
 
 // =============================================================================================

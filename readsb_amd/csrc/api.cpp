@@ -44,6 +44,9 @@ struct Slot {
     uint16_t *d_mag = nullptr;
     PhaseRec *d_pool = nullptr;
     uint32_t *d_pool_used = nullptr, *d_unit_first = nullptr, *d_unit_count = nullptr, *d_unit_live = nullptr, *d_class_bitmap = nullptr;
+    // one zero-initialised scratch block per chunk: counters | pool_used | per-buffer sums (1 memset, 1 copy back)
+    unsigned long long *d_scratch = nullptr, *h_scratch = nullptr;
+    size_t scratch_bytes = 0;
     unsigned long long *d_counters = nullptr, *d_sum_level = nullptr, *d_sum_power = nullptr, *d_win = nullptr, *d_msg_sig = nullptr;
     double *d_fsum_level = nullptr, *d_fsum_power = nullptr;
     uint32_t *d_msg_pos = nullptr, *d_msg_limit = nullptr;
@@ -55,7 +58,7 @@ struct Slot {
     bool window_pending = false;
     unsigned long long *h_counters = nullptr, *h_sums = nullptr, *h_win = nullptr, *h_sig = nullptr;
     double *h_fsums = nullptr;
-    uint32_t *h_total = nullptr, *h_msg_pos = nullptr, *h_msg_limit = nullptr;
+    uint32_t *h_msg_pos = nullptr, *h_msg_limit = nullptr;
     uint16_t *h_msg_len = nullptr, *h_msg_skip = nullptr;
     hipEvent_t ev[4] = {};
     // the job
@@ -75,7 +78,8 @@ struct mgpu_ctx {
     uint64_t cap_units = 0, cap_buffers = 0, cap_pool = 0, cap_msgs = 0;   // per slot
 
     uint8_t *d_iq = nullptr;
-    uint16_t *d_tail = nullptr;
+    const uint16_t *tail_src = nullptr;   // device: the 326 magnitudes before the next chunk (end of the previous chunk's d_mag)
+    uint64_t chunk_seq = 0;               // chunks alternate between the two slots across feeds
     uint32_t *d_adder_bitmap = nullptr;
     uint32_t *d_bit_syndrome = nullptr, *d_group_syndrome = nullptr;
     uint64_t *d_parity = nullptr, *d_tab_long = nullptr, *d_tab_short = nullptr;
@@ -99,7 +103,7 @@ struct mgpu_ctx {
     mgpu_counters counters{};
     mgpu_timing timing{}, acc{};
     uint64_t stream_pos = 0;
-    bool eof = false, have_tail = false;
+    bool eof = false;
     int sweep_version = 3;     // MGPU_SWEEP_VERSION=1|2: earlier generations of k_sweep_slice (A/B measurements)
 
     // worker thread: ordered walk + signal power of the slots, in submission order
@@ -194,16 +198,25 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
     HIPCHK(c, hipMalloc(&sl.d_mag, mag_len * sizeof(uint16_t)));
     HIPCHK(c, hipMemsetAsync(sl.d_mag, 0, mag_len * sizeof(uint16_t), c->stream));
     HIPCHK(c, hipMalloc(&sl.d_pool, c->cap_pool * sizeof(PhaseRec)));
-    HIPCHK(c, hipMalloc(&sl.d_pool_used, 64));
     HIPCHK(c, hipMalloc(&sl.d_unit_first, (c->cap_units + 1) * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc(&sl.d_unit_count, (c->cap_units + 1) * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc(&sl.d_unit_live, (c->cap_units + 2) * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc(&sl.d_class_bitmap, (mag_len / 32 + 64) * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc(&sl.d_counters, CNT_NUM * sizeof(unsigned long long)));
-    HIPCHK(c, hipMalloc(&sl.d_sum_level, c->cap_buffers * sizeof(unsigned long long)));
-    HIPCHK(c, hipMalloc(&sl.d_sum_power, c->cap_buffers * sizeof(unsigned long long)));
-    HIPCHK(c, hipMalloc(&sl.d_fsum_level, c->cap_buffers * sizeof(double)));
-    HIPCHK(c, hipMalloc(&sl.d_fsum_power, c->cap_buffers * sizeof(double)));
+    {
+        const size_t nb = c->cap_buffers, words = CNT_NUM + 1 + 4 * nb;
+        sl.scratch_bytes = words * sizeof(unsigned long long);
+        HIPCHK(c, hipMalloc(&sl.d_scratch, sl.scratch_bytes));
+        HIPCHK(c, hipHostMalloc(&sl.h_scratch, sl.scratch_bytes));
+        sl.d_counters = sl.d_scratch;
+        sl.d_pool_used = (uint32_t *) (sl.d_scratch + CNT_NUM);
+        sl.d_sum_level = sl.d_scratch + CNT_NUM + 1;
+        sl.d_sum_power = sl.d_sum_level + nb;
+        sl.d_fsum_level = (double *) (sl.d_sum_power + nb);
+        sl.d_fsum_power = sl.d_fsum_level + nb;
+        sl.h_counters = sl.h_scratch;
+        sl.h_sums = sl.h_scratch + CNT_NUM + 1;                 // level[nb] then power[nb]
+        sl.h_fsums = (double *) (sl.h_scratch + CNT_NUM + 1 + 2 * nb);   // level[nb] then power[nb]
+    }
     HIPCHK(c, hipMalloc(&sl.d_win, 8 * sizeof(unsigned long long)));
     HIPCHK(c, hipMalloc(&sl.d_msg_pos, c->cap_msgs * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc(&sl.d_msg_limit, c->cap_msgs * sizeof(uint32_t)));
@@ -213,12 +226,8 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
     HIPCHK(c, hipHostMalloc(&sl.h_live, c->cap_pool * sizeof(PhaseRec)));
     HIPCHK(c, hipHostMalloc(&sl.h_live_sig, c->cap_pool * sizeof(unsigned long long)));
     HIPCHK(c, hipEventCreateWithFlags(&sl.ev_window, hipEventDisableTiming));
-    HIPCHK(c, hipHostMalloc(&sl.h_counters, CNT_NUM * sizeof(unsigned long long)));
-    HIPCHK(c, hipHostMalloc(&sl.h_sums, 2 * c->cap_buffers * sizeof(unsigned long long)));
-    HIPCHK(c, hipHostMalloc(&sl.h_fsums, 2 * c->cap_buffers * sizeof(double)));
     HIPCHK(c, hipHostMalloc(&sl.h_win, 8 * sizeof(unsigned long long)));
     HIPCHK(c, hipHostMalloc(&sl.h_sig, c->cap_msgs * sizeof(unsigned long long)));
-    HIPCHK(c, hipHostMalloc(&sl.h_total, 64));
     HIPCHK(c, hipHostMalloc(&sl.h_msg_pos, c->cap_msgs * sizeof(uint32_t)));
     HIPCHK(c, hipHostMalloc(&sl.h_msg_limit, c->cap_msgs * sizeof(uint32_t)));
     HIPCHK(c, hipHostMalloc(&sl.h_msg_len, c->cap_msgs * sizeof(uint16_t)));
@@ -228,13 +237,13 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
 }
 
 static void free_slot(Slot &sl) {
-    void *dev[] = {sl.d_mag, sl.d_pool, sl.d_pool_used, sl.d_unit_first, sl.d_unit_count, sl.d_unit_live, sl.d_class_bitmap,
-                   sl.d_counters, sl.d_sum_level, sl.d_sum_power, sl.d_fsum_level, sl.d_fsum_power, sl.d_win, sl.d_msg_pos,
+    void *dev[] = {sl.d_mag, sl.d_pool, sl.d_scratch, sl.d_unit_first, sl.d_unit_count, sl.d_unit_live, sl.d_class_bitmap,
+                   sl.d_win, sl.d_msg_pos,
                    sl.d_msg_limit, sl.d_msg_len, sl.d_msg_skip, sl.d_msg_sig};
     for (void *p : dev)
         if (p) (void) hipFree(p);
     if (sl.ev_window) (void) hipEventDestroy(sl.ev_window);
-    void *host[] = {sl.h_live, sl.h_live_sig, sl.h_counters, sl.h_sums, sl.h_fsums, sl.h_win, sl.h_sig, sl.h_total, sl.h_msg_pos,
+    void *host[] = {sl.h_live, sl.h_live_sig, sl.h_scratch, sl.h_win, sl.h_sig, sl.h_msg_pos,
                     sl.h_msg_limit, sl.h_msg_len, sl.h_msg_skip};
     for (void *p : host)
         if (p) (void) hipHostFree(p);
@@ -265,7 +274,6 @@ static int alloc_all(mgpu_ctx *c) {
     const size_t bps = cfg.format == MGPU_FMT_UC8 ? 2 : 4;
 
     HIPCHK(c, hipMalloc(&c->d_iq, n * bps + 64));
-    HIPCHK(c, hipMalloc(&c->d_tail, kTrailing * sizeof(uint16_t)));
     HIPCHK(c, hipMalloc(&c->d_win, 8 * sizeof(unsigned long long)));
     HIPCHK(c, hipHostMalloc(&c->h_win, 8 * sizeof(unsigned long long)));
     HIPCHK(c, hipMalloc(&c->d_adder_bitmap, (1u << 24) / 8));
@@ -347,7 +355,7 @@ void mgpu_destroy(mgpu_ctx *c) {
     if (c->stream2) (void) hipStreamSynchronize(c->stream2);
     for (auto &sl : c->slot) free_slot(sl);
     if (c->h_win) (void) hipHostFree(c->h_win);
-    void *dev[] = {c->d_iq, c->d_tail, c->d_win, c->d_adder_bitmap, c->d_bit_syndrome, c->d_group_syndrome, c->d_parity,
+    void *dev[] = {c->d_iq, c->d_win, c->d_adder_bitmap, c->d_bit_syndrome, c->d_group_syndrome, c->d_parity,
                    c->d_tab_long, c->d_tab_short, c->d_uc8_folded};
     for (void *p : dev)
         if (p) (void) hipFree(p);
@@ -365,7 +373,7 @@ int mgpu_reset(mgpu_ctx *c) {
     std::memset(&c->timing, 0, sizeof(c->timing));
     c->stream_pos = 0;
     c->eof = false;
-    c->have_tail = false;
+    c->tail_src = nullptr;
     c->worker_rc = MGPU_OK;
     HIPCHK(c, hipMemsetAsync(c->d_adder_bitmap, 0, (1u << 24) / 8, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -378,35 +386,25 @@ int mgpu_reset(mgpu_ctx *c) {
 static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
     const mgpu_config &cfg = c->cfg;
     const uint64_t n = sl.n;
-    const uint32_t nbuf = (uint32_t) sl.buffers.size();
     const uint32_t nunits = (uint32_t) ((n + kUnit - 1) / kUnit);
     hipStream_t s = c->stream;
     // the slot's magnitudes / class bitmap / message lists are still read by the window-statistics
     // kernel of its previous use (stream2)
     if (sl.window_pending) { HIPCHK(c, hipStreamWaitEvent(s, sl.ev_window, 0)); sl.window_pending = false; }
-    HIPCHK(c, hipMemsetAsync(sl.d_counters, 0, CNT_NUM * sizeof(unsigned long long), s));
-    HIPCHK(c, hipMemsetAsync(sl.d_pool_used, 0, sizeof(uint32_t), s));
+    HIPCHK(c, hipMemsetAsync(sl.d_scratch, 0, sl.scratch_bytes, s));   // counters, pool_used, per-buffer sums
     HIPCHK(c, hipEventRecord(sl.ev[0], s));
     if (!sl.have_mag) {
-        HIPCHK(c, hipMemsetAsync(sl.d_sum_level, 0, nbuf * sizeof(unsigned long long), s));
-        HIPCHK(c, hipMemsetAsync(sl.d_sum_power, 0, nbuf * sizeof(unsigned long long), s));
-        HIPCHK(c, hipMemsetAsync(sl.d_fsum_level, 0, nbuf * sizeof(double), s));
-        HIPCHK(c, hipMemsetAsync(sl.d_fsum_power, 0, nbuf * sizeof(double), s));
-        // the 326 magnitudes before this chunk (sdr_ifile.c:209-213)
-        if (c->have_tail) HIPCHK(c, hipMemcpyAsync(sl.d_mag, c->d_tail, kTrailing * sizeof(uint16_t), hipMemcpyDeviceToDevice, s));
-        else HIPCHK(c, hipMemsetAsync(sl.d_mag, 0, kTrailing * sizeof(uint16_t), s));
         ConvertParams cp{};
         cp.iq = iq; cp.mag = sl.d_mag; cp.n = n; cp.buf_samples = cfg.buf_samples;
+        cp.tail = c->tail_src;          // the 326 magnitudes before this chunk (sdr_ifile.c:209-213), read in place
         cp.uc8_folded = c->d_uc8_folded;
         cp.sum_level = sl.d_sum_level; cp.sum_power = sl.d_sum_power;
         cp.fsum_level = sl.d_fsum_level; cp.fsum_power = sl.d_fsum_power;
         launch_convert(cfg.format, cp, s);
-        if (n >= (uint64_t) kTrailing) {
-            HIPCHK(c, hipMemcpyAsync(c->d_tail, sl.d_mag + n, kTrailing * sizeof(uint16_t), hipMemcpyDeviceToDevice, s));
-            c->have_tail = true;
-        } else {
-            c->have_tail = false;   // lastbuf->length < trailing_samples -> zeros
-        }
+        // lastbuf->length < trailing_samples -> zeros (only possible for a stream shorter than 326 samples)
+        c->tail_src = n >= (uint64_t) kTrailing ? sl.d_mag + n : nullptr;
+    } else {
+        c->tail_src = sl.d_mag + n;
     }
     HIPCHK(c, hipEventRecord(sl.ev[1], s));
     SweepParams sp{};
@@ -426,15 +424,7 @@ static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
     // pre-screen; the surviving records are written by the kernel straight into pinned host memory
     launch_prescreen(sl.d_pool, sl.d_unit_first, nunits, c->d_adder_bitmap, sl.d_unit_live, sl.h_live, sl.d_mag, sl.h_live_sig,
                      sl.d_counters, s);
-    HIPCHK(c, hipMemcpyAsync(sl.h_counters, sl.d_counters, CNT_NUM * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-    if (nunits) HIPCHK(c, hipMemcpyAsync(sl.h_total, sl.d_unit_live + nunits, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    else sl.h_total[0] = 0;
-    if (!sl.have_mag) {
-        HIPCHK(c, hipMemcpyAsync(sl.h_sums, sl.d_sum_level, nbuf * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipMemcpyAsync(sl.h_sums + nbuf, sl.d_sum_power, nbuf * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipMemcpyAsync(sl.h_fsums, sl.d_fsum_level, nbuf * sizeof(double), hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipMemcpyAsync(sl.h_fsums + nbuf, sl.d_fsum_power, nbuf * sizeof(double), hipMemcpyDeviceToHost, s));
-    }
+    HIPCHK(c, hipMemcpyAsync(sl.h_scratch, sl.d_scratch, sl.scratch_bytes, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipEventRecord(sl.ev[3], s));
     return MGPU_OK;
 }
@@ -460,7 +450,7 @@ static int finish_slot(mgpu_ctx *c, Slot &sl) {
     if (hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]) == hipSuccess) c->acc.convert_ms += ms;
     if (hipEventElapsedTime(&ms, sl.ev[1], sl.ev[2]) == hipSuccess) c->acc.sweep_ms += ms;
     if (hipEventElapsedTime(&ms, sl.ev[2], sl.ev[3]) == hipSuccess) c->acc.prescreen_ms += ms;
-    const uint64_t nlive = sl.h_total[0];
+    const uint64_t nlive = sl.h_counters[CNT_LIVE_TOTAL];
 
     if (const char *dd = getenv("MGPU_DUMP_DIR")) {   // replay material for tools/walk_replay.cpp
         static int dumped = 0;
@@ -521,7 +511,7 @@ static int finish_slot(mgpu_ctx *c, Slot &sl) {
     // what the skip windows hid from the counters: asynchronous on the second stream, totals are
     // accumulated on the device and read once at the end of the feed
     const double t_sig0 = wall_ms();
-    if (nmsg) {
+    if (nmsg && !getenv("MGPU_DEBUG_NO_WINDOW")) {
         hipStream_t s2 = c->stream2;
         HIPCHK(c, hipMemcpyAsync(sl.d_msg_pos, sl.h_msg_pos, nmsg * sizeof(uint32_t), hipMemcpyHostToDevice, s2));
         HIPCHK(c, hipMemcpyAsync(sl.d_msg_limit, sl.h_msg_limit, nmsg * sizeof(uint32_t), hipMemcpyHostToDevice, s2));
@@ -561,8 +551,8 @@ static int finish_slot(mgpu_ctx *c, Slot &sl) {
         }
         double mean_power;
         if (!sl.given_mean_power.empty()) mean_power = sl.given_mean_power[b];
-        else if (cfg.format == MGPU_FMT_UC8) mean_power = (double) sl.h_sums[nbuf + b] / 65535.0 / 65535.0 / bc.length;   // convert.c:105-107
-        else mean_power = sl.h_fsums[nbuf + b] / bc.length;
+        else if (cfg.format == MGPU_FMT_UC8) mean_power = (double) sl.h_sums[c->cap_buffers + b] / 65535.0 / 65535.0 / bc.length;   // convert.c:105-107
+        else mean_power = sl.h_fsums[c->cap_buffers + b] / bc.length;
         const double sum_signal_power = (double) sum_scaled / 65535.0 / 65535.0;
         k.noise_power_sum += (mean_power * bc.length - sum_signal_power);
         k.noise_power_count += bc.length;
@@ -685,16 +675,16 @@ static int feed_common(mgpu_ctx *c, const void *src, bool src_is_device, uint64_
     }
     // software pipeline over chunks: GPU works on chunk i+1 while the worker walks chunk i
     int rc = MGPU_OK;
-    int k = 0;
-    for (uint64_t off = 0; off < n && rc == MGPU_OK; off += c->chunk_samples, ++k) {
+    for (uint64_t off = 0; off < n && rc == MGPU_OK; off += c->chunk_samples) {
         const uint64_t len = n - off < c->chunk_samples ? n - off : c->chunk_samples;
-        Slot &sl = acquire_slot(c, k & 1);
+        const int k = (int) (c->chunk_seq++ & 1);
+        Slot &sl = acquire_slot(c, k);
         sl.n = len;
         sl.have_mag = false;
         sl.given_mean_power.clear();
         ifile_grid(c, c->stream_pos + off, len, sl.buffers);
         rc = enqueue_slot(c, sl, iq + off * bps);
-        submit_slot(c, k & 1);   // even after an enqueue error: the worker releases the slot
+        submit_slot(c, k);   // even after an enqueue error: the worker releases the slot
         if (rc != MGPU_OK) { std::lock_guard<std::mutex> lk(c->mu); if (c->worker_rc == MGPU_OK) c->worker_rc = rc; }
     }
     const int wrc = wait_all(c);
@@ -818,7 +808,8 @@ int mgpu_demod_mag_buf(mgpu_ctx *c, const uint16_t *data, uint32_t length, int64
     }
     const double t_start = wall_ms();
     { int brc = feed_begin(c); if (brc != MGPU_OK) return brc; }
-    Slot &sl = acquire_slot(c, 0);
+    const int slot_idx = (int) (c->chunk_seq++ & 1);
+    Slot &sl = acquire_slot(c, slot_idx);
     sl.n = length;
     sl.have_mag = true;
     sl.given_mean_power.assign(1, mean_power);
@@ -829,7 +820,7 @@ int mgpu_demod_mag_buf(mgpu_ctx *c, const uint16_t *data, uint32_t length, int64
         if (e != hipSuccess) { c->err = std::string("H2D of the magnitude buffer: ") + hipGetErrorString(e); rc = MGPU_E_HIP; }
     }
     if (rc == MGPU_OK) rc = enqueue_slot(c, sl, nullptr);
-    submit_slot(c, 0);
+    submit_slot(c, slot_idx);
     if (rc != MGPU_OK) { std::lock_guard<std::mutex> lk(c->mu); if (c->worker_rc == MGPU_OK) c->worker_rc = rc; }
     const int wrc = wait_all(c);
     if (rc == MGPU_OK) rc = wrc;

@@ -66,6 +66,7 @@ enum {
     CNT_CLASS_COND = 8,      // candidates whose records are all conditional (REC_COND)
     CNT_CLASS_UNCOND = 9,    // candidates with >= 1 unconditional record
     CNT_DEBUG0 = 16,         // .. 31: cycle counters of k_sweep_slice's stages (thread 0 of every workgroup)
+    CNT_LIVE_TOTAL = 31,     // records surviving the pre-screen (written by k_scan_units)
     CNT_NUM = 32,
 };
 
@@ -99,7 +100,7 @@ struct ConvertParams {
     uint16_t *mag;            // d_mag (written from index kTrailing on)
     uint64_t n;
     uint32_t buf_samples;
-    uint64_t first_buffer_offset;   // always 0: feeds start on the buffer grid
+    const uint16_t *tail;           // 326 magnitudes preceding the chunk (device), nullptr = zeros
     const uint16_t *uc8_folded;     // device copy of the folded UC8 table
     unsigned long long *sum_level;  // [nbuffers] UC8: exact integer sum of mag
     unsigned long long *sum_power;  // [nbuffers] UC8: exact integer sum of mag^2

@@ -99,15 +99,30 @@ struct BufSums {
     }
 };
 
+// d_mag[0 .. 326) = the 326 magnitudes that preceded this chunk (sdr_ifile.c:209-213): copied from the
+// end of the previous chunk's magnitude buffer (p.tail) or zero at stream start, by workgroup 0.
+__device__ __forceinline__ void convert_tail_prologue(const ConvertParams &p) {
+    if (blockIdx.x != 0) return;
+    for (int i = threadIdx.x; i < kTrailing; i += kBlock) p.mag[i] = p.tail ? p.tail[i] : (uint16_t) 0;
+}
+
 // UC8: magnitude = table[I | Q<<8] (convert.c:64-108).  The 65536-entry table has two mirror
 // symmetries (I -> 255-I, Q -> 255-Q) so a 128x128 quadrant, padded to an odd-ish row stride,
 // is staged in LDS (33 KB) and every sample is one ds_read_u16.
 // Thread work item: one 16-byte-aligned chunk of 8 output magnitudes d_mag[8c .. 8c+8) =
 // samples 8c-326 .. 8c-319; the 16 IQ bytes are one (4-byte aligned) global_load_dwordx4.
 __global__ __launch_bounds__(kBlock) void k_convert_uc8(ConvertParams p) {
-    __shared__ uint16_t s_lut[128 * UC8_FOLD_STRIDE];
-    for (int i = threadIdx.x; i < 128 * UC8_FOLD_STRIDE / 2; i += kBlock)
-        ((uint32_t *) s_lut)[i] = ((const uint32_t *) p.uc8_folded)[i];
+    __shared__ __attribute__((aligned(16))) uint16_t s_lut[128 * UC8_FOLD_STRIDE];
+    {   // 33 KB table: all of a thread's 16-byte loads are issued before the first LDS store
+        constexpr int kVec = 128 * UC8_FOLD_STRIDE / 8;                 // 2080 x 16 B
+        constexpr int kPer = (kVec + kBlock - 1) / kBlock;
+        u32x4 t[kPer];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) { const int i = threadIdx.x + k * kBlock; if (i < kVec) t[k] = ((const u32x4 *) p.uc8_folded)[i]; }
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) { const int i = threadIdx.x + k * kBlock; if (i < kVec) ((u32x4 *) s_lut)[i] = t[k]; }
+    }
+    convert_tail_prologue(p);
     __syncthreads();
 
     const uint64_t c_first = kTrailing / 8;                       // chunk holding d_mag[326]
@@ -196,6 +211,7 @@ __global__ __launch_bounds__(kBlock) void k_convert_uc8(ConvertParams p) {
 template <int SCALE_SHIFT>
 __global__ __launch_bounds__(kBlock) void k_convert_sc16(ConvertParams p) {
 #pragma clang fp contract(off)
+    convert_tail_prologue(p);
     const uint64_t c_first = kTrailing / 8;
     const uint64_t c_end = (kTrailing + p.n + 7) / 8;
     const uint64_t nchunks = c_end - c_first;
@@ -1196,10 +1212,10 @@ constexpr int kWT = kWaveTile;
 constexpr int kWTChunks = (kWT + kHalo) / 8;                 // 16-byte chunks per tile (294)
 constexpr int kWPre = (kWTChunks + WAVE - 1) / WAVE;         // 16-byte loads per lane and tile (5)
 constexpr int kWStep = WAVE * 8;                             // positions per sweep step (512)
-constexpr int kWCQCap = kWStep + 64;                         // candidate queue (drained when > 64 wait)
+constexpr int kWCQCap = kWStep + 32;                         // candidate queue (drained when > 32 wait)
 constexpr int kWVCap = 128;                                  // ring of valid pairs (power of two)
 constexpr int kWFrames = WAVE / 4;                           // frames sliced per round (16)
-constexpr int kWStageCap = 32;                               // staged records per wave
+constexpr int kWStageCap = 24;                               // staged records per wave (4 workgroups per CU must fit in 160 KB)
 constexpr int kWAdderCache = 256;
 
 struct WaveLds {                                             // wave-private LDS, 16-byte aligned members first
@@ -1653,7 +1669,7 @@ __global__ __launch_bounds__(1024) void k_scan_units(uint32_t *unit_live, uint32
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { unit_live[n] = s_carry; (void) counters; }
+    if (threadIdx.x == 0) { unit_live[n] = s_carry; if (counters) counters[CNT_LIVE_TOTAL] = s_carry; }
 }
 
 void launch_prescreen(const PhaseRec *pool, const uint32_t *unit_first, uint32_t nunits, const uint32_t *adder_bitmap,

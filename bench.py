@@ -136,6 +136,15 @@ def main():
         sweep = float(np.mean(sweep_ms))                  # per step: sum over the step's launches
         nlaunch = int(np.mean(launches))
         achieved = n * SWEEP_BYTES_PER_SAMPLE / (sweep * 1e-3) / 1e9
+        # HBM traffic of one k_sweep_slice launch from the committed rocprofv3 PMC passes of this same
+        # command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, tools/pmc_summary.py); null if the launch size differs
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_final_pmc_hbm.json")))
+            if int(n * SWEEP_BYTES_PER_SAMPLE / nlaunch) == 134217728:
+                traffic = round(pm["mgpu::k_sweep_slice"]["hbm_bytes"])
+        except Exception:
+            traffic = None
         out = {
             "metric": "IQ Msamples/s demodulated (UC8 2.4 MSps stream, --fix), whole job",
             "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -152,7 +161,7 @@ def main():
                          "resolve_host": round(float(np.mean(resolve_ms)), 3), "sigpower": round(tm["sigpower_ms"], 3),
                          "feed_total": round(float(np.mean(total_ms)), 3)},
             "roofline": {"kernel": "k_sweep_slice", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "launches_per_step": nlaunch, "algorithmic_bytes_per_launch": int(n * SWEEP_BYTES_PER_SAMPLE / nlaunch),
                          "avg_launch_ms": round(sweep / nlaunch, 4)},
             "synth_gen_s": round(t_gen, 2),

@@ -1,0 +1,18 @@
+#!/bin/bash
+# rocprofv3 evidence for bench.py's roofline numbers: kernel trace + stats, then one --pmc pass per
+# counter (FETCH_SIZE, WRITE_SIZE) as MI355X_MICROARCH.md prescribes.  Run on the GPU box via gpurun;
+# copy the summaries from gpurun_out/ into profiles/ afterwards.
+#   usage: tools/profile_round.sh <tag>
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+tag=${1:-r01}
+out=$R/gpurun_out/$tag
+mkdir -p $out
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python $R/bench.py --steps 5 --warmup 1 > $out/bench_under_rocprof.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/pmc_fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/pmc_write.log 2>&1
+cd $R
+timeout 200 python bench.py --steps 10 --warmup 2 > $out/bench_plain.log 2>&1
+tail -1 $out/bench_plain.log | cut -c1-400
+cat $out/stats/bench_kernel_stats.csv | cut -c1-160

@@ -1208,6 +1208,12 @@ void launch_sweep_slice_v2(const SweepParams &p, hipStream_t s) {
 // Shared by the workgroup (read-only after the preload, or benign races): group-syndrome tables,
 // syndrome keys, the adder-address cache.
 // ---------------------------------------------------------------------------------------------
+// Register prefetch of the next tile costs 20 VGPRs and keeps the kernel at 3 waves/SIMD (151 VGPRs).
+// Measured alternative: -DMGPU_V3_PREFETCH=0 fits 4 waves/SIMD (128 VGPRs, no spills) but is 9 % slower
+// (4.91 vs 4.52 ms per 537 M positions): the exposed tile-load latency costs more than the fourth wave hides.
+#ifndef MGPU_V3_PREFETCH
+#define MGPU_V3_PREFETCH 1
+#endif
 constexpr int kWT = kWaveTile;
 constexpr int kWTChunks = (kWT + kHalo) / 8;                 // 16-byte chunks per tile (294)
 constexpr int kWPre = (kWTChunks + WAVE - 1) / WAVE;         // 16-byte loads per lane and tile (5)
@@ -1229,7 +1235,7 @@ struct WaveLds {                                             // wave-private LDS
 
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
-__global__ __launch_bounds__(kBlock) void k_sweep_slice(SweepParams p) {
+__global__ __launch_bounds__(kBlock, MGPU_V3_PREFETCH ? 3 : 4) void k_sweep_slice(SweepParams p) {
     __shared__ __attribute__((aligned(16))) WaveLds s_w[kBlock / WAVE];
     __shared__ uint32_t s_gsyn[(kGroupsLong + kGroupsShort) * 32];
     __shared__ uint32_t s_acache[kWAdderCache];
@@ -1314,7 +1320,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_slice(SweepParams p) {
                 uint64_t Dn = D0 + kWT;
                 bool next_unit = false;
                 if (tile + 1 >= kUnit / kWT || Dn >= p.n) { Dn = (uint64_t) (unit + nwaves) * kUnit; next_unit = true; }
-                have_pre = next_unit ? (unit + nwaves < p.nunits) : true;
+                have_pre = MGPU_V3_PREFETCH && (next_unit ? (unit + nwaves < p.nunits) : true);
                 if (have_pre) {
 #pragma unroll
                     for (int k = 0; k < kWPre; ++k) {

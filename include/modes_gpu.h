@@ -105,7 +105,7 @@ struct mgpu_counters {
 struct mgpu_timing {
     float h2d_ms;        /* host->device copy of the IQ block (0 for resident input) */
     float convert_ms;    /* k_convert_* */
-    float sweep_ms;      /* k_sweep_slice: preamble sweep + bit slicer + CRC, the roofline kernel */
+    float sweep_ms;      /* k_sweep: the preamble sweep, the roofline kernel (fused generations: sweep + slicer) */
     float prescreen_ms;  /* record pre-screen + compaction */
     float resolve_ms;    /* ordered accept / skip-ahead / ICAO filter walk (host wall time) */
     float sigpower_ms;   /* host time spent launching the skip-window statistics kernel */
@@ -116,6 +116,8 @@ struct mgpu_timing {
     uint64_t n_live_records; /* records that survived the pre-screen (reach the ordered walk) */
     uint64_t n_messages;     /* accepted messages */
     uint64_t n_chunks;       /* pipeline chunks = launches of each kernel; the *_ms fields above are sums over them */
+    float slice_ms;          /* k_slice (bit slicer + CRC + score); sweep_ms is then k_sweep alone */
+    float reserved1;
 };
 
 /* ---- lifecycle -------------------------------------------------------------------- */

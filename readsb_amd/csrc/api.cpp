@@ -44,6 +44,9 @@ struct Slot {
     uint16_t *d_mag = nullptr;
     PhaseRec *d_pool = nullptr;
     uint32_t *d_pool_used = nullptr, *d_unit_first = nullptr, *d_unit_count = nullptr, *d_unit_live = nullptr, *d_class_bitmap = nullptr;
+    uint32_t *d_class_uncond = nullptr, *d_cand_count = nullptr;
+    uint16_t *d_cand = nullptr;
+    size_t class_bytes = 0;
     // one zero-initialised scratch block per chunk: counters | pool_used | per-buffer sums (1 memset, 1 copy back)
     unsigned long long *d_scratch = nullptr, *h_scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -60,7 +63,7 @@ struct Slot {
     double *h_fsums = nullptr;
     uint32_t *h_msg_pos = nullptr, *h_msg_limit = nullptr;
     uint16_t *h_msg_len = nullptr, *h_msg_skip = nullptr;
-    hipEvent_t ev[4] = {};
+    hipEvent_t ev[5] = {};
     // the job
     uint64_t n = 0;
     bool have_mag = false, busy = false;
@@ -104,7 +107,7 @@ struct mgpu_ctx {
     mgpu_timing timing{}, acc{};
     uint64_t stream_pos = 0;
     bool eof = false;
-    int sweep_version = 3;     // MGPU_SWEEP_VERSION=1|2: earlier generations of k_sweep_slice (A/B measurements)
+    int sweep_version = 4;     // MGPU_SWEEP_VERSION=1|2|3: earlier (fused) generations of the sweep/slice stage (A/B measurements)
 
     // worker thread: ordered walk + signal power of the slots, in submission order
     std::thread worker;
@@ -201,7 +204,11 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
     HIPCHK(c, hipMalloc(&sl.d_unit_first, (c->cap_units + 1) * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc(&sl.d_unit_count, (c->cap_units + 1) * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc(&sl.d_unit_live, (c->cap_units + 2) * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc(&sl.d_class_bitmap, (mag_len / 32 + 64) * sizeof(uint32_t)));
+    sl.class_bytes = (mag_len / 32 + 64) * sizeof(uint32_t);
+    HIPCHK(c, hipMalloc(&sl.d_class_bitmap, sl.class_bytes));
+    HIPCHK(c, hipMalloc(&sl.d_class_uncond, sl.class_bytes));
+    HIPCHK(c, hipMalloc(&sl.d_cand, (c->cap_units * (size_t) kUnit + 64) * sizeof(uint16_t)));
+    HIPCHK(c, hipMalloc(&sl.d_cand_count, (c->cap_units + 1) * sizeof(uint32_t)));
     {
         const size_t nb = c->cap_buffers, words = CNT_NUM + 1 + 4 * nb;
         sl.scratch_bytes = words * sizeof(unsigned long long);
@@ -238,6 +245,7 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
 
 static void free_slot(Slot &sl) {
     void *dev[] = {sl.d_mag, sl.d_pool, sl.d_scratch, sl.d_unit_first, sl.d_unit_count, sl.d_unit_live, sl.d_class_bitmap,
+                   sl.d_class_uncond, sl.d_cand, sl.d_cand_count,
                    sl.d_win, sl.d_msg_pos,
                    sl.d_msg_limit, sl.d_msg_len, sl.d_msg_skip, sl.d_msg_sig};
     for (void *p : dev)
@@ -321,7 +329,7 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     mgpu_ctx *c = new (std::nothrow) mgpu_ctx();
     if (!c) return MGPU_E_NOMEM;
     c->cfg = *cfg;
-    if (const char *e = getenv("MGPU_SWEEP_VERSION")) { const int v = atoi(e); if (v >= 1 && v <= 3) c->sweep_version = v; }
+    if (const char *e = getenv("MGPU_SWEEP_VERSION")) { const int v = atoi(e); if (v >= 1 && v <= 4) c->sweep_version = v; }
     if (hipSetDevice(cfg->device) != hipSuccess) { delete c; return MGPU_E_NODEVICE; }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { mgpu_destroy(c); return MGPU_E_HIP; }
@@ -417,9 +425,18 @@ static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
     sp.unit_first = sl.d_unit_first; sp.unit_count = sl.d_unit_count; sp.nunits = nunits;
     { const char *e = getenv("MGPU_DEBUG_STAGE"); sp.debug_stage = e ? atoi(e) : 0; }
     sp.adder_bitmap = c->d_adder_bitmap; sp.class_bitmap = sl.d_class_bitmap; sp.counters = sl.d_counters;
+    sp.cand = sl.d_cand; sp.cand_count = sl.d_cand_count; sp.class_uncond = sl.d_class_uncond;
     if (c->sweep_version == 1) launch_sweep_slice_v1(sp, s);
     else if (c->sweep_version == 2) launch_sweep_slice_v2(sp, s);
-    else launch_sweep_slice(sp, s);
+    else if (c->sweep_version == 3) launch_sweep_slice(sp, s);
+    else {
+        const size_t cb = ((size_t) ((n + 31) / 32) + 1) * sizeof(uint32_t);
+        HIPCHK(c, hipMemsetAsync(sl.d_class_bitmap, 0, cb, s));
+        HIPCHK(c, hipMemsetAsync(sl.d_class_uncond, 0, cb, s));
+        launch_sweep(sp, s);
+        HIPCHK(c, hipEventRecord(sl.ev[4], s));
+        launch_slice(sp, s);
+    }
     HIPCHK(c, hipEventRecord(sl.ev[2], s));
     // pre-screen; the surviving records are written by the kernel straight into pinned host memory
     launch_prescreen(sl.d_pool, sl.d_unit_first, nunits, c->d_adder_bitmap, sl.d_unit_live, sl.h_live, sl.d_mag, sl.h_live_sig,
@@ -439,8 +456,8 @@ static int finish_slot(mgpu_ctx *c, Slot &sl) {
         const unsigned long long *h = sl.h_counters;
         fprintf(stderr, "dbg: stage_b cycles %llu calls %llu frames %llu block cycles %llu slice %llu classify %llu records %llu\n",
                 h[10], h[11], h[12], h[13], h[14], h[15], h[CNT_RECORDS]);
-        fprintf(stderr, "dbg: per-tile cycles: stage %llu sweep %llu drainA %llu stageB %llu tail %llu | stage: barrier0 %llu loads %llu\n",
-                h[16], h[17], h[18], h[19], h[20], h[21], h[22]);
+        fprintf(stderr, "dbg: v3 wave cycles: sweep %llu expand %llu stageA %llu slice %llu classify %llu emit %llu total %llu | rounds A %llu B %llu\n",
+                h[16], h[17], h[18], h[19], h[20], h[21], h[22], h[23], h[24]);
     }
     if (sl.h_counters[CNT_POOL_OVERFLOW]) {
         c->err = "record pool overflow: recreate the context with a larger record_pool_records";
@@ -448,7 +465,10 @@ static int finish_slot(mgpu_ctx *c, Slot &sl) {
     }
     float ms;
     if (hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]) == hipSuccess) c->acc.convert_ms += ms;
-    if (hipEventElapsedTime(&ms, sl.ev[1], sl.ev[2]) == hipSuccess) c->acc.sweep_ms += ms;
+    if (c->sweep_version == 4) {
+        if (hipEventElapsedTime(&ms, sl.ev[1], sl.ev[4]) == hipSuccess) c->acc.sweep_ms += ms;
+        if (hipEventElapsedTime(&ms, sl.ev[4], sl.ev[2]) == hipSuccess) c->acc.slice_ms += ms;
+    } else if (hipEventElapsedTime(&ms, sl.ev[1], sl.ev[2]) == hipSuccess) c->acc.sweep_ms += ms;
     if (hipEventElapsedTime(&ms, sl.ev[2], sl.ev[3]) == hipSuccess) c->acc.prescreen_ms += ms;
     const uint64_t nlive = sl.h_counters[CNT_LIVE_TOTAL];
 

@@ -89,8 +89,11 @@ struct SweepParams {
     uint32_t *unit_first;     // [nunits] index of the unit's first segment header, kNone if empty
     uint32_t *unit_count;     // [nunits] records of the unit (without headers)
     uint32_t nunits;
+    uint16_t *cand;           // generation 4: per-unit candidate codes (pos_in_unit<<3 | phase mask), kUnit slots per unit
+    uint32_t *cand_count;     // [nunits]
     uint32_t *adder_bitmap;   // 2^24 bits: addresses some clean DF17 / DF11 IID 0 frame carries
     uint32_t *class_bitmap;   // 1 bit per scan position: candidate whose records are all conditional
+    uint32_t *class_uncond;   // generation 4 scratch plane: candidate with >= 1 unconditional record (both planes zeroed per chunk)
     unsigned long long *counters;   // [CNT_NUM]
     int32_t debug_stage;      // 0 = full; 1 = sweep only; 2 = sweep + DF stage (timing experiments, MGPU_DEBUG_STAGE)
 };
@@ -109,7 +112,9 @@ struct ConvertParams {
 };
 
 void launch_convert(int format, const ConvertParams &p, hipStream_t s);
-void launch_sweep_slice(const SweepParams &p, hipStream_t s);      // wave-autonomous sweep + lane-per-frame slicer
+void launch_sweep(const SweepParams &p, hipStream_t s);            // generation 4: k_sweep (streaming preamble sweep -> candidate lists)
+void launch_slice(const SweepParams &p, hipStream_t s);            //               k_slice (frames sliced straight from HBM/L2, no LDS tile)
+void launch_sweep_slice(const SweepParams &p, hipStream_t s);      // generation 3: fused, wave-autonomous LDS tiles
 void launch_sweep_slice_v2(const SweepParams &p, hipStream_t s);   // second version: workgroup tiles, block barriers
 void launch_sweep_slice_v1(const SweepParams &p, hipStream_t s);   // first version: wave per candidate
 // pre-screen: count / write the records whose address may matter to the ordered walk

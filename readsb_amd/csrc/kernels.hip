@@ -1258,6 +1258,8 @@ __global__ __launch_bounds__(kBlock, MGPU_V3_PREFETCH ? 3 : 4) void k_sweep_slic
 
     uint32_t n_cand = 0, n_ph[3] = {0, 0, 0}, n_cls_cond = 0, n_cls_uncond = 0, n_rec = 0;
     uint32_t chunk_base = 0, chunk_left = 0;     // wave-uniform: reserved pool space
+    long long tm_sweep = 0, tm_expand = 0, tm_a = 0, tm_slice = 0, tm_class = 0, tm_emit = 0, tm_load = 0, n_rounds_b = 0, n_rounds_a = 0;
+    const long long tm_t0 = DBG_CLOCK();
     u32x4 pre[kWPre];
     bool have_pre = false;
 
@@ -1335,6 +1337,7 @@ __global__ __launch_bounds__(kBlock, MGPU_V3_PREFETCH ? 3 : 4) void k_sweep_slic
 
             // ---- slicing: 4 lanes per frame, 16 frames per round ----
             auto stage_b = [&](int take) __attribute__((always_inline)) {
+                const long long tq0 = DBG_CLOCK();
                 const int quad = lane >> 2, qj = lane & 3;
                 const bool have = quad < take;
                 uint32_t e = 0, chunk = 0, psyn = 0, df = 0;
@@ -1354,6 +1357,7 @@ __global__ __launch_bounds__(kBlock, MGPU_V3_PREFETCH ? 3 : 4) void k_sweep_slic
                 }
                 const uint32_t c0 = quad_bcast<0>(chunk), c1 = quad_bcast<1>(chunk), c2 = quad_bcast<2>(chunk), c3 = quad_bcast<3>(chunk);
                 const uint32_t sx = quad_bcast<0>(psyn) ^ quad_bcast<1>(psyn) ^ quad_bcast<2>(psyn) ^ quad_bcast<3>(psyn);
+                const long long tq1 = DBG_CLOCK();
                 bool emit = false;
                 u32x4 ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0};
                 if (have && qj == 0) {
@@ -1433,6 +1437,7 @@ __global__ __launch_bounds__(kBlock, MGPU_V3_PREFETCH ? 3 : 4) void k_sweep_slic
                         }
                     }
                 }
+                const long long tq2 = DBG_CLOCK();
                 const uint64_t em = __ballot(emit);
                 if (emit) {
                     u32x4 *d = (u32x4 *) &L.stage[scount + __popcll(em & lt_mask)];
@@ -1443,11 +1448,13 @@ __global__ __launch_bounds__(kBlock, MGPU_V3_PREFETCH ? 3 : 4) void k_sweep_slic
                 vcount -= take;
                 WAVE_SYNC();
                 if (scount > kWStageCap - kWFrames) flush();
+                tm_slice += tq1 - tq0; tm_class += tq2 - tq1; tm_emit += DBG_CLOCK() - tq2; n_rounds_b += 1;
             };
 
             // ---- candidates -> pairs -> DF stage -> ring ----
             auto drain = [&]() __attribute__((always_inline)) {
                 for (int c0 = 0; c0 < ccount; c0 += WAVE) {
+                    const long long te0 = DBG_CLOCK();
                     const int ci = c0 + lane;
                     const uint32_t code = ci < ccount ? L.cq[ci] : 0u;
                     const uint32_t mask = code & 7u;
@@ -1459,7 +1466,9 @@ __global__ __launch_bounds__(kBlock, MGPU_V3_PREFETCH ? 3 : 4) void k_sweep_slic
                     if (mask & 2u) { L.pairs[off++] = (uint16_t) (pl | 2u); L.pairs[off++] = (uint16_t) (pl | 3u); }
                     if (mask & 4u) { L.pairs[off++] = (uint16_t) (pl | 4u); }
                     WAVE_SYNC();
+                    tm_expand += DBG_CLOCK() - te0;
                     for (int a0 = 0; a0 < npairs; a0 += WAVE) {
+                        const long long ta0 = DBG_CLOCK();
                         const int j = a0 + lane;
                         bool valid = false;
                         uint32_t entry = 0;
@@ -1475,6 +1484,7 @@ __global__ __launch_bounds__(kBlock, MGPU_V3_PREFETCH ? 3 : 4) void k_sweep_slic
                         if (valid) L.v[(vhead + vcount + __popcll(vm & lt_mask)) & (kWVCap - 1)] = entry;
                         vcount += __popcll(vm);
                         WAVE_SYNC();
+                        tm_a += DBG_CLOCK() - ta0; n_rounds_a += 1;
                         while (vcount >= kWFrames) stage_b(kWFrames);
                     }
                 }
@@ -1485,6 +1495,7 @@ __global__ __launch_bounds__(kBlock, MGPU_V3_PREFETCH ? 3 : 4) void k_sweep_slic
             for (int sub = 0; sub < kWT / kWStep; ++sub) {
                 if (D0 + (uint64_t) sub * kWStep >= p.n) break;
                 if (ccount > kWCQCap - kWStep) drain();
+                const long long ts0 = DBG_CLOCK();
                 const int p0 = sub * kWStep + lane * 8;
                 uint32_t w[13];
                 {
@@ -1529,6 +1540,7 @@ __global__ __launch_bounds__(kBlock, MGPU_V3_PREFETCH ? 3 : 4) void k_sweep_slic
                     ccount += total;
                     WAVE_SYNC();
                 }
+                tm_sweep += DBG_CLOCK() - ts0;
             }
             drain();
             while (vcount > 0) stage_b(vcount < kWFrames ? vcount : kWFrames);
@@ -1552,6 +1564,16 @@ __global__ __launch_bounds__(kBlock, MGPU_V3_PREFETCH ? 3 : 4) void k_sweep_slic
     atomicAdd(&s_cnt[CNT_CLASS_COND], (unsigned long long) n_cls_cond);
     atomicAdd(&s_cnt[CNT_CLASS_UNCOND], (unsigned long long) n_cls_uncond);
     if (lane == 0) atomicAdd(&s_cnt[CNT_RECORDS], (unsigned long long) n_rec);
+#if MGPU_KERNEL_TIMERS
+    if (lane == 0) {
+        atomicAdd(&s_cnt[16], (unsigned long long) tm_sweep); atomicAdd(&s_cnt[17], (unsigned long long) tm_expand);
+        atomicAdd(&s_cnt[18], (unsigned long long) tm_a); atomicAdd(&s_cnt[19], (unsigned long long) tm_slice);
+        atomicAdd(&s_cnt[20], (unsigned long long) tm_class); atomicAdd(&s_cnt[21], (unsigned long long) tm_emit);
+        atomicAdd(&s_cnt[22], (unsigned long long) (DBG_CLOCK() - tm_t0)); atomicAdd(&s_cnt[23], (unsigned long long) n_rounds_a);
+        atomicAdd(&s_cnt[24], (unsigned long long) n_rounds_b);
+    }
+#endif
+    (void) tm_load;
     __syncthreads();
     if (tid < CNT_NUM && s_cnt[tid]) {
         unsigned long long v = s_cnt[tid];
@@ -1579,6 +1601,379 @@ void launch_sweep_slice(const SweepParams &p, hipStream_t s) {
     const unsigned want = (p.nunits + (kBlock / WAVE) - 1) / (kBlock / WAVE);
     const unsigned blocks = want < maxb ? want : maxb;
     hipLaunchKernelGGL(k_sweep_slice, dim3(blocks), dim3(kBlock), dyn, s, p);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generation 4: the sweep and the slicer are separate kernels.
+//
+//   k_sweep  pure streaming: every magnitude is read once (16-byte loads, no LDS), each lane evaluates
+//            8 consecutive positions from a 26-sample register window and the wave appends the
+//            candidates of its unit, in position order, to the unit's slice of `cand`.  This is the
+//            kernel the HBM roofline applies to: 2 bytes per position in, ~1 % of positions out.
+//   k_slice  one wave per unit again, but it only touches the samples frames actually need
+//            (~1 % of positions x 5 rows x 2 dwords for the DF stage, 22 groups x 11 dwords for the
+//            ~0.4 % that survive it), read straight from global memory: the chunk's magnitudes
+//            (134 MB) were just streamed and sit in the 256 MB Infinity Cache.  No LDS tile, so the
+//            occupancy is set by registers alone and the slicer's latency no longer stalls the sweep.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSwStep = WAVE * 8;        // positions per wave step
+
+__global__ __launch_bounds__(kBlock) void k_sweep(SweepParams p) {
+    __shared__ unsigned long long s_cnt[8];
+    const int tid = threadIdx.x, lane = lane_id();
+    if (tid < 8) s_cnt[tid] = 0;
+    __syncthreads();
+    const uint32_t wave_global = blockIdx.x * (kBlock / WAVE) + (tid >> 6);
+    const uint32_t nwaves = gridDim.x * (kBlock / WAVE);
+    uint32_t n_cand = 0, n_ph[3] = {0, 0, 0};
+
+    for (uint32_t unit = wave_global; unit < p.nunits; unit += nwaves) {
+        const uint64_t U0 = (uint64_t) unit * kUnit;
+        uint16_t *out = p.cand + U0;
+        int count = 0;
+        u32x4 a, b, c;
+        uint32_t d;
+        {
+            const uint16_t *src = p.mag + U0 + lane * 8;
+            a = *(const u32x4 *) src; b = *(const u32x4 *) (src + 8); c = *(const u32x4 *) (src + 16); d = *(const uint32_t *) (src + 24);
+        }
+        for (int step = 0; step < kUnit / kSwStep; ++step) {
+            const uint64_t S0 = U0 + (uint64_t) step * kSwStep;
+            if (S0 >= p.n) break;
+            uint32_t w[13] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d};
+            if (step + 1 < kUnit / kSwStep && S0 + kSwStep < p.n) {      // next step's window while this one is evaluated
+                const uint16_t *src = p.mag + S0 + kSwStep + lane * 8;
+                a = *(const u32x4 *) src; b = *(const u32x4 *) (src + 8); c = *(const u32x4 *) (src + 16); d = *(const uint32_t *) (src + 24);
+            }
+            const uint64_t P0 = S0 + (uint64_t) lane * 8;
+            uint32_t f = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+#define SM(i) ((int) ((w[((e) + (i)) >> 1] >> ((((e) + (i)) & 1) * 16)) & 0xffffu))
+                const bool pc = SM(1) > SM(7) && SM(12) > SM(14) && SM(12) > SM(15);
+                const int base_noise = SM(5) + SM(8) + SM(16) + SM(17) + SM(18);
+                const int ref = (base_noise * p.thr) >> 5;
+                const int d23 = SM(2) - SM(3), s14 = SM(1) + SM(4), d1011 = SM(10) - SM(11);
+                const int common = s14 - d23 + SM(9) + SM(12);
+                uint32_t m = 0;
+                if (common - d1011 >= ref) m |= 1;
+                if (common + d1011 >= ref) m |= 2;
+                if (s14 + 2 * d23 + d1011 + SM(12) >= ref) m |= 4;
+#undef SM
+                if (!pc || P0 + e >= p.n) m = 0;
+                f |= m << (3 * e);
+            }
+            const uint32_t nz = (f | (f >> 1) | (f >> 2)) & 0x249249u;
+            const int cnt = __popc(nz);
+            n_cand += cnt;
+            n_ph[0] += __popc(f & 0x249249u);
+            n_ph[1] += __popc((f >> 1) & 0x249249u);
+            n_ph[2] += __popc((f >> 2) & 0x249249u);
+            if (__ballot(cnt != 0)) {
+                int total;
+                int dst = count + wave_excl_scan(cnt, total);
+                const int pl0 = step * kSwStep + lane * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint32_t m = (f >> (3 * e)) & 7u;
+                    if (m) out[dst++] = (uint16_t) (((pl0 + e) << 3) | m);
+                }
+                count += total;
+            }
+        }
+        if (lane == 0) p.cand_count[unit] = (uint32_t) count;
+    }
+    atomicAdd(&s_cnt[0], (unsigned long long) n_cand);
+    atomicAdd(&s_cnt[1], (unsigned long long) n_ph[0]);
+    atomicAdd(&s_cnt[2], (unsigned long long) n_ph[1]);
+    atomicAdd(&s_cnt[3], (unsigned long long) n_ph[2]);
+    __syncthreads();
+    if (tid == 0 && s_cnt[0]) atomicAdd(&p.counters[CNT_CANDIDATES], s_cnt[0]);
+    if (tid == 1 && s_cnt[1]) { atomicAdd(&p.counters[CNT_PHASE0 + 0], s_cnt[1]); atomicAdd(&p.counters[CNT_PHASE0 + 1], s_cnt[1]); }
+    if (tid == 2 && s_cnt[2]) { atomicAdd(&p.counters[CNT_PHASE0 + 2], s_cnt[2]); atomicAdd(&p.counters[CNT_PHASE0 + 3], s_cnt[2]); }
+    if (tid == 3 && s_cnt[3]) atomicAdd(&p.counters[CNT_PHASE0 + 4], s_cnt[3]);
+}
+
+struct SliceLds {                                            // wave-private LDS of k_slice
+    PhaseRec stage[kWStageCap];
+    uint16_t pairs[WAVE * 5];
+    uint32_t v[kWVCap];
+};
+
+__global__ __launch_bounds__(kBlock) void k_slice(SweepParams p) {
+    __shared__ __attribute__((aligned(16))) SliceLds s_w[kBlock / WAVE];
+    __shared__ uint32_t s_gsyn[(kGroupsLong + kGroupsShort) * 32];
+    __shared__ uint32_t s_acache[kWAdderCache];
+    __shared__ unsigned long long s_cnt[4];
+    extern __shared__ uint32_t s_keys[];
+
+    const int tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    for (int i = tid; i < (kGroupsLong + kGroupsShort) * 32; i += kBlock) s_gsyn[i] = p.group_syndrome[i];
+    for (int i = tid; i < kWAdderCache; i += kBlock) s_acache[i] = 0xFFFFFFFFu;
+    for (int i = tid; i < p.n_long; i += kBlock) s_keys[i] = (uint32_t) (p.tab_long[i] >> 16);
+    for (int i = tid; i < p.n_short; i += kBlock) s_keys[p.n_long + i] = (uint32_t) (p.tab_short[i] >> 16);
+    if (tid < 4) s_cnt[tid] = 0;
+    __syncthreads();
+
+    SliceLds &L = s_w[wv];
+    const uint64_t lt_mask = (1ull << lane) - 1;
+    const uint32_t wave_global = blockIdx.x * (kBlock / WAVE) + wv;
+    const uint32_t nwaves = gridDim.x * (kBlock / WAVE);
+    uint32_t n_cls_cond = 0, n_cls_uncond = 0, n_rec = 0;
+    uint32_t chunk_base = 0, chunk_left = 0;
+
+    for (uint32_t unit = wave_global; unit < p.nunits; unit += nwaves) {
+        const uint64_t U0 = (uint64_t) unit * kUnit;
+        const uint32_t *w32 = (const uint32_t *) (p.mag + U0);      // unit-relative sample pairs, global memory
+        const uint16_t *cq = p.cand + U0;
+        const int ccount = (int) p.cand_count[unit];
+        uint32_t prev_hdr = kNone, unit_records = 0;
+        int scount = 0, vhead = 0, vcount = 0;
+        if (lane == 0) p.unit_first[unit] = kNone;
+        uint32_t last_cond_pos = 0xFFFFFFFFu, last_uncond_pos = 0xFFFFFFFFu;   // lane-local: last position this lane classified
+
+        auto flush = [&]() __attribute__((always_inline)) {
+            if (scount == 0) return;
+            if (chunk_left < (uint32_t) scount + 1u) {
+                uint32_t b = 0;
+                if (lane == 0) b = atomicAdd(p.pool_used, (uint32_t) kPoolChunkRecords);
+                chunk_base = rfl(b);
+                chunk_left = kPoolChunkRecords;
+            }
+            const uint32_t base = chunk_base;
+            chunk_base += (uint32_t) scount + 1u;
+            chunk_left -= (uint32_t) scount + 1u;
+            if ((uint64_t) base + kPoolChunkRecords <= p.pool_cap) {
+                if (lane < scount) {
+                    const u32x4 *src = (const u32x4 *) &L.stage[lane];
+                    u32x4 *d = (u32x4 *) &p.pool[base + 1 + lane];
+                    d[0] = src[0]; d[1] = src[1];
+                }
+                if (lane == 0) {
+                    u32x4 h0 = {(uint32_t) scount, 0xFFu, 0u, kNone}, h1 = {0, 0, 0, 0};
+                    u32x4 *hd = (u32x4 *) &p.pool[base];
+                    hd[0] = h0; hd[1] = h1;
+                    if (prev_hdr == kNone) p.unit_first[unit] = base; else p.pool[prev_hdr].addr = base;
+                }
+                prev_hdr = base;
+                unit_records += scount;
+                n_rec += scount;
+            } else if (lane == 0) {
+                atomicAdd(&p.counters[CNT_POOL_OVERFLOW], 1ull);
+            }
+            scount = 0;
+            WAVE_SYNC();
+        };
+
+        auto stage_b = [&](int take) __attribute__((always_inline)) {
+            const int quad = lane >> 2, qj = lane & 3;
+            const bool have = quad < take;
+            uint32_t e = 0, chunk = 0, psyn = 0, df = 0;
+            bool is_long = false;
+            int pos_local = 0, t = 4;
+            if (have) {
+                e = L.v[(vhead + quad) & (kWVCap - 1)];
+                pos_local = (int) ((e & 0xffffu) >> 3);
+                t = 4 + (int) (e & 7u);
+                df = e >> 16;
+                is_long = (p.valid_long >> df) & 1;
+                if (is_long || qj < 2) {
+                    SliceGeom g;
+                    make_geom(pos_local, t, g);
+                    slice_chunk(w32, s_gsyn, g, is_long, qj, chunk, psyn);
+                }
+            }
+            const uint32_t c0 = quad_bcast<0>(chunk), c1 = quad_bcast<1>(chunk), c2 = quad_bcast<2>(chunk), c3 = quad_bcast<3>(chunk);
+            const uint32_t sx = quad_bcast<0>(psyn) ^ quad_bcast<1>(psyn) ^ quad_bcast<2>(psyn) ^ quad_bcast<3>(psyn);
+            bool emit = false;
+            u32x4 ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0};
+            if (have && qj == 0) {
+                uint32_t W[4];
+                W[0] = (df << 27) | (c0 >> 3);
+                W[1] = ((c0 & 7u) << 29) | (c1 >> 1);
+                W[2] = ((c1 & 1u) << 31) | (c2 << 1) | (c3 >> 19);
+                W[3] = (c3 << 13) & 0xffff0000u;
+                const uint32_t synd = sx ^ s_gsyn[(is_long ? 0 : kGroupsLong * 32) + df];
+                const uint32_t aa = W[0] & 0xffffffu;
+                int sk = -2, su = -2, fb0 = 0xff, fb1 = 0xff;
+                uint32_t addr = 0, flags = is_long ? REC_LONG : 0;
+                if (is_long) {
+                    bool handled = false;
+                    if (p.fix_df && (df == 1 || df == 16 || df == 19 || df == 21 || df == 25)) {
+                        const int j = 4 - (__ffs(df ^ 17u) - 1);
+                        if (synd == s_gsyn[16u >> j]) {
+                            sk = 900; su = 700; addr = aa;
+                            flags |= REC_ACCEPT_IF_UNKNOWN | REC_DFFIX | (1u << REC_CORR_SHIFT);
+                            fb0 = j; emit = handled = true;
+                        }
+                    }
+                    if (!handled && !(W[0] == 0 && (W[1] >> 8) == 0)) {
+                        if (df == 16 || df == 20 || df == 21) {
+                            sk = 1000; su = -1; addr = synd; flags |= REC_COND; emit = true;
+                        } else if (df == 17 || df == 18) {
+                            int b0 = 0xff, b1 = 0xff;
+                            const int nerr = synd == 0 ? 0 : lane_diagnose(s_keys, p.tab_long, p.n_long, synd, b0, b1);
+                            if (nerr >= 0) {
+                                uint32_t a2 = aa;
+                                if (nerr >= 1) a2 = fix_aa(a2, b0);
+                                if (nerr >= 2) a2 = fix_aa(a2, b1);
+                                sk = 1800 / (nerr + 1); su = 1400 / (nerr + 1); addr = a2;
+                                flags |= (uint32_t) nerr << REC_CORR_SHIFT;
+                                if (a2 == aa) flags |= REC_ACCEPT_IF_UNKNOWN;
+                                if (nerr == 0 && df == 17) flags |= REC_ADDER;
+                                if (nerr >= 1) fb0 = b0;
+                                if (nerr >= 2) fb1 = b1;
+                                emit = true;
+                            }
+                        }
+                    }
+                } else if (!(W[0] == 0 && (W[1] >> 8) == 0)) {
+                    if (df == 11) {
+                        if (synd & 0xffff80u) {
+                            int b0 = 0xff, b1 = 0xff;
+                            if (lane_diagnose(s_keys + p.n_long, p.tab_short, p.n_short, synd, b0, b1) == 1) {
+                                sk = 800; su = -1; addr = fix_aa(aa, b0);
+                                flags |= REC_COND | (1u << REC_CORR_SHIFT);
+                                fb0 = b0; emit = true;
+                            }
+                        } else if ((synd & 0x7f) == 0) {
+                            sk = 1600; su = 750; addr = aa; flags |= REC_ACCEPT_IF_UNKNOWN | REC_ADDER; emit = true;
+                        } else {
+                            sk = 1000; su = -1; addr = aa; flags |= REC_COND; emit = true;
+                        }
+                    } else {
+                        sk = 1000; su = -1; addr = synd; flags |= REC_COND; emit = true;
+                    }
+                }
+                if (emit) {
+                    const uint64_t gpos = U0 + (uint64_t) pos_local;
+                    ra.x = (uint32_t) gpos;
+                    ra.y = (uint32_t) t | (flags << 8) | ((uint32_t) (uint16_t) sk << 16);
+                    ra.z = (uint32_t) (uint16_t) su | ((uint32_t) fb0 << 16) | ((uint32_t) fb1 << 24);
+                    ra.w = addr;
+                    if (!is_long) { W[1] &= 0xffffff00u; W[2] = 0; W[3] = 0; }
+                    rb.x = __builtin_bswap32(W[0]); rb.y = __builtin_bswap32(W[1]);
+                    rb.z = __builtin_bswap32(W[2]); rb.w = __builtin_bswap32(W[3]) & 0xffffu;
+                    // class planes (zeroed per chunk): bit = candidate has a conditional / an unconditional record
+                    // (a 32-position word belongs to exactly one unit = one wave, so workgroup scope is enough: the
+                    //  atomic runs in this XCD's L2, not at the memory side)
+                    if (flags & REC_COND) {
+                        if (last_cond_pos != (uint32_t) gpos) { __hip_atomic_fetch_or(&p.class_bitmap[gpos >> 5], 1u << (gpos & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); last_cond_pos = (uint32_t) gpos; }
+                    } else if (last_uncond_pos != (uint32_t) gpos) {
+                        __hip_atomic_fetch_or(&p.class_uncond[gpos >> 5], 1u << (gpos & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); last_uncond_pos = (uint32_t) gpos;
+                    }
+                    if (flags & REC_ADDER) {
+                        const uint32_t h = (addr ^ (addr >> 8) ^ (addr >> 16)) & (kWAdderCache - 1);
+                        if (s_acache[h] != addr) {
+                            s_acache[h] = addr;
+                            atomicOr(&p.adder_bitmap[addr >> 5], 1u << (addr & 31));
+                        }
+                    }
+                }
+            }
+            const uint64_t em = __ballot(emit);
+            if (emit) {
+                u32x4 *d = (u32x4 *) &L.stage[scount + __popcll(em & lt_mask)];
+                d[0] = ra; d[1] = rb;
+            }
+            scount += __popcll(em);
+            vhead += take;
+            vcount -= take;
+            WAVE_SYNC();
+            if (scount > kWStageCap - kWFrames) flush();
+        };
+
+        for (int c0 = 0; c0 < ccount; c0 += WAVE) {
+            const int ci = c0 + lane;
+            const uint32_t code = ci < ccount ? cq[ci] : 0u;
+            const uint32_t mask = code & 7u;
+            const int np = 2 * (int) (mask & 1u) + (int) (mask & 2u) + (int) ((mask >> 2) & 1u);
+            int npairs;
+            int off = wave_excl_scan(np, npairs);
+            const uint32_t pl = code & 0xfff8u;
+            if (mask & 1u) { L.pairs[off++] = (uint16_t) (pl | 0u); L.pairs[off++] = (uint16_t) (pl | 1u); }
+            if (mask & 2u) { L.pairs[off++] = (uint16_t) (pl | 2u); L.pairs[off++] = (uint16_t) (pl | 3u); }
+            if (mask & 4u) { L.pairs[off++] = (uint16_t) (pl | 4u); }
+            WAVE_SYNC();
+            for (int a0 = 0; a0 < npairs; a0 += WAVE) {
+                const int j = a0 + lane;
+                bool valid = false;
+                uint32_t entry = 0;
+                if (j < npairs) {
+                    const uint32_t pc = L.pairs[j];
+                    SliceGeom g;
+                    make_geom((int) (pc >> 3), 4 + (int) (pc & 7u), g);
+                    const uint32_t df = slice_group(w32, g, 0);
+                    valid = ((p.valid_long | p.valid_short) >> df) & 1;
+                    entry = pc | (df << 16);
+                }
+                const uint64_t vm = __ballot(valid);
+                if (valid) L.v[(vhead + vcount + __popcll(vm & lt_mask)) & (kWVCap - 1)] = entry;
+                vcount += __popcll(vm);
+                WAVE_SYNC();
+                while (vcount >= kWFrames) stage_b(kWFrames);
+            }
+        }
+        while (vcount > 0) stage_b(vcount < kWFrames ? vcount : kWFrames);
+        flush();
+        if (lane == 0) p.unit_count[unit] = unit_records;
+    }
+    if (lane == 0) atomicAdd(&s_cnt[0], (unsigned long long) n_rec);
+    (void) n_cls_cond; (void) n_cls_uncond;
+    __syncthreads();
+    if (tid == 0 && s_cnt[0]) atomicAdd(&p.counters[CNT_RECORDS], s_cnt[0]);
+}
+
+// Class planes -> final class bitmap (cond & ~uncond) + the two class counters; one pass over n/32 words.
+__global__ __launch_bounds__(kBlock) void k_class_finalize(uint32_t *cond, const uint32_t *uncond, uint64_t nwords,
+                                                           unsigned long long *counters) {
+    __shared__ unsigned long long s_c[2];
+    if (threadIdx.x < 2) s_c[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t nc = 0, nu = 0;
+    for (uint64_t i = (uint64_t) blockIdx.x * kBlock + threadIdx.x; i < nwords; i += (uint64_t) gridDim.x * kBlock) {
+        const uint32_t uc = uncond[i], cd = cond[i] & ~uc;
+        if (cond[i] != cd) cond[i] = cd;
+        nc += __popc(cd);
+        nu += __popc(uc);
+    }
+    atomicAdd(&s_c[0], (unsigned long long) nc);
+    atomicAdd(&s_c[1], (unsigned long long) nu);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_c[0]) atomicAdd(&counters[CNT_CLASS_COND], s_c[0]);
+    if (threadIdx.x == 1 && s_c[1]) atomicAdd(&counters[CNT_CLASS_UNCOND], s_c[1]);
+}
+
+static int resident_blocks(const void *kernel, size_t dyn_lds) {
+    int per_cu = 0, dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, dyn_lds) != hipSuccess || per_cu < 1) per_cu = 2;
+    if (per_cu > 8) per_cu = 8;
+    return per_cu * cus;
+}
+
+void launch_sweep(const SweepParams &p, hipStream_t s) {
+    if (p.nunits == 0) return;
+    static int resident = 0;
+    if (!resident) resident = resident_blocks((const void *) k_sweep, 0);
+    const unsigned want = (p.nunits + (kBlock / WAVE) - 1) / (kBlock / WAVE);
+    const unsigned blocks = want < (unsigned) resident ? want : (unsigned) resident;
+    hipLaunchKernelGGL(k_sweep, dim3(blocks), dim3(kBlock), 0, s, p);
+}
+
+void launch_slice(const SweepParams &p, hipStream_t s) {
+    if (p.nunits == 0) return;
+    const size_t dyn = (size_t) (p.n_long + p.n_short + 4) * sizeof(uint32_t);
+    static int resident = 0;
+    if (!resident) resident = resident_blocks((const void *) k_slice, dyn);
+    const unsigned want = (p.nunits + (kBlock / WAVE) - 1) / (kBlock / WAVE);
+    const unsigned blocks = want < (unsigned) resident ? want : (unsigned) resident;
+    hipLaunchKernelGGL(k_slice, dim3(blocks), dim3(kBlock), dyn, s, p);
+    const uint64_t nwords = (p.n + 31) / 32;
+    unsigned cb = (unsigned) ((nwords + kBlock - 1) / kBlock);
+    if (cb > 2048) cb = 2048;
+    hipLaunchKernelGGL(k_class_finalize, dim3(cb), dim3(kBlock), 0, s, p.class_bitmap, p.class_uncond, nwords, p.counters);
 }
 
 // =============================================================================================

@@ -25,7 +25,7 @@ print("OK", len(got))
 """
 
 
-@pytest.mark.parametrize("version", ["1", "2", "3"])
+@pytest.mark.parametrize("version", ["1", "2", "3", "4"])
 def test_generation_matches_oracle(built, version):
     env = dict(os.environ, MGPU_SWEEP_VERSION=version)
     code = SCRIPT.format(root=helpers.ROOT, tests=os.path.join(helpers.ROOT, "tests"))

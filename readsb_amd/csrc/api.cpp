@@ -107,7 +107,7 @@ struct mgpu_ctx {
     mgpu_timing timing{}, acc{};
     uint64_t stream_pos = 0;
     bool eof = false;
-    int sweep_version = 4;     // MGPU_SWEEP_VERSION=1|2|3: earlier (fused) generations of the sweep/slice stage (A/B measurements)
+    int sweep_version = 3;     // MGPU_SWEEP_VERSION=1|2|3: earlier (fused) generations of the sweep/slice stage (A/B measurements)
 
     // worker thread: ordered walk + signal power of the slots, in submission order
     std::thread worker;
@@ -428,11 +428,14 @@ static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
     sp.cand = sl.d_cand; sp.cand_count = sl.d_cand_count; sp.class_uncond = sl.d_class_uncond;
     if (c->sweep_version == 1) launch_sweep_slice_v1(sp, s);
     else if (c->sweep_version == 2) launch_sweep_slice_v2(sp, s);
-    else if (c->sweep_version == 3) launch_sweep_slice(sp, s);
     else {
-        const size_t cb = ((size_t) ((n + 31) / 32) + 1) * sizeof(uint32_t);
+        // class planes: the scoring passes OR single bits into them
+        const size_t cb = (((size_t) ((n + 31) / 32) + 4) & ~(size_t) 3) * sizeof(uint32_t);   // whole 16-byte groups
         HIPCHK(c, hipMemsetAsync(sl.d_class_bitmap, 0, cb, s));
         HIPCHK(c, hipMemsetAsync(sl.d_class_uncond, 0, cb, s));
+    }
+    if (c->sweep_version == 3) launch_sweep_slice(sp, s);
+    else if (c->sweep_version == 4) {
         launch_sweep(sp, s);
         HIPCHK(c, hipEventRecord(sl.ev[4], s));
         launch_slice(sp, s);
@@ -456,8 +459,8 @@ static int finish_slot(mgpu_ctx *c, Slot &sl) {
         const unsigned long long *h = sl.h_counters;
         fprintf(stderr, "dbg: stage_b cycles %llu calls %llu frames %llu block cycles %llu slice %llu classify %llu records %llu\n",
                 h[10], h[11], h[12], h[13], h[14], h[15], h[CNT_RECORDS]);
-        fprintf(stderr, "dbg: v3 wave cycles: sweep %llu expand %llu stageA %llu slice %llu classify %llu emit %llu total %llu | rounds A %llu B %llu\n",
-                h[16], h[17], h[18], h[19], h[20], h[21], h[22], h[23], h[24]);
+        fprintf(stderr, "dbg: v3 wave cycles: load %llu sweep %llu stageA %llu slice %llu score %llu total %llu | rounds B %llu passes %llu\n",
+                h[16], h[17], h[18], h[19], h[20], h[21], h[22], h[23]);
     }
     if (sl.h_counters[CNT_POOL_OVERFLOW]) {
         c->err = "record pool overflow: recreate the context with a larger record_pool_records";

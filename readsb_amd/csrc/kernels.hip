@@ -72,21 +72,40 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 // IQ -> magnitude
 // =============================================================================================
 
-// Per-thread running (level, power) sums for the buffer the thread is currently inside; flushed
-// with two atomics whenever the thread crosses a 131072-sample buffer boundary.
+// Per-thread running (level, power) sums for the buffer the thread is currently inside.  A thread
+// that crosses a 131072-sample buffer boundary, or ends, folds its sums into workgroup accumulators
+// in LDS (a workgroup's contiguous range touches kBlockBufs buffers at most in the usual geometry;
+// anything beyond goes to memory directly); one thread per touched buffer then issues the
+// device-scope atomics.  One RMW per thread was ~5x10^5 memory-side atomics on <= 1024 addresses per
+// launch and cost more than the conversion itself.
+constexpr int kBlockBufs = 4;
+struct BlockSums {
+    unsigned long long level[kBlockBufs], power[kBlockBufs];
+    double flevel[kBlockBufs], fpower[kBlockBufs];
+    uint32_t first;          // buffer index of slot 0
+};
+
 struct BufSums {
     unsigned long long level, power;
     uint64_t next_boundary;   // first sample index of the next buffer
     uint32_t cur;             // current buffer index
-    __device__ void init(uint64_t sample, uint32_t B) {
+    BlockSums *blk;
+    __device__ void init(uint64_t sample, uint32_t B, BlockSums *b) {
         cur = (uint32_t) (sample / B);
         next_boundary = (uint64_t) (cur + 1) * B;
         level = power = 0;
+        blk = b;
     }
     __device__ void flush(const ConvertParams &p) {
         if (level | power) {
-            atomicAdd(&p.sum_level[cur], level);
-            atomicAdd(&p.sum_power[cur], power);
+            const uint32_t k = cur - blk->first;
+            if (k < (uint32_t) kBlockBufs) {
+                atomicAdd(&blk->level[k], level);
+                atomicAdd(&blk->power[k], power);
+            } else {
+                atomicAdd(&p.sum_level[cur], level);
+                atomicAdd(&p.sum_power[cur], power);
+            }
         }
         level = power = 0;
     }
@@ -98,6 +117,14 @@ struct BufSums {
         }
     }
 };
+
+__device__ __forceinline__ void block_sums_init(BlockSums &b, uint64_t first_sample, uint32_t B) {
+    if (threadIdx.x < kBlockBufs) {
+        b.level[threadIdx.x] = b.power[threadIdx.x] = 0;
+        b.flevel[threadIdx.x] = b.fpower[threadIdx.x] = 0.0;
+    }
+    if (threadIdx.x == 0) b.first = (uint32_t) (first_sample / B);
+}
 
 // d_mag[0 .. 326) = the 326 magnitudes that preceded this chunk (sdr_ifile.c:209-213): copied from the
 // end of the previous chunk's magnitude buffer (p.tail) or zero at stream start, by workgroup 0.
@@ -123,7 +150,6 @@ __global__ __launch_bounds__(kBlock) void k_convert_uc8(ConvertParams p) {
         for (int k = 0; k < kPer; ++k) { const int i = threadIdx.x + k * kBlock; if (i < kVec) ((u32x4 *) s_lut)[i] = t[k]; }
     }
     convert_tail_prologue(p);
-    __syncthreads();
 
     const uint64_t c_first = kTrailing / 8;                       // chunk holding d_mag[326]
     const uint64_t c_end = (kTrailing + p.n + 7) / 8;
@@ -132,12 +158,18 @@ __global__ __launch_bounds__(kBlock) void k_convert_uc8(ConvertParams p) {
     per_block = (per_block + kBlock - 1) / kBlock * kBlock;
     const uint64_t blk_lo = c_first + (uint64_t) blockIdx.x * per_block;
     const uint64_t blk_hi = blk_lo + per_block < c_end ? blk_lo + per_block : c_end;
-    if (blk_lo >= c_end) return;
+    if (blk_lo >= c_end) return;                                  // workgroup-uniform
+    __shared__ BlockSums s_sums;
+    {
+        const int64_t b0 = (int64_t) blk_lo * 8 - kTrailing;
+        block_sums_init(s_sums, b0 < 0 ? 0 : (uint64_t) b0, p.buf_samples);
+    }
+    __syncthreads();
 
     BufSums sums;
     {
         int64_t s0 = (int64_t) (blk_lo + threadIdx.x) * 8 - kTrailing;
-        sums.init(s0 < 0 ? 0 : (uint64_t) s0, p.buf_samples);
+        sums.init(s0 < 0 ? 0 : (uint64_t) s0, p.buf_samples, &s_sums);
     }
     for (uint64_t c = blk_lo + threadIdx.x; c < blk_hi; c += kBlock) {
         const int64_t i0 = (int64_t) c * 8 - kTrailing;   // sample index of element 0
@@ -203,6 +235,11 @@ __global__ __launch_bounds__(kBlock) void k_convert_uc8(ConvertParams p) {
         }
     }
     sums.flush(p);
+    __syncthreads();
+    if (threadIdx.x < kBlockBufs && (s_sums.level[threadIdx.x] | s_sums.power[threadIdx.x])) {
+        atomicAdd(&p.sum_level[s_sums.first + threadIdx.x], s_sums.level[threadIdx.x]);
+        atomicAdd(&p.sum_power[s_sums.first + threadIdx.x], s_sums.power[threadIdx.x]);
+    }
 }
 
 // SC16 / SC16Q11: mag = sqrtf(min(1, fI*fI + fQ*fQ)), fI = I/scale, u16 = (uint16_t)(mag*65535+0.5)
@@ -219,8 +256,19 @@ __global__ __launch_bounds__(kBlock) void k_convert_sc16(ConvertParams p) {
     per_block = (per_block + kBlock - 1) / kBlock * kBlock;
     const uint64_t blk_lo = c_first + (uint64_t) blockIdx.x * per_block;
     const uint64_t blk_hi = blk_lo + per_block < c_end ? blk_lo + per_block : c_end;
-    if (blk_lo >= c_end) return;
+    if (blk_lo >= c_end) return;                                  // workgroup-uniform
+    __shared__ BlockSums s_sums;
+    {
+        const int64_t b0 = (int64_t) blk_lo * 8 - kTrailing;
+        block_sums_init(s_sums, b0 < 0 ? 0 : (uint64_t) b0, p.buf_samples);
+    }
+    __syncthreads();
     const float inv = 1.0f / (float) (1 << SCALE_SHIFT);   // power of two: I * inv == I / scale exactly
+    auto fold = [&](uint32_t buf, double l, double w) __attribute__((always_inline)) {
+        const uint32_t k = buf - s_sums.first;
+        if (k < (uint32_t) kBlockBufs) { atomicAdd(&s_sums.flevel[k], l); atomicAdd(&s_sums.fpower[k], w); }
+        else { atomicAdd(&p.fsum_level[buf], l); atomicAdd(&p.fsum_power[buf], w); }
+    };
 
     double lvl = 0.0, pw = 0.0;
     uint32_t cur = 0xFFFFFFFFu;
@@ -257,7 +305,7 @@ __global__ __launch_bounds__(kBlock) void k_convert_sc16(ConvertParams p) {
             if (i >= 0 && (uint64_t) i < p.n) {
                 const uint32_t b_e = (uint32_t) ((uint64_t) i / p.buf_samples);
                 if (b_e != cur) {
-                    if (cur != 0xFFFFFFFFu) { atomicAdd(&p.fsum_level[cur], lvl); atomicAdd(&p.fsum_power[cur], pw); }
+                    if (cur != 0xFFFFFFFFu) fold(cur, lvl, pw);
                     cur = b_e; lvl = pw = 0.0;
                 }
                 lvl += (double) mag;
@@ -276,7 +324,12 @@ __global__ __launch_bounds__(kBlock) void k_convert_sc16(ConvertParams p) {
             }
         }
     }
-    if (cur != 0xFFFFFFFFu) { atomicAdd(&p.fsum_level[cur], lvl); atomicAdd(&p.fsum_power[cur], pw); }
+    if (cur != 0xFFFFFFFFu) fold(cur, lvl, pw);
+    __syncthreads();
+    if (threadIdx.x < kBlockBufs && (s_sums.flevel[threadIdx.x] != 0.0 || s_sums.fpower[threadIdx.x] != 0.0)) {
+        atomicAdd(&p.fsum_level[s_sums.first + threadIdx.x], s_sums.flevel[threadIdx.x]);
+        atomicAdd(&p.fsum_power[s_sums.first + threadIdx.x], s_sums.fpower[threadIdx.x]);
+    }
 }
 
 void launch_convert(int format, const ConvertParams &p, hipStream_t s) {
@@ -440,7 +493,8 @@ __device__ __forceinline__ uint32_t slice_and_score(const SweepParams &p, const 
         u32x4 *d = (u32x4 *) slot;
         d[0] = a;
         d[1] = b;
-        if (flags & REC_ADDER) atomicOr(&p.adder_bitmap[addr >> 5], 1u << (addr & 31));
+        if ((flags & REC_ADDER) && !(__hip_atomic_load(&p.adder_bitmap[addr >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (1u << (addr & 31))))
+            atomicOr(&p.adder_bitmap[addr >> 5], 1u << (addr & 31));   // look first: device-scope RMWs serialise per address
     }
     return flags | 0x100u;
 }
@@ -674,6 +728,21 @@ constexpr int kSub = kBlock * 8;            // positions per sweep step
 constexpr int kCQCap = kSub + 512;          // candidate queue: a whole worst-case step fits after a drain
 constexpr int kPairCap = kBlock * 5;        // pairs of one 256-candidate expansion
 constexpr int kVCap = 512;                  // ring of valid-DF pairs waiting for stage B (power of two)
+// Publish "a clean DF17 / DF11-IID0 frame of this stream carries `addr`" (mode_s.c:766-779) in the
+// 2^24-bit adder bitmap.  Device-scope RMWs execute at the memory side (the 8 XCD L2s are not
+// coherent with each other) and serialise per address; a few hundred aircraft addresses are hit
+// millions of times, and sending every sighting doubled the sweep kernel's run time.  So: a
+// direct-mapped LDS cache of what this workgroup already published, and — bits are only ever
+// set — a look (agent-scope load) before the RMW.
+template <int CACHE>
+__device__ __forceinline__ void adder_publish(uint32_t *bitmap, uint32_t *cache, uint32_t addr) {
+    const uint32_t h = (addr ^ (addr >> 10) ^ (addr >> 17)) & (CACHE - 1);
+    if (cache[h] == addr) return;
+    cache[h] = addr;
+    const uint32_t bit = 1u << (addr & 31);
+    if (!(__hip_atomic_load(&bitmap[addr >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(&bitmap[addr >> 5], bit);
+}
+
 constexpr int kAdderCache = 512;            // direct-mapped LDS cache of adder addresses already published
 constexpr int kPoolChunk = 1024;            // v2: pool records a workgroup reserves per returning atomic
 constexpr int kQuadsPerRound = kBlock / 4;  // frames sliced per stage-B round (4 lanes each)
@@ -1025,11 +1094,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_slice_v2(SweepParams p) {
                             // Device-scope atomics are executed at the memory side (the 8 XCD L2s are not coherent) and a
                             // few hundred aircraft addresses are hit millions of times: remember what this workgroup
                             // already published in a small LDS cache and only send first sightings.
-                            const uint32_t h = (addr ^ (addr >> 8) ^ (addr >> 16)) & (kAdderCache - 1);
-                            if (s_acache[h] != addr) {
-                                s_acache[h] = addr;
-                                atomicOr(&p.adder_bitmap[addr >> 5], 1u << (addr & 31));
-                            }
+                            adder_publish<kAdderCache>(p.adder_bitmap, s_acache, addr);
                         }
                     }
                 }
@@ -1208,7 +1273,7 @@ void launch_sweep_slice_v2(const SweepParams &p, hipStream_t s) {
 // Shared by the workgroup (read-only after the preload, or benign races): group-syndrome tables,
 // syndrome keys, the adder-address cache.
 // ---------------------------------------------------------------------------------------------
-// Register prefetch of the next tile costs 20 VGPRs and keeps the kernel at 3 waves/SIMD (151 VGPRs).
+// Register prefetch of the next tile costs 20 VGPRs and keeps the kernel at 3 waves/SIMD (<= 168 VGPRs).
 // Measured alternative: -DMGPU_V3_PREFETCH=0 fits 4 waves/SIMD (128 VGPRs, no spills) but is 9 % slower
 // (4.91 vs 4.52 ms per 537 M positions): the exposed tile-load latency costs more than the fourth wave hides.
 #ifndef MGPU_V3_PREFETCH
@@ -1221,19 +1286,99 @@ constexpr int kWStep = WAVE * 8;                             // positions per sw
 constexpr int kWCQCap = kWStep + 32;                         // candidate queue (drained when > 32 wait)
 constexpr int kWVCap = 128;                                  // ring of valid pairs (power of two)
 constexpr int kWFrames = WAVE / 4;                           // frames sliced per round (16)
-constexpr int kWStageCap = 24;                               // staged records per wave (4 workgroups per CU must fit in 160 KB)
-constexpr int kWAdderCache = 256;
+constexpr int kWStageCap = 24;                               // (generation 4) staged records per wave
+constexpr int kWFrameCap = WAVE;                             // sliced frames waiting for the scoring pass
+constexpr int kWAdderCache = 1024;
+
+struct SlicedFrame {          // 32 bytes: a frame as sliced, waiting for CRC classification
+    uint32_t W[4];            // frame bits 0..127, bit 0 = MSB of W[0]
+    uint32_t synd;            // CRC-24 syndrome (112- or 56-bit, by DF)
+    uint32_t meta;            // df | try-phase << 8
+    uint32_t pos;             // scan position within the chunk
+    uint32_t pad;
+};
 
 struct WaveLds {                                             // wave-private LDS, 16-byte aligned members first
     uint16_t mag[kWT + kHalo + 8];                           // 4720 B
-    PhaseRec stage[kWStageCap];                              // 1024 B
-    uint16_t cq[kWCQCap];                                    // 1152 B
+    SlicedFrame frames[kWFrameCap];                          // 2048 B
+    uint16_t cq[kWCQCap];                                    // 1088 B
     uint16_t pairs[WAVE * 5];                                //  640 B
     uint32_t v[kWVCap];                                      //  512 B
-    uint32_t cls_cond[kWT / 32], cls_uncond[kWT / 32];       //  512 B
 };
 
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+// Everything scoreModesMessage / decodeModesMessage's CRC stage decide about one sliced frame without
+// the ICAO filter (mode_s.c:276-419, 443-606): fills the two record halves, returns false when the
+// frame scores -2 whatever the filter holds.
+__device__ __forceinline__ bool classify_frame(const SweepParams &p, const uint32_t *s_gsyn, const uint32_t *s_keys,
+                                               uint32_t W0, uint32_t W1, uint32_t W2, uint32_t W3, uint32_t synd, uint32_t df,
+                                               int t, uint32_t pos, u32x4 &ra, u32x4 &rb, uint32_t &flags_out, uint32_t &addr_out) {
+    const bool is_long = (p.valid_long >> df) & 1;
+    const uint32_t aa = W0 & 0xffffffu;          // getbits(msg, 9, 32)
+    int sk = -2, su = -2, fb0 = 0xff, fb1 = 0xff;
+    uint32_t addr = 0, flags = is_long ? REC_LONG : 0;
+    bool emit = false;
+    if (is_long) {
+        bool handled = false;
+        if (p.fix_df && (df == 1 || df == 16 || df == 19 || df == 21 || df == 25)) {
+            const int j = 4 - (__ffs(df ^ 17u) - 1);
+            if (synd == s_gsyn[16u >> j]) {             // == bit_syndrome[j]; fixDF17msgtype, mode_s.c:276-301
+                sk = 900; su = 700; addr = aa;
+                flags |= REC_ACCEPT_IF_UNKNOWN | REC_DFFIX | (1u << REC_CORR_SHIFT);
+                fb0 = j; emit = handled = true;
+            }
+        }
+        if (!handled && !(W0 == 0 && (W1 >> 8) == 0)) {
+            if (df == 16 || df == 20 || df == 21) {
+                sk = 1000; su = -1; addr = synd; flags |= REC_COND; emit = true;      // Address/Parity
+            } else if (df == 17 || df == 18) {
+                int b0 = 0xff, b1 = 0xff;
+                const int nerr = synd == 0 ? 0 : lane_diagnose(s_keys, p.tab_long, p.n_long, synd, b0, b1);
+                if (nerr >= 0) {
+                    uint32_t a2 = aa;
+                    if (nerr >= 1) a2 = fix_aa(a2, b0);
+                    if (nerr >= 2) a2 = fix_aa(a2, b1);
+                    sk = 1800 / (nerr + 1); su = 1400 / (nerr + 1); addr = a2;
+                    flags |= (uint32_t) nerr << REC_CORR_SHIFT;
+                    if (a2 == aa) flags |= REC_ACCEPT_IF_UNKNOWN;   // mode_s.c:560: only a changed AA needs the filter
+                    if (nerr == 0 && df == 17) flags |= REC_ADDER;
+                    if (nerr >= 1) fb0 = b0;
+                    if (nerr >= 2) fb1 = b1;
+                    emit = true;
+                }
+            }
+        }
+    } else if (!(W0 == 0 && (W1 >> 8) == 0)) {
+        if (df == 11) {
+            if (synd & 0xffff80u) {
+                int b0 = 0xff, b1 = 0xff;
+                if (lane_diagnose(s_keys + p.n_long, p.tab_short, p.n_short, synd, b0, b1) == 1) {   // 2-bit errors are ambiguous in DF11
+                    sk = 800; su = -1; addr = fix_aa(aa, b0);
+                    flags |= REC_COND | (1u << REC_CORR_SHIFT);
+                    fb0 = b0; emit = true;
+                }
+            } else if ((synd & 0x7f) == 0) {
+                sk = 1600; su = 750; addr = aa; flags |= REC_ACCEPT_IF_UNKNOWN | REC_ADDER; emit = true;
+            } else {
+                sk = 1000; su = -1; addr = aa; flags |= REC_COND; emit = true;
+            }
+        } else {   // DF 0, 4, 5
+            sk = 1000; su = -1; addr = synd; flags |= REC_COND; emit = true;
+        }
+    }
+    if (!emit) return false;
+    ra.x = pos;
+    ra.y = (uint32_t) t | (flags << 8) | ((uint32_t) (uint16_t) sk << 16);
+    ra.z = (uint32_t) (uint16_t) su | ((uint32_t) fb0 << 16) | ((uint32_t) fb1 << 24);
+    ra.w = addr;
+    if (!is_long) { W1 &= 0xffffff00u; W2 = 0; W3 = 0; }
+    rb.x = __builtin_bswap32(W0); rb.y = __builtin_bswap32(W1);
+    rb.z = __builtin_bswap32(W2); rb.w = __builtin_bswap32(W3) & 0xffffu;
+    flags_out = flags;
+    addr_out = addr;
+    return true;
+}
 
 __global__ __launch_bounds__(kBlock, MGPU_V3_PREFETCH ? 3 : 4) void k_sweep_slice(SweepParams p) {
     __shared__ __attribute__((aligned(16))) WaveLds s_w[kBlock / WAVE];
@@ -1256,55 +1401,86 @@ __global__ __launch_bounds__(kBlock, MGPU_V3_PREFETCH ? 3 : 4) void k_sweep_slic
     const uint32_t wave_global = blockIdx.x * (kBlock / WAVE) + wv;
     const uint32_t nwaves = gridDim.x * (kBlock / WAVE);
 
-    uint32_t n_cand = 0, n_ph[3] = {0, 0, 0}, n_cls_cond = 0, n_cls_uncond = 0, n_rec = 0;
+    uint32_t n_cand = 0, n_ph[3] = {0, 0, 0}, n_rec = 0;
+    long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // MGPU_KERNEL_TIMERS: load, sweep, stage A, slice, score, total, rounds B, passes
+    const long long tm_start = DBG_CLOCK();
     uint32_t chunk_base = 0, chunk_left = 0;     // wave-uniform: reserved pool space
-    long long tm_sweep = 0, tm_expand = 0, tm_a = 0, tm_slice = 0, tm_class = 0, tm_emit = 0, tm_load = 0, n_rounds_b = 0, n_rounds_a = 0;
-    const long long tm_t0 = DBG_CLOCK();
     u32x4 pre[kWPre];
     bool have_pre = false;
 
     for (uint32_t unit = wave_global; unit < p.nunits; unit += nwaves) {
         uint32_t prev_hdr = kNone, unit_records = 0;
-        int scount = 0;
+        int fcount = 0;                               // sliced frames waiting in L.frames (wave-uniform)
         if (lane == 0) p.unit_first[unit] = kNone;
 
-        auto flush = [&]() __attribute__((always_inline)) {
-            if (scount == 0) return;
-            if (chunk_left < (uint32_t) scount + 1u) {
-                uint32_t b = 0;
-                if (lane == 0) b = atomicAdd(p.pool_used, (uint32_t) kPoolChunkRecords);
-                chunk_base = rfl(b);
-                chunk_left = kPoolChunkRecords;
-            }
-            const uint32_t base = chunk_base;
-            chunk_base += (uint32_t) scount + 1u;
-            chunk_left -= (uint32_t) scount + 1u;
-            if ((uint64_t) base + kPoolChunkRecords <= p.pool_cap) {
-                if (lane < scount) {
-                    const u32x4 *src = (const u32x4 *) &L.stage[lane];
-                    u32x4 *d = (u32x4 *) &p.pool[base + 1 + lane];
-                    d[0] = src[0]; d[1] = src[1];
+        // Scoring pass over the waiting frames, lane = frame: CRC classification, class planes, adder
+        // bitmap, and the records go straight from registers into the wave's slice of the pool as one
+        // segment of the unit's chain.  Runs right after a tile has been staged (never between a
+        // prefetch and the wait for it), so its stores and atomics have a whole tile's time to retire
+        // before the next s_waitcnt vmcnt(0).
+        auto score_pass = [&]() __attribute__((always_inline)) {
+            if (fcount == 0) return;
+            if (p.debug_stage & 8) { fcount = 0; return; }
+            const long long ts0 = DBG_CLOCK();
+            bool emit = false;
+            u32x4 ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0};
+            if (lane < fcount) {
+                const u32x4 f0 = *(const u32x4 *) &L.frames[lane].W[0];
+                const u32x4 f1 = *(const u32x4 *) &L.frames[lane].synd;
+                uint32_t flags = 0, addr = 0;
+                emit = classify_frame(p, s_gsyn, s_keys, f0.x, f0.y, f0.z, f0.w, f1.x, f1.y & 0xffu, (int) (f1.y >> 8), f1.z,
+                                      ra, rb, flags, addr);
+                if (emit) {
+                    const uint32_t gpos = f1.z;
+                    // class planes (zeroed per chunk); a 32-position word belongs to one unit = one wave, so
+                    // workgroup scope suffices: the atomic runs in this XCD's L2, not at the memory side
+                    if (p.debug_stage & 1) {} else if (flags & REC_COND) __hip_atomic_fetch_or(&p.class_bitmap[gpos >> 5], 1u << (gpos & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else __hip_atomic_fetch_or(&p.class_uncond[gpos >> 5], 1u << (gpos & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if ((flags & REC_ADDER) && !(p.debug_stage & 2)) {
+                        adder_publish<kWAdderCache>(p.adder_bitmap, s_acache, addr);
+                    }
                 }
-                if (lane == 0) {
-                    u32x4 h0 = {(uint32_t) scount, 0xFFu, 0u, kNone}, h1 = {0, 0, 0, 0};
-                    u32x4 *hd = (u32x4 *) &p.pool[base];
-                    hd[0] = h0; hd[1] = h1;
-                    if (prev_hdr == kNone) p.unit_first[unit] = base; else p.pool[prev_hdr].addr = base;
-                }
-                prev_hdr = base;
-                unit_records += scount;
-                n_rec += scount;
-            } else if (lane == 0) {
-                atomicAdd(&p.counters[CNT_POOL_OVERFLOW], 1ull);
             }
-            scount = 0;
+            const uint64_t em = __ballot(emit);
+            const int cnt = __popcll(em);
+            if (cnt && !(p.debug_stage & 4)) {
+                if (chunk_left < (uint32_t) cnt + 1u) {
+                    uint32_t b = 0;
+                    if (lane == 0) b = atomicAdd(p.pool_used, (uint32_t) kPoolChunkRecords);
+                    chunk_base = rfl(b);
+                    chunk_left = kPoolChunkRecords;
+                }
+                const uint32_t base = chunk_base;
+                chunk_base += (uint32_t) cnt + 1u;
+                chunk_left -= (uint32_t) cnt + 1u;
+                if ((uint64_t) base + kPoolChunkRecords <= p.pool_cap) {
+                    if (emit) {
+                        u32x4 *d = (u32x4 *) &p.pool[base + 1 + __popcll(em & lt_mask)];
+                        d[0] = ra; d[1] = rb;
+                    }
+                    if (lane == 0) {
+                        u32x4 h0 = {(uint32_t) cnt, 0xFFu, 0u, kNone}, h1 = {0, 0, 0, 0};
+                        u32x4 *hd = (u32x4 *) &p.pool[base];
+                        hd[0] = h0; hd[1] = h1;
+                        if (prev_hdr == kNone) p.unit_first[unit] = base; else p.pool[prev_hdr].addr = base;
+                    }
+                    prev_hdr = base;
+                    unit_records += cnt;
+                    n_rec += cnt;
+                } else if (lane == 0) {
+                    atomicAdd(&p.counters[CNT_POOL_OVERFLOW], 1ull);
+                }
+            }
+            fcount = 0;
             WAVE_SYNC();
+            tm[4] += DBG_CLOCK() - ts0; tm[7] += 1;
         };
 
         for (int tile = 0; tile < kUnit / kWT; ++tile) {
             const uint64_t D0 = (uint64_t) unit * kUnit + (uint64_t) tile * kWT;
             if (D0 >= p.n) break;
             // ---- tile into LDS (prefetched while the previous tile was sliced) ----
+            const long long tl0 = DBG_CLOCK();
             if (!have_pre) {
 #pragma unroll
                 for (int k = 0; k < kWPre; ++k) {
@@ -1317,12 +1493,11 @@ __global__ __launch_bounds__(kBlock, MGPU_V3_PREFETCH ? 3 : 4) void k_sweep_slic
                 const int i = lane + k * WAVE;
                 if (i < kWTChunks) *(u32x4 *) &L.mag[8 * i] = pre[k];
             }
-            L.cls_cond[lane] = 0; L.cls_uncond[lane] = 0;     // kWT / 32 == 64 words each
             {
                 uint64_t Dn = D0 + kWT;
                 bool next_unit = false;
                 if (tile + 1 >= kUnit / kWT || Dn >= p.n) { Dn = (uint64_t) (unit + nwaves) * kUnit; next_unit = true; }
-                have_pre = MGPU_V3_PREFETCH && (next_unit ? (unit + nwaves < p.nunits) : true);
+                have_pre = MGPU_V3_PREFETCH && !(p.debug_stage & 16) && (next_unit ? (unit + nwaves < p.nunits) : true);
                 if (have_pre) {
 #pragma unroll
                     for (int k = 0; k < kWPre; ++k) {
@@ -1332,12 +1507,15 @@ __global__ __launch_bounds__(kBlock, MGPU_V3_PREFETCH ? 3 : 4) void k_sweep_slic
                 }
             }
             WAVE_SYNC();
+            tm[0] += DBG_CLOCK() - tl0;
+            if (fcount > kWFrameCap - 2 * kWFrames) score_pass();   // typical place: stores overlap this tile's sweep
 
             int ccount = 0, vhead = 0, vcount = 0;
 
-            // ---- slicing: 4 lanes per frame, 16 frames per round ----
+            // ---- slicing: 4 lanes per frame, 16 frames per round; the sliced frames wait in LDS ----
             auto stage_b = [&](int take) __attribute__((always_inline)) {
-                const long long tq0 = DBG_CLOCK();
+                if (fcount + take > kWFrameCap) score_pass();       // dense regions only
+                const long long tb0 = DBG_CLOCK();
                 const int quad = lane >> 2, qj = lane & 3;
                 const bool have = quad < take;
                 uint32_t e = 0, chunk = 0, psyn = 0, df = 0;
@@ -1357,104 +1535,30 @@ __global__ __launch_bounds__(kBlock, MGPU_V3_PREFETCH ? 3 : 4) void k_sweep_slic
                 }
                 const uint32_t c0 = quad_bcast<0>(chunk), c1 = quad_bcast<1>(chunk), c2 = quad_bcast<2>(chunk), c3 = quad_bcast<3>(chunk);
                 const uint32_t sx = quad_bcast<0>(psyn) ^ quad_bcast<1>(psyn) ^ quad_bcast<2>(psyn) ^ quad_bcast<3>(psyn);
-                const long long tq1 = DBG_CLOCK();
-                bool emit = false;
-                u32x4 ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0};
                 if (have && qj == 0) {
-                    uint32_t W[4];
-                    W[0] = (df << 27) | (c0 >> 3);
-                    W[1] = ((c0 & 7u) << 29) | (c1 >> 1);
-                    W[2] = ((c1 & 1u) << 31) | (c2 << 1) | (c3 >> 19);
-                    W[3] = (c3 << 13) & 0xffff0000u;
-                    const uint32_t synd = sx ^ s_gsyn[(is_long ? 0 : kGroupsLong * 32) + df];
-                    const uint32_t aa = W[0] & 0xffffffu;          // getbits(msg, 9, 32)
-                    int sk = -2, su = -2, fb0 = 0xff, fb1 = 0xff;
-                    uint32_t addr = 0, flags = is_long ? REC_LONG : 0;
-                    if (is_long) {
-                        bool handled = false;
-                        if (p.fix_df && (df == 1 || df == 16 || df == 19 || df == 21 || df == 25)) {
-                            const int j = 4 - (__ffs(df ^ 17u) - 1);
-                            if (synd == s_gsyn[16u >> j]) {             // == bit_syndrome[j]; fixDF17msgtype, mode_s.c:276-301
-                                sk = 900; su = 700; addr = aa;
-                                flags |= REC_ACCEPT_IF_UNKNOWN | REC_DFFIX | (1u << REC_CORR_SHIFT);
-                                fb0 = j; emit = handled = true;
-                            }
-                        }
-                        if (!handled && !(W[0] == 0 && (W[1] >> 8) == 0)) {
-                            if (df == 16 || df == 20 || df == 21) {
-                                sk = 1000; su = -1; addr = synd; flags |= REC_COND; emit = true;
-                            } else if (df == 17 || df == 18) {
-                                int b0 = 0xff, b1 = 0xff;
-                                const int nerr = synd == 0 ? 0 : lane_diagnose(s_keys, p.tab_long, p.n_long, synd, b0, b1);
-                                if (nerr >= 0) {
-                                    uint32_t a2 = aa;
-                                    if (nerr >= 1) a2 = fix_aa(a2, b0);
-                                    if (nerr >= 2) a2 = fix_aa(a2, b1);
-                                    sk = 1800 / (nerr + 1); su = 1400 / (nerr + 1); addr = a2;
-                                    flags |= (uint32_t) nerr << REC_CORR_SHIFT;
-                                    if (a2 == aa) flags |= REC_ACCEPT_IF_UNKNOWN;
-                                    if (nerr == 0 && df == 17) flags |= REC_ADDER;
-                                    if (nerr >= 1) fb0 = b0;
-                                    if (nerr >= 2) fb1 = b1;
-                                    emit = true;
-                                }
-                            }
-                        }
-                    } else if (!(W[0] == 0 && (W[1] >> 8) == 0)) {
-                        if (df == 11) {
-                            if (synd & 0xffff80u) {
-                                int b0 = 0xff, b1 = 0xff;
-                                if (lane_diagnose(s_keys + p.n_long, p.tab_short, p.n_short, synd, b0, b1) == 1) {
-                                    sk = 800; su = -1; addr = fix_aa(aa, b0);
-                                    flags |= REC_COND | (1u << REC_CORR_SHIFT);
-                                    fb0 = b0; emit = true;
-                                }
-                            } else if ((synd & 0x7f) == 0) {
-                                sk = 1600; su = 750; addr = aa; flags |= REC_ACCEPT_IF_UNKNOWN | REC_ADDER; emit = true;
-                            } else {
-                                sk = 1000; su = -1; addr = aa; flags |= REC_COND; emit = true;
-                            }
-                        } else {
-                            sk = 1000; su = -1; addr = synd; flags |= REC_COND; emit = true;
-                        }
-                    }
-                    if (emit) {
-                        ra.x = (uint32_t) (D0 + pos_local);
-                        ra.y = (uint32_t) t | (flags << 8) | ((uint32_t) (uint16_t) sk << 16);
-                        ra.z = (uint32_t) (uint16_t) su | ((uint32_t) fb0 << 16) | ((uint32_t) fb1 << 24);
-                        ra.w = addr;
-                        if (!is_long) { W[1] &= 0xffffff00u; W[2] = 0; W[3] = 0; }
-                        rb.x = __builtin_bswap32(W[0]); rb.y = __builtin_bswap32(W[1]);
-                        rb.z = __builtin_bswap32(W[2]); rb.w = __builtin_bswap32(W[3]) & 0xffffu;
-                        if (flags & REC_COND) atomicOr(&L.cls_cond[pos_local >> 5], 1u << (pos_local & 31));
-                        else atomicOr(&L.cls_uncond[pos_local >> 5], 1u << (pos_local & 31));
-                        if (flags & REC_ADDER) {
-                            const uint32_t h = (addr ^ (addr >> 8) ^ (addr >> 16)) & (kWAdderCache - 1);
-                            if (s_acache[h] != addr) {
-                                s_acache[h] = addr;
-                                atomicOr(&p.adder_bitmap[addr >> 5], 1u << (addr & 31));
-                            }
-                        }
-                    }
+                    u32x4 f0, f1;
+                    f0.x = (df << 27) | (c0 >> 3);
+                    f0.y = ((c0 & 7u) << 29) | (c1 >> 1);
+                    f0.z = ((c1 & 1u) << 31) | (c2 << 1) | (c3 >> 19);
+                    f0.w = (c3 << 13) & 0xffff0000u;
+                    f1.x = sx ^ s_gsyn[(is_long ? 0 : kGroupsLong * 32) + df];
+                    f1.y = df | ((uint32_t) t << 8);
+                    f1.z = (uint32_t) (D0 + pos_local);
+                    f1.w = 0;
+                    SlicedFrame &fr = L.frames[fcount + quad];
+                    *(u32x4 *) &fr.W[0] = f0;
+                    *(u32x4 *) &fr.synd = f1;
                 }
-                const long long tq2 = DBG_CLOCK();
-                const uint64_t em = __ballot(emit);
-                if (emit) {
-                    u32x4 *d = (u32x4 *) &L.stage[scount + __popcll(em & lt_mask)];
-                    d[0] = ra; d[1] = rb;
-                }
-                scount += __popcll(em);
+                fcount += take;
                 vhead += take;
                 vcount -= take;
                 WAVE_SYNC();
-                if (scount > kWStageCap - kWFrames) flush();
-                tm_slice += tq1 - tq0; tm_class += tq2 - tq1; tm_emit += DBG_CLOCK() - tq2; n_rounds_b += 1;
+                tm[3] += DBG_CLOCK() - tb0; tm[6] += 1;
             };
 
             // ---- candidates -> pairs -> DF stage -> ring ----
             auto drain = [&]() __attribute__((always_inline)) {
                 for (int c0 = 0; c0 < ccount; c0 += WAVE) {
-                    const long long te0 = DBG_CLOCK();
                     const int ci = c0 + lane;
                     const uint32_t code = ci < ccount ? L.cq[ci] : 0u;
                     const uint32_t mask = code & 7u;
@@ -1466,7 +1570,6 @@ __global__ __launch_bounds__(kBlock, MGPU_V3_PREFETCH ? 3 : 4) void k_sweep_slic
                     if (mask & 2u) { L.pairs[off++] = (uint16_t) (pl | 2u); L.pairs[off++] = (uint16_t) (pl | 3u); }
                     if (mask & 4u) { L.pairs[off++] = (uint16_t) (pl | 4u); }
                     WAVE_SYNC();
-                    tm_expand += DBG_CLOCK() - te0;
                     for (int a0 = 0; a0 < npairs; a0 += WAVE) {
                         const long long ta0 = DBG_CLOCK();
                         const int j = a0 + lane;
@@ -1484,7 +1587,7 @@ __global__ __launch_bounds__(kBlock, MGPU_V3_PREFETCH ? 3 : 4) void k_sweep_slic
                         if (valid) L.v[(vhead + vcount + __popcll(vm & lt_mask)) & (kWVCap - 1)] = entry;
                         vcount += __popcll(vm);
                         WAVE_SYNC();
-                        tm_a += DBG_CLOCK() - ta0; n_rounds_a += 1;
+                        tm[2] += DBG_CLOCK() - ta0;
                         while (vcount >= kWFrames) stage_b(kWFrames);
                     }
                 }
@@ -1495,7 +1598,7 @@ __global__ __launch_bounds__(kBlock, MGPU_V3_PREFETCH ? 3 : 4) void k_sweep_slic
             for (int sub = 0; sub < kWT / kWStep; ++sub) {
                 if (D0 + (uint64_t) sub * kWStep >= p.n) break;
                 if (ccount > kWCQCap - kWStep) drain();
-                const long long ts0 = DBG_CLOCK();
+                const long long tw0 = DBG_CLOCK();
                 const int p0 = sub * kWStep + lane * 8;
                 uint32_t w[13];
                 {
@@ -1540,40 +1643,23 @@ __global__ __launch_bounds__(kBlock, MGPU_V3_PREFETCH ? 3 : 4) void k_sweep_slic
                     ccount += total;
                     WAVE_SYNC();
                 }
-                tm_sweep += DBG_CLOCK() - ts0;
+                tm[1] += DBG_CLOCK() - tw0;
             }
             drain();
             while (vcount > 0) stage_b(vcount < kWFrames ? vcount : kWFrames);
-
-            // ---- class bitmap of the tile (all 64 words: no clearing needed) ----
-            {
-                const uint32_t uc = L.cls_uncond[lane], cd = L.cls_cond[lane] & ~uc;
-                p.class_bitmap[(D0 >> 5) + lane] = cd;
-                n_cls_cond += __popc(cd);
-                n_cls_uncond += __popc(uc);
-            }
-            WAVE_SYNC();
         }
-        flush();
+        score_pass();
         if (lane == 0) p.unit_count[unit] = unit_records;
     }
     atomicAdd(&s_cnt[CNT_CANDIDATES], (unsigned long long) n_cand);
     atomicAdd(&s_cnt[CNT_PHASE0 + 0], (unsigned long long) n_ph[0]);
     atomicAdd(&s_cnt[CNT_PHASE0 + 2], (unsigned long long) n_ph[1]);
     atomicAdd(&s_cnt[CNT_PHASE0 + 4], (unsigned long long) n_ph[2]);
-    atomicAdd(&s_cnt[CNT_CLASS_COND], (unsigned long long) n_cls_cond);
-    atomicAdd(&s_cnt[CNT_CLASS_UNCOND], (unsigned long long) n_cls_uncond);
     if (lane == 0) atomicAdd(&s_cnt[CNT_RECORDS], (unsigned long long) n_rec);
 #if MGPU_KERNEL_TIMERS
-    if (lane == 0) {
-        atomicAdd(&s_cnt[16], (unsigned long long) tm_sweep); atomicAdd(&s_cnt[17], (unsigned long long) tm_expand);
-        atomicAdd(&s_cnt[18], (unsigned long long) tm_a); atomicAdd(&s_cnt[19], (unsigned long long) tm_slice);
-        atomicAdd(&s_cnt[20], (unsigned long long) tm_class); atomicAdd(&s_cnt[21], (unsigned long long) tm_emit);
-        atomicAdd(&s_cnt[22], (unsigned long long) (DBG_CLOCK() - tm_t0)); atomicAdd(&s_cnt[23], (unsigned long long) n_rounds_a);
-        atomicAdd(&s_cnt[24], (unsigned long long) n_rounds_b);
-    }
+    tm[5] = DBG_CLOCK() - tm_start;
+    if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&s_cnt[CNT_DEBUG0 + i], (unsigned long long) tm[i]);
 #endif
-    (void) tm_load;
     __syncthreads();
     if (tid < CNT_NUM && s_cnt[tid]) {
         unsigned long long v = s_cnt[tid];
@@ -1582,6 +1668,9 @@ __global__ __launch_bounds__(kBlock, MGPU_V3_PREFETCH ? 3 : 4) void k_sweep_slic
         else atomicAdd(&p.counters[tid], v);
     }
 }
+
+__global__ void k_class_finalize(uint32_t *cond, const uint32_t *uncond, uint64_t nwords, unsigned long long *counters);
+static void launch_class_finalize(const SweepParams &p, hipStream_t s);
 
 void launch_sweep_slice(const SweepParams &p, hipStream_t s) {
     if (p.nunits == 0) return;
@@ -1601,6 +1690,7 @@ void launch_sweep_slice(const SweepParams &p, hipStream_t s) {
     const unsigned want = (p.nunits + (kBlock / WAVE) - 1) / (kBlock / WAVE);
     const unsigned blocks = want < maxb ? want : maxb;
     hipLaunchKernelGGL(k_sweep_slice, dim3(blocks), dim3(kBlock), dyn, s, p);
+    launch_class_finalize(p, s);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1863,11 +1953,7 @@ __global__ __launch_bounds__(kBlock) void k_slice(SweepParams p) {
                         __hip_atomic_fetch_or(&p.class_uncond[gpos >> 5], 1u << (gpos & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); last_uncond_pos = (uint32_t) gpos;
                     }
                     if (flags & REC_ADDER) {
-                        const uint32_t h = (addr ^ (addr >> 8) ^ (addr >> 16)) & (kWAdderCache - 1);
-                        if (s_acache[h] != addr) {
-                            s_acache[h] = addr;
-                            atomicOr(&p.adder_bitmap[addr >> 5], 1u << (addr & 31));
-                        }
+                        adder_publish<kWAdderCache>(p.adder_bitmap, s_acache, addr);
                     }
                 }
             }
@@ -1931,14 +2017,18 @@ __global__ __launch_bounds__(kBlock) void k_class_finalize(uint32_t *cond, const
     if (threadIdx.x < 2) s_c[threadIdx.x] = 0;
     __syncthreads();
     uint32_t nc = 0, nu = 0;
-    for (uint64_t i = (uint64_t) blockIdx.x * kBlock + threadIdx.x; i < nwords; i += (uint64_t) gridDim.x * kBlock) {
-        const uint32_t uc = uncond[i], cd = cond[i] & ~uc;
-        if (cond[i] != cd) cond[i] = cd;
-        nc += __popc(cd);
-        nu += __popc(uc);
+    const uint64_t nvec = (nwords + 3) / 4;      // the planes are allocated (and zeroed) in whole 16-byte groups
+    for (uint64_t i = (uint64_t) blockIdx.x * kBlock + threadIdx.x; i < nvec; i += (uint64_t) gridDim.x * kBlock) {
+        const u32x4 uc = ((const u32x4 *) uncond)[i], c0 = ((const u32x4 *) cond)[i];
+        if ((c0.x | c0.y | c0.z | c0.w | uc.x | uc.y | uc.z | uc.w) == 0) continue;
+        const u32x4 cd = {c0.x & ~uc.x, c0.y & ~uc.y, c0.z & ~uc.z, c0.w & ~uc.w};
+        if (cd.x != c0.x || cd.y != c0.y || cd.z != c0.z || cd.w != c0.w) ((u32x4 *) cond)[i] = cd;
+        nc += __popc(cd.x) + __popc(cd.y) + __popc(cd.z) + __popc(cd.w);
+        nu += __popc(uc.x) + __popc(uc.y) + __popc(uc.z) + __popc(uc.w);
     }
-    atomicAdd(&s_c[0], (unsigned long long) nc);
-    atomicAdd(&s_c[1], (unsigned long long) nu);
+    nc = (uint32_t) wave_sum_u64(nc);
+    nu = (uint32_t) wave_sum_u64(nu);
+    if (lane_id() == 0) { atomicAdd(&s_c[0], (unsigned long long) nc); atomicAdd(&s_c[1], (unsigned long long) nu); }
     __syncthreads();
     if (threadIdx.x == 0 && s_c[0]) atomicAdd(&counters[CNT_CLASS_COND], s_c[0]);
     if (threadIdx.x == 1 && s_c[1]) atomicAdd(&counters[CNT_CLASS_UNCOND], s_c[1]);
@@ -1970,9 +2060,13 @@ void launch_slice(const SweepParams &p, hipStream_t s) {
     const unsigned want = (p.nunits + (kBlock / WAVE) - 1) / (kBlock / WAVE);
     const unsigned blocks = want < (unsigned) resident ? want : (unsigned) resident;
     hipLaunchKernelGGL(k_slice, dim3(blocks), dim3(kBlock), dyn, s, p);
+    launch_class_finalize(p, s);
+}
+
+static void launch_class_finalize(const SweepParams &p, hipStream_t s) {
     const uint64_t nwords = (p.n + 31) / 32;
-    unsigned cb = (unsigned) ((nwords + kBlock - 1) / kBlock);
-    if (cb > 2048) cb = 2048;
+    unsigned cb = (unsigned) ((nwords / 4 + kBlock) / kBlock);
+    if (cb > 1024) cb = 1024;
     hipLaunchKernelGGL(k_class_finalize, dim3(cb), dim3(kBlock), 0, s, p.class_bitmap, p.class_uncond, nwords, p.counters);
 }
 

@@ -158,9 +158,9 @@ def main():
             "messages_per_step": total_msgs,
             "stage_ms": {"convert": round(float(np.mean(conv_ms)), 3), "sweep": round(sweep, 3), "slice": round(tm.get("slice_ms", 0.0), 3),
                          "prescreen": round(tm["prescreen_ms"], 3), "d2h": round(tm["d2h_ms"], 3),
-                         "resolve_host": round(float(np.mean(resolve_ms)), 3), "sigpower": round(tm["sigpower_ms"], 3),
+                         "resolve_host": round(float(np.mean(resolve_ms)), 3), "build_host": round(tm.get("build_ms", 0.0), 3), "sigpower": round(tm["sigpower_ms"], 3),
                          "feed_total": round(float(np.mean(total_ms)), 3)},
-            "roofline": {"kernel": "k_sweep", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "roofline": {"kernel": "k_sweep_slice", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "launches_per_step": nlaunch, "algorithmic_bytes_per_launch": int(n * SWEEP_BYTES_PER_SAMPLE / nlaunch),
                          "avg_launch_ms": round(sweep / nlaunch, 4)},

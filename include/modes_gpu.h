@@ -117,7 +117,7 @@ struct mgpu_timing {
     uint64_t n_messages;     /* accepted messages */
     uint64_t n_chunks;       /* pipeline chunks = launches of each kernel; the *_ms fields above are sums over them */
     float slice_ms;          /* k_slice (bit slicer + CRC + score); sweep_ms is then k_sweep alone */
-    float reserved1;
+    float build_ms;          /* builder thread: struct modesMessage fields + signal / noise statistics (host) */
 };
 
 /* ---- lifecycle -------------------------------------------------------------------- */

@@ -9,6 +9,7 @@
 #include <sched.h>
 
 #include <cctype>
+#include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -71,6 +72,47 @@ struct Slot {
     std::vector<double> given_mean_power;
 };
 
+// Decoded messages waiting for mgpu_collect: a 64-byte aligned array that grows geometrically and is
+// never value-initialised (the builder writes every byte of every message with streaming stores).
+struct MsgBuf {
+    mgpu_msg *p = nullptr;
+    size_t n = 0, cap = 0;
+    ~MsgBuf() { free(p); }
+    size_t size() const { return n; }
+    mgpu_msg *data() { return p; }
+    void clear() { n = 0; }
+    bool grow_for(size_t extra) {                     // room for `extra` more messages
+        if (cap - n >= extra) return true;
+        size_t want = n + extra;
+        if (want < 2 * cap) want = 2 * cap;
+        void *q = nullptr;
+        if (posix_memalign(&q, 64, want * sizeof(mgpu_msg)) != 0) return false;
+        if (n) std::memcpy(q, p, n * sizeof(mgpu_msg));
+        free(p);
+        p = (mgpu_msg *) q;
+        cap = want;
+        return true;
+    }
+    void drop_front(size_t k) {
+        if (k < n) std::memmove(p, p + k, (n - k) * sizeof(mgpu_msg));
+        n -= k;
+    }
+};
+
+// What the builder thread needs of a chunk once its slot has gone back to the GPU.
+struct HostJob {
+    std::vector<PhaseRec> recs;              // the chunk's live records (heap copy of Slot::h_live)
+    std::vector<unsigned long long> sig;
+    std::vector<Accepted> acc;               // the walker's decisions
+    std::vector<uint32_t> pos;               // their chunk-relative scan positions
+    std::vector<BufferClock> buffers;
+    std::vector<double> given_mean_power;
+    std::vector<unsigned long long> sums;    // per-buffer level / power sums of the converter
+    std::vector<double> fsums;
+    ResolveCounts rc;
+    bool busy = false;
+};
+
 struct mgpu_ctx {
     mgpu_config cfg{};
     hipStream_t stream = nullptr, stream2 = nullptr;
@@ -92,28 +134,29 @@ struct mgpu_ctx {
     unsigned long long *d_win = nullptr, *h_win = nullptr;   // skip-window totals of the current feed
     uint64_t feed_cand[8] = {0, 0, 0, 0, 0, 0, 0, 0};         // C, phase[5], U, R of the current feed
     ResolveCounts feed_rc;
-    std::vector<PhaseRec> w_recs;                             // worker scratch (ordinary memory)
-    std::vector<unsigned long long> w_sig;
-    std::vector<uint32_t> w_pos, w_limit;
+    std::vector<uint32_t> w_limit;                            // walker scratch (ordinary memory)
     std::vector<uint16_t> w_skip;
-    std::vector<mgpu_msg> w_msgs;
+    HostJob job[3];                                           // walker -> builder hand-off ring
+    uint64_t job_seq = 0;
 
     std::vector<SyndromeEntry> tab_long, tab_short;
     uint32_t valid_long = 0, valid_short = 0;
 
     Resolver resolver;
-    std::vector<mgpu_msg> pending;
+    MsgBuf pending;
     mgpu_counters counters{};
     mgpu_timing timing{}, acc{};
     uint64_t stream_pos = 0;
     bool eof = false;
     int sweep_version = 3;     // MGPU_SWEEP_VERSION=1|2|3: earlier (fused) generations of the sweep/slice stage (A/B measurements)
 
-    // worker thread: ordered walk + signal power of the slots, in submission order
-    std::thread worker;
+    // host pipeline behind the GPU: the walker thread takes the slots in submission order (record copy,
+    // ordered accept walk, window-statistics launch) and hands a HostJob to the builder thread
+    // (messages, signal / noise statistics), so that the serial walk is all the walker does
+    std::thread worker, builder;
     std::mutex mu;
     std::condition_variable cv;
-    std::deque<int> queue;
+    std::deque<int> queue, build_queue;
     bool stop = false;
     int worker_rc = MGPU_OK;
 };
@@ -127,13 +170,27 @@ struct mgpu_ctx {
         }                                                                                          \
     } while (0)
 
-static int finish_slot(mgpu_ctx *c, Slot &sl);
+static int walk_slot(mgpu_ctx *c, Slot &sl, HostJob &job);
+static int build_job(mgpu_ctx *c, HostJob &job);
 static void worker_main(mgpu_ctx *c);
+static void builder_main(mgpu_ctx *c);
 
-// Run the walk on the CPUs of the GPU's NUMA node: the record buffers are pinned host memory the GPU
-// writes over PCIe (allocated next to the device), and a walk from the other socket reads every
-// record across the inter-socket link.  MGPU_NO_AFFINITY=1 leaves the thread unbound.
-static void bind_near_device(std::thread &th, int device) {
+// Put the two host threads next to the device and next to each other: on the GPU's NUMA node (the
+// record buffers are pinned host memory the GPU writes over PCIe, allocated there), and on two
+// physical cores that share one L3 — the builder reads the records and decisions the walker has just
+// written, and a cross-CCD hand-off costs a fabric round trip per cache line.  The L3 group is
+// picked by device ordinal so that the ranks of a node do not pile onto one CCD.
+// MGPU_NO_AFFINITY=1 leaves the threads unbound.
+static int sysfs_int(const std::string &path, int dflt) {
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f) return dflt;
+    int v = dflt;
+    if (fscanf(f, "%d", &v) != 1) v = dflt;
+    fclose(f);
+    return v;
+}
+
+static void bind_near_device(std::thread &walker, std::thread &builder, int device) {
     if (getenv("MGPU_NO_AFFINITY")) return;
     char bus[64] = {0};
     if (hipDeviceGetPCIBusId(bus, (int) sizeof(bus), device) != hipSuccess) return;
@@ -145,17 +202,44 @@ static void bind_near_device(std::thread &th, int device) {
     const bool ok = fgets(line, sizeof(line), f) != nullptr;
     fclose(f);
     if (!ok) return;
-    cpu_set_t set;
-    CPU_ZERO(&set);
-    int ncpu = 0;
+    cpu_set_t allowed;                     // never step outside what the process may use (cgroups, taskset)
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
+    std::vector<int> cpus;
     for (char *tok = strtok(line, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
         int a = 0, b = 0;
         const int got = sscanf(tok, "%d-%d", &a, &b);
         if (got == 1) b = a;
         if (got >= 1)
-            for (int k = a; k <= b && k < CPU_SETSIZE; ++k) { CPU_SET(k, &set); ++ncpu; }
+            for (int k = a; k <= b && k < CPU_SETSIZE; ++k)
+                if (CPU_ISSET(k, &allowed)) cpus.push_back(k);
     }
-    if (ncpu > 0) (void) pthread_setaffinity_np(th.native_handle(), sizeof(set), &set);
+    if (cpus.empty()) return;
+    // L3 groups of the node, in first-appearance order
+    std::vector<int> l3_ids, l3_of(cpus.size());
+    for (size_t i = 0; i < cpus.size(); ++i) {
+        l3_of[i] = sysfs_int("/sys/devices/system/cpu/cpu" + std::to_string(cpus[i]) + "/cache/index3/id", -1);
+        if (std::find(l3_ids.begin(), l3_ids.end(), l3_of[i]) == l3_ids.end()) l3_ids.push_back(l3_of[i]);
+    }
+    const int want = l3_ids[(size_t) device % l3_ids.size()];
+    int cpu_w = -1, cpu_b = -1, core_w = -1;
+    for (size_t i = 0; i < cpus.size(); ++i) {
+        if (l3_of[i] != want) continue;
+        const int core = sysfs_int("/sys/devices/system/cpu/cpu" + std::to_string(cpus[i]) + "/topology/core_id", (int) i);
+        if (cpu_w < 0) { cpu_w = cpus[i]; core_w = core; }
+        else if (cpu_b < 0 && core != core_w) cpu_b = cpus[i];
+    }
+    cpu_set_t set;
+    if (cpu_w >= 0 && cpu_b >= 0 && want >= 0) {
+        CPU_ZERO(&set); CPU_SET(cpu_w, &set);
+        (void) pthread_setaffinity_np(walker.native_handle(), sizeof(set), &set);
+        CPU_ZERO(&set); CPU_SET(cpu_b, &set);
+        (void) pthread_setaffinity_np(builder.native_handle(), sizeof(set), &set);
+    } else {                               // no cache topology in sysfs: the whole node
+        CPU_ZERO(&set);
+        for (int k : cpus) CPU_SET(k, &set);
+        (void) pthread_setaffinity_np(walker.native_handle(), sizeof(set), &set);
+        (void) pthread_setaffinity_np(builder.native_handle(), sizeof(set), &set);
+    }
 }
 
 extern "C" {
@@ -346,17 +430,19 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     }
     c->resolver.reset(cfg->startup_time_ms);
     c->worker = std::thread(worker_main, c);
-    bind_near_device(c->worker, cfg->device);
+    c->builder = std::thread(builder_main, c);
+    bind_near_device(c->worker, c->builder, cfg->device);
     *out = c;
     return MGPU_OK;
 }
 
 void mgpu_destroy(mgpu_ctx *c) {
     if (!c) return;
-    if (c->worker.joinable()) {
+    if (c->worker.joinable() || c->builder.joinable()) {
         { std::lock_guard<std::mutex> lk(c->mu); c->stop = true; }
         c->cv.notify_all();
-        c->worker.join();
+        if (c->worker.joinable()) c->worker.join();
+        if (c->builder.joinable()) c->builder.join();
     }
     (void) hipSetDevice(c->cfg.device);
     if (c->stream) (void) hipStreamSynchronize(c->stream);
@@ -449,16 +535,13 @@ static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
     return MGPU_OK;
 }
 
-// ---- host half of a chunk (worker thread): ordered walk, signal power, counters -------------------
-static int finish_slot(mgpu_ctx *c, Slot &sl) {
+// ---- host half of a chunk, part 1 (walker thread): record copy, ordered accept walk, window statistics ----
+static int walk_slot(mgpu_ctx *c, Slot &sl, HostJob &job) {
     const mgpu_config &cfg = c->cfg;
     const uint64_t n = sl.n;
-    const uint32_t nbuf = (uint32_t) sl.buffers.size();
     HIPCHK(c, hipEventSynchronize(sl.ev[3]));
     if (getenv("MGPU_DEBUG_PRINT")) {
         const unsigned long long *h = sl.h_counters;
-        fprintf(stderr, "dbg: stage_b cycles %llu calls %llu frames %llu block cycles %llu slice %llu classify %llu records %llu\n",
-                h[10], h[11], h[12], h[13], h[14], h[15], h[CNT_RECORDS]);
         fprintf(stderr, "dbg: v3 wave cycles: load %llu sweep %llu stageA %llu slice %llu score %llu total %llu | rounds B %llu passes %llu\n",
                 h[16], h[17], h[18], h[19], h[20], h[21], h[22], h[23]);
     }
@@ -484,52 +567,33 @@ static int finish_slot(mgpu_ctx *c, Slot &sl) {
             f = fopen((base + "bufs.bin").c_str(), "wb"); fwrite(sl.buffers.data(), sizeof(BufferClock), sl.buffers.size(), f); fclose(f);
         }
     }
-    if (getenv("MGPU_DEBUG_WALK2")) {   // experiment: the same walk on a heap copy of the records, with a throw-away filter
-        static Resolver r2; static bool init = false; if (!init) { r2.reset(c->cfg.startup_time_ms); init = true; }
-        const double tc0 = wall_ms();
-        std::vector<PhaseRec> cp(sl.h_live, sl.h_live + nlive);
-        std::vector<unsigned long long> cs(sl.h_live_sig, sl.h_live_sig + nlive);
-        const double tc1 = wall_ms();
-        std::vector<mgpu_msg> o; o.reserve(nlive / 4 + 16);
-        std::vector<uint32_t> a(nlive + 1), b(nlive + 1); std::vector<uint16_t> d(nlive + 1);
-        ResolveCounts rr;
-        r2.walk(cp.data(), cs.data(), nlive, sl.buffers, o, a.data(), d.data(), b.data(), nlive + 1, rr);
-        fprintf(stderr, "dbg: copy of pinned records %.3f ms, walk on heap copy %.3f ms\n", tc1 - tc0, wall_ms() - tc1);
-    }
-    // ordered walk; accepted messages go straight to the pending list, the window-statistics inputs
-    // straight into the slot's pinned staging arrays
     const double t_res0 = wall_ms();
-    const size_t first_msg = c->pending.size();
-    if (c->pending.capacity() - first_msg < nlive / 4 + 16) {   // geometric growth: never re-copy per chunk
-        const size_t want = first_msg + nlive / 4 + 16;
-        c->pending.reserve(want > 2 * c->pending.capacity() ? want : 2 * c->pending.capacity());
-    }
-    ResolveCounts rc;
     // The pinned buffers the GPU writes are slow for the CPU's small scattered reads (4x slower walk)
-    // but stream at tens of GB/s: copy the chunk's records into ordinary memory first (0.25 ms for
-    // 180 k records), walk there, and keep the per-message scratch on the heap too.
-    c->w_recs.resize(nlive);
-    c->w_sig.resize(nlive);
-    std::memcpy(c->w_recs.data(), sl.h_live, nlive * sizeof(PhaseRec));
-    std::memcpy(c->w_sig.data(), sl.h_live_sig, nlive * sizeof(unsigned long long));
+    // but stream at tens of GB/s: copy the chunk's records into ordinary memory first (0.2 ms for
+    // 180 k records) and walk there.
+    job.recs.resize(nlive + 1);
+    job.recs[nlive].pos = 0xFFFFFFFFu;          // sentinel for the walk
+    job.sig.resize(nlive);
+    std::memcpy(job.recs.data(), sl.h_live, nlive * sizeof(PhaseRec));
+    std::memcpy(job.sig.data(), sl.h_live_sig, nlive * sizeof(unsigned long long));
     const double t_cp = wall_ms() - t_res0;
     const uint64_t aux_cap = nlive + 1 < c->cap_msgs ? nlive + 1 : c->cap_msgs;
-    c->w_pos.resize(aux_cap); c->w_limit.resize(aux_cap); c->w_skip.resize(aux_cap);
-    c->w_msgs.clear();
-    const int64_t wn = c->resolver.walk(c->w_recs.data(), c->w_sig.data(), nlive, sl.buffers, c->w_msgs, c->w_pos.data(),
-                                        c->w_skip.data(), c->w_limit.data(), aux_cap, rc);
+    job.pos.resize(aux_cap); c->w_limit.resize(aux_cap); c->w_skip.resize(aux_cap);
+    job.acc.clear();
+    job.rc = ResolveCounts();
+    const int64_t wn = c->resolver.decide(job.recs.data(), nlive, sl.buffers, job.acc, job.pos.data(), c->w_skip.data(),
+                                          c->w_limit.data(), aux_cap, job.rc);
     const double t_wk = wall_ms() - t_res0 - t_cp;
-    c->pending.insert(c->pending.end(), c->w_msgs.begin(), c->w_msgs.end());
     if (wn > 0) {
-        std::memcpy(sl.h_msg_pos, c->w_pos.data(), (size_t) wn * sizeof(uint32_t));
+        std::memcpy(sl.h_msg_pos, job.pos.data(), (size_t) wn * sizeof(uint32_t));
         std::memcpy(sl.h_msg_limit, c->w_limit.data(), (size_t) wn * sizeof(uint32_t));
         std::memcpy(sl.h_msg_skip, c->w_skip.data(), (size_t) wn * sizeof(uint16_t));
     }
     c->acc.resolve_ms += (float) (wall_ms() - t_res0);
-    if (getenv("MGPU_DEBUG_PRINT")) fprintf(stderr, "dbg: copy %.3f ms + walk %.3f ms for %llu live records -> %lld msgs (pending cap %zu)\n", t_cp, t_wk, (unsigned long long) nlive, (long long) wn, c->pending.capacity());
+    if (getenv("MGPU_DEBUG_PRINT")) fprintf(stderr, "dbg: copy %.3f ms + walk %.3f ms for %llu live records -> %lld msgs\n", t_cp, t_wk, (unsigned long long) nlive, (long long) wn);
     if (wn < 0) { c->err = "max_messages exceeded"; return MGPU_E_OVERFLOW; }
     const uint32_t nmsg = (uint32_t) wn;
-    c->feed_rc.add(rc);
+    c->feed_rc.add(job.rc);
 
     // what the skip windows hid from the counters: asynchronous on the second stream, totals are
     // accumulated on the device and read once at the end of the feed
@@ -547,35 +611,63 @@ static int finish_slot(mgpu_ctx *c, Slot &sl) {
     c->acc.sigpower_ms += (float) (wall_ms() - t_sig0);
 
     // ---- counters that do not depend on the skip windows ----
-    mgpu_counters &k = c->counters;
     const unsigned long long *hc = sl.h_counters;
     c->feed_cand[0] += hc[CNT_CANDIDATES];
     for (int i = 0; i < 5; ++i) c->feed_cand[1 + i] += hc[CNT_PHASE0 + i];
     c->feed_cand[6] += hc[CNT_CLASS_COND];
     c->feed_cand[7] += hc[CNT_CLASS_UNCOND];
-    for (int i = 0; i < 3; ++i) k.demod_accepted[i] += rc.accepted[i];
-    for (int i = 0; i < 5; ++i) k.demod_bestPhase[i] += rc.best_phase[i];
+    c->acc.n_candidates += hc[CNT_CANDIDATES];
+    c->acc.n_records += hc[CNT_RECORDS];
+    c->acc.n_live_records += nlive;
+    c->acc.n_messages += nmsg;
+    c->acc.n_chunks += 1;
 
+    // the rest of the chunk's host work needs nothing of the slot
+    job.buffers = sl.buffers;
+    job.given_mean_power = sl.given_mean_power;
+    job.sums.assign(sl.h_sums, sl.h_sums + 2 * c->cap_buffers);
+    job.fsums.assign(sl.h_fsums, sl.h_fsums + 2 * c->cap_buffers);
+    return MGPU_OK;
+}
+
+// ---- host half of a chunk, part 2 (builder thread): messages, signal and noise statistics ----------
+static int build_job(mgpu_ctx *c, HostJob &job) {
+    const mgpu_config &cfg = c->cfg;
+    const double t0 = wall_ms();
+    const uint32_t nmsg = (uint32_t) job.acc.size();
+    const uint32_t nbuf = (uint32_t) job.buffers.size();
+    const size_t first_msg = c->pending.size();
+    if (!c->pending.grow_for(nmsg)) { c->err = "out of memory for the decoded messages"; return MGPU_E_NOMEM; }
+    const double t1 = wall_ms();
+    Resolver::build_messages(job.recs.data(), job.sig.data(), job.buffers, job.acc.data(), nmsg, c->pending.data() + first_msg);
+    c->pending.n = first_msg + nmsg;
+    const double t2 = wall_ms();
+
+    mgpu_counters &k = c->counters;
+    for (int i = 0; i < 3; ++i) k.demod_accepted[i] += job.rc.accepted[i];
+    for (int i = 0; i < 5; ++i) k.demod_bestPhase[i] += job.rc.best_phase[i];
     // per-message signal level, per-buffer noise power (demod_2400.c:436-457, 474-479)
     uint32_t mi = 0;
     for (uint32_t b = 0; b < nbuf; ++b) {
-        const BufferClock &bc = sl.buffers[b];
+        const BufferClock &bc = job.buffers[b];
         uint64_t sum_scaled = 0;
-        while (mi < nmsg && c->w_pos[mi] < (uint64_t) bc.first + bc.length) {
-            const mgpu_msg &m = c->pending[first_msg + mi];
-            const double signal_power = (double) m.sig_sumsq / 65535.0 / 65535.0;
-            const double level = signal_power / m.sig_len;
+        while (mi < nmsg && job.pos[mi] < (uint64_t) bc.first + bc.length) {
+            const uint32_t ri = job.acc[mi].rec;              // not from the message: those went out with streaming stores
+            const unsigned long long sumsq = job.sig[ri];
+            const unsigned sig_len = (job.recs[ri].msg[0] & 0x80) ? 268u : 134u;   // msglen * 12 / 5, demod_2400.c:439
+            const double signal_power = (double) sumsq / 65535.0 / 65535.0;
+            const double level = signal_power / sig_len;
             k.signal_power_sum += signal_power;
-            k.signal_power_count += m.sig_len;
-            sum_scaled += m.sig_sumsq;
+            k.signal_power_count += sig_len;
+            sum_scaled += sumsq;
             if (level > k.peak_signal_power) k.peak_signal_power = level;
             if (level > 0.50119) k.strong_signal_count++;
             ++mi;
         }
         double mean_power;
-        if (!sl.given_mean_power.empty()) mean_power = sl.given_mean_power[b];
-        else if (cfg.format == MGPU_FMT_UC8) mean_power = (double) sl.h_sums[c->cap_buffers + b] / 65535.0 / 65535.0 / bc.length;   // convert.c:105-107
-        else mean_power = sl.h_fsums[c->cap_buffers + b] / bc.length;
+        if (!job.given_mean_power.empty()) mean_power = job.given_mean_power[b];
+        else if (cfg.format == MGPU_FMT_UC8) mean_power = (double) job.sums[c->cap_buffers + b] / 65535.0 / 65535.0 / bc.length;   // convert.c:105-107
+        else mean_power = job.fsums[c->cap_buffers + b] / bc.length;
         const double sum_signal_power = (double) sum_scaled / 65535.0 / 65535.0;
         k.noise_power_sum += (mean_power * bc.length - sum_signal_power);
         k.noise_power_count += bc.length;
@@ -583,12 +675,8 @@ static int finish_slot(mgpu_ctx *c, Slot &sl) {
         k.samples_lost += cfg.buf_samples - bc.length;        // readsb.c:886
         k.nbuffers++;
     }
-    k.nflips = c->resolver.nflips();
-    c->acc.n_candidates += hc[CNT_CANDIDATES];
-    c->acc.n_records += hc[CNT_RECORDS];
-    c->acc.n_live_records += nlive;
-    c->acc.n_messages += nmsg;
-    c->acc.n_chunks += 1;
+    c->acc.build_ms += (float) (wall_ms() - t0);
+    if (getenv("MGPU_DEBUG_PRINT")) fprintf(stderr, "dbg: build: grow %.3f ms, messages %.3f ms, statistics %.3f ms for %u msgs\n", t1 - t0, t2 - t1, wall_ms() - t2, nmsg);
     return MGPU_OK;
 }
 
@@ -606,6 +694,7 @@ static int feed_end(mgpu_ctx *c) {
     HIPCHK(c, hipMemcpyAsync(c->h_win, c->d_win, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream2));
     HIPCHK(c, hipStreamSynchronize(c->stream2));
     mgpu_counters &k = c->counters;
+    k.nflips = c->resolver.nflips();
     const unsigned long long *hw = c->h_win;
     const ResolveCounts &rc = c->feed_rc;
     const uint64_t C = c->feed_cand[0], U = c->feed_cand[6], R = c->feed_cand[7];
@@ -626,20 +715,45 @@ static int feed_end(mgpu_ctx *c) {
 static void worker_main(mgpu_ctx *c) {
     (void) hipSetDevice(c->cfg.device);
     for (;;) {
-        int idx;
+        int idx, jidx;
         {
             std::unique_lock<std::mutex> lk(c->mu);
             c->cv.wait(lk, [&] { return c->stop || !c->queue.empty(); });
             if (c->queue.empty()) return;   // stop requested and nothing left
             idx = c->queue.front();
             c->queue.pop_front();
+            jidx = (int) (c->job_seq++ % 3);
+            c->cv.wait(lk, [&] { return !c->job[jidx].busy; });
+            c->job[jidx].busy = true;
         }
         Slot &sl = c->slot[idx];
-        int rc = c->worker_rc == MGPU_OK ? finish_slot(c, sl) : c->worker_rc;   // after an error just drain
+        HostJob &job = c->job[jidx];
+        int rc = c->worker_rc == MGPU_OK ? walk_slot(c, sl, job) : c->worker_rc;   // after an error just drain
         {
             std::lock_guard<std::mutex> lk(c->mu);
             if (rc != MGPU_OK && c->worker_rc == MGPU_OK) c->worker_rc = rc;
             sl.busy = false;
+            if (rc == MGPU_OK) c->build_queue.push_back(jidx); else job.busy = false;
+        }
+        c->cv.notify_all();
+    }
+}
+
+static void builder_main(mgpu_ctx *c) {
+    for (;;) {
+        int jidx;
+        {
+            std::unique_lock<std::mutex> lk(c->mu);
+            c->cv.wait(lk, [&] { return c->stop || !c->build_queue.empty(); });
+            if (c->build_queue.empty()) return;
+            jidx = c->build_queue.front();
+        }
+        int rc = build_job(c, c->job[jidx]);
+        {
+            std::lock_guard<std::mutex> lk(c->mu);
+            if (rc != MGPU_OK && c->worker_rc == MGPU_OK) c->worker_rc = rc;
+            c->build_queue.pop_front();      // popped only now: wait_all sees the job until it is done
+            c->job[jidx].busy = false;
         }
         c->cv.notify_all();
     }
@@ -659,7 +773,7 @@ static void submit_slot(mgpu_ctx *c, int idx) {
 
 static int wait_all(mgpu_ctx *c) {
     std::unique_lock<std::mutex> lk(c->mu);
-    c->cv.wait(lk, [&] { return !c->slot[0].busy && !c->slot[1].busy && c->queue.empty(); });
+    c->cv.wait(lk, [&] { return !c->slot[0].busy && !c->slot[1].busy && c->queue.empty() && c->build_queue.empty(); });
     return c->worker_rc;
 }
 
@@ -755,7 +869,7 @@ int mgpu_collect(mgpu_ctx *c, struct mgpu_msg *out, uint64_t cap, uint64_t *n, s
     if (!c || (!out && cap)) return MGPU_E_INVAL;
     uint64_t k = c->pending.size() < cap ? c->pending.size() : cap;
     if (k) std::memcpy(out, c->pending.data(), k * sizeof(mgpu_msg));
-    c->pending.erase(c->pending.begin(), c->pending.begin() + (long) k);
+    c->pending.drop_front(k);
     if (n) *n = k;
     if (counters) *counters = c->counters;
     return MGPU_OK;

@@ -1101,7 +1101,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_slice_v2(SweepParams p) {
                 const long long tb2 = DBG_CLOCK();
                 int total;
                 const int idx = scan().flags(emit, total);
-                const long long tb3 = DBG_CLOCK();
+                const long long tb3 = DBG_CLOCK(); (void) tb3;
                 if (emit) {
                     u32x4 *d = (u32x4 *) &s_stage[scount + idx];
                     d[0] = ra; d[1] = rb;
@@ -1404,6 +1404,7 @@ __global__ __launch_bounds__(kBlock, MGPU_V3_PREFETCH ? 3 : 4) void k_sweep_slic
     uint32_t n_cand = 0, n_ph[3] = {0, 0, 0}, n_rec = 0;
     long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // MGPU_KERNEL_TIMERS: load, sweep, stage A, slice, score, total, rounds B, passes
     const long long tm_start = DBG_CLOCK();
+    (void) tm_start;
     uint32_t chunk_base = 0, chunk_left = 0;     // wave-uniform: reserved pool space
     u32x4 pre[kWPre];
     bool have_pre = false;
@@ -2102,12 +2103,30 @@ __global__ __launch_bounds__(kBlock) void k_prescreen(const PhaseRec *pool, cons
         for (uint32_t i0 = 0; i0 < cnt; i0 += WAVE) {
             const uint32_t i = i0 + lane;
             bool ok = false;
-            uint32_t pos = 0, len = 0;
+            uint32_t pos = 0, len = 0, addr = 0;
+            int sk = 0, su = 0;
             if (i < cnt) {
                 const PhaseRec &r = pool[h + 1 + i];
                 ok = rec_live(r, bitmap);
                 pos = r.pos;
+                addr = r.addr;
+                sk = r.score_known;
+                su = r.score_unknown;
                 len = (r.msg[0] & 0x80) ? 268u : 134u;
+            }
+            // Dominated records: an earlier try-phase of the same position with the same address and scores at
+            // least as good wins every comparison the walk can make (same address = same filter answer, the
+            // best-phase test is a strict '>', demod_2400.c:246) — typically 2 of the 3 records of a clean frame.
+            {
+                const uint64_t live0 = __ballot(ok);
+                bool dom = false;
+#pragma unroll
+                for (int d = 1; d <= 4; ++d) {
+                    const uint32_t pj = __shfl_up(pos, d), aj = __shfl_up(addr, d);
+                    const int kj = __shfl_up(sk, d), uj = __shfl_up(su, d);
+                    if (lane >= d && ((live0 >> (lane - d)) & 1) && pj == pos && aj == addr && kj >= sk && uj >= su) dom = true;
+                }
+                ok = ok && !dom;
             }
             const uint64_t m = __ballot(ok);
             if (WRITE) {

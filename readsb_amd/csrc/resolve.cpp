@@ -2,7 +2,11 @@
 #include "resolve.h"
 
 #include <algorithm>
+#include <cstddef>
 #include <cstring>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 namespace mgpu {
 
@@ -84,77 +88,58 @@ void Resolver::tick_empty(int64_t sysTimestamp) {
     after_buffer();
 }
 
-static inline void flip_bit(uint8_t *msg, int bit) { msg[bit >> 3] ^= (uint8_t) (0x80u >> (bit & 7)); }
+static inline int frame_bits(const PhaseRec &r) { return (r.msg[0] & 0x80) ? 112 : 56; }   // demod_2400.c:399, DF as sliced
 
-int64_t Resolver::walk(const PhaseRec *recs, const unsigned long long *sig, uint64_t nrecs,
-                       const std::vector<BufferClock> &buffers, std::vector<mgpu_msg> &out, uint32_t *aux_pos,
-                       uint16_t *aux_skip, uint32_t *aux_limit, uint64_t aux_cap, ResolveCounts &c) {
+int64_t Resolver::decide(const PhaseRec *recs, uint64_t nrecs, const std::vector<BufferClock> &buffers, std::vector<Accepted> &acc,
+                         uint32_t *aux_pos, uint16_t *aux_skip, uint32_t *aux_limit, uint64_t aux_cap, ResolveCounts &c) {
+    // recs[nrecs] is a sentinel the caller provides (pos = 0xFFFFFFFF)
     uint64_t i = 0, nout = 0;
-    for (const BufferClock &b : buffers) {
+    for (uint32_t bi = 0; bi < (uint32_t) buffers.size(); ++bi) {
+        const BufferClock &b = buffers[bi];
         synthetic_now_ = b.sysTimestamp;                       // demod_2400.c:283-285
         const uint64_t end = (uint64_t) b.first + b.length;
         int64_t skip_until = -1;                               // the skip never crosses a buffer (loop-local pa)
-        while (i < nrecs && recs[i].pos < end) {
+        while (recs[i].pos < end) {
             const uint32_t pos = recs[i].pos;
-            uint64_t j = i;
-            bool has_uncond = false;
-            while (j < nrecs && recs[j].pos == pos) { has_uncond |= !(recs[j].flags & REC_COND); ++j; }
-            if ((int64_t) pos <= skip_until) {
-                if (has_uncond) ++c.skipped_uncond_groups; else ++c.skipped_cond_groups;
-                i = j;
+            if ((int64_t) pos <= skip_until) {                 // hidden by the previous frame (:468)
+                uint32_t all_cond = REC_COND;
+                do { all_cond &= recs[i].flags; ++i; } while (recs[i].pos == pos);
+                if (all_cond) ++c.skipped_cond_groups; else ++c.skipped_uncond_groups;
                 continue;
             }
-            ++c.visited_groups;
-            if (has_uncond) ++c.visited_uncond_groups; else ++c.visited_cond_groups;
             // best over the tried phases, in phase order, strict '>' (demod_2400.c:246)
             int best = -2;
             const PhaseRec *br = nullptr;
             bool best_known = false;
-            for (uint64_t k = i; k < j; ++k) {
-                const PhaseRec &r = recs[k];
+            uint32_t all_cond = REC_COND;
+            do {
+                const PhaseRec &r = recs[i];
+                all_cond &= r.flags;
                 bool known = false;
                 int s;
                 if (r.score_known == r.score_unknown) s = r.score_known;
                 else { known = filter_.test(r.addr); s = known ? r.score_known : r.score_unknown; }
                 if (s > best) { best = s; br = &r; best_known = known || r.score_known == r.score_unknown; }
-            }
-            i = j;
+                ++i;
+            } while (recs[i].pos == pos);
+            ++c.visited_groups;
+            if (all_cond) ++c.visited_cond_groups; else ++c.visited_uncond_groups;
             if (best < 0) {                                    // demod_2400.c:390-397
                 if (best == -1) ++c.rejected_unknown; else ++c.rejected_bad;
                 continue;
             }
-            const int msglen = (br->msg[0] & 0x80) ? 112 : 56; // :399, DF as sliced
-            mgpu_msg m;
-            std::memset(&m, 0, sizeof(m));
-            m.timestamp = b.sampleTimestamp + (int64_t) (pos - b.first) * 5 + (8 + 56) * 12 + br->phase;   // :406
-            m.sysTimestamp = b.sysTimestamp + (m.timestamp - b.sampleTimestamp) / 12000;                    // :409
-            synthetic_now_ = m.sysTimestamp;                   // :412-414
+            const int msglen = frame_bits(*br);
+            const int64_t timestamp = b.sampleTimestamp + (int64_t) (pos - b.first) * 5 + (8 + 56) * 12 + br->phase;   // :406
+            synthetic_now_ = b.sysTimestamp + (timestamp - b.sampleTimestamp) / 12000;                                 // :409-414
             // decodeModesMessage's CRC/address stage: same filter state as the scoring above
             bool accept = (br->flags & REC_ACCEPT_IF_UNKNOWN) != 0;
             if (!accept) accept = (br->score_known == br->score_unknown) ? best_known : filter_.test(br->addr);
             if (!accept) { ++c.rejected_unknown; continue; }   // :423-429, no skip-ahead
-            m.score = (int16_t) best;
-            m.phase = br->phase;
-            m.correctedbits = (br->flags >> REC_CORR_SHIFT) & 3;
-            const int raw_bytes = (br->flags & REC_LONG) ? 14 : 7;
-            std::memcpy(m.raw, br->msg, raw_bytes);
-            std::memcpy(m.msg, br->msg, raw_bytes);
-            if (br->flags & REC_DFFIX) m.msg[0] = (uint8_t) ((m.msg[0] & 7) | (17 << 3));
-            else {
-                if (br->fixbit0 != 0xff) flip_bit(m.msg, br->fixbit0);
-                if (br->fixbit1 != 0xff) flip_bit(m.msg, br->fixbit1);
-            }
-            m.msgtype = m.msg[0] >> 3;
-            m.msgbits = (m.msgtype & 0x10) ? 112 : 56;
-            if (m.msgbits == 56) { std::memset(m.msg + 7, 0, 7); std::memset(m.raw + 7, 0, 7); }
-            m.addr = br->addr & 0xffffffu;
-            m.sig_len = (uint16_t) (msglen * 12 / 5);          // :439
-            m.sig_sumsq = sig[br - recs];                      // :442-445, precomputed per record on the GPU
-            if (br->flags & REC_ADDER) filter_.add(m.addr);    // mode_s.c:766-779
-            ++c.accepted[m.correctedbits];
+            if (br->flags & REC_ADDER) filter_.add(br->addr & 0xffffffu);   // mode_s.c:766-779
+            ++c.accepted[(br->flags >> REC_CORR_SHIFT) & 3];
             ++c.best_phase[br->phase - 4];
             if (nout >= aux_cap) return -1;
-            out.push_back(m);
+            acc.push_back(Accepted{(uint32_t) (br - recs), bi, best});
             aux_pos[nout] = pos;
             aux_skip[nout] = (uint16_t) (msglen * 8 / 4);     // :468
             aux_limit[nout] = (uint32_t) end;
@@ -164,6 +149,67 @@ int64_t Resolver::walk(const PhaseRec *recs, const unsigned long long *sig, uint
         after_buffer();
     }
     return (int64_t) nout;
+}
+
+void Resolver::build_messages(const PhaseRec *recs, const unsigned long long *sig, const std::vector<BufferClock> &buffers,
+                              const Accepted *acc, uint64_t nacc, mgpu_msg *out) {
+    static_assert(sizeof(PhaseRec) == 32 && offsetof(PhaseRec, msg) == 16, "frame bytes are the record's second half");
+    for (uint64_t n = 0; n < nacc; ++n) {
+        const PhaseRec &r = recs[acc[n].rec];
+        const BufferClock &b = buffers[acc[n].buffer];
+        // the frame as two little-endian words: byte k of the frame = bits 8k.. of lo (k < 8) / hi (k >= 8)
+        uint64_t lo, hi;
+        std::memcpy(&lo, r.msg, 8);
+        std::memcpy(&hi, r.msg + 8, 8);
+        if (r.flags & REC_LONG) hi &= 0x0000ffffffffffffull; else { lo &= 0x00ffffffffffffffull; hi = 0; }
+        uint64_t mlo = lo, mhi = hi;                           // msg = raw with the CRC repair applied
+        if (r.flags & REC_DFFIX) mlo = (mlo & ~0xf8ull) | (17u << 3);      // fixDF17msgtype, mode_s.c:276-301
+        else {
+            if (r.fixbit0 != 0xff) { const uint64_t f = 0x80ull >> (r.fixbit0 & 7); if (r.fixbit0 < 64) mlo ^= f << (r.fixbit0 & 56); else mhi ^= f << (r.fixbit0 & 56); }
+            if (r.fixbit1 != 0xff) { const uint64_t f = 0x80ull >> (r.fixbit1 & 7); if (r.fixbit1 < 64) mlo ^= f << (r.fixbit1 & 56); else mhi ^= f << (r.fixbit1 & 56); }
+        }
+        const unsigned msgtype = (unsigned) (mlo & 0xff) >> 3;
+        const unsigned msgbits = (msgtype & 0x10) ? 112 : 56;
+        if (msgbits == 56) { mlo &= 0x00ffffffffffffffull; mhi = 0; lo &= 0x00ffffffffffffffull; hi = 0; }
+        mgpu_msg m;
+        m.timestamp = b.sampleTimestamp + (int64_t) (r.pos - b.first) * 5 + (8 + 56) * 12 + r.phase;   // demod_2400.c:406
+        m.sysTimestamp = b.sysTimestamp + (m.timestamp - b.sampleTimestamp) / 12000;                    // :409
+        m.sig_sumsq = sig[acc[n].rec];                         // :442-445, precomputed per record on the GPU
+        m.sig_len = (uint16_t) (frame_bits(r) * 12 / 5);       // :439
+        m.score = (int16_t) acc[n].score;
+        m.phase = r.phase;
+        m.correctedbits = (r.flags >> REC_CORR_SHIFT) & 3;
+        m.msgtype = (uint8_t) msgtype;
+        m.msgbits = (uint8_t) msgbits;
+        m.addr = r.addr & 0xffffffu;
+        std::memcpy(m.msg, &mlo, 8); std::memcpy(m.msg + 8, &mhi, 6);
+        std::memcpy(m.raw, &lo, 8); std::memcpy(m.raw + 8, &hi, 6);
+#if defined(__SSE2__)
+        if ((reinterpret_cast<uintptr_t>(out) & 15) == 0) {   // streaming stores: the consumer is another core, skip the RFO
+            __m128i v[4];
+            std::memcpy(v, &m, 64);
+            __m128i *d = reinterpret_cast<__m128i *>(out + n);
+            _mm_stream_si128(d + 0, v[0]); _mm_stream_si128(d + 1, v[1]);
+            _mm_stream_si128(d + 2, v[2]); _mm_stream_si128(d + 3, v[3]);
+        } else
+#endif
+        out[n] = m;
+    }
+#if defined(__SSE2__)
+    _mm_sfence();
+#endif
+}
+
+int64_t Resolver::walk(const PhaseRec *recs, const unsigned long long *sig, uint64_t nrecs,
+                       const std::vector<BufferClock> &buffers, std::vector<mgpu_msg> &out, uint32_t *aux_pos,
+                       uint16_t *aux_skip, uint32_t *aux_limit, uint64_t aux_cap, ResolveCounts &c) {
+    std::vector<Accepted> acc;
+    const int64_t n = decide(recs, nrecs, buffers, acc, aux_pos, aux_skip, aux_limit, aux_cap, c);
+    if (n <= 0) return n;
+    const size_t first = out.size();
+    out.resize(first + (size_t) n);
+    build_messages(recs, sig, buffers, acc.data(), (uint64_t) n, out.data() + first);
+    return n;
 }
 
 }  // namespace mgpu

@@ -66,13 +66,29 @@ struct ResolveCounts {
     uint64_t visited_uncond_groups = 0;
 };
 
+// One accepted frame, as the ordered walk decided it: which live record won, in which buffer, with
+// what score.  Everything else about the message is a pure function of these (build_messages).
+struct Accepted {
+    uint32_t rec;      // index into the chunk's live records
+    uint32_t buffer;   // index into the chunk's buffer grid
+    int32_t score;
+};
+
 class Resolver {
   public:
     void reset(int64_t startup_ms);
-    // Walk the ordered live records of one chunk.  sig[i] = sum of mag^2 over the frame record i
-    // would occupy.  Appends the accepted messages to `out` and writes their chunk-relative
-    // positions / skip lengths / buffer limits (inputs of k_window_stats) to the aux arrays
-    // (capacity aux_cap); returns the number of messages, or -1 if aux_cap was too small.
+    // The serial part: walk the ordered live records of one chunk and decide which frames the
+    // reference accepts (best phase, ICAO filter, skip-ahead, filter clock).  Appends to `acc` and
+    // writes each accepted frame's chunk-relative position / skip length / buffer limit (inputs of
+    // k_window_stats) to the aux arrays (capacity aux_cap); returns the number of accepted frames,
+    // or -1 if aux_cap was too small.  recs[nrecs] must be a readable sentinel with pos = 0xFFFFFFFF.
+    int64_t decide(const PhaseRec *recs, uint64_t nrecs, const std::vector<BufferClock> &buffers, std::vector<Accepted> &acc,
+                   uint32_t *aux_pos, uint16_t *aux_skip, uint32_t *aux_limit, uint64_t aux_cap, ResolveCounts &counts);
+    // The stateless part: struct modesMessage fields of the accepted frames (demod_2400.c:399-445,
+    // mode_s.c:443-606).  sig[i] = sum of mag^2 over the frame record i would occupy.
+    static void build_messages(const PhaseRec *recs, const unsigned long long *sig, const std::vector<BufferClock> &buffers,
+                               const Accepted *acc, uint64_t nacc, mgpu_msg *out);
+    // decide + build_messages in one call
     int64_t walk(const PhaseRec *recs, const unsigned long long *sig, uint64_t nrecs,
                  const std::vector<BufferClock> &buffers, std::vector<mgpu_msg> &out, uint32_t *aux_pos,
                  uint16_t *aux_skip, uint32_t *aux_limit, uint64_t aux_cap, ResolveCounts &counts);

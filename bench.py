@@ -100,7 +100,7 @@ def main():
         d.reset()
         d.feed_resident(n)                      # timed: everything from HBM-resident IQ to ordered messages
         d.finish()                              # ifile EOF bookkeeping (zero-length buffer on exact multiples)
-        msgs, counters = d.collect()
+        msgs, counters = d.collect(reuse=True)   # the consumer's standing buffer
         if world > 1:                           # aggregator role: counts + records to rank 0 over RCCL
             gather_messages(msgs, torch.device("cuda", local_rank))
         return msgs, counters

@@ -109,7 +109,7 @@ struct mgpu_timing {
     float prescreen_ms;  /* record pre-screen + compaction */
     float resolve_ms;    /* ordered accept / skip-ahead / ICAO filter walk (host wall time) */
     float sigpower_ms;   /* host time spent launching the skip-window statistics kernel */
-    float d2h_ms;        /* explicit record copies back (0: records are written to pinned host memory by the kernel) */
+    float d2h_ms;        /* fetcher thread: live records out of the pinned buffer the pre-screen kernel wrote (host) */
     float total_ms;      /* wall time of the whole call */
     uint64_t n_candidates;   /* positions that passed a preamble threshold */
     uint64_t n_records;      /* per-phase records the slicer emitted */

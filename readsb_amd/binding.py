@@ -128,6 +128,7 @@ class Demodulator:
         cfg.record_pool_records, cfg.max_messages, cfg.buf_samples = record_pool_records, max_messages, buf_samples
         self.cfg = cfg
         self.fmt = fmt
+        self._collect_buf = None
         self.ctx = C.c_void_p()
         rc = self.lib.mgpu_create(C.byref(cfg), C.byref(self.ctx))
         if rc != 0:
@@ -174,9 +175,19 @@ class Demodulator:
     def finish(self):
         self._chk(self.lib.mgpu_finish(self.ctx), "mgpu_finish")
 
-    def collect(self):
+    def collect(self, reuse=False):
+        """Drain the decoded messages (stream order) and read the counters.
+
+        reuse=True returns a view of a buffer the Demodulator keeps and overwrites on the next
+        collect(reuse=True): a steady consumer then pays one copy and no page faults per call.
+        """
         n = int(self.lib.mgpu_pending_messages(self.ctx))
-        out = np.zeros(n, dtype=MSG_DTYPE)
+        if reuse:
+            if self._collect_buf is None or self._collect_buf.size < n:
+                self._collect_buf = np.empty(max(n, 1024) * 5 // 4, dtype=MSG_DTYPE)
+            out = self._collect_buf
+        else:
+            out = np.empty(n, dtype=MSG_DTYPE)
         got = C.c_uint64(0)
         cnt = Counters()
         self._chk(self.lib.mgpu_collect(self.ctx, out.ctypes.data, n, C.byref(got), C.byref(cnt)), "mgpu_collect")

@@ -110,6 +110,9 @@ struct HostJob {
     std::vector<unsigned long long> sums;    // per-buffer level / power sums of the converter
     std::vector<double> fsums;
     ResolveCounts rc;
+    uint64_t nlive = 0;
+    uint32_t nmsg = 0;                       // accepted frames: acc[0..nmsg), pos[0..nmsg)
+    int slot = -1;                           // the slot the chunk ran in (the walker still needs its device side)
     bool busy = false;
 };
 
@@ -136,7 +139,7 @@ struct mgpu_ctx {
     ResolveCounts feed_rc;
     std::vector<uint32_t> w_limit;                            // walker scratch (ordinary memory)
     std::vector<uint16_t> w_skip;
-    HostJob job[3];                                           // walker -> builder hand-off ring
+    HostJob job[4];                                           // fetcher -> walker -> builder hand-off ring
     uint64_t job_seq = 0;
 
     std::vector<SyndromeEntry> tab_long, tab_short;
@@ -153,10 +156,10 @@ struct mgpu_ctx {
     // host pipeline behind the GPU: the walker thread takes the slots in submission order (record copy,
     // ordered accept walk, window-statistics launch) and hands a HostJob to the builder thread
     // (messages, signal / noise statistics), so that the serial walk is all the walker does
-    std::thread worker, builder;
+    std::thread fetcher, worker, builder;
     std::mutex mu;
     std::condition_variable cv;
-    std::deque<int> queue, build_queue;
+    std::deque<int> queue, walk_queue, build_queue;
     bool stop = false;
     int worker_rc = MGPU_OK;
 };
@@ -170,15 +173,16 @@ struct mgpu_ctx {
         }                                                                                          \
     } while (0)
 
-static int walk_slot(mgpu_ctx *c, Slot &sl, HostJob &job);
+static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job);
+static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job);
 static int build_job(mgpu_ctx *c, HostJob &job);
+static void fetcher_main(mgpu_ctx *c);
 static void worker_main(mgpu_ctx *c);
 static void builder_main(mgpu_ctx *c);
 
-// Put the two host threads next to the device and next to each other: on the GPU's NUMA node (the
-// record buffers are pinned host memory the GPU writes over PCIe, allocated there), and on two
-// physical cores that share one L3 — the builder reads the records and decisions the walker has just
-// written, and a cross-CCD hand-off costs a fabric round trip per cache line.  The L3 group is
+// Put the host threads next to the device and next to each other: on the GPU's NUMA node (the
+// record buffers are pinned host memory the GPU writes over PCIe, allocated there), and on
+// physical cores that share one L3 — each stage reads what the previous one has just written, and a cross-CCD hand-off costs a fabric round trip per cache line.  The L3 group is
 // picked by device ordinal so that the ranks of a node do not pile onto one CCD.
 // MGPU_NO_AFFINITY=1 leaves the threads unbound.
 static int sysfs_int(const std::string &path, int dflt) {
@@ -190,7 +194,7 @@ static int sysfs_int(const std::string &path, int dflt) {
     return v;
 }
 
-static void bind_near_device(std::thread &walker, std::thread &builder, int device) {
+static void bind_near_device(std::thread *const *threads, int nthreads, int device) {
     if (getenv("MGPU_NO_AFFINITY")) return;
     char bus[64] = {0};
     if (hipDeviceGetPCIBusId(bus, (int) sizeof(bus), device) != hipSuccess) return;
@@ -221,24 +225,25 @@ static void bind_near_device(std::thread &walker, std::thread &builder, int devi
         if (std::find(l3_ids.begin(), l3_ids.end(), l3_of[i]) == l3_ids.end()) l3_ids.push_back(l3_of[i]);
     }
     const int want = l3_ids[(size_t) device % l3_ids.size()];
-    int cpu_w = -1, cpu_b = -1, core_w = -1;
-    for (size_t i = 0; i < cpus.size(); ++i) {
+    // one logical CPU per physical core of that group
+    std::vector<int> pick, cores;
+    for (size_t i = 0; i < cpus.size() && (int) pick.size() < nthreads; ++i) {
         if (l3_of[i] != want) continue;
         const int core = sysfs_int("/sys/devices/system/cpu/cpu" + std::to_string(cpus[i]) + "/topology/core_id", (int) i);
-        if (cpu_w < 0) { cpu_w = cpus[i]; core_w = core; }
-        else if (cpu_b < 0 && core != core_w) cpu_b = cpus[i];
+        if (std::find(cores.begin(), cores.end(), core) != cores.end()) continue;
+        cores.push_back(core);
+        pick.push_back(cpus[i]);
     }
     cpu_set_t set;
-    if (cpu_w >= 0 && cpu_b >= 0 && want >= 0) {
-        CPU_ZERO(&set); CPU_SET(cpu_w, &set);
-        (void) pthread_setaffinity_np(walker.native_handle(), sizeof(set), &set);
-        CPU_ZERO(&set); CPU_SET(cpu_b, &set);
-        (void) pthread_setaffinity_np(builder.native_handle(), sizeof(set), &set);
+    if (want >= 0 && (int) pick.size() == nthreads) {
+        for (int t = 0; t < nthreads; ++t) {
+            CPU_ZERO(&set); CPU_SET(pick[t], &set);
+            (void) pthread_setaffinity_np(threads[t]->native_handle(), sizeof(set), &set);
+        }
     } else {                               // no cache topology in sysfs: the whole node
         CPU_ZERO(&set);
         for (int k : cpus) CPU_SET(k, &set);
-        (void) pthread_setaffinity_np(walker.native_handle(), sizeof(set), &set);
-        (void) pthread_setaffinity_np(builder.native_handle(), sizeof(set), &set);
+        for (int t = 0; t < nthreads; ++t) (void) pthread_setaffinity_np(threads[t]->native_handle(), sizeof(set), &set);
     }
 }
 
@@ -429,18 +434,20 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
         return rc;
     }
     c->resolver.reset(cfg->startup_time_ms);
+    c->fetcher = std::thread(fetcher_main, c);
     c->worker = std::thread(worker_main, c);
     c->builder = std::thread(builder_main, c);
-    bind_near_device(c->worker, c->builder, cfg->device);
+    { std::thread *const th[3] = {&c->worker, &c->builder, &c->fetcher}; bind_near_device(th, 3, cfg->device); }
     *out = c;
     return MGPU_OK;
 }
 
 void mgpu_destroy(mgpu_ctx *c) {
     if (!c) return;
-    if (c->worker.joinable() || c->builder.joinable()) {
+    if (c->fetcher.joinable() || c->worker.joinable() || c->builder.joinable()) {
         { std::lock_guard<std::mutex> lk(c->mu); c->stop = true; }
         c->cv.notify_all();
+        if (c->fetcher.joinable()) c->fetcher.join();
         if (c->worker.joinable()) c->worker.join();
         if (c->builder.joinable()) c->builder.join();
     }
@@ -535,10 +542,8 @@ static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
     return MGPU_OK;
 }
 
-// ---- host half of a chunk, part 1 (walker thread): record copy, ordered accept walk, window statistics ----
-static int walk_slot(mgpu_ctx *c, Slot &sl, HostJob &job) {
-    const mgpu_config &cfg = c->cfg;
-    const uint64_t n = sl.n;
+// ---- host half of a chunk, part 1 (fetcher thread): wait for the GPU, copy the live records out of pinned memory ----
+static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job) {
     HIPCHK(c, hipEventSynchronize(sl.ev[3]));
     if (getenv("MGPU_DEBUG_PRINT")) {
         const unsigned long long *h = sl.h_counters;
@@ -567,30 +572,52 @@ static int walk_slot(mgpu_ctx *c, Slot &sl, HostJob &job) {
             f = fopen((base + "bufs.bin").c_str(), "wb"); fwrite(sl.buffers.data(), sizeof(BufferClock), sl.buffers.size(), f); fclose(f);
         }
     }
-    const double t_res0 = wall_ms();
+    const double t_f0 = wall_ms();
     // The pinned buffers the GPU writes are slow for the CPU's small scattered reads (4x slower walk)
-    // but stream at tens of GB/s: copy the chunk's records into ordinary memory first (0.2 ms for
-    // 180 k records) and walk there.
+    // but stream at tens of GB/s: copy the chunk's records into ordinary memory (0.1 ms for 70 k
+    // records) and walk there.
+    job.nlive = nlive;
     job.recs.resize(nlive + 1);
     job.recs[nlive].pos = 0xFFFFFFFFu;          // sentinel for the walk
     job.sig.resize(nlive);
     std::memcpy(job.recs.data(), sl.h_live, nlive * sizeof(PhaseRec));
     std::memcpy(job.sig.data(), sl.h_live_sig, nlive * sizeof(unsigned long long));
-    const double t_cp = wall_ms() - t_res0;
+    job.buffers = sl.buffers;
+    job.given_mean_power = sl.given_mean_power;
+    job.sums.assign(sl.h_sums, sl.h_sums + 2 * c->cap_buffers);
+    job.fsums.assign(sl.h_fsums, sl.h_fsums + 2 * c->cap_buffers);
+    // ---- counters that do not depend on the skip windows ----
+    const unsigned long long *hc = sl.h_counters;
+    c->feed_cand[0] += hc[CNT_CANDIDATES];
+    for (int i = 0; i < 5; ++i) c->feed_cand[1 + i] += hc[CNT_PHASE0 + i];
+    c->feed_cand[6] += hc[CNT_CLASS_COND];
+    c->feed_cand[7] += hc[CNT_CLASS_UNCOND];
+    c->acc.n_candidates += hc[CNT_CANDIDATES];
+    c->acc.n_records += hc[CNT_RECORDS];
+    c->acc.n_live_records += nlive;
+    c->acc.n_chunks += 1;
+    c->acc.d2h_ms += (float) (wall_ms() - t_f0);
+    return MGPU_OK;
+}
+
+// ---- part 2 (walker thread): the ordered accept walk, then the window statistics of what it hid ----
+static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
+    const mgpu_config &cfg = c->cfg;
+    const uint64_t n = sl.n;
+    const uint64_t nlive = job.nlive;
+    const double t_res0 = wall_ms();
     const uint64_t aux_cap = nlive + 1 < c->cap_msgs ? nlive + 1 : c->cap_msgs;
     job.pos.resize(aux_cap); c->w_limit.resize(aux_cap); c->w_skip.resize(aux_cap);
-    job.acc.clear();
     job.rc = ResolveCounts();
     const int64_t wn = c->resolver.decide(job.recs.data(), nlive, sl.buffers, job.acc, job.pos.data(), c->w_skip.data(),
                                           c->w_limit.data(), aux_cap, job.rc);
-    const double t_wk = wall_ms() - t_res0 - t_cp;
     if (wn > 0) {
         std::memcpy(sl.h_msg_pos, job.pos.data(), (size_t) wn * sizeof(uint32_t));
         std::memcpy(sl.h_msg_limit, c->w_limit.data(), (size_t) wn * sizeof(uint32_t));
         std::memcpy(sl.h_msg_skip, c->w_skip.data(), (size_t) wn * sizeof(uint16_t));
     }
     c->acc.resolve_ms += (float) (wall_ms() - t_res0);
-    if (getenv("MGPU_DEBUG_PRINT")) fprintf(stderr, "dbg: copy %.3f ms + walk %.3f ms for %llu live records -> %lld msgs\n", t_cp, t_wk, (unsigned long long) nlive, (long long) wn);
+    if (getenv("MGPU_DEBUG_PRINT")) fprintf(stderr, "dbg: walk %.3f ms for %llu live records -> %lld msgs\n", wall_ms() - t_res0, (unsigned long long) nlive, (long long) wn);
     if (wn < 0) { c->err = "max_messages exceeded"; return MGPU_E_OVERFLOW; }
     const uint32_t nmsg = (uint32_t) wn;
     c->feed_rc.add(job.rc);
@@ -610,31 +637,16 @@ static int walk_slot(mgpu_ctx *c, Slot &sl, HostJob &job) {
     }
     c->acc.sigpower_ms += (float) (wall_ms() - t_sig0);
 
-    // ---- counters that do not depend on the skip windows ----
-    const unsigned long long *hc = sl.h_counters;
-    c->feed_cand[0] += hc[CNT_CANDIDATES];
-    for (int i = 0; i < 5; ++i) c->feed_cand[1 + i] += hc[CNT_PHASE0 + i];
-    c->feed_cand[6] += hc[CNT_CLASS_COND];
-    c->feed_cand[7] += hc[CNT_CLASS_UNCOND];
-    c->acc.n_candidates += hc[CNT_CANDIDATES];
-    c->acc.n_records += hc[CNT_RECORDS];
-    c->acc.n_live_records += nlive;
+    job.nmsg = nmsg;
     c->acc.n_messages += nmsg;
-    c->acc.n_chunks += 1;
-
-    // the rest of the chunk's host work needs nothing of the slot
-    job.buffers = sl.buffers;
-    job.given_mean_power = sl.given_mean_power;
-    job.sums.assign(sl.h_sums, sl.h_sums + 2 * c->cap_buffers);
-    job.fsums.assign(sl.h_fsums, sl.h_fsums + 2 * c->cap_buffers);
     return MGPU_OK;
 }
 
-// ---- host half of a chunk, part 2 (builder thread): messages, signal and noise statistics ----------
+// ---- part 3 (builder thread): messages, signal and noise statistics ----------
 static int build_job(mgpu_ctx *c, HostJob &job) {
     const mgpu_config &cfg = c->cfg;
     const double t0 = wall_ms();
-    const uint32_t nmsg = (uint32_t) job.acc.size();
+    const uint32_t nmsg = job.nmsg;
     const uint32_t nbuf = (uint32_t) job.buffers.size();
     const size_t first_msg = c->pending.size();
     if (!c->pending.grow_for(nmsg)) { c->err = "out of memory for the decoded messages"; return MGPU_E_NOMEM; }
@@ -712,7 +724,7 @@ static int feed_end(mgpu_ctx *c) {
     return MGPU_OK;
 }
 
-static void worker_main(mgpu_ctx *c) {
+static void fetcher_main(mgpu_ctx *c) {
     (void) hipSetDevice(c->cfg.device);
     for (;;) {
         int idx, jidx;
@@ -721,18 +733,42 @@ static void worker_main(mgpu_ctx *c) {
             c->cv.wait(lk, [&] { return c->stop || !c->queue.empty(); });
             if (c->queue.empty()) return;   // stop requested and nothing left
             idx = c->queue.front();
-            c->queue.pop_front();
-            jidx = (int) (c->job_seq++ % 3);
+            jidx = (int) (c->job_seq++ % 4);
             c->cv.wait(lk, [&] { return !c->job[jidx].busy; });
             c->job[jidx].busy = true;
         }
         Slot &sl = c->slot[idx];
         HostJob &job = c->job[jidx];
-        int rc = c->worker_rc == MGPU_OK ? walk_slot(c, sl, job) : c->worker_rc;   // after an error just drain
+        job.slot = idx;
+        int rc = c->worker_rc == MGPU_OK ? fetch_slot(c, sl, job) : c->worker_rc;   // after an error just drain
         {
             std::lock_guard<std::mutex> lk(c->mu);
             if (rc != MGPU_OK && c->worker_rc == MGPU_OK) c->worker_rc = rc;
-            sl.busy = false;
+            c->queue.pop_front();            // popped only now: wait_all sees the chunk at every stage
+            if (rc == MGPU_OK) c->walk_queue.push_back(jidx); else { job.busy = false; sl.busy = false; }
+        }
+        c->cv.notify_all();
+    }
+}
+
+static void worker_main(mgpu_ctx *c) {
+    (void) hipSetDevice(c->cfg.device);
+    for (;;) {
+        int jidx;
+        {
+            std::unique_lock<std::mutex> lk(c->mu);
+            c->cv.wait(lk, [&] { return c->stop || !c->walk_queue.empty(); });
+            if (c->walk_queue.empty()) return;
+            jidx = c->walk_queue.front();
+        }
+        HostJob &job = c->job[jidx];
+        Slot &sl = c->slot[job.slot];
+        int rc = c->worker_rc == MGPU_OK ? walk_job(c, sl, job) : c->worker_rc;
+        {
+            std::lock_guard<std::mutex> lk(c->mu);
+            if (rc != MGPU_OK && c->worker_rc == MGPU_OK) c->worker_rc = rc;
+            c->walk_queue.pop_front();
+            sl.busy = false;                 // the GPU may have the slot back
             if (rc == MGPU_OK) c->build_queue.push_back(jidx); else job.busy = false;
         }
         c->cv.notify_all();
@@ -773,7 +809,7 @@ static void submit_slot(mgpu_ctx *c, int idx) {
 
 static int wait_all(mgpu_ctx *c) {
     std::unique_lock<std::mutex> lk(c->mu);
-    c->cv.wait(lk, [&] { return !c->slot[0].busy && !c->slot[1].busy && c->queue.empty() && c->build_queue.empty(); });
+    c->cv.wait(lk, [&] { return !c->slot[0].busy && !c->slot[1].busy && c->queue.empty() && c->walk_queue.empty() && c->build_queue.empty(); });
     return c->worker_rc;
 }
 

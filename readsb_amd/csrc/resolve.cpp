@@ -91,19 +91,24 @@ void Resolver::tick_empty(int64_t sysTimestamp) {
 static inline int frame_bits(const PhaseRec &r) { return (r.msg[0] & 0x80) ? 112 : 56; }   // demod_2400.c:399, DF as sliced
 
 int64_t Resolver::decide(const PhaseRec *recs, uint64_t nrecs, const std::vector<BufferClock> &buffers, std::vector<Accepted> &acc,
-                         uint32_t *aux_pos, uint16_t *aux_skip, uint32_t *aux_limit, uint64_t aux_cap, ResolveCounts &c) {
+                         uint32_t *aux_pos, uint16_t *aux_skip, uint32_t *aux_limit, uint64_t aux_cap, ResolveCounts &counts) {
     // recs[nrecs] is a sentinel the caller provides (pos = 0xFFFFFFFF)
-    uint64_t i = 0, nout = 0;
+    (void) nrecs;
+    ResolveCounts c;                                           // locals: the optimiser keeps them out of memory
+    if (acc.size() < aux_cap) acc.resize(aux_cap);             // a pre-sized array, its length is the return value
+    Accepted *out = acc.data();
+    const PhaseRec *r = recs;
+    uint64_t nout = 0;
     for (uint32_t bi = 0; bi < (uint32_t) buffers.size(); ++bi) {
         const BufferClock &b = buffers[bi];
         synthetic_now_ = b.sysTimestamp;                       // demod_2400.c:283-285
         const uint64_t end = (uint64_t) b.first + b.length;
         int64_t skip_until = -1;                               // the skip never crosses a buffer (loop-local pa)
-        while (recs[i].pos < end) {
-            const uint32_t pos = recs[i].pos;
+        while (r->pos < end) {
+            const uint32_t pos = r->pos;
             if ((int64_t) pos <= skip_until) {                 // hidden by the previous frame (:468)
                 uint32_t all_cond = REC_COND;
-                do { all_cond &= recs[i].flags; ++i; } while (recs[i].pos == pos);
+                do { all_cond &= r->flags; ++r; } while (r->pos == pos);
                 if (all_cond) ++c.skipped_cond_groups; else ++c.skipped_uncond_groups;
                 continue;
             }
@@ -113,15 +118,13 @@ int64_t Resolver::decide(const PhaseRec *recs, uint64_t nrecs, const std::vector
             bool best_known = false;
             uint32_t all_cond = REC_COND;
             do {
-                const PhaseRec &r = recs[i];
-                all_cond &= r.flags;
-                bool known = false;
-                int s;
-                if (r.score_known == r.score_unknown) s = r.score_known;
-                else { known = filter_.test(r.addr); s = known ? r.score_known : r.score_unknown; }
-                if (s > best) { best = s; br = &r; best_known = known || r.score_known == r.score_unknown; }
-                ++i;
-            } while (recs[i].pos == pos);
+                all_cond &= r->flags;
+                const bool fixed = r->score_known == r->score_unknown;
+                const bool known = fixed || filter_.test(r->addr);     // for fixed scores either answer scores the same
+                const int s = known ? r->score_known : r->score_unknown;
+                if (s > best) { best = s; br = r; best_known = known; }
+                ++r;
+            } while (r->pos == pos);
             ++c.visited_groups;
             if (all_cond) ++c.visited_cond_groups; else ++c.visited_uncond_groups;
             if (best < 0) {                                    // demod_2400.c:390-397
@@ -129,17 +132,17 @@ int64_t Resolver::decide(const PhaseRec *recs, uint64_t nrecs, const std::vector
                 continue;
             }
             const int msglen = frame_bits(*br);
-            const int64_t timestamp = b.sampleTimestamp + (int64_t) (pos - b.first) * 5 + (8 + 56) * 12 + br->phase;   // :406
-            synthetic_now_ = b.sysTimestamp + (timestamp - b.sampleTimestamp) / 12000;                                 // :409-414
+            const int64_t rel = (int64_t) (pos - b.first) * 5 + (8 + 56) * 12 + br->phase;   // timestamp - sampleTimestamp, :406
+            synthetic_now_ = b.sysTimestamp + rel / 12000;                                   // :409-414
             // decodeModesMessage's CRC/address stage: same filter state as the scoring above
             bool accept = (br->flags & REC_ACCEPT_IF_UNKNOWN) != 0;
-            if (!accept) accept = (br->score_known == br->score_unknown) ? best_known : filter_.test(br->addr);
+            if (!accept) accept = best_known;
             if (!accept) { ++c.rejected_unknown; continue; }   // :423-429, no skip-ahead
             if (br->flags & REC_ADDER) filter_.add(br->addr & 0xffffffu);   // mode_s.c:766-779
             ++c.accepted[(br->flags >> REC_CORR_SHIFT) & 3];
             ++c.best_phase[br->phase - 4];
-            if (nout >= aux_cap) return -1;
-            acc.push_back(Accepted{(uint32_t) (br - recs), bi, best});
+            if (nout >= aux_cap) { counts.add(c); return -1; }
+            out[nout] = Accepted{(uint32_t) (br - recs), bi, best};
             aux_pos[nout] = pos;
             aux_skip[nout] = (uint16_t) (msglen * 8 / 4);     // :468
             aux_limit[nout] = (uint32_t) end;
@@ -148,6 +151,7 @@ int64_t Resolver::decide(const PhaseRec *recs, uint64_t nrecs, const std::vector
         }
         after_buffer();
     }
+    counts.add(c);
     return (int64_t) nout;
 }
 

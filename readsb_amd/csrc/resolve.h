@@ -78,7 +78,8 @@ class Resolver {
   public:
     void reset(int64_t startup_ms);
     // The serial part: walk the ordered live records of one chunk and decide which frames the
-    // reference accepts (best phase, ICAO filter, skip-ahead, filter clock).  Appends to `acc` and
+    // reference accepts (best phase, ICAO filter, skip-ahead, filter clock).  Fills acc[0..return) (the
+    // vector is only ever grown, to aux_cap entries) and
     // writes each accepted frame's chunk-relative position / skip length / buffer limit (inputs of
     // k_window_stats) to the aux arrays (capacity aux_cap); returns the number of accepted frames,
     // or -1 if aux_cap was too small.  recs[nrecs] must be a readable sentinel with pos = 0xFFFFFFFF.

@@ -26,8 +26,8 @@ int main(int argc, char **argv) {
     double best_d = 1e9, best_b = 1e9; size_t nm = 0;
     for (int it = 0; it < 20; ++it) {
         Resolver r; r.reset(1000000);
-        std::vector<Accepted> acc; acc.reserve(nrecs / 2);
-        std::vector<mgpu_msg> out(nrecs / 2 + 16);
+        std::vector<Accepted> acc; acc.reserve(nrecs);
+        std::vector<mgpu_msg> out(nrecs + 16);
         ResolveCounts rc;
         auto t0 = std::chrono::steady_clock::now();
         int64_t n = r.decide(recs.data(), nrecs, bufs, acc, pos.data(), skip.data(), lim.data(), nrecs, rc);

@@ -105,8 +105,8 @@ struct mgpu_counters {
 struct mgpu_timing {
     float h2d_ms;        /* host->device copy of the IQ block (0 for resident input) */
     float convert_ms;    /* k_convert_* */
-    float sweep_ms;      /* k_sweep: the preamble sweep, the roofline kernel (fused generations: sweep + slicer) */
-    float prescreen_ms;  /* record pre-screen + compaction */
+    float sweep_ms;      /* the sweep kernel alone (k_sweep_slice: sweep + slicer + scoring), HIP events around its launches */
+    float prescreen_ms;  /* class-plane finalize + record pre-screen + compaction + scratch copy-back */
     float resolve_ms;    /* ordered accept / skip-ahead / ICAO filter walk (host wall time) */
     float sigpower_ms;   /* host time spent launching the skip-window statistics kernel */
     float d2h_ms;        /* fetcher thread: live records out of the pinned buffer the pre-screen kernel wrote (host) */
@@ -116,7 +116,7 @@ struct mgpu_timing {
     uint64_t n_live_records; /* records that survived the pre-screen (reach the ordered walk) */
     uint64_t n_messages;     /* accepted messages */
     uint64_t n_chunks;       /* pipeline chunks = launches of each kernel; the *_ms fields above are sums over them */
-    float slice_ms;          /* k_slice (bit slicer + CRC + score); sweep_ms is then k_sweep alone */
+    float slice_ms;          /* generation 4 only: k_slice (bit slicer + CRC + score); sweep_ms is then k_sweep alone */
     float build_ms;          /* builder thread: struct modesMessage fields + signal / noise statistics (host) */
 };
 

@@ -493,6 +493,11 @@ static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
     // kernel of its previous use (stream2)
     if (sl.window_pending) { HIPCHK(c, hipStreamWaitEvent(s, sl.ev_window, 0)); sl.window_pending = false; }
     HIPCHK(c, hipMemsetAsync(sl.d_scratch, 0, sl.scratch_bytes, s));   // counters, pool_used, per-buffer sums
+    if (c->sweep_version >= 3) {   // class planes: the scoring passes OR single bits into them
+        const size_t cb = (((size_t) ((n + 31) / 32) + 4) & ~(size_t) 3) * sizeof(uint32_t);   // whole 16-byte groups
+        HIPCHK(c, hipMemsetAsync(sl.d_class_bitmap, 0, cb, s));
+        HIPCHK(c, hipMemsetAsync(sl.d_class_uncond, 0, cb, s));
+    }
     HIPCHK(c, hipEventRecord(sl.ev[0], s));
     if (!sl.have_mag) {
         ConvertParams cp{};
@@ -519,21 +524,15 @@ static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
     { const char *e = getenv("MGPU_DEBUG_STAGE"); sp.debug_stage = e ? atoi(e) : 0; }
     sp.adder_bitmap = c->d_adder_bitmap; sp.class_bitmap = sl.d_class_bitmap; sp.counters = sl.d_counters;
     sp.cand = sl.d_cand; sp.cand_count = sl.d_cand_count; sp.class_uncond = sl.d_class_uncond;
+    // ev[1] .. ev[4] bracket exactly one kernel: the sweep kernel of the active generation (bench.py's roofline)
     if (c->sweep_version == 1) launch_sweep_slice_v1(sp, s);
     else if (c->sweep_version == 2) launch_sweep_slice_v2(sp, s);
-    else {
-        // class planes: the scoring passes OR single bits into them
-        const size_t cb = (((size_t) ((n + 31) / 32) + 4) & ~(size_t) 3) * sizeof(uint32_t);   // whole 16-byte groups
-        HIPCHK(c, hipMemsetAsync(sl.d_class_bitmap, 0, cb, s));
-        HIPCHK(c, hipMemsetAsync(sl.d_class_uncond, 0, cb, s));
-    }
-    if (c->sweep_version == 3) launch_sweep_slice(sp, s);
-    else if (c->sweep_version == 4) {
-        launch_sweep(sp, s);
-        HIPCHK(c, hipEventRecord(sl.ev[4], s));
-        launch_slice(sp, s);
-    }
+    else if (c->sweep_version == 3) launch_sweep_slice(sp, s);
+    else launch_sweep(sp, s);
+    HIPCHK(c, hipEventRecord(sl.ev[4], s));
+    if (c->sweep_version == 4) launch_slice(sp, s);
     HIPCHK(c, hipEventRecord(sl.ev[2], s));
+    if (c->sweep_version >= 3) launch_class_finalize(sp, s);
     // pre-screen; the surviving records are written by the kernel straight into pinned host memory
     launch_prescreen(sl.d_pool, sl.d_unit_first, nunits, c->d_adder_bitmap, sl.d_unit_live, sl.h_live, sl.d_mag, sl.h_live_sig,
                      sl.d_counters, s);
@@ -556,10 +555,8 @@ static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job) {
     }
     float ms;
     if (hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]) == hipSuccess) c->acc.convert_ms += ms;
-    if (c->sweep_version == 4) {
-        if (hipEventElapsedTime(&ms, sl.ev[1], sl.ev[4]) == hipSuccess) c->acc.sweep_ms += ms;
-        if (hipEventElapsedTime(&ms, sl.ev[4], sl.ev[2]) == hipSuccess) c->acc.slice_ms += ms;
-    } else if (hipEventElapsedTime(&ms, sl.ev[1], sl.ev[2]) == hipSuccess) c->acc.sweep_ms += ms;
+    if (hipEventElapsedTime(&ms, sl.ev[1], sl.ev[4]) == hipSuccess) c->acc.sweep_ms += ms;
+    if (c->sweep_version == 4 && hipEventElapsedTime(&ms, sl.ev[4], sl.ev[2]) == hipSuccess) c->acc.slice_ms += ms;
     if (hipEventElapsedTime(&ms, sl.ev[2], sl.ev[3]) == hipSuccess) c->acc.prescreen_ms += ms;
     const uint64_t nlive = sl.h_counters[CNT_LIVE_TOTAL];
 

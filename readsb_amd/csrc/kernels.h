@@ -114,7 +114,8 @@ struct ConvertParams {
 void launch_convert(int format, const ConvertParams &p, hipStream_t s);
 void launch_sweep(const SweepParams &p, hipStream_t s);            // generation 4: k_sweep (streaming preamble sweep -> candidate lists)
 void launch_slice(const SweepParams &p, hipStream_t s);            //               k_slice (frames sliced straight from HBM/L2, no LDS tile)
-void launch_sweep_slice(const SweepParams &p, hipStream_t s);      // generation 3: fused, wave-autonomous LDS tiles
+void launch_sweep_slice(const SweepParams &p, hipStream_t s);      // generation 3: fused, wave-autonomous LDS tiles (default)
+void launch_class_finalize(const SweepParams &p, hipStream_t s);   // generations 3/4: class planes -> class bitmap + class counters
 void launch_sweep_slice_v2(const SweepParams &p, hipStream_t s);   // second version: workgroup tiles, block barriers
 void launch_sweep_slice_v1(const SweepParams &p, hipStream_t s);   // first version: wave per candidate
 // pre-screen: count / write the records whose address may matter to the ordered walk

@@ -1671,7 +1671,6 @@ __global__ __launch_bounds__(kBlock, MGPU_V3_PREFETCH ? 3 : 4) void k_sweep_slic
 }
 
 __global__ void k_class_finalize(uint32_t *cond, const uint32_t *uncond, uint64_t nwords, unsigned long long *counters);
-static void launch_class_finalize(const SweepParams &p, hipStream_t s);
 
 void launch_sweep_slice(const SweepParams &p, hipStream_t s) {
     if (p.nunits == 0) return;
@@ -1691,7 +1690,6 @@ void launch_sweep_slice(const SweepParams &p, hipStream_t s) {
     const unsigned want = (p.nunits + (kBlock / WAVE) - 1) / (kBlock / WAVE);
     const unsigned blocks = want < maxb ? want : maxb;
     hipLaunchKernelGGL(k_sweep_slice, dim3(blocks), dim3(kBlock), dyn, s, p);
-    launch_class_finalize(p, s);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2061,10 +2059,9 @@ void launch_slice(const SweepParams &p, hipStream_t s) {
     const unsigned want = (p.nunits + (kBlock / WAVE) - 1) / (kBlock / WAVE);
     const unsigned blocks = want < (unsigned) resident ? want : (unsigned) resident;
     hipLaunchKernelGGL(k_slice, dim3(blocks), dim3(kBlock), dyn, s, p);
-    launch_class_finalize(p, s);
 }
 
-static void launch_class_finalize(const SweepParams &p, hipStream_t s) {
+void launch_class_finalize(const SweepParams &p, hipStream_t s) {
     const uint64_t nwords = (p.n + 31) / 32;
     unsigned cb = (unsigned) ((nwords / 4 + kBlock) / kBlock);
     if (cb > 1024) cb = 1024;

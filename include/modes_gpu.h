@@ -191,6 +191,15 @@ int mgpu_crc_table_size(int nfix_crc, int bits);                           /* cr
 /* the 65536-entry UC8 magnitude table (init_uc8_lookup, convert.c:35-62), index I | Q<<8 */
 const uint16_t *mgpu_uc8_table(void);
 
+/* ---- diagnostics ------------------------------------------------------------------------------
+ * Host-logic self-check, needs no GPU: walks a seeded synthetic record stream (aircraft that appear,
+ * go quiet long enough to expire from the ICAO filter, and return) once serially and once as
+ * `nsegments` speculative buffer ranges per chunk, and compares every decision, counter and the
+ * final filter.  0 = identical, k > 0 = first differing chunk + 1, < 0 = bad arguments.
+ * *speculated_permille (may be NULL) = share of ranges whose speculation held. */
+int mgpu_selftest_walk(uint64_t seed, uint32_t nchunks, uint32_t buffers_per_chunk, uint32_t nsegments,
+                       uint32_t naircraft, uint32_t *speculated_permille);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,6 +10,8 @@
 
 #include <cctype>
 #include <algorithm>
+#include <atomic>
+#include <functional>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -37,6 +39,86 @@ double wall_ms() {
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 }  // namespace
+
+// A few persistent helper threads for fork-join over small task counts (the caller takes tasks too).
+// Helpers spin briefly before blocking: the forks come every few hundred microseconds while a feed runs.
+class Team {
+  public:
+    ~Team() { stop(); }
+    void start(int helpers) {
+        for (int i = 0; i < helpers; ++i) threads.emplace_back([this] { loop(); });
+    }
+    void stop() {
+        { std::lock_guard<std::mutex> lk(mu_); quit_ = true; ++gen_; }
+        wake_.fetch_add(1, std::memory_order_release);
+        cv_work_.notify_all();
+        for (auto &t : threads) if (t.joinable()) t.join();
+        threads.clear();
+    }
+    void run(int ntasks, const std::function<void(int)> &fn) {
+        if (ntasks <= 0) return;
+        if (threads.empty() || ntasks == 1) { for (int i = 0; i < ntasks; ++i) fn(i); return; }
+        uint32_t g;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            g = ++gen_;
+            fn_ = &fn; ntasks_ = ntasks;
+            pending_.store(ntasks, std::memory_order_relaxed);
+            ticket_.store((uint64_t) g << 32, std::memory_order_release);
+        }
+        wake_.fetch_add(1, std::memory_order_release);
+        cv_work_.notify_all();
+        work(g, &fn, ntasks);
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_done_.wait(lk, [&] { return pending_.load(std::memory_order_acquire) == 0; });
+        fn_ = nullptr;
+    }
+    std::vector<std::thread> threads;
+
+  private:
+    // tasks are handed out through one word that also carries the generation, so a helper that is late
+    // leaving generation g can never take a task of generation g+1 with g's function
+    void work(uint32_t g, const std::function<void(int)> *fn, int n) {
+        int done = 0;
+        uint64_t t = ticket_.load(std::memory_order_acquire);
+        for (;;) {
+            if ((uint32_t) (t >> 32) != g || (int) (uint32_t) t >= n) break;
+            if (!ticket_.compare_exchange_weak(t, t + 1, std::memory_order_acq_rel)) continue;
+            (*fn)((int) (uint32_t) t);
+            ++done;
+            t = ticket_.load(std::memory_order_acquire);
+        }
+        if (done && pending_.fetch_sub(done, std::memory_order_acq_rel) == done) {
+            std::lock_guard<std::mutex> lk(mu_);
+            cv_done_.notify_all();
+        }
+    }
+    void loop() {
+        uint64_t seen = wake_.load(std::memory_order_acquire);
+        for (;;) {
+            for (int spin = 0; spin < 20000 && wake_.load(std::memory_order_acquire) == seen; ++spin) __builtin_ia32_pause();
+            const std::function<void(int)> *fn;
+            int n;
+            uint32_t g;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_work_.wait(lk, [&] { return quit_ || wake_.load(std::memory_order_acquire) != seen; });
+                if (quit_) return;
+                seen = wake_.load(std::memory_order_acquire);
+                fn = fn_; n = ntasks_; g = gen_;
+            }
+            if (fn) work(g, fn, n);
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_work_, cv_done_;
+    const std::function<void(int)> *fn_ = nullptr;
+    int ntasks_ = 0;
+    uint32_t gen_ = 0;
+    std::atomic<uint64_t> ticket_{0}, wake_{0};
+    std::atomic<int> pending_{0};
+    bool quit_ = false;
+};
 
 // One pipeline stage's worth of buffers: a chunk of the stream is converted, swept and pre-screened
 // into a slot on the GPU while the worker thread walks the previous chunk's records on the host.
@@ -157,6 +239,10 @@ struct mgpu_ctx {
     // ordered accept walk, window-statistics launch) and hands a HostJob to the builder thread
     // (messages, signal / noise statistics), so that the serial walk is all the walker does
     std::thread fetcher, worker, builder;
+    Team walk_team, build_team;                               // helpers of the walker / builder stage (MGPU_WALK_THREADS, MGPU_BUILD_THREADS)
+    int walk_threads = 4, build_threads = 2;
+    std::vector<SegmentWalk> segs;                            // the walker's buffer ranges
+    uint64_t spec_segments = 0, spec_batches = 0, spec_serial = 0;   // ranges walked, speculation batches, ranges that fell back to the serial loop
     std::mutex mu;
     std::condition_variable cv;
     std::deque<int> queue, walk_queue, build_queue;
@@ -225,9 +311,9 @@ static void bind_near_device(std::thread *const *threads, int nthreads, int devi
         if (std::find(l3_ids.begin(), l3_ids.end(), l3_of[i]) == l3_ids.end()) l3_ids.push_back(l3_of[i]);
     }
     const int want = l3_ids[(size_t) device % l3_ids.size()];
-    // one logical CPU per physical core of that group
+    // one logical CPU per physical core of that group; more threads than cores share cores round-robin
     std::vector<int> pick, cores;
-    for (size_t i = 0; i < cpus.size() && (int) pick.size() < nthreads; ++i) {
+    for (size_t i = 0; i < cpus.size(); ++i) {
         if (l3_of[i] != want) continue;
         const int core = sysfs_int("/sys/devices/system/cpu/cpu" + std::to_string(cpus[i]) + "/topology/core_id", (int) i);
         if (std::find(cores.begin(), cores.end(), core) != cores.end()) continue;
@@ -235,9 +321,9 @@ static void bind_near_device(std::thread *const *threads, int nthreads, int devi
         pick.push_back(cpus[i]);
     }
     cpu_set_t set;
-    if (want >= 0 && (int) pick.size() == nthreads) {
+    if (want >= 0 && pick.size() >= 2) {
         for (int t = 0; t < nthreads; ++t) {
-            CPU_ZERO(&set); CPU_SET(pick[t], &set);
+            CPU_ZERO(&set); CPU_SET(pick[(size_t) t % pick.size()], &set);
             (void) pthread_setaffinity_np(threads[t]->native_handle(), sizeof(set), &set);
         }
     } else {                               // no cache topology in sysfs: the whole node
@@ -434,10 +520,19 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
         return rc;
     }
     c->resolver.reset(cfg->startup_time_ms);
+    if (const char *e = getenv("MGPU_WALK_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) c->walk_threads = v; }
+    if (const char *e = getenv("MGPU_BUILD_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) c->build_threads = v; }
     c->fetcher = std::thread(fetcher_main, c);
     c->worker = std::thread(worker_main, c);
     c->builder = std::thread(builder_main, c);
-    { std::thread *const th[3] = {&c->worker, &c->builder, &c->fetcher}; bind_near_device(th, 3, cfg->device); }
+    c->walk_team.start(c->walk_threads - 1);
+    c->build_team.start(c->build_threads - 1);
+    {
+        std::vector<std::thread *> th = {&c->worker, &c->builder, &c->fetcher};
+        for (auto &t : c->walk_team.threads) th.push_back(&t);
+        for (auto &t : c->build_team.threads) th.push_back(&t);
+        bind_near_device(th.data(), (int) th.size(), cfg->device);
+    }
     *out = c;
     return MGPU_OK;
 }
@@ -451,6 +546,8 @@ void mgpu_destroy(mgpu_ctx *c) {
         if (c->worker.joinable()) c->worker.join();
         if (c->builder.joinable()) c->builder.join();
     }
+    c->walk_team.stop();
+    c->build_team.stop();
     (void) hipSetDevice(c->cfg.device);
     if (c->stream) (void) hipStreamSynchronize(c->stream);
     if (c->stream2) (void) hipStreamSynchronize(c->stream2);
@@ -606,8 +703,53 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
     const uint64_t aux_cap = nlive + 1 < c->cap_msgs ? nlive + 1 : c->cap_msgs;
     job.pos.resize(aux_cap); c->w_limit.resize(aux_cap); c->w_skip.resize(aux_cap);
     job.rc = ResolveCounts();
-    const int64_t wn = c->resolver.decide(job.recs.data(), nlive, sl.buffers, job.acc, job.pos.data(), c->w_skip.data(),
-                                          c->w_limit.data(), aux_cap, job.rc);
+    int64_t wn;
+    const uint32_t nbuf_all = (uint32_t) sl.buffers.size();
+    const int K = c->walk_threads;
+    if (K >= 2 && nbuf_all >= (uint32_t) (4 * K) && nlive >= 4096) {
+        // buffer ranges walked in parallel against the filter as it stands now, committed in stream order
+        // (resolve.h: Resolver::parallel_walk); exact, and serial only where speculation fails
+        std::vector<SegmentWalk> &segs = c->segs;
+        if ((int) segs.size() != K) segs.resize(K);
+        for (int k = 0; k < K; ++k) {
+            segs[k].b_lo = (uint32_t) ((uint64_t) nbuf_all * k / K);
+            segs[k].b_hi = (uint32_t) ((uint64_t) nbuf_all * (k + 1) / K);
+            segs[k].rec_lo = k == 0 ? 0 : segment_first_record(job.recs.data(), nlive, sl.buffers[segs[k].b_lo].first);
+        }
+        for (int k = 0; k < K; ++k) segs[k].rec_hi = k + 1 < K ? segs[k + 1].rec_lo : nlive;
+        const double tp0 = wall_ms();
+        uint64_t batches = 0, serial_ranges = 0;
+        c->resolver.parallel_walk(job.recs.data(), nlive, sl.buffers, segs,
+                                  [&](int ntasks, const std::function<void(int)> &task) { c->walk_team.run(ntasks, task); },
+                                  &batches, &serial_ranges);
+        const double tp2 = wall_ms();
+        uint64_t total = 0;
+        for (int k = 0; k < K; ++k) {
+            total += segs[k].nacc;
+            job.rc.add(segs[k].counts);
+        }
+        c->spec_segments += (uint64_t) K;
+        c->spec_batches += batches;
+        c->spec_serial += serial_ranges;
+        if (total > aux_cap) wn = -1;
+        else {
+            if (job.acc.size() < total) job.acc.resize(total);
+            uint64_t off = 0;
+            for (int k = 0; k < K; ++k) {
+                const uint64_t m = segs[k].nacc;
+                std::memcpy(job.acc.data() + off, segs[k].acc.data(), m * sizeof(Accepted));
+                std::memcpy(job.pos.data() + off, segs[k].pos.data(), m * sizeof(uint32_t));
+                std::memcpy(c->w_limit.data() + off, segs[k].limit.data(), m * sizeof(uint32_t));
+                std::memcpy(c->w_skip.data() + off, segs[k].skip.data(), m * sizeof(uint16_t));
+                off += m;
+            }
+            wn = (int64_t) total;
+        }
+        if (getenv("MGPU_DEBUG_PRINT")) fprintf(stderr, "dbg: %d ranges in %llu batches, %llu walked serially: %.3f ms, gather %.3f ms\n", K, (unsigned long long) batches, (unsigned long long) serial_ranges, tp2 - tp0, wall_ms() - tp2);
+    } else {
+        wn = c->resolver.decide(job.recs.data(), nlive, sl.buffers, job.acc, job.pos.data(), c->w_skip.data(),
+                                c->w_limit.data(), aux_cap, job.rc);
+    }
     if (wn > 0) {
         std::memcpy(sl.h_msg_pos, job.pos.data(), (size_t) wn * sizeof(uint32_t));
         std::memcpy(sl.h_msg_limit, c->w_limit.data(), (size_t) wn * sizeof(uint32_t));
@@ -648,7 +790,14 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
     const size_t first_msg = c->pending.size();
     if (!c->pending.grow_for(nmsg)) { c->err = "out of memory for the decoded messages"; return MGPU_E_NOMEM; }
     const double t1 = wall_ms();
-    Resolver::build_messages(job.recs.data(), job.sig.data(), job.buffers, job.acc.data(), nmsg, c->pending.data() + first_msg);
+    {
+        const int parts = nmsg >= 4096 ? c->build_threads : 1;
+        mgpu_msg *out = c->pending.data() + first_msg;
+        c->build_team.run(parts, [&](int i) {
+            const uint64_t lo = (uint64_t) nmsg * i / parts, hi = (uint64_t) nmsg * (i + 1) / parts;
+            Resolver::build_messages(job.recs.data(), job.sig.data(), job.buffers, job.acc.data() + lo, hi - lo, out + lo);
+        });
+    }
     c->pending.n = first_msg + nmsg;
     const double t2 = wall_ms();
 
@@ -1032,5 +1181,110 @@ int mgpu_crc_diagnose(int nfix_crc, uint32_t syndrome, int bits, int *bit0, int 
 int mgpu_crc_table_size(int nfix_crc, int bits) { return (int) host_table(nfix_crc, bits).size(); }
 
 const uint16_t *mgpu_uc8_table(void) { return uc8_table(); }
+
+// Host-logic self-check (no GPU): a seeded synthetic record stream — aircraft that appear, go quiet and
+// return, so that addresses enter the ICAO filter, expire on the 60 s clock and come back — is walked
+// chunk by chunk once with Resolver::decide and once with Resolver::parallel_walk over `nsegments`
+// buffer ranges per chunk (real threads).  Returns 0 when every decision, every counter and the final
+// filter agree; k > 0 = first differing chunk + 1.  *speculated_permille = share of ranges whose
+// speculation held (a test that only ever took the serial fallback would prove nothing).
+int mgpu_selftest_walk(uint64_t seed, uint32_t nchunks, uint32_t buffers_per_chunk, uint32_t nsegments, uint32_t naircraft,
+                       uint32_t *speculated_permille) {
+    if (nchunks == 0 || buffers_per_chunk == 0 || nsegments == 0 || naircraft == 0) return -1;
+    uint64_t x = seed ? seed : 88172645463325252ull;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    const uint32_t B = 131072;
+    Resolver serial, parallel;
+    serial.reset(1000000);
+    parallel.reset(1000000);
+    uint64_t held = 0, ranges = 0;
+    // aircraft a transmits during [on, off) of every `period` seconds: quiet spells longer than two filter
+    // generations make addresses expire, short ones do not
+    struct Plane { uint32_t addr; double on, off, period; };
+    std::vector<Plane> planes(naircraft);
+    for (uint32_t i = 0; i < naircraft; ++i) {
+        planes[i].addr = 0x400000u + (uint32_t) (rnd() % 4096) * 7u + i;
+        planes[i].period = 40.0 + (double) (rnd() % 400);
+        planes[i].on = (double) (rnd() % 1000) / 1000.0 * planes[i].period;
+        planes[i].off = planes[i].on + 5.0 + (double) (rnd() % 1000) / 1000.0 * planes[i].period;
+    }
+    const uint32_t K = nsegments < buffers_per_chunk ? nsegments : buffers_per_chunk;
+    std::vector<SegmentWalk> segs(K);
+    uint64_t stream_pos = 0;
+    for (uint32_t ch = 0; ch < nchunks; ++ch) {
+        std::vector<BufferClock> bufs;
+        for (uint32_t b = 0; b < buffers_per_chunk; ++b) {
+            BufferClock bc;
+            bc.first = b * B; bc.length = B;
+            bc.sampleTimestamp = (int64_t) (stream_pos + (uint64_t) b * B) * 5;
+            bc.sysTimestamp = bc.sampleTimestamp / 12000 + 1000000;
+            bufs.push_back(bc);
+        }
+        std::vector<PhaseRec> recs;
+        const uint64_t npos = (uint64_t) buffers_per_chunk * B;
+        for (uint64_t pos = rnd() % 600; pos < npos; pos += 40 + rnd() % 900) {
+            const double t = (double) (stream_pos + pos) / 2.4e6;
+            const Plane &pl = planes[rnd() % naircraft];
+            const double ph = std::fmod(t, pl.period);
+            const bool active = ph >= pl.on && ph < pl.off;
+            const int nrec = 1 + (int) (rnd() % 3);
+            int phase = 4 + (int) (rnd() % 3);
+            for (int k = 0; k < nrec && phase <= 8; ++k, phase += 1 + (int) (rnd() % 2)) {
+                PhaseRec r{};
+                r.pos = (uint32_t) pos; r.phase = (uint8_t) phase; r.fixbit0 = r.fixbit1 = 0xff;
+                const uint32_t kind = (uint32_t) (rnd() % 100);
+                const uint32_t other = planes[rnd() % naircraft].addr;
+                if (active && kind < 45) { r.flags = REC_ACCEPT_IF_UNKNOWN | REC_ADDER | REC_LONG; r.score_known = 1800; r.score_unknown = 1400; r.addr = pl.addr; r.msg[0] = 0x8d; }
+                else if (active && kind < 55) { r.flags = REC_ACCEPT_IF_UNKNOWN | REC_ADDER; r.score_known = 1600; r.score_unknown = 750; r.addr = pl.addr; r.msg[0] = 0x5d; }
+                else if (kind < 65) { r.flags = REC_LONG | (1u << REC_CORR_SHIFT); r.score_known = 900; r.score_unknown = 700; r.addr = other; r.msg[0] = 0x8d; r.fixbit0 = 40; }
+                else if (kind < 80) { r.flags = REC_COND | REC_LONG; r.score_known = 1000; r.score_unknown = -1; r.addr = other; r.msg[0] = 0xa0; }
+                else if (kind < 90) { r.flags = REC_COND; r.score_known = 1000; r.score_unknown = -1; r.addr = pl.addr; r.msg[0] = 0x20; }
+                else { r.flags = REC_COND | (1u << REC_CORR_SHIFT); r.score_known = 800; r.score_unknown = -1; r.addr = other; r.msg[0] = 0x5d; r.fixbit0 = 12; }
+                recs.push_back(r);
+            }
+        }
+        const uint64_t n = recs.size();
+        { PhaseRec s{}; s.pos = 0xFFFFFFFFu; recs.push_back(s); }
+        std::vector<uint32_t> pos(n + 1), lim(n + 1);
+        std::vector<uint16_t> skip(n + 1);
+        std::vector<Accepted> acc_s;
+        ResolveCounts rc_s, rc_p;
+        const int64_t ns = serial.decide(recs.data(), n, bufs, acc_s, pos.data(), skip.data(), lim.data(), n + 1, rc_s);
+        for (uint32_t k = 0; k < K; ++k) {
+            segs[k].b_lo = (uint32_t) ((uint64_t) buffers_per_chunk * k / K);
+            segs[k].b_hi = (uint32_t) ((uint64_t) buffers_per_chunk * (k + 1) / K);
+            segs[k].rec_lo = k == 0 ? 0 : segment_first_record(recs.data(), n, bufs[segs[k].b_lo].first);
+        }
+        for (uint32_t k = 0; k < K; ++k) segs[k].rec_hi = k + 1 < K ? segs[k + 1].rec_lo : n;
+        parallel.parallel_walk(recs.data(), n, bufs, segs, [&](int ntasks, const std::function<void(int)> &task) {
+            std::vector<std::thread> th;
+            for (int i = 0; i < ntasks; ++i) th.emplace_back([&task, i] { task(i); });
+            for (auto &t : th) t.join();
+        });
+        uint64_t np = 0;
+        bool same = true;
+        for (uint32_t k = 0; k < K; ++k) {
+            rc_p.add(segs[k].counts);
+            held += segs[k].speculated ? 1 : 0;
+            ++ranges;
+            for (uint64_t i = 0; i < segs[k].nacc; ++i, ++np) {
+                if (np >= (uint64_t) ns) { same = false; break; }
+                const Accepted &p = segs[k].acc[i], &s = acc_s[np];
+                if (p.rec != s.rec || p.buffer != s.buffer || p.score != s.score || segs[k].pos[i] != pos[np] ||
+                    segs[k].skip[i] != skip[np] || segs[k].limit[i] != lim[np]) same = false;
+            }
+        }
+        std::vector<uint32_t> us, up;
+        serial.union_snapshot(us);
+        parallel.union_snapshot(up);
+        if (!same || np != (uint64_t) ns || std::memcmp(&rc_s, &rc_p, sizeof(rc_s)) != 0 || us != up ||
+            serial.nflips() != parallel.nflips() || serial.filter().occupied() != parallel.filter().occupied() ||
+            serial.filter().table_bits() != parallel.filter().table_bits())
+            return (int) ch + 1;
+        stream_pos += npos;
+    }
+    if (speculated_permille) *speculated_permille = ranges ? (uint32_t) (held * 1000 / ranges) : 0;
+    return 0;
+}
 
 }  // extern "C"

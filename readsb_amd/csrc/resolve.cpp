@@ -19,6 +19,9 @@ IcaoFilter::IcaoFilter() {
 }
 
 void IcaoFilter::clear_gen(int g) {
+    if (drops_)   // what leaves the union: members of this generation the other one does not hold
+        for (uint32_t a : members_[g])
+            if (!((bits_[g ^ 1][a >> 6] >> (a & 63)) & 1)) drops_->push_back(a);
     for (uint32_t a : members_[g]) bits_[g][a >> 6] = 0;
     members_[g].clear();
     big_[g].clear();
@@ -50,7 +53,10 @@ void IcaoFilter::add(uint32_t addr) {
     if (addr < (1u << 24)) {
         uint64_t &w = bits_[active_][addr >> 6];
         const uint64_t bit = 1ull << (addr & 63);
-        if (!(w & bit)) { w |= bit; members_[active_].push_back(addr); inserted = true; }
+        if (!(w & bit)) {
+            w |= bit; members_[active_].push_back(addr); inserted = true;
+            if (news_ && !((bits_[active_ ^ 1][addr >> 6] >> (addr & 63)) & 1)) news_->push_back(addr);
+        }
     } else if (std::find(big_[active_].begin(), big_[active_].end(), addr) == big_[active_].end()) {
         big_[active_].push_back(addr);
         inserted = true;
@@ -64,6 +70,32 @@ void IcaoFilter::expire() {
     occupied_ = 0;
     clear_gen(active_ ^ 1);
     active_ ^= 1;
+}
+
+void IcaoFilter::snapshot(Snapshot &s) const {
+    for (int g = 0; g < 2; ++g) { s.members[g] = members_[g]; s.big[g] = big_[g]; }
+    s.active = active_; s.occupied = occupied_; s.filter_bits = filter_bits_;
+}
+
+void IcaoFilter::restore(const Snapshot &s) {
+    std::vector<uint32_t> *keep = drops_;
+    drops_ = nullptr;   // (news_ is only touched by add)
+    for (int g = 0; g < 2; ++g) {
+        clear_gen(g);
+        for (uint32_t a : s.members[g]) bits_[g][a >> 6] |= 1ull << (a & 63);
+        members_[g] = s.members[g];
+        big_[g] = s.big[g];
+    }
+    active_ = s.active; occupied_ = s.occupied; filter_bits_ = s.filter_bits;
+    drops_ = keep;
+}
+
+void IcaoFilter::union_sorted(std::vector<uint32_t> &out) const {
+    out.clear();
+    out.insert(out.end(), members_[0].begin(), members_[0].end());
+    out.insert(out.end(), members_[1].begin(), members_[1].end());
+    std::sort(out.begin(), out.end());
+    out.erase(std::unique(out.begin(), out.end()), out.end());
 }
 
 void Resolver::reset(int64_t startup_ms) {
@@ -90,18 +122,19 @@ void Resolver::tick_empty(int64_t sysTimestamp) {
 
 static inline int frame_bits(const PhaseRec &r) { return (r.msg[0] & 0x80) ? 112 : 56; }   // demod_2400.c:399, DF as sliced
 
-int64_t Resolver::decide(const PhaseRec *recs, uint64_t nrecs, const std::vector<BufferClock> &buffers, std::vector<Accepted> &acc,
-                         uint32_t *aux_pos, uint16_t *aux_skip, uint32_t *aux_limit, uint64_t aux_cap, ResolveCounts &counts) {
-    // recs[nrecs] is a sentinel the caller provides (pos = 0xFFFFFFFF)
-    (void) nrecs;
+// The accept walk over buffers [b_lo, b_hi) of a chunk, starting at live record rec_lo.  `pol` answers
+// icaoFilterTest, takes icaoFilterAdd and is told the clock (Modes.synthetic_now) at every buffer end.
+// recs ends with a sentinel (pos = 0xFFFFFFFF).  Indices written are chunk-relative.
+template <class Policy>
+int64_t Resolver::walk_range(Policy &pol, const PhaseRec *recs, uint64_t rec_lo, const BufferClock *bufs, uint32_t b_lo, uint32_t b_hi,
+                             Accepted *out, uint32_t *aux_pos, uint16_t *aux_skip, uint32_t *aux_limit, uint64_t aux_cap,
+                             ResolveCounts &counts) const {
     ResolveCounts c;                                           // locals: the optimiser keeps them out of memory
-    if (acc.size() < aux_cap) acc.resize(aux_cap);             // a pre-sized array, its length is the return value
-    Accepted *out = acc.data();
-    const PhaseRec *r = recs;
+    const PhaseRec *r = recs + rec_lo;
     uint64_t nout = 0;
-    for (uint32_t bi = 0; bi < (uint32_t) buffers.size(); ++bi) {
-        const BufferClock &b = buffers[bi];
-        synthetic_now_ = b.sysTimestamp;                       // demod_2400.c:283-285
+    for (uint32_t bi = b_lo; bi < b_hi; ++bi) {
+        const BufferClock &b = bufs[bi];
+        int64_t now = b.sysTimestamp;                          // Modes.synthetic_now, demod_2400.c:283-285
         const uint64_t end = (uint64_t) b.first + b.length;
         int64_t skip_until = -1;                               // the skip never crosses a buffer (loop-local pa)
         while (r->pos < end) {
@@ -120,7 +153,7 @@ int64_t Resolver::decide(const PhaseRec *recs, uint64_t nrecs, const std::vector
             do {
                 all_cond &= r->flags;
                 const bool fixed = r->score_known == r->score_unknown;
-                const bool known = fixed || filter_.test(r->addr);     // for fixed scores either answer scores the same
+                const bool known = fixed || pol.test(r->addr);         // for fixed scores either answer scores the same
                 const int s = known ? r->score_known : r->score_unknown;
                 if (s > best) { best = s; br = r; best_known = known; }
                 ++r;
@@ -133,12 +166,11 @@ int64_t Resolver::decide(const PhaseRec *recs, uint64_t nrecs, const std::vector
             }
             const int msglen = frame_bits(*br);
             const int64_t rel = (int64_t) (pos - b.first) * 5 + (8 + 56) * 12 + br->phase;   // timestamp - sampleTimestamp, :406
-            synthetic_now_ = b.sysTimestamp + rel / 12000;                                   // :409-414
+            now = b.sysTimestamp + rel / 12000;                                              // :409-414
             // decodeModesMessage's CRC/address stage: same filter state as the scoring above
-            bool accept = (br->flags & REC_ACCEPT_IF_UNKNOWN) != 0;
-            if (!accept) accept = best_known;
+            const bool accept = (br->flags & REC_ACCEPT_IF_UNKNOWN) || best_known;
             if (!accept) { ++c.rejected_unknown; continue; }   // :423-429, no skip-ahead
-            if (br->flags & REC_ADDER) filter_.add(br->addr & 0xffffffu);   // mode_s.c:766-779
+            if (br->flags & REC_ADDER) pol.add(br->addr & 0xffffffu);       // mode_s.c:766-779
             ++c.accepted[(br->flags >> REC_CORR_SHIFT) & 3];
             ++c.best_phase[br->phase - 4];
             if (nout >= aux_cap) { counts.add(c); return -1; }
@@ -149,11 +181,171 @@ int64_t Resolver::decide(const PhaseRec *recs, uint64_t nrecs, const std::vector
             ++nout;
             skip_until = (int64_t) pos + msglen * 8 / 4;
         }
-        after_buffer();
+        pol.buffer_end(now);
     }
     counts.add(c);
     return (int64_t) nout;
 }
+
+namespace {
+// the true filter: icao_filter.c semantics, the 60 s clock after every buffer (readsb.c:1227-1231)
+struct LivePolicy {
+    IcaoFilter &flt;
+    int64_t &synthetic_now;
+    Resolver &res;
+    void (Resolver::*tick)();
+    bool test(uint32_t a) const { return flt.test(a); }
+    void add(uint32_t a) { flt.add(a); }
+    void buffer_end(int64_t now) { synthetic_now = now; (res.*tick)(); }
+};
+
+// speculation: membership as it was when the chunk started, plus the range's own adds
+struct SpecPolicy {
+    const IcaoFilter &flt;
+    SegmentWalk &w;
+    bool test(uint32_t a) {
+        if (a >> 24) { w.odd = true; return flt.test(a); }
+        if (w.added.test(a)) return true;
+        w.q_pre.set(a);
+        return flt.test(a) || w.assumed.test(a);
+    }
+    void add(uint32_t a) { if (!w.added.test(a)) { w.added.set(a); w.adds.push_back(a); } }
+    void buffer_end(int64_t now) { w.adds_end.push_back((uint32_t) w.adds.size()); w.end_clock.push_back(now); }
+};
+
+uint64_t first_record_at(const PhaseRec *recs, uint64_t nrecs, uint32_t pos) {
+    uint64_t lo = 0, hi = nrecs;
+    while (lo < hi) { const uint64_t mid = (lo + hi) / 2; if (recs[mid].pos < pos) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+}  // namespace
+
+int64_t Resolver::decide(const PhaseRec *recs, uint64_t nrecs, const std::vector<BufferClock> &buffers, std::vector<Accepted> &acc,
+                         uint32_t *aux_pos, uint16_t *aux_skip, uint32_t *aux_limit, uint64_t aux_cap, ResolveCounts &counts) {
+    (void) nrecs;
+    if (acc.size() < aux_cap) acc.resize(aux_cap);             // a pre-sized array, its length is the return value
+    LivePolicy pol{filter_, synthetic_now_, *this, &Resolver::after_buffer};
+    return walk_range(pol, recs, 0, buffers.data(), 0, (uint32_t) buffers.size(), acc.data(), aux_pos, aux_skip, aux_limit, aux_cap, counts);
+}
+
+void Resolver::collect_adders(const PhaseRec *recs, SegmentWalk &w) const {
+    w.cand_seen.ensure();
+    w.cand_seen.clear();
+    w.candidates.clear();
+    for (uint64_t i = w.rec_lo; i < w.rec_hi; ++i) {
+        if (!(recs[i].flags & REC_ADDER)) continue;
+        const uint32_t a = recs[i].addr & 0xffffffu;
+        if (filter_.test(a) || w.cand_seen.test(a)) continue;
+        w.cand_seen.set(a);
+        w.candidates.push_back(a);
+    }
+}
+
+void Resolver::spec_walk(const PhaseRec *recs, const std::vector<BufferClock> &buffers, SegmentWalk &w) const {
+    w.added.ensure(); w.q_pre.ensure();
+    w.added.clear(); w.q_pre.clear();
+    w.adds.clear(); w.adds_end.clear(); w.end_clock.clear();
+    w.counts = ResolveCounts();
+    w.odd = false;
+    w.speculated = false;
+    // a range cannot accept more frames than it has records
+    const uint64_t cap = w.rec_hi - w.rec_lo + 1;
+    if (w.acc.size() < cap) { w.acc.resize(cap); w.pos.resize(cap); w.limit.resize(cap); w.skip.resize(cap); }
+    SpecPolicy pol{filter_, w};
+    const int64_t n = walk_range(pol, recs, w.rec_lo, buffers.data(), w.b_lo, w.b_hi, w.acc.data(), w.pos.data(), w.skip.data(),
+                                 w.limit.data(), cap, w.counts);
+    if (n < 0) { w.odd = true; w.nacc = 0; } else w.nacc = (uint64_t) n;
+}
+
+bool Resolver::commit_segment(const PhaseRec *recs, const std::vector<BufferClock> &buffers, SegmentWalk &w) {
+    (void) recs; (void) buffers;
+    bool ok = !w.odd;
+    // (1) what the range assumed about the state at its start against the true filter: adds it expected from
+    //     earlier ranges that did not happen, and anything the earlier ranges of the batch dropped (or dropped
+    //     and brought back: the trackers only say "changed")
+    for (size_t i = 0; ok && i < w.assumed.list.size(); ++i) {
+        const uint32_t a = w.assumed.list[i];
+        if (!filter_.test(a) && w.q_pre.test(a)) ok = false;
+    }
+    for (size_t i = 0; ok && i < chunk_drops_.size(); ++i) ok = !w.q_pre.test(chunk_drops_[i]);
+    for (size_t i = 0; ok && i < chunk_news_.size(); ++i) {
+        const uint32_t a = chunk_news_[i];
+        if (!w.assumed.test(a) && w.q_pre.test(a)) ok = false;
+    }
+    // (2) catch the true filter up: the range's first adds in order, the clock after every buffer.  Whatever an
+    //     expiry or a resize inside the range drops must not be something the range asked about, and an
+    //     expiry before the last buffer would make the repeats the range left out count again.
+    const size_t drops0 = chunk_drops_.size(), news0 = chunk_news_.size();
+    const int64_t now0 = synthetic_now_, flip0 = next_flip_;
+    const uint64_t nflips0 = nflips_;
+    if (ok) {
+        IcaoFilter::Snapshot snap;
+        filter_.snapshot(snap);
+        uint32_t k = 0;
+        for (uint32_t bi = w.b_lo; ok && bi < w.b_hi; ++bi) {
+            const uint32_t e = w.adds_end[bi - w.b_lo];
+            for (; k < e; ++k) filter_.add(w.adds[k]);
+            synthetic_now_ = w.end_clock[bi - w.b_lo];
+            const uint64_t f = nflips_;
+            after_buffer();
+            if (nflips_ != f && bi + 1 < w.b_hi) ok = false;
+        }
+        for (size_t i = drops0; ok && i < chunk_drops_.size(); ++i) ok = !w.q_pre.test(chunk_drops_[i]);
+        if (!ok) {
+            filter_.restore(snap);
+            chunk_drops_.resize(drops0); chunk_news_.resize(news0);
+            synthetic_now_ = now0; next_flip_ = flip0; nflips_ = nflips0;
+        }
+    }
+    w.speculated = ok;
+    return ok;
+}
+
+void Resolver::serial_segment(const PhaseRec *recs, const std::vector<BufferClock> &buffers, SegmentWalk &w) {
+    const uint64_t cap = w.rec_hi - w.rec_lo + 1;
+    if (w.acc.size() < cap) { w.acc.resize(cap); w.pos.resize(cap); w.limit.resize(cap); w.skip.resize(cap); }
+    w.counts = ResolveCounts();
+    w.speculated = false;
+    LivePolicy pol{filter_, synthetic_now_, *this, &Resolver::after_buffer};
+    const int64_t n = walk_range(pol, recs, w.rec_lo, buffers.data(), w.b_lo, w.b_hi, w.acc.data(), w.pos.data(), w.skip.data(),
+                                 w.limit.data(), cap, w.counts);
+    w.nacc = n < 0 ? 0 : (uint64_t) n;      // n < 0 cannot happen: a range accepts at most one frame per record
+}
+
+void Resolver::parallel_walk(const PhaseRec *recs, uint64_t nrecs, const std::vector<BufferClock> &buffers, std::vector<SegmentWalk> &segs,
+                             const Runner &run, uint64_t *batches, uint64_t *serial_ranges) {
+    (void) nrecs;
+    const int K = (int) segs.size();
+    int t0 = 0;
+    while (t0 < K) {
+        // one batch: ranges [t0, K) against the filter as it stands now
+        chunk_drops_.clear();
+        chunk_news_.clear();
+        const int nb = K - t0;
+        if (batches) ++*batches;
+        run(nb, [&](int i) { collect_adders(recs, segs[t0 + i]); });
+        for (int t = t0; t < K; ++t) {                       // assumed(t) = candidates of ranges t0 .. t-1
+            SegmentWalk &w = segs[t];
+            w.assumed.ensure();
+            w.assumed.clear();
+            for (int u = t0; u < t; ++u)
+                for (uint32_t a : segs[u].candidates) w.assumed.set(a);
+        }
+        run(nb, [&](int i) { spec_walk(recs, buffers, segs[t0 + i]); });
+        filter_.track_changes(&chunk_drops_, &chunk_news_);
+        int t = t0;
+        while (t < K && commit_segment(recs, buffers, segs[t])) ++t;
+        filter_.track_changes(nullptr, nullptr);
+        if (t == t0 && t < K) {                               // even the first range of the batch failed: no speculation left to make
+            serial_segment(recs, buffers, segs[t]);
+            if (serial_ranges) ++*serial_ranges;
+            ++t;
+        }
+        t0 = t;
+    }
+}
+
+uint64_t segment_first_record(const PhaseRec *recs, uint64_t nrecs, uint32_t pos) { return first_record_at(recs, nrecs, pos); }
 
 void Resolver::build_messages(const PhaseRec *recs, const unsigned long long *sig, const std::vector<BufferClock> &buffers,
                               const Accepted *acc, uint64_t nacc, mgpu_msg *out) {

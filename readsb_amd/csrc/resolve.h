@@ -8,6 +8,7 @@
 // stream.  It touches only the records that survived the pre-screen (about one per real frame).
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <vector>
 
 #include "../../include/modes_gpu.h"
@@ -30,6 +31,18 @@ class IcaoFilter {
     uint32_t occupied() const { return occupied_; }
     uint32_t table_bits() const { return filter_bits_; }
 
+    // --- support for the speculative parallel walk (resolve.cpp: Resolver::spec_walk / commit_segment) ---
+    struct Snapshot {
+        std::vector<uint32_t> members[2], big[2];
+        int active = 0;
+        uint32_t occupied = 0, filter_bits = 8;
+    };
+    void snapshot(Snapshot &s) const;
+    void restore(const Snapshot &s);
+    void union_sorted(std::vector<uint32_t> &out) const;      // addresses < 2^24 in either generation, ascending
+    // addresses that leave the union (expire / resize) and addresses that enter it (first add)
+    void track_changes(std::vector<uint32_t> *drops, std::vector<uint32_t> *news) { drops_ = drops; news_ = news; }
+
   private:
     void resize(uint32_t bits);
     bool big_test(uint32_t addr) const;
@@ -39,6 +52,7 @@ class IcaoFilter {
     std::vector<uint32_t> big_[2];        // addresses >= 2^24 (only Modes.show_only's default)
     int active_ = 0;
     uint32_t occupied_ = 0, filter_bits_ = 8;
+    std::vector<uint32_t> *drops_ = nullptr, *news_ = nullptr;
 };
 
 struct BufferClock {
@@ -74,6 +88,47 @@ struct Accepted {
     int32_t score;
 };
 
+// A sparse set over 24-bit addresses: bitmap + list of what is set (for O(set) clearing).
+struct AddrSet {
+    std::vector<uint64_t> bits;
+    std::vector<uint32_t> list;
+    bool test(uint32_t a) const { return (bits[a >> 6] >> (a & 63)) & 1; }
+    void set(uint32_t a) {
+        uint64_t &w = bits[a >> 6];
+        const uint64_t b = 1ull << (a & 63);
+        if (!(w & b)) { w |= b; list.push_back(a); }
+    }
+    void clear() { for (uint32_t a : list) bits[a >> 6] = 0; list.clear(); }
+    void ensure() { if (bits.empty()) bits.assign(1u << 18, 0); }
+};
+
+// One contiguous range of buffers of a chunk, walked speculatively by one thread against the
+// filter as it stood at the start of the chunk (Resolver::spec_walk), then validated and folded
+// into the true filter state in stream order (Resolver::commit_segment).
+struct SegmentWalk {
+    // the range
+    uint32_t b_lo = 0, b_hi = 0;          // buffers [b_lo, b_hi) of the chunk
+    uint64_t rec_lo = 0, rec_hi = 0;      // live records [rec_lo, rec_hi) = those at positions inside the range
+    // decisions (the same outputs as Resolver::decide, indices chunk-relative)
+    std::vector<Accepted> acc;
+    std::vector<uint32_t> pos, limit;
+    std::vector<uint16_t> skip;
+    uint64_t nacc = 0;
+    ResolveCounts counts;
+    // what the true filter needs to catch up: the first icaoFilterAdd of every address, per buffer (repeats are
+    // no-ops until the next expiry), and the clock at each buffer end
+    std::vector<uint32_t> adds, adds_end;
+    std::vector<int64_t> end_clock;
+    // what the decisions assumed
+    AddrSet added;                        // own adds so far
+    AddrSet q_pre;                        // addresses asked about before their own first add in this range
+    AddrSet assumed;                      // addresses assumed to have been added by the earlier ranges of the batch
+    AddrSet cand_seen;
+    std::vector<uint32_t> candidates;     // addresses of this range's adder records the filter does not hold yet
+    bool odd = false;                     // something the speculation does not model (address >= 2^24, overflow)
+    bool speculated = false;              // outcome: false = re-walked serially by commit_segment
+};
+
 class Resolver {
   public:
     void reset(int64_t startup_ms);
@@ -85,6 +140,24 @@ class Resolver {
     // or -1 if aux_cap was too small.  recs[nrecs] must be a readable sentinel with pos = 0xFFFFFFFF.
     int64_t decide(const PhaseRec *recs, uint64_t nrecs, const std::vector<BufferClock> &buffers, std::vector<Accepted> &acc,
                    uint32_t *aux_pos, uint16_t *aux_skip, uint32_t *aux_limit, uint64_t aux_cap, ResolveCounts &counts);
+
+    // The same walk, parallel over buffer ranges and still exact.  The skip window never crosses a
+    // buffer, so ranges only interact through the ICAO filter, and the filter only enters through
+    // "is this address known right now".  A batch of ranges is walked at once (spec_walk, const, one
+    // thread per range), each assuming: an address is known iff the filter holds it at the start of the
+    // batch, or an earlier range of the batch has a clean DF17 / DF11-IID0 record of it (collect_adders;
+    // such a frame is accepted unless something hides it), or the range itself has added it.  Every
+    // address asked about before the range's own first add is remembered.  commit_segment (ranges in
+    // stream order, one thread) checks those assumptions against the true filter at the start of the
+    // range and against what expiry / resize dropped, replays the range's adds and buffer clocks on the
+    // true filter when they hold, and reports failure when they do not; parallel_walk then starts a new
+    // batch at the failed range from the now-known true state, or — if the failed range was the first
+    // of its batch — walks it with the serial loop.  Every range ends up holding the reference's decisions.
+    using Runner = std::function<void(int ntasks, const std::function<void(int)> &task)>;
+    void parallel_walk(const PhaseRec *recs, uint64_t nrecs, const std::vector<BufferClock> &buffers, std::vector<SegmentWalk> &segs,
+                       const Runner &run, uint64_t *batches = nullptr, uint64_t *serial_ranges = nullptr);
+    void union_snapshot(std::vector<uint32_t> &sorted_union) const { filter_.union_sorted(sorted_union); }
+
     // The stateless part: struct modesMessage fields of the accepted frames (demod_2400.c:399-445,
     // mode_s.c:443-606).  sig[i] = sum of mag^2 over the frame record i would occupy.
     static void build_messages(const PhaseRec *recs, const unsigned long long *sig, const std::vector<BufferClock> &buffers,
@@ -99,10 +172,22 @@ class Resolver {
     uint64_t nflips() const { return nflips_; }
 
   private:
+    void collect_adders(const PhaseRec *recs, SegmentWalk &w) const;
+    void spec_walk(const PhaseRec *recs, const std::vector<BufferClock> &buffers, SegmentWalk &w) const;
+    bool commit_segment(const PhaseRec *recs, const std::vector<BufferClock> &buffers, SegmentWalk &w);
+    void serial_segment(const PhaseRec *recs, const std::vector<BufferClock> &buffers, SegmentWalk &w);
+    template <class Policy>
+    int64_t walk_range(Policy &pol, const PhaseRec *recs, uint64_t rec_lo, const BufferClock *bufs, uint32_t b_lo, uint32_t b_hi,
+                       Accepted *out, uint32_t *aux_pos, uint16_t *aux_skip, uint32_t *aux_limit, uint64_t aux_cap,
+                       ResolveCounts &c) const;
     void after_buffer();
     IcaoFilter filter_;
+    std::vector<uint32_t> chunk_drops_, chunk_news_;   // union changes since begin_chunk
     int64_t synthetic_now_ = 0, next_flip_ = 0;
     uint64_t nflips_ = 0;
 };
+
+// index of the first of nrecs position-sorted records with position >= pos
+uint64_t segment_first_record(const PhaseRec *recs, uint64_t nrecs, uint32_t pos);
 
 }  // namespace mgpu

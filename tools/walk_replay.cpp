@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../readsb_amd/csrc/resolve.h"
 using namespace mgpu;
@@ -40,5 +41,41 @@ int main(int argc, char **argv) {
     }
     printf("%zu records, %zu buffers -> %zu messages: decide %.3f ms (%.1f ns/record), build %.3f ms (%.1f ns/message)\n", nrecs, bufs.size(), nm,
            best_d, best_d * 1e6 / nrecs, best_b, best_b * 1e6 / nm);
+    // ---- the speculative parallel walk against the serial one (same chunk walked twice: cold filter, then warm) ----
+    const int K = argc > 2 ? atoi(argv[2]) : 4;
+    {
+        Resolver rs, rp; rs.reset(1000000); rp.reset(1000000);
+        std::vector<SegmentWalk> seg(K);
+        for (int round = 0; round < 4; ++round) {
+            std::vector<Accepted> acc_s; ResolveCounts rc_s;
+            int64_t ns = rs.decide(recs.data(), nrecs, bufs, acc_s, pos.data(), skip.data(), lim.data(), nrecs, rc_s);
+            const uint32_t nb = (uint32_t) bufs.size();
+            for (int k = 0; k < K; ++k) {
+                seg[k].b_lo = (uint32_t) ((uint64_t) nb * k / K); seg[k].b_hi = (uint32_t) ((uint64_t) nb * (k + 1) / K);
+                seg[k].rec_lo = segment_first_record(recs.data(), nrecs, bufs[seg[k].b_lo].first);
+            }
+            for (int k = 0; k < K; ++k) seg[k].rec_hi = k + 1 < K ? seg[k + 1].rec_lo : nrecs;
+            auto t0 = std::chrono::steady_clock::now();
+            uint64_t batches = 0, serial_ranges = 0;
+            rp.parallel_walk(recs.data(), nrecs, bufs, seg, [&](int ntasks, const std::function<void(int)> &task) {
+                std::vector<std::thread> th;
+                for (int i = 0; i < ntasks; ++i) th.emplace_back([&task, i] { task(i); });
+                for (auto &x : th) x.join();
+            }, &batches, &serial_ranges);
+            auto t1 = std::chrono::steady_clock::now();
+            size_t np = 0; int nspec = 0; bool same = true;
+            for (int k = 0; k < K; ++k) {
+                nspec += seg[k].speculated;
+                for (uint64_t i = 0; i < seg[k].nacc; ++i, ++np)
+                    if (np >= (size_t) ns || acc_s[np].rec != seg[k].acc[i].rec || acc_s[np].buffer != seg[k].acc[i].buffer || acc_s[np].score != seg[k].acc[i].score) same = false;
+            }
+            auto t2 = std::chrono::steady_clock::now();
+            (void) batches; (void) serial_ranges;
+            std::vector<uint32_t> us, up; rs.union_snapshot(us); rp.union_snapshot(up);
+            printf("round %d: serial %lld msgs, parallel(%d) %zu msgs, identical %d, filter unions equal %d, flips %llu/%llu, speculated %d/%d, walk %.3f ms + commit %.3f ms\n",
+                   round, (long long) ns, K, np, (int) (same && np == (size_t) ns), (int) (us == up), (unsigned long long) rs.nflips(), (unsigned long long) rp.nflips(), nspec, K,
+                   std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count());
+        }
+    }
     return 0;
 }

@@ -242,6 +242,7 @@ struct mgpu_ctx {
     Team walk_team, build_team;                               // helpers of the walker / builder stage (MGPU_WALK_THREADS, MGPU_BUILD_THREADS)
     int walk_threads = 4, build_threads = 2;
     std::vector<SegmentWalk> segs;                            // the walker's buffer ranges
+    double feed_t0 = 0;                                       // wall clock at feed start (MGPU_DEBUG_PRINT timeline)
     uint64_t spec_segments = 0, spec_batches = 0, spec_serial = 0;   // ranges walked, speculation batches, ranges that fell back to the serial loop
     std::mutex mu;
     std::condition_variable cv;
@@ -641,6 +642,7 @@ static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
 // ---- host half of a chunk, part 1 (fetcher thread): wait for the GPU, copy the live records out of pinned memory ----
 static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job) {
     HIPCHK(c, hipEventSynchronize(sl.ev[3]));
+    const double t_gpu_done = wall_ms();
     if (getenv("MGPU_DEBUG_PRINT")) {
         const unsigned long long *h = sl.h_counters;
         fprintf(stderr, "dbg: v3 wave cycles: load %llu sweep %llu stageA %llu slice %llu score %llu total %llu | rounds B %llu passes %llu\n",
@@ -691,6 +693,7 @@ static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job) {
     c->acc.n_live_records += nlive;
     c->acc.n_chunks += 1;
     c->acc.d2h_ms += (float) (wall_ms() - t_f0);
+    if (getenv("MGPU_DEBUG_PRINT")) fprintf(stderr, "dbg: timeline: gpu done %.3f, fetched %.3f\n", t_gpu_done - c->feed_t0, wall_ms() - c->feed_t0);
     return MGPU_OK;
 }
 
@@ -777,6 +780,7 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
     c->acc.sigpower_ms += (float) (wall_ms() - t_sig0);
 
     job.nmsg = nmsg;
+    if (getenv("MGPU_DEBUG_PRINT")) fprintf(stderr, "dbg: timeline: walk %.3f .. %.3f\n", t_res0 - c->feed_t0, wall_ms() - c->feed_t0);
     c->acc.n_messages += nmsg;
     return MGPU_OK;
 }
@@ -834,6 +838,7 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
         k.nbuffers++;
     }
     c->acc.build_ms += (float) (wall_ms() - t0);
+    if (getenv("MGPU_DEBUG_PRINT")) fprintf(stderr, "dbg: timeline: build %.3f .. %.3f\n", t0 - c->feed_t0, wall_ms() - c->feed_t0);
     if (getenv("MGPU_DEBUG_PRINT")) fprintf(stderr, "dbg: build: grow %.3f ms, messages %.3f ms, statistics %.3f ms for %u msgs\n", t1 - t0, t2 - t1, wall_ms() - t2, nmsg);
     return MGPU_OK;
 }
@@ -983,6 +988,7 @@ static int feed_common(mgpu_ctx *c, const void *src, bool src_is_device, uint64_
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const size_t bps = c->cfg.format == MGPU_FMT_UC8 ? 2 : 4;
     const double t_start = wall_ms();
+    c->feed_t0 = t_start;
     { int brc = feed_begin(c); if (brc != MGPU_OK) return brc; }
     const uint8_t *iq = (const uint8_t *) src;
     if (!src_is_device) {

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstddef>
 #include <cstring>
+#include <limits>
 #if defined(__SSE2__)
 #include <emmintrin.h>
 #endif
@@ -12,6 +13,7 @@ namespace mgpu {
 
 static constexpr uint32_t kShowOnlyDefault = 0xff123456u;   // BADDR, readsb.h:296; modesInit adds it (readsb.c:310)
 static constexpr int64_t kFilterTtlMs = 60000;              // MODES_ICAO_FILTER_TTL, readsb.h:315
+static constexpr int64_t kBufferSpanMs = 64;                // > the clock span of one 131072-sample buffer (54.7 ms) + one frame
 
 IcaoFilter::IcaoFilter() {
     for (int g = 0; g < 2; ++g) bits_[g].assign(1u << 18, 0);
@@ -209,8 +211,22 @@ struct SpecPolicy {
         w.q_pre.set(a);
         return flt.test(a) || w.assumed.test(a);
     }
-    void add(uint32_t a) { if (!w.added.test(a)) { w.added.set(a); w.adds.push_back(a); } }
-    void buffer_end(int64_t now) { w.adds_end.push_back((uint32_t) w.adds.size()); w.end_clock.push_back(now); }
+    void add(uint32_t a) {
+        w.added.set(a);
+        if (!w.recorded.test(a)) { w.recorded.set(a); w.adds.push_back(a); }
+    }
+    // the 60 s expiry clock (readsb.c:1227-1231) with the threshold the batch started with: exact as long as
+    // the decisions are, which is what commit_segment establishes
+    void buffer_end(int64_t now) {
+        w.adds_end.push_back((uint32_t) w.adds.size());
+        w.end_clock.push_back(now);
+        if (now >= w.flip_clock) {
+            w.flip_at = (int32_t) (w.b_lo + w.end_clock.size() - 1);
+            ++w.nflip;
+            w.flip_clock = now + kFilterTtlMs;
+            w.recorded.clear();          // after an expiry the active generation is empty: every address counts again
+        }
+    }
 };
 
 uint64_t first_record_at(const PhaseRec *recs, uint64_t nrecs, uint32_t pos) {
@@ -242,11 +258,11 @@ void Resolver::collect_adders(const PhaseRec *recs, SegmentWalk &w) const {
 }
 
 void Resolver::spec_walk(const PhaseRec *recs, const std::vector<BufferClock> &buffers, SegmentWalk &w) const {
-    w.added.ensure(); w.q_pre.ensure();
-    w.added.clear(); w.q_pre.clear();
+    w.added.ensure(); w.q_pre.ensure(); w.recorded.ensure();
+    w.added.clear(); w.q_pre.clear(); w.recorded.clear();
+    w.flip_at = -1; w.nflip = 0;
     w.adds.clear(); w.adds_end.clear(); w.end_clock.clear();
     w.counts = ResolveCounts();
-    w.odd = false;
     w.speculated = false;
     // a range cannot accept more frames than it has records
     const uint64_t cap = w.rec_hi - w.rec_lo + 1;
@@ -273,23 +289,27 @@ bool Resolver::commit_segment(const PhaseRec *recs, const std::vector<BufferCloc
         if (!w.assumed.test(a) && w.q_pre.test(a)) ok = false;
     }
     // (2) catch the true filter up: the range's first adds in order, the clock after every buffer.  Whatever an
-    //     expiry or a resize inside the range drops must not be something the range asked about, and an
-    //     expiry before the last buffer would make the repeats the range left out count again.
+    //     expiry or a resize inside the range drops must not be something the range asked about; the expiry must
+    //     come where the range itself put it (it restarted its list of first adds there), and only once (a
+    //     second one could drop the range's own adds).
     const size_t drops0 = chunk_drops_.size(), news0 = chunk_news_.size();
     const int64_t now0 = synthetic_now_, flip0 = next_flip_;
     const uint64_t nflips0 = nflips_;
+    if (ok) ok = w.nflip <= 1;
     if (ok) {
         IcaoFilter::Snapshot snap;
         filter_.snapshot(snap);
         uint32_t k = 0;
+        int32_t flipped_at = -1;
         for (uint32_t bi = w.b_lo; ok && bi < w.b_hi; ++bi) {
             const uint32_t e = w.adds_end[bi - w.b_lo];
             for (; k < e; ++k) filter_.add(w.adds[k]);
             synthetic_now_ = w.end_clock[bi - w.b_lo];
             const uint64_t f = nflips_;
             after_buffer();
-            if (nflips_ != f && bi + 1 < w.b_hi) ok = false;
+            if (nflips_ != f) { if (flipped_at >= 0) ok = false; flipped_at = (int32_t) bi; }
         }
+        if (flipped_at != w.flip_at) ok = false;
         for (size_t i = drops0; ok && i < chunk_drops_.size(); ++i) ok = !w.q_pre.test(chunk_drops_[i]);
         if (!ok) {
             filter_.restore(snap);
@@ -330,6 +350,19 @@ void Resolver::parallel_walk(const PhaseRec *recs, uint64_t nrecs, const std::ve
             w.assumed.clear();
             for (int u = t0; u < t; ++u)
                 for (uint32_t a : segs[u].candidates) w.assumed.set(a);
+            // The expiry clock.  The first range of the batch runs the true rule.  A later range can tell from the
+            // buffer grid alone whether the expiry that is due has happened before it starts (the clock at a buffer's
+            // end lies within the buffer's own 55 ms): surely not -> it watches for it itself; surely yes -> the
+            // next one is 60 s away; the buffer in between, or a chunk longer than the filter's TTL -> no speculation.
+            w.odd = false;
+            w.flip_clock = next_flip_;
+            if (t > t0) {
+                const int64_t prev = buffers[w.b_lo - 1].sysTimestamp;
+                if (prev + kBufferSpanMs < next_flip_) w.flip_clock = next_flip_;
+                else if (prev >= next_flip_ && buffers[w.b_hi - 1].sysTimestamp + kBufferSpanMs < next_flip_ + kFilterTtlMs - kBufferSpanMs)
+                    w.flip_clock = std::numeric_limits<int64_t>::max();
+                else w.odd = true;
+            }
         }
         run(nb, [&](int i) { spec_walk(recs, buffers, segs[t0 + i]); });
         filter_.track_changes(&chunk_drops_, &chunk_news_);

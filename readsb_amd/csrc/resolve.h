@@ -115,12 +115,16 @@ struct SegmentWalk {
     std::vector<uint16_t> skip;
     uint64_t nacc = 0;
     ResolveCounts counts;
-    // what the true filter needs to catch up: the first icaoFilterAdd of every address, per buffer (repeats are
-    // no-ops until the next expiry), and the clock at each buffer end
+    // what the true filter needs to catch up: per buffer, the first icaoFilterAdd of every address since the last
+    // expiry (repeats are no-ops), and the clock at each buffer end
     std::vector<uint32_t> adds, adds_end;
     std::vector<int64_t> end_clock;
     // what the decisions assumed
     AddrSet added;                        // own adds so far
+    AddrSet recorded;                     // own adds since the range's last expiry (what `adds` leaves out as repeats)
+    int64_t flip_clock = 0;               // the range expires the filter at the first buffer end with clock >= this
+    int32_t flip_at = -1;                 // buffer after which it did (-1: never), nflip = how often
+    int32_t nflip = 0;
     AddrSet q_pre;                        // addresses asked about before their own first add in this range
     AddrSet assumed;                      // addresses assumed to have been added by the earlier ranges of the batch
     AddrSet cand_seen;

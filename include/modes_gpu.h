@@ -196,7 +196,7 @@ const uint16_t *mgpu_uc8_table(void);
  * go quiet long enough to expire from the ICAO filter, and return) once serially and once as
  * `nsegments` speculative buffer ranges per chunk, and compares every decision, counter and the
  * final filter.  0 = identical, k > 0 = first differing chunk + 1, < 0 = bad arguments.
- * *speculated_permille (may be NULL) = share of ranges whose speculation held. */
+ * *speculated_permille (may be NULL) = share of chunks whose ranges all committed in the first batch. */
 int mgpu_selftest_walk(uint64_t seed, uint32_t nchunks, uint32_t buffers_per_chunk, uint32_t nsegments,
                        uint32_t naircraft, uint32_t *speculated_permille);
 

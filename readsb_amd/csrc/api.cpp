@@ -243,7 +243,7 @@ struct mgpu_ctx {
     int walk_threads = 4, build_threads = 2;
     std::vector<SegmentWalk> segs;                            // the walker's buffer ranges
     double feed_t0 = 0;                                       // wall clock at feed start (MGPU_DEBUG_PRINT timeline)
-    uint64_t spec_segments = 0, spec_batches = 0, spec_serial = 0;   // ranges walked, speculation batches, ranges that fell back to the serial loop
+    uint64_t spec_segments = 0, spec_batches = 0;            // ranges walked, batches it took
     std::mutex mu;
     std::condition_variable cv;
     std::deque<int> queue, walk_queue, build_queue;
@@ -721,10 +721,9 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
         }
         for (int k = 0; k < K; ++k) segs[k].rec_hi = k + 1 < K ? segs[k + 1].rec_lo : nlive;
         const double tp0 = wall_ms();
-        uint64_t batches = 0, serial_ranges = 0;
+        uint64_t batches = 0;
         c->resolver.parallel_walk(job.recs.data(), nlive, sl.buffers, segs,
-                                  [&](int ntasks, const std::function<void(int)> &task) { c->walk_team.run(ntasks, task); },
-                                  &batches, &serial_ranges);
+                                  [&](int ntasks, const std::function<void(int)> &task) { c->walk_team.run(ntasks, task); }, &batches);
         const double tp2 = wall_ms();
         uint64_t total = 0;
         for (int k = 0; k < K; ++k) {
@@ -733,7 +732,6 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
         }
         c->spec_segments += (uint64_t) K;
         c->spec_batches += batches;
-        c->spec_serial += serial_ranges;
         if (total > aux_cap) wn = -1;
         else {
             if (job.acc.size() < total) job.acc.resize(total);
@@ -748,7 +746,7 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
             }
             wn = (int64_t) total;
         }
-        if (getenv("MGPU_DEBUG_PRINT")) fprintf(stderr, "dbg: %d ranges in %llu batches, %llu walked serially: %.3f ms, gather %.3f ms\n", K, (unsigned long long) batches, (unsigned long long) serial_ranges, tp2 - tp0, wall_ms() - tp2);
+        if (getenv("MGPU_DEBUG_PRINT")) fprintf(stderr, "dbg: %d ranges in %llu batches: %.3f ms, gather %.3f ms\n", K, (unsigned long long) batches, tp2 - tp0, wall_ms() - tp2);
     } else {
         wn = c->resolver.decide(job.recs.data(), nlive, sl.buffers, job.acc, job.pos.data(), c->w_skip.data(),
                                 c->w_limit.data(), aux_cap, job.rc);
@@ -1192,8 +1190,8 @@ const uint16_t *mgpu_uc8_table(void) { return uc8_table(); }
 // return, so that addresses enter the ICAO filter, expire on the 60 s clock and come back — is walked
 // chunk by chunk once with Resolver::decide and once with Resolver::parallel_walk over `nsegments`
 // buffer ranges per chunk (real threads).  Returns 0 when every decision, every counter and the final
-// filter agree; k > 0 = first differing chunk + 1.  *speculated_permille = share of ranges whose
-// speculation held (a test that only ever took the serial fallback would prove nothing).
+// filter agree; k > 0 = first differing chunk + 1.  *speculated_permille = share of chunks whose ranges
+// all committed in the first batch (a test that never restarted a batch, or always did, would prove little).
 int mgpu_selftest_walk(uint64_t seed, uint32_t nchunks, uint32_t buffers_per_chunk, uint32_t nsegments, uint32_t naircraft,
                        uint32_t *speculated_permille) {
     if (nchunks == 0 || buffers_per_chunk == 0 || nsegments == 0 || naircraft == 0) return -1;
@@ -1203,7 +1201,7 @@ int mgpu_selftest_walk(uint64_t seed, uint32_t nchunks, uint32_t buffers_per_chu
     Resolver serial, parallel;
     serial.reset(1000000);
     parallel.reset(1000000);
-    uint64_t held = 0, ranges = 0;
+    uint64_t held = 0, ranges = 0;   // chunks that took a single batch / chunks
     // aircraft a transmits during [on, off) of every `period` seconds: quiet spells longer than two filter
     // generations make addresses expire, short ones do not
     struct Plane { uint32_t addr; double on, off, period; };
@@ -1262,17 +1260,18 @@ int mgpu_selftest_walk(uint64_t seed, uint32_t nchunks, uint32_t buffers_per_chu
             segs[k].rec_lo = k == 0 ? 0 : segment_first_record(recs.data(), n, bufs[segs[k].b_lo].first);
         }
         for (uint32_t k = 0; k < K; ++k) segs[k].rec_hi = k + 1 < K ? segs[k + 1].rec_lo : n;
+        uint64_t batches = 0;
         parallel.parallel_walk(recs.data(), n, bufs, segs, [&](int ntasks, const std::function<void(int)> &task) {
             std::vector<std::thread> th;
             for (int i = 0; i < ntasks; ++i) th.emplace_back([&task, i] { task(i); });
             for (auto &t : th) t.join();
-        });
+        }, &batches);
+        held += batches == 1 ? 1 : 0;
+        ++ranges;
         uint64_t np = 0;
         bool same = true;
         for (uint32_t k = 0; k < K; ++k) {
             rc_p.add(segs[k].counts);
-            held += segs[k].speculated ? 1 : 0;
-            ++ranges;
             for (uint64_t i = 0; i < segs[k].nacc; ++i, ++np) {
                 if (np >= (uint64_t) ns) { same = false; break; }
                 const Accepted &p = segs[k].acc[i], &s = acc_s[np];

@@ -332,48 +332,64 @@ void Resolver::serial_segment(const PhaseRec *recs, const std::vector<BufferCloc
     w.nacc = n < 0 ? 0 : (uint64_t) n;      // n < 0 cannot happen: a range accepts at most one frame per record
 }
 
+void Resolver::copy_state_from(const Resolver &o) {
+    IcaoFilter::Snapshot snap;
+    o.filter_.snapshot(snap);
+    filter_.restore(snap);
+    synthetic_now_ = o.synthetic_now_; next_flip_ = o.next_flip_; nflips_ = o.nflips_;
+}
+
+void Resolver::adopt(Resolver &shadow) {
+    std::swap(filter_, shadow.filter_);        // vectors change hands, nothing is copied
+    filter_.track_changes(nullptr, nullptr);
+    shadow.filter_.track_changes(nullptr, nullptr);
+    synthetic_now_ = shadow.synthetic_now_; next_flip_ = shadow.next_flip_; nflips_ = shadow.nflips_;
+    chunk_drops_.swap(shadow.chunk_drops_);
+    chunk_news_.swap(shadow.chunk_news_);
+}
+
 void Resolver::parallel_walk(const PhaseRec *recs, uint64_t nrecs, const std::vector<BufferClock> &buffers, std::vector<SegmentWalk> &segs,
-                             const Runner &run, uint64_t *batches, uint64_t *serial_ranges) {
+                             const Runner &run, uint64_t *batches) {
     (void) nrecs;
     const int K = (int) segs.size();
+    if (!shadow_) shadow_.reset(new Resolver());
     int t0 = 0;
     while (t0 < K) {
         // one batch: ranges [t0, K) against the filter as it stands now
-        chunk_drops_.clear();
-        chunk_news_.clear();
         const int nb = K - t0;
         if (batches) ++*batches;
         run(nb, [&](int i) { collect_adders(recs, segs[t0 + i]); });
-        for (int t = t0; t < K; ++t) {                       // assumed(t) = candidates of ranges t0 .. t-1
+        for (int t = t0 + 1; t < K; ++t) {                   // assumed(t) = candidates of ranges t0 .. t-1
             SegmentWalk &w = segs[t];
             w.assumed.ensure();
             w.assumed.clear();
             for (int u = t0; u < t; ++u)
                 for (uint32_t a : segs[u].candidates) w.assumed.set(a);
-            // The expiry clock.  The first range of the batch runs the true rule.  A later range can tell from the
-            // buffer grid alone whether the expiry that is due has happened before it starts (the clock at a buffer's
-            // end lies within the buffer's own 55 ms): surely not -> it watches for it itself; surely yes -> the
-            // next one is 60 s away; the buffer in between, or a chunk longer than the filter's TTL -> no speculation.
+            // The expiry clock.  A range can tell from the buffer grid alone whether the expiry that is due has
+            // happened before it starts (the clock at a buffer's end lies within the buffer's own 55 ms): surely
+            // not -> it watches for it itself; surely yes -> the next one is 60 s away; the buffer in between, or
+            // a chunk longer than the filter's TTL -> no speculation.
             w.odd = false;
-            w.flip_clock = next_flip_;
-            if (t > t0) {
-                const int64_t prev = buffers[w.b_lo - 1].sysTimestamp;
-                if (prev + kBufferSpanMs < next_flip_) w.flip_clock = next_flip_;
-                else if (prev >= next_flip_ && buffers[w.b_hi - 1].sysTimestamp + kBufferSpanMs < next_flip_ + kFilterTtlMs - kBufferSpanMs)
-                    w.flip_clock = std::numeric_limits<int64_t>::max();
-                else w.odd = true;
-            }
+            const int64_t prev = buffers[w.b_lo - 1].sysTimestamp;
+            if (prev + kBufferSpanMs < next_flip_) w.flip_clock = next_flip_;
+            else if (prev >= next_flip_ && buffers[w.b_hi - 1].sysTimestamp + kBufferSpanMs < next_flip_ + kFilterTtlMs - kBufferSpanMs)
+                w.flip_clock = std::numeric_limits<int64_t>::max();
+            else w.odd = true;
         }
-        run(nb, [&](int i) { spec_walk(recs, buffers, segs[t0 + i]); });
+        shadow_->copy_state_from(*this);
+        shadow_->chunk_drops_.clear();
+        shadow_->chunk_news_.clear();
+        shadow_->filter_.track_changes(&shadow_->chunk_drops_, &shadow_->chunk_news_);
+        run(nb, [&](int i) {
+            if (i == 0) shadow_->serial_segment(recs, buffers, segs[t0]);      // the true walk, on the private copy
+            else spec_walk(recs, buffers, segs[t0 + i]);
+        });
+        adopt(*shadow_);                                      // range t0 is done; its drops / news are the trackers' start
+        segs[t0].speculated = true;
         filter_.track_changes(&chunk_drops_, &chunk_news_);
-        int t = t0;
+        int t = t0 + 1;
         while (t < K && commit_segment(recs, buffers, segs[t])) ++t;
         filter_.track_changes(nullptr, nullptr);
-        if (t == t0 && t < K) {                               // even the first range of the batch failed: no speculation left to make
-            serial_segment(recs, buffers, segs[t]);
-            if (serial_ranges) ++*serial_ranges;
-            ++t;
-        }
         t0 = t;
     }
 }

@@ -9,6 +9,7 @@
 #pragma once
 #include <cstdint>
 #include <functional>
+#include <memory>
 #include <vector>
 
 #include "../../include/modes_gpu.h"
@@ -147,19 +148,21 @@ class Resolver {
 
     // The same walk, parallel over buffer ranges and still exact.  The skip window never crosses a
     // buffer, so ranges only interact through the ICAO filter, and the filter only enters through
-    // "is this address known right now".  A batch of ranges is walked at once (spec_walk, const, one
-    // thread per range), each assuming: an address is known iff the filter holds it at the start of the
-    // batch, or an earlier range of the batch has a clean DF17 / DF11-IID0 record of it (collect_adders;
-    // such a frame is accepted unless something hides it), or the range itself has added it.  Every
-    // address asked about before the range's own first add is remembered.  commit_segment (ranges in
-    // stream order, one thread) checks those assumptions against the true filter at the start of the
-    // range and against what expiry / resize dropped, replays the range's adds and buffer clocks on the
-    // true filter when they hold, and reports failure when they do not; parallel_walk then starts a new
-    // batch at the failed range from the now-known true state, or — if the failed range was the first
-    // of its batch — walks it with the serial loop.  Every range ends up holding the reference's decisions.
+    // "is this address known right now".  A batch of ranges is walked at once, one thread per range.
+    // The first range of a batch starts from the true state, so it simply runs the serial loop on a
+    // private copy of the state (adopted afterwards).  The others speculate (spec_walk, const): an
+    // address is known iff the filter holds it at the start of the batch, or an earlier range of the
+    // batch has a clean DF17 / DF11-IID0 record of it (collect_adders; such a frame is accepted unless
+    // something hides it), or the range itself has added it; every address asked about before the
+    // range's own first add is remembered, and the range runs the 60 s expiry clock itself when the
+    // buffer grid says the expiry cannot have happened before it.  commit_segment (stream order, one
+    // thread) checks those assumptions against the true filter at the start of the range and against
+    // what expiry / resize dropped, and replays the range's adds and buffer clocks on the true filter
+    // when they hold; when they do not, a new batch starts at that range — which is then the exact one.
+    // Every range ends up holding the reference's decisions; a batch always completes at least one.
     using Runner = std::function<void(int ntasks, const std::function<void(int)> &task)>;
     void parallel_walk(const PhaseRec *recs, uint64_t nrecs, const std::vector<BufferClock> &buffers, std::vector<SegmentWalk> &segs,
-                       const Runner &run, uint64_t *batches = nullptr, uint64_t *serial_ranges = nullptr);
+                       const Runner &run, uint64_t *batches = nullptr);
     void union_snapshot(std::vector<uint32_t> &sorted_union) const { filter_.union_sorted(sorted_union); }
 
     // The stateless part: struct modesMessage fields of the accepted frames (demod_2400.c:399-445,
@@ -176,6 +179,9 @@ class Resolver {
     uint64_t nflips() const { return nflips_; }
 
   private:
+    void copy_state_from(const Resolver &o);
+    void adopt(Resolver &shadow);
+    std::unique_ptr<Resolver> shadow_;   // private copy of the state for the first range of a batch
     void collect_adders(const PhaseRec *recs, SegmentWalk &w) const;
     void spec_walk(const PhaseRec *recs, const std::vector<BufferClock> &buffers, SegmentWalk &w) const;
     bool commit_segment(const PhaseRec *recs, const std::vector<BufferClock> &buffers, SegmentWalk &w);

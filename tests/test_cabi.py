@@ -101,7 +101,7 @@ def test_parallel_walk_equals_serial_walk(built):
     """Host logic, no GPU: the speculative buffer-range walk (real threads) must make exactly the decisions
     of the serial walk on streams whose aircraft come, expire from the ICAO filter and return (chunks shorter
     and longer than the filter's 60 s clock) — and the cases together must have exercised both outcomes of
-    the speculation (range committed / range re-walked serially)."""
+    the speculation (range committed / batch restarted at the range)."""
     import readsb_amd
     lib = C.CDLL(readsb_amd.lib_path())
     f = lib.mgpu_selftest_walk
@@ -112,5 +112,5 @@ def test_parallel_walk_equals_serial_walk(built):
         pm = C.c_uint32(0)
         assert f(*case, C.byref(pm)) == 0, f"parallel walk differs from the serial walk for {case}"
         held.append(pm.value)
-    assert all(h > 0 for h in held), held
-    assert any(h < 1000 for h in held), held
+    # permille of chunks whose ranges all committed in the first batch: some did, some needed a restart
+    assert any(h > 500 for h in held) and any(h < 1000 for h in held), held

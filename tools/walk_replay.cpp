@@ -56,12 +56,12 @@ int main(int argc, char **argv) {
             }
             for (int k = 0; k < K; ++k) seg[k].rec_hi = k + 1 < K ? seg[k + 1].rec_lo : nrecs;
             auto t0 = std::chrono::steady_clock::now();
-            uint64_t batches = 0, serial_ranges = 0;
+            uint64_t batches = 0;
             rp.parallel_walk(recs.data(), nrecs, bufs, seg, [&](int ntasks, const std::function<void(int)> &task) {
                 std::vector<std::thread> th;
                 for (int i = 0; i < ntasks; ++i) th.emplace_back([&task, i] { task(i); });
                 for (auto &x : th) x.join();
-            }, &batches, &serial_ranges);
+            }, &batches);
             auto t1 = std::chrono::steady_clock::now();
             size_t np = 0; int nspec = 0; bool same = true;
             for (int k = 0; k < K; ++k) {
@@ -70,7 +70,7 @@ int main(int argc, char **argv) {
                     if (np >= (size_t) ns || acc_s[np].rec != seg[k].acc[i].rec || acc_s[np].buffer != seg[k].acc[i].buffer || acc_s[np].score != seg[k].acc[i].score) same = false;
             }
             auto t2 = std::chrono::steady_clock::now();
-            (void) batches; (void) serial_ranges;
+            (void) batches;
             std::vector<uint32_t> us, up; rs.union_snapshot(us); rp.union_snapshot(up);
             printf("round %d: serial %lld msgs, parallel(%d) %zu msgs, identical %d, filter unions equal %d, flips %llu/%llu, speculated %d/%d, walk %.3f ms + commit %.3f ms\n",
                    round, (long long) ns, K, np, (int) (same && np == (size_t) ns), (int) (us == up), (unsigned long long) rs.nflips(), (unsigned long long) rp.nflips(), nspec, K,

@@ -127,7 +127,7 @@ struct Slot {
     uint16_t *d_mag = nullptr;
     PhaseRec *d_pool = nullptr;
     uint32_t *d_pool_used = nullptr, *d_unit_first = nullptr, *d_unit_count = nullptr, *d_unit_live = nullptr, *d_class_bitmap = nullptr;
-    uint32_t *d_class_uncond = nullptr, *d_cand_count = nullptr;
+    uint32_t *d_class_uncond = nullptr, *d_class_final = nullptr, *d_cand_count = nullptr;
     uint16_t *d_cand = nullptr;
     size_t class_bytes = 0;
     // one zero-initialised scratch block per chunk: counters | pool_used | per-buffer sums (1 memset, 1 copy back)
@@ -383,12 +383,17 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
     sl.class_bytes = (mag_len / 32 + 64) * sizeof(uint32_t);
     HIPCHK(c, hipMalloc(&sl.d_class_bitmap, sl.class_bytes));
     HIPCHK(c, hipMalloc(&sl.d_class_uncond, sl.class_bytes));
+    HIPCHK(c, hipMalloc(&sl.d_class_final, sl.class_bytes));
+    // the class planes and the scratch block are handed back zeroed by the kernels that consume them
+    HIPCHK(c, hipMemsetAsync(sl.d_class_bitmap, 0, sl.class_bytes, c->stream));
+    HIPCHK(c, hipMemsetAsync(sl.d_class_uncond, 0, sl.class_bytes, c->stream));
     HIPCHK(c, hipMalloc(&sl.d_cand, (c->cap_units * (size_t) kUnit + 64) * sizeof(uint16_t)));
     HIPCHK(c, hipMalloc(&sl.d_cand_count, (c->cap_units + 1) * sizeof(uint32_t)));
     {
         const size_t nb = c->cap_buffers, words = CNT_NUM + 1 + 4 * nb;
         sl.scratch_bytes = words * sizeof(unsigned long long);
         HIPCHK(c, hipMalloc(&sl.d_scratch, sl.scratch_bytes));
+        HIPCHK(c, hipMemsetAsync(sl.d_scratch, 0, sl.scratch_bytes, c->stream));
         HIPCHK(c, hipHostMalloc(&sl.h_scratch, sl.scratch_bytes));
         sl.d_counters = sl.d_scratch;
         sl.d_pool_used = (uint32_t *) (sl.d_scratch + CNT_NUM);
@@ -421,7 +426,7 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
 
 static void free_slot(Slot &sl) {
     void *dev[] = {sl.d_mag, sl.d_pool, sl.d_scratch, sl.d_unit_first, sl.d_unit_count, sl.d_unit_live, sl.d_class_bitmap,
-                   sl.d_class_uncond, sl.d_cand, sl.d_cand_count,
+                   sl.d_class_uncond, sl.d_class_final, sl.d_cand, sl.d_cand_count,
                    sl.d_win, sl.d_msg_pos,
                    sl.d_msg_limit, sl.d_msg_len, sl.d_msg_skip, sl.d_msg_sig};
     for (void *p : dev)
@@ -590,12 +595,7 @@ static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
     // the slot's magnitudes / class bitmap / message lists are still read by the window-statistics
     // kernel of its previous use (stream2)
     if (sl.window_pending) { HIPCHK(c, hipStreamWaitEvent(s, sl.ev_window, 0)); sl.window_pending = false; }
-    HIPCHK(c, hipMemsetAsync(sl.d_scratch, 0, sl.scratch_bytes, s));   // counters, pool_used, per-buffer sums
-    if (c->sweep_version >= 3) {   // class planes: the scoring passes OR single bits into them
-        const size_t cb = (((size_t) ((n + 31) / 32) + 4) & ~(size_t) 3) * sizeof(uint32_t);   // whole 16-byte groups
-        HIPCHK(c, hipMemsetAsync(sl.d_class_bitmap, 0, cb, s));
-        HIPCHK(c, hipMemsetAsync(sl.d_class_uncond, 0, cb, s));
-    }
+    // (scratch block and class planes are zero: k_publish / k_count_finalize of the slot's previous chunk left them so)
     HIPCHK(c, hipEventRecord(sl.ev[0], s));
     if (!sl.have_mag) {
         ConvertParams cp{};
@@ -630,11 +630,16 @@ static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
     HIPCHK(c, hipEventRecord(sl.ev[4], s));
     if (c->sweep_version == 4) launch_slice(sp, s);
     HIPCHK(c, hipEventRecord(sl.ev[2], s));
-    if (c->sweep_version >= 3) launch_class_finalize(sp, s);
-    // pre-screen; the surviving records are written by the kernel straight into pinned host memory
-    launch_prescreen(sl.d_pool, sl.d_unit_first, nunits, c->d_adder_bitmap, sl.d_unit_live, sl.h_live, sl.d_mag, sl.h_live_sig,
-                     sl.d_counters, s);
-    HIPCHK(c, hipMemcpyAsync(sl.h_scratch, sl.d_scratch, sl.scratch_bytes, hipMemcpyDeviceToHost, s));
+    // class planes -> class bitmap, pre-screen (the surviving records are written by the kernel straight into
+    // pinned host memory), counters and per-buffer sums to the host
+    PostSweepParams q{};
+    q.pool = sl.d_pool; q.unit_first = sl.d_unit_first; q.nunits = nunits; q.adder_bitmap = c->d_adder_bitmap;
+    q.unit_live = sl.d_unit_live; q.live = sl.h_live; q.mag = sl.d_mag; q.live_sig = sl.h_live_sig; q.counters = sl.d_counters;
+    q.class_cond = sl.d_class_bitmap; q.class_uncond = sl.d_class_uncond;
+    q.class_final = c->sweep_version >= 3 ? sl.d_class_final : nullptr;
+    q.class_words = (n + 31) / 32;
+    q.d_scratch = sl.d_scratch; q.h_scratch = sl.h_scratch; q.scratch_words = (uint32_t) (sl.scratch_bytes / sizeof(unsigned long long));
+    launch_prescreen(q, s);
     HIPCHK(c, hipEventRecord(sl.ev[3], s));
     return MGPU_OK;
 }
@@ -770,7 +775,7 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
         HIPCHK(c, hipMemcpyAsync(sl.d_msg_pos, sl.h_msg_pos, nmsg * sizeof(uint32_t), hipMemcpyHostToDevice, s2));
         HIPCHK(c, hipMemcpyAsync(sl.d_msg_limit, sl.h_msg_limit, nmsg * sizeof(uint32_t), hipMemcpyHostToDevice, s2));
         HIPCHK(c, hipMemcpyAsync(sl.d_msg_skip, sl.h_msg_skip, nmsg * sizeof(uint16_t), hipMemcpyHostToDevice, s2));
-        launch_window_stats(sl.d_mag, n, cfg.preamble_threshold, sl.d_class_bitmap, sl.d_msg_pos, sl.d_msg_skip,
+        launch_window_stats(sl.d_mag, n, cfg.preamble_threshold, c->sweep_version >= 3 ? sl.d_class_final : sl.d_class_bitmap, sl.d_msg_pos, sl.d_msg_skip,
                             sl.d_msg_limit, nmsg, c->d_win, s2);
         HIPCHK(c, hipEventRecord(sl.ev_window, s2));
         sl.window_pending = true;
@@ -1109,6 +1114,12 @@ int mgpu_convert(mgpu_ctx *c, const void *iq_host, uint16_t *mag_host, uint32_t 
             mp = sl.h_fsums[1] / n;
         }
     }
+    // leave the slot's accumulation buckets zero again (the chunk pipeline relies on it)
+    HIPCHK(c, hipMemsetAsync(sl.d_sum_level, 0, sizeof(unsigned long long), s));
+    HIPCHK(c, hipMemsetAsync(sl.d_sum_power, 0, sizeof(unsigned long long), s));
+    HIPCHK(c, hipMemsetAsync(sl.d_fsum_level, 0, sizeof(double), s));
+    HIPCHK(c, hipMemsetAsync(sl.d_fsum_power, 0, sizeof(double), s));
+    HIPCHK(c, hipStreamSynchronize(s));
     if (out_mean_level) *out_mean_level = ml;
     if (out_mean_power) *out_mean_power = mp;
     return MGPU_OK;

@@ -115,15 +115,28 @@ void launch_convert(int format, const ConvertParams &p, hipStream_t s);
 void launch_sweep(const SweepParams &p, hipStream_t s);            // generation 4: k_sweep (streaming preamble sweep -> candidate lists)
 void launch_slice(const SweepParams &p, hipStream_t s);            //               k_slice (frames sliced straight from HBM/L2, no LDS tile)
 void launch_sweep_slice(const SweepParams &p, hipStream_t s);      // generation 3: fused, wave-autonomous LDS tiles (default)
-void launch_class_finalize(const SweepParams &p, hipStream_t s);   // generations 3/4: class planes -> class bitmap + class counters
 void launch_sweep_slice_v2(const SweepParams &p, hipStream_t s);   // second version: workgroup tiles, block barriers
 void launch_sweep_slice_v1(const SweepParams &p, hipStream_t s);   // first version: wave per candidate
 // pre-screen: count / write the records whose address may matter to the ordered walk
 // (the write pass also stores each live record's would-be signal power: sum of mag^2 over its frame)
-void launch_prescreen(const PhaseRec *pool, const uint32_t *unit_first, uint32_t nunits,
-                      const uint32_t *adder_bitmap, uint32_t *unit_live /*[nunits+1]*/,
-                      PhaseRec *live, const uint16_t *mag, unsigned long long *live_sig,
-                      unsigned long long *counters, hipStream_t s);
+// everything between the sweep and the host: class planes -> class bitmap (+ counters, planes zeroed again),
+// pre-screen count / scan / write, scratch block to the host (and zeroed again)
+struct PostSweepParams {
+    const PhaseRec *pool;
+    const uint32_t *unit_first;
+    uint32_t nunits;
+    const uint32_t *adder_bitmap;
+    uint32_t *unit_live;
+    PhaseRec *live;                       // pinned host memory
+    const uint16_t *mag;
+    unsigned long long *live_sig;         // pinned host memory
+    unsigned long long *counters;
+    uint32_t *class_cond, *class_uncond, *class_final;   // class_final == nullptr: generations 1/2 (bitmap written by the sweep)
+    uint64_t class_words;
+    unsigned long long *d_scratch, *h_scratch;
+    uint32_t scratch_words;
+};
+void launch_prescreen(const PostSweepParams &q, hipStream_t s);
 // signal power of accepted messages: sum of mag^2 over d_mag[pos+19 .. pos+19+len)
 void launch_signal_power(const uint16_t *mag, const uint32_t *pos, const uint16_t *len, uint32_t nmsg,
                          unsigned long long *out, hipStream_t s);

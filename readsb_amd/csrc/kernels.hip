@@ -1670,7 +1670,6 @@ __global__ __launch_bounds__(kBlock, MGPU_V3_PREFETCH ? 3 : 4) void k_sweep_slic
     }
 }
 
-__global__ void k_class_finalize(uint32_t *cond, const uint32_t *uncond, uint64_t nwords, unsigned long long *counters);
 
 void launch_sweep_slice(const SweepParams &p, hipStream_t s) {
     if (p.nunits == 0) return;
@@ -2010,18 +2009,21 @@ __global__ __launch_bounds__(kBlock) void k_slice(SweepParams p) {
 }
 
 // Class planes -> final class bitmap (cond & ~uncond) + the two class counters; one pass over n/32 words.
-__global__ __launch_bounds__(kBlock) void k_class_finalize(uint32_t *cond, const uint32_t *uncond, uint64_t nwords,
-                                                           unsigned long long *counters) {
+// The planes are handed back zeroed, ready for the slot's next chunk (no memset on the stream).
+__device__ __forceinline__ void class_finalize_part(uint32_t block, uint32_t nblocks, uint32_t *cond, uint32_t *uncond, uint32_t *final_bitmap,
+                                                    uint64_t nwords, unsigned long long *counters) {
     __shared__ unsigned long long s_c[2];
     if (threadIdx.x < 2) s_c[threadIdx.x] = 0;
     __syncthreads();
     uint32_t nc = 0, nu = 0;
     const uint64_t nvec = (nwords + 3) / 4;      // the planes are allocated (and zeroed) in whole 16-byte groups
-    for (uint64_t i = (uint64_t) blockIdx.x * kBlock + threadIdx.x; i < nvec; i += (uint64_t) gridDim.x * kBlock) {
+    const u32x4 zero = {0, 0, 0, 0};
+    for (uint64_t i = (uint64_t) block * kBlock + threadIdx.x; i < nvec; i += (uint64_t) nblocks * kBlock) {
         const u32x4 uc = ((const u32x4 *) uncond)[i], c0 = ((const u32x4 *) cond)[i];
-        if ((c0.x | c0.y | c0.z | c0.w | uc.x | uc.y | uc.z | uc.w) == 0) continue;
         const u32x4 cd = {c0.x & ~uc.x, c0.y & ~uc.y, c0.z & ~uc.z, c0.w & ~uc.w};
-        if (cd.x != c0.x || cd.y != c0.y || cd.z != c0.z || cd.w != c0.w) ((u32x4 *) cond)[i] = cd;
+        ((u32x4 *) final_bitmap)[i] = cd;
+        if (c0.x | c0.y | c0.z | c0.w) ((u32x4 *) cond)[i] = zero;
+        if (uc.x | uc.y | uc.z | uc.w) ((u32x4 *) uncond)[i] = zero;
         nc += __popc(cd.x) + __popc(cd.y) + __popc(cd.z) + __popc(cd.w);
         nu += __popc(uc.x) + __popc(uc.y) + __popc(uc.z) + __popc(uc.w);
     }
@@ -2061,13 +2063,6 @@ void launch_slice(const SweepParams &p, hipStream_t s) {
     hipLaunchKernelGGL(k_slice, dim3(blocks), dim3(kBlock), dyn, s, p);
 }
 
-void launch_class_finalize(const SweepParams &p, hipStream_t s) {
-    const uint64_t nwords = (p.n + 31) / 32;
-    unsigned cb = (unsigned) ((nwords / 4 + kBlock) / kBlock);
-    if (cb > 1024) cb = 1024;
-    hipLaunchKernelGGL(k_class_finalize, dim3(cb), dim3(kBlock), 0, s, p.class_bitmap, p.class_uncond, nwords, p.counters);
-}
-
 // =============================================================================================
 // pre-screen: a conditional record (score_unknown < 0) can only matter if its address is one
 // that some clean DF17 / DF11-IID0 frame of this stream carries (the only frames that ever add
@@ -2086,11 +2081,10 @@ __device__ __forceinline__ bool rec_live(const PhaseRec &r, const uint32_t *bitm
 // DF as sliced (demod_2400.c:399,436-457).  ~5 records per real frame, 5 coalesced loads per lane
 // each — and the ordered walk then needs no second GPU round trip.
 template <bool WRITE>
-__global__ __launch_bounds__(kBlock) void k_prescreen(const PhaseRec *pool, const uint32_t *unit_first, uint32_t nunits,
-                                                      const uint32_t *bitmap, uint32_t *unit_live, PhaseRec *live,
-                                                      const uint16_t *mag, unsigned long long *live_sig) {
+__device__ __forceinline__ void prescreen_unit(uint32_t u, const PhaseRec *pool, const uint32_t *unit_first, uint32_t nunits,
+                                               const uint32_t *bitmap, uint32_t *unit_live, PhaseRec *live,
+                                               const uint16_t *mag, unsigned long long *live_sig) {
     const int lane = lane_id();
-    const uint32_t u = blockIdx.x * (kBlock / WAVE) + (threadIdx.x >> 6);
     if (u >= nunits) return;
     uint32_t h = unit_first[u];
     uint32_t nlive = 0;
@@ -2155,6 +2149,33 @@ __global__ __launch_bounds__(kBlock) void k_prescreen(const PhaseRec *pool, cons
     if (!WRITE && lane == 0) unit_live[u] = nlive;
 }
 
+// COUNT pass (one wave per unit) and, in the remaining workgroups of the same launch, the class-plane
+// finalize: two small latency-bound jobs that do not depend on each other.
+__global__ __launch_bounds__(kBlock) void k_count_finalize(const PhaseRec *pool, const uint32_t *unit_first, uint32_t nunits,
+                                                           const uint32_t *bitmap, uint32_t *unit_live, uint32_t nb_count,
+                                                           uint32_t *cond, uint32_t *uncond, uint32_t *final_bitmap, uint64_t nwords,
+                                                           unsigned long long *counters) {
+    if (blockIdx.x < nb_count)
+        prescreen_unit<false>(blockIdx.x * (kBlock / WAVE) + (threadIdx.x >> 6), pool, unit_first, nunits, bitmap, unit_live, nullptr, nullptr, nullptr);
+    else
+        class_finalize_part(blockIdx.x - nb_count, gridDim.x - nb_count, cond, uncond, final_bitmap, nwords, counters);
+}
+
+__global__ __launch_bounds__(kBlock) void k_prescreen_write(const PhaseRec *pool, const uint32_t *unit_first, uint32_t nunits,
+                                                            const uint32_t *bitmap, uint32_t *unit_live, PhaseRec *live,
+                                                            const uint16_t *mag, unsigned long long *live_sig) {
+    prescreen_unit<true>(blockIdx.x * (kBlock / WAVE) + (threadIdx.x >> 6), pool, unit_first, nunits, bitmap, unit_live, live, mag, live_sig);
+}
+
+// The chunk's scratch block (counters, pool cursor, per-buffer sums) goes to the host's pinned copy and is
+// handed back zeroed for the slot's next chunk: replaces a D2H copy and a memset on the stream.
+__global__ __launch_bounds__(kBlock) void k_publish(unsigned long long *d_scratch, unsigned long long *h_scratch, uint32_t nwords) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < nwords; i += gridDim.x * kBlock) {
+        h_scratch[i] = d_scratch[i];
+        d_scratch[i] = 0;
+    }
+}
+
 // exclusive scan of unit_live[0..n) in place; unit_live[n] = total.  One workgroup.
 __global__ __launch_bounds__(1024) void k_scan_units(uint32_t *unit_live, uint32_t n, unsigned long long *counters) {
     __shared__ uint32_t s_wave[16];
@@ -2183,14 +2204,22 @@ __global__ __launch_bounds__(1024) void k_scan_units(uint32_t *unit_live, uint32
     if (threadIdx.x == 0) { unit_live[n] = s_carry; if (counters) counters[CNT_LIVE_TOTAL] = s_carry; }
 }
 
-void launch_prescreen(const PhaseRec *pool, const uint32_t *unit_first, uint32_t nunits, const uint32_t *adder_bitmap,
-                      uint32_t *unit_live, PhaseRec *live, const uint16_t *mag, unsigned long long *live_sig,
-                      unsigned long long *counters, hipStream_t s) {
-    if (nunits == 0) return;
-    const unsigned blocks = (nunits + 3) / 4;
-    hipLaunchKernelGGL(k_prescreen<false>, dim3(blocks), dim3(kBlock), 0, s, pool, unit_first, nunits, adder_bitmap, unit_live, live, mag, live_sig);
-    hipLaunchKernelGGL(k_scan_units, dim3(1), dim3(1024), 0, s, unit_live, nunits, counters);
-    hipLaunchKernelGGL(k_prescreen<true>, dim3(blocks), dim3(kBlock), 0, s, pool, unit_first, nunits, adder_bitmap, unit_live, live, mag, live_sig);
+void launch_prescreen(const PostSweepParams &q, hipStream_t s) {
+    if (q.nunits == 0) return;
+    const unsigned nb_count = (q.nunits + 3) / 4;
+    unsigned nb_fin = 0;
+    if (q.class_final) {
+        nb_fin = (unsigned) ((q.class_words / 4 + kBlock) / kBlock);
+        if (nb_fin > 1024) nb_fin = 1024;
+    }
+    hipLaunchKernelGGL(k_count_finalize, dim3(nb_count + nb_fin), dim3(kBlock), 0, s, q.pool, q.unit_first, q.nunits, q.adder_bitmap,
+                       q.unit_live, nb_count, q.class_cond, q.class_uncond, q.class_final, q.class_words, q.counters);
+    hipLaunchKernelGGL(k_scan_units, dim3(1), dim3(1024), 0, s, q.unit_live, q.nunits, q.counters);
+    hipLaunchKernelGGL(k_prescreen_write, dim3(nb_count), dim3(kBlock), 0, s, q.pool, q.unit_first, q.nunits, q.adder_bitmap, q.unit_live,
+                       q.live, q.mag, q.live_sig);
+    unsigned pb = (q.scratch_words + kBlock - 1) / kBlock;
+    if (pb > 64) pb = 64;
+    hipLaunchKernelGGL(k_publish, dim3(pb), dim3(kBlock), 0, s, q.d_scratch, q.h_scratch, q.scratch_words);
 }
 
 // =============================================================================================

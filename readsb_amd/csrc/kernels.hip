@@ -38,6 +38,7 @@ namespace mgpu {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 
@@ -1283,7 +1284,8 @@ constexpr int kWT = kWaveTile;
 constexpr int kWTChunks = (kWT + kHalo) / 8;                 // 16-byte chunks per tile (294)
 constexpr int kWPre = (kWTChunks + WAVE - 1) / WAVE;         // 16-byte loads per lane and tile (5)
 constexpr int kWStep = WAVE * 8;                             // positions per sweep step (512)
-constexpr int kWCQCap = kWStep + 32;                         // candidate queue (drained when > 32 wait)
+constexpr int kWCQCap = 3 * WAVE;                            // candidate queue (drained before it could overflow)
+constexpr int kWPQCap = kWStep + WAVE;                       // pre-check survivor queue: one step's worth + the leftovers
 constexpr int kWVCap = 128;                                  // ring of valid pairs (power of two)
 constexpr int kWFrames = WAVE / 4;                           // frames sliced per round (16)
 constexpr int kWStageCap = 24;                               // (generation 4) staged records per wave
@@ -1301,7 +1303,8 @@ struct SlicedFrame {          // 32 bytes: a frame as sliced, waiting for CRC cl
 struct WaveLds {                                             // wave-private LDS, 16-byte aligned members first
     uint16_t mag[kWT + kHalo + 8];                           // 4720 B
     SlicedFrame frames[kWFrameCap];                          // 2048 B
-    uint16_t cq[kWCQCap];                                    // 1088 B
+    uint16_t cq[kWCQCap];                                    //  384 B
+    uint16_t pq[kWPQCap];                                    // 1152 B  pre-check survivors waiting for the threshold tests
     uint16_t pairs[WAVE * 5];                                //  640 B
     uint32_t v[kWVCap];                                      //  512 B
 };
@@ -1595,68 +1598,118 @@ __global__ __launch_bounds__(kBlock, MGPU_V3_PREFETCH ? 3 : 4) void k_sweep_slic
                 ccount = 0;
             };
 
-            // ---- sweep, 512 positions per step ----
+            // ---- threshold tests (demod_2400.c:324-378) for up to 64 pre-check survivors, lane = survivor ----
+            // samples pa[1..18] as 9 dword pairs fetched at the survivor's own alignment
+            int pqn = 0, pqh = 0;                                 // survivors waiting in L.pq[pqh .. pqn)
+            auto eval_round = [&](int take) __attribute__((always_inline)) {
+                if (ccount > kWCQCap - WAVE) drain();
+                uint32_t m = 0;
+                int pos = 0;
+                if (lane < take) {
+                    pos = L.pq[pqh + lane];
+                    const int q = (pos + 1) >> 1;
+                    const uint32_t sh = ((uint32_t) (pos + 1) & 1u) * 16u;
+                    uint32_t d[10], P[9];
+#pragma unroll
+                    for (int k = 0; k < 10; ++k) d[k] = w32[q + k];
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) P[k] = __builtin_amdgcn_alignbit(d[k + 1], d[k], sh);   // (pa[2k+1], pa[2k+2])
+#define LO16(x) ((int) ((x) & 0xffffu))
+#define HI16(x) ((int) ((x) >> 16))
+                    const int m1 = LO16(P[0]), m2 = HI16(P[0]), m3 = LO16(P[1]), m4 = HI16(P[1]), m5 = LO16(P[2]), m8 = HI16(P[3]),
+                              m9 = LO16(P[4]), m10 = HI16(P[4]), m11 = LO16(P[5]), m12 = HI16(P[5]), m16 = HI16(P[7]),
+                              m17 = LO16(P[8]), m18 = HI16(P[8]);
+#undef LO16
+#undef HI16
+                    const int base_noise = m5 + m8 + m16 + m17 + m18;
+                    const int ref = (base_noise * p.thr) >> 5;
+                    const int d23 = m2 - m3, s14 = m1 + m4, d1011 = m10 - m11;
+                    const int common = s14 - d23 + m9 + m12;
+                    if (common - d1011 >= ref) m |= 1;
+                    if (common + d1011 >= ref) m |= 2;
+                    if (s14 + 2 * d23 + d1011 + m12 >= ref) m |= 4;
+                }
+                const uint64_t cm = __ballot(m != 0);
+                if (cm) {
+                    n_cand += __popcll(cm);                       // wave-uniform tallies, added once per wave at the end
+                    n_ph[0] += __popcll(__ballot(m & 1u));
+                    n_ph[1] += __popcll(__ballot(m & 2u));
+                    n_ph[2] += __popcll(__ballot(m & 4u));
+                    if (m) L.cq[ccount + __popcll(cm & lt_mask)] = (uint16_t) ((pos << 3) | m);
+                    ccount += __popcll(cm);
+                    WAVE_SYNC();
+                }
+                pqh += take;
+            };
+
+            // ---- pre-check pa[1]>pa[7] && pa[12]>pa[14] && pa[12]>pa[15] (demod_2400.c:311-322), 512 positions per
+            //      step, 8 per lane, two per packed-u16 instruction; about 1 position in 6 survives into L.pq ----
+            const int nvalid = p.n - D0 < (uint64_t) kWT ? (int) (p.n - D0) : kWT;
             for (int sub = 0; sub < kWT / kWStep; ++sub) {
-                if (D0 + (uint64_t) sub * kWStep >= p.n) break;
-                if (ccount > kWCQCap - kWStep) drain();
+                if (sub * kWStep >= nvalid) break;
                 const long long tw0 = DBG_CLOCK();
                 const int p0 = sub * kWStep + lane * 8;
-                uint32_t w[13];
+                uint32_t w[12];
                 {
                     const u32x4 a = *(const u32x4 *) &L.mag[p0], b = *(const u32x4 *) &L.mag[p0 + 8],
                                 c = *(const u32x4 *) &L.mag[p0 + 16];
                     w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
                     w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
                     w[8] = c.x; w[9] = c.y; w[10] = c.z; w[11] = c.w;
-                    w[12] = *(const uint32_t *) &L.mag[p0 + 24];
                 }
-                uint32_t f = 0;
+                uint32_t odd[11];                                  // odd[k] = (m[2k+1], m[2k+2]), m[i] = sample p0+i
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-#define SM(i) ((int) ((w[((e) + (i)) >> 1] >> ((((e) + (i)) & 1) * 16)) & 0xffffu))
-                    const bool pc = SM(1) > SM(7) && SM(12) > SM(14) && SM(12) > SM(15);
-                    const int base_noise = SM(5) + SM(8) + SM(16) + SM(17) + SM(18);
-                    const int ref = (base_noise * p.thr) >> 5;
-                    const int d23 = SM(2) - SM(3), s14 = SM(1) + SM(4), d1011 = SM(10) - SM(11);
-                    const int common = s14 - d23 + SM(9) + SM(12);
-                    uint32_t m = 0;
-                    if (common - d1011 >= ref) m |= 1;
-                    if (common + d1011 >= ref) m |= 2;
-                    if (s14 + 2 * d23 + d1011 + SM(12) >= ref) m |= 4;
-#undef SM
-                    if (!pc || D0 + p0 + e >= p.n) m = 0;
-                    f |= m << (3 * e);
+                for (int k = 0; k < 11; ++k) odd[k] = __builtin_amdgcn_alignbit(w[k + 1], w[k], 16);
+                uint32_t sm = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {                      // positions p0+2j (low half) and p0+2j+1 (high half)
+                    const v2u16 A = __builtin_bit_cast(v2u16, odd[j]), B = __builtin_bit_cast(v2u16, odd[j + 3]),
+                                C = __builtin_bit_cast(v2u16, w[j + 6]), Dd = __builtin_bit_cast(v2u16, w[j + 7]),
+                                E = __builtin_bit_cast(v2u16, odd[j + 7]);
+                    const v2u16 t1 = __builtin_elementwise_sub_sat(A, B);                                 // != 0 <=> pa[1] > pa[7]
+                    const v2u16 t2 = __builtin_elementwise_sub_sat(C, __builtin_elementwise_max(Dd, E));  // != 0 <=> pa[12] > max(pa[14], pa[15])
+                    const uint32_t r = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(t1, t2));
+                    if (r & 0xffffu) sm |= 1u << (2 * j);
+                    if (r >> 16) sm |= 2u << (2 * j);
                 }
-                const uint32_t nz = (f | (f >> 1) | (f >> 2)) & 0x249249u;
-                const int cnt = __popc(nz);
-                n_cand += cnt;
-                n_ph[0] += __popc(f & 0x249249u);
-                n_ph[1] += __popc((f >> 1) & 0x249249u);
-                n_ph[2] += __popc((f >> 2) & 0x249249u);
-                if (__ballot(cnt != 0)) {
-                    int total;
-                    int dst = ccount + wave_excl_scan(cnt, total);
+                {   // positions beyond the end of the stream (last tile only)
+                    const int room = nvalid - p0;
+                    if (room < 8) sm = room <= 0 ? 0u : (sm & ((1u << room) - 1u));
+                }
+                const int cnt = __popc(sm);
+                int total;
+                int dst = pqn + wave_excl_scan(cnt, total);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const uint32_t m = (f >> (3 * e)) & 7u;
-                        if (m) L.cq[dst++] = (uint16_t) (((p0 + e) << 3) | m);
-                    }
-                    ccount += total;
+                for (int e = 0; e < 8; ++e)
+                    if ((sm >> e) & 1u) L.pq[dst++] = (uint16_t) (p0 + e);
+                pqn += total;
+                WAVE_SYNC();
+                while (pqn - pqh >= WAVE) eval_round(WAVE);
+                if (pqh) {                                         // keep the (< 64) leftovers at the front
+                    const int rem = pqn - pqh;
+                    uint16_t t = 0;
+                    if (lane < rem) t = L.pq[pqh + lane];
+                    WAVE_SYNC();
+                    if (lane < rem) L.pq[lane] = t;
+                    pqn = rem; pqh = 0;
                     WAVE_SYNC();
                 }
                 tm[1] += DBG_CLOCK() - tw0;
             }
+            if (pqn) eval_round(pqn);
             drain();
             while (vcount > 0) stage_b(vcount < kWFrames ? vcount : kWFrames);
         }
         score_pass();
         if (lane == 0) p.unit_count[unit] = unit_records;
     }
-    atomicAdd(&s_cnt[CNT_CANDIDATES], (unsigned long long) n_cand);
-    atomicAdd(&s_cnt[CNT_PHASE0 + 0], (unsigned long long) n_ph[0]);
-    atomicAdd(&s_cnt[CNT_PHASE0 + 2], (unsigned long long) n_ph[1]);
-    atomicAdd(&s_cnt[CNT_PHASE0 + 4], (unsigned long long) n_ph[2]);
-    if (lane == 0) atomicAdd(&s_cnt[CNT_RECORDS], (unsigned long long) n_rec);
+    if (lane == 0) {
+        atomicAdd(&s_cnt[CNT_CANDIDATES], (unsigned long long) n_cand);
+        atomicAdd(&s_cnt[CNT_PHASE0 + 0], (unsigned long long) n_ph[0]);
+        atomicAdd(&s_cnt[CNT_PHASE0 + 2], (unsigned long long) n_ph[1]);
+        atomicAdd(&s_cnt[CNT_PHASE0 + 4], (unsigned long long) n_ph[2]);
+        atomicAdd(&s_cnt[CNT_RECORDS], (unsigned long long) n_rec);
+    }
 #if MGPU_KERNEL_TIMERS
     tm[5] = DBG_CLOCK() - tm_start;
     if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&s_cnt[CNT_DEBUG0 + i], (unsigned long long) tm[i]);

@@ -792,6 +792,34 @@ __device__ __forceinline__ uint32_t slice_group(const uint32_t *w32, const Slice
     }
     return v;
 }
+
+// The same five correlators on a tile whose samples are stored with the top bit flipped (u16 m -> i16 m - 32768),
+// so that two taps go through one v_dot2_i32_i16.  sum(c_j * m_j) > 0  <=>  sum(c_j * (m_j - 32768)) > -32768 * sum(c_j),
+// and the rows' coefficient sums are 0, 0, 1, 0, 0 (demod_2400.c:74-93).
+typedef short v2i16 __attribute__((ext_vector_type(2)));
+// All eleven LDS dwords of the group are requested before the first is used: the five bits are independent, and
+// one round trip to the LDS per group instead of five is what the slicer's speed hangs on.
+__device__ __forceinline__ uint32_t slice_group_biased(const uint32_t *w32, const SliceGeom &g, int gw) {
+    uint32_t a[5], b[5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) { a[r] = w32[g.wi[r] + gw]; b[r] = w32[g.wi[r] + gw + 1]; }
+    const uint32_t c4 = w32[g.wi[4] + gw + 2];
+    __builtin_amdgcn_sched_barrier(0);          // keep the loads above, the arithmetic below
+    const v2i16 k0a = {18, -15}, k0b = {-3, 0}, k1a = {14, -5}, k1b = {-9, 0}, k2a = {16, 5}, k2b = {-20, 0},
+                k3a = {7, 11}, k3b = {-18, 0}, k4a = {4, 15}, k4b = {-20, 1};
+#define PK01(R) __builtin_bit_cast(v2i16, __builtin_amdgcn_alignbit(b[R], a[R], g.par[R]))   /* taps 0, 1 */
+#define PK2(R) __builtin_bit_cast(v2i16, b[R] >> g.par[R])                                    /* tap 2 in the low half */
+    const int s0 = __builtin_amdgcn_sdot2(PK2(0), k0b, __builtin_amdgcn_sdot2(PK01(0), k0a, 0, false), false);
+    const int s1 = __builtin_amdgcn_sdot2(PK2(1), k1b, __builtin_amdgcn_sdot2(PK01(1), k1a, 0, false), false);
+    const int s2 = __builtin_amdgcn_sdot2(PK2(2), k2b, __builtin_amdgcn_sdot2(PK01(2), k2a, 0, false), false);
+    const int s3 = __builtin_amdgcn_sdot2(PK2(3), k3b, __builtin_amdgcn_sdot2(PK01(3), k3a, 0, false), false);
+    const v2i16 y4 = __builtin_bit_cast(v2i16, __builtin_amdgcn_alignbit(c4, b[4], g.par[4]));   // taps 2, 3
+    const int s4 = __builtin_amdgcn_sdot2(y4, k4b, __builtin_amdgcn_sdot2(PK01(4), k4a, 0, false), false);
+#undef PK01
+#undef PK2
+    return ((uint32_t) (s0 > 0) << g.sh[0]) | ((uint32_t) (s1 > 0) << g.sh[1]) | ((uint32_t) (s2 > -32768) << g.sh[2]) |
+           ((uint32_t) (s3 > 0) << g.sh[3]) | ((uint32_t) (s4 > 0) << g.sh[4]);
+}
 #undef TAPS3
 
 // per-lane modesChecksumDiagnose (crc.c:383-406): binary search over the sorted syndromes, which
@@ -817,6 +845,7 @@ __device__ __forceinline__ int lane_diagnose(const uint32_t *keys, const uint64_
 // 256-thread round handles 64 frames with every wave busy and a 6-iteration dependent chain per
 // lane instead of 22.  The loop stays rolled: the unrolled form is ~11 KB of straight-line code
 // per inlined copy.  Lanes of a 56-bit frame stop after group 11 and contribute zeros.
+template <bool BIASED = false>
 __device__ __forceinline__ void slice_chunk(const uint32_t *w32, const uint32_t *s_gsyn, const SliceGeom &g, bool is_long,
                                             int j, uint32_t &chunk, uint32_t &synd) {
     const uint32_t *gs = s_gsyn + (is_long ? 0 : kGroupsLong * 32);
@@ -828,7 +857,7 @@ __device__ __forceinline__ void slice_chunk(const uint32_t *w32, const uint32_t 
         const int G = g0 + k;
         uint32_t grp = 0;
         if (is_long || G <= 11) {
-            grp = slice_group(w32, g, 6 * G);
+            grp = BIASED ? slice_group_biased(w32, g, 6 * G) : slice_group(w32, g, 6 * G);
             if (G == 22) grp &= 0x18u;                    // frame bits 110, 111 only
             if (G == 11 && !is_long) grp &= 0x10u;        // frame bit 55 only
             synd ^= gs[G * 32 + grp];
@@ -1495,7 +1524,10 @@ __global__ __launch_bounds__(kBlock, MGPU_V3_PREFETCH ? 3 : 4) void k_sweep_slic
 #pragma unroll
             for (int k = 0; k < kWPre; ++k) {
                 const int i = lane + k * WAVE;
-                if (i < kWTChunks) *(u32x4 *) &L.mag[8 * i] = pre[k];
+                if (i < kWTChunks) {   // the tile holds the samples with the top bit flipped: see slice_group_biased
+                    const u32x4 v = {pre[k].x ^ 0x80008000u, pre[k].y ^ 0x80008000u, pre[k].z ^ 0x80008000u, pre[k].w ^ 0x80008000u};
+                    *(u32x4 *) &L.mag[8 * i] = v;
+                }
             }
             {
                 uint64_t Dn = D0 + kWT;
@@ -1534,7 +1566,7 @@ __global__ __launch_bounds__(kBlock, MGPU_V3_PREFETCH ? 3 : 4) void k_sweep_slic
                     if (is_long || qj < 2) {
                         SliceGeom g;
                         make_geom(pos_local, t, g);
-                        slice_chunk(w32, s_gsyn, g, is_long, qj, chunk, psyn);
+                        slice_chunk<true>(w32, s_gsyn, g, is_long, qj, chunk, psyn);
                     }
                 }
                 const uint32_t c0 = quad_bcast<0>(chunk), c1 = quad_bcast<1>(chunk), c2 = quad_bcast<2>(chunk), c3 = quad_bcast<3>(chunk);
@@ -1583,7 +1615,7 @@ __global__ __launch_bounds__(kBlock, MGPU_V3_PREFETCH ? 3 : 4) void k_sweep_slic
                             const uint32_t pc = L.pairs[j];
                             SliceGeom g;
                             make_geom((int) (pc >> 3), 4 + (int) (pc & 7u), g);
-                            const uint32_t df = slice_group(w32, g, 0);
+                            const uint32_t df = slice_group_biased(w32, g, 0);
                             valid = ((p.valid_long | p.valid_short) >> df) & 1;
                             entry = pc | (df << 16);
                         }
@@ -1613,7 +1645,7 @@ __global__ __launch_bounds__(kBlock, MGPU_V3_PREFETCH ? 3 : 4) void k_sweep_slic
 #pragma unroll
                     for (int k = 0; k < 10; ++k) d[k] = w32[q + k];
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) P[k] = __builtin_amdgcn_alignbit(d[k + 1], d[k], sh);   // (pa[2k+1], pa[2k+2])
+                    for (int k = 0; k < 9; ++k) P[k] = __builtin_amdgcn_alignbit(d[k + 1], d[k], sh) ^ 0x80008000u;   // (pa[2k+1], pa[2k+2]), bias removed
 #define LO16(x) ((int) ((x) & 0xffffu))
 #define HI16(x) ((int) ((x) >> 16))
                     const int m1 = LO16(P[0]), m2 = HI16(P[0]), m3 = LO16(P[1]), m4 = HI16(P[1]), m5 = LO16(P[2]), m8 = HI16(P[3]),
@@ -1663,14 +1695,15 @@ __global__ __launch_bounds__(kBlock, MGPU_V3_PREFETCH ? 3 : 4) void k_sweep_slic
                 uint32_t sm = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {                      // positions p0+2j (low half) and p0+2j+1 (high half)
-                    const v2u16 A = __builtin_bit_cast(v2u16, odd[j]), B = __builtin_bit_cast(v2u16, odd[j + 3]),
-                                C = __builtin_bit_cast(v2u16, w[j + 6]), Dd = __builtin_bit_cast(v2u16, w[j + 7]),
-                                E = __builtin_bit_cast(v2u16, odd[j + 7]);
-                    const v2u16 t1 = __builtin_elementwise_sub_sat(A, B);                                 // != 0 <=> pa[1] > pa[7]
-                    const v2u16 t2 = __builtin_elementwise_sub_sat(C, __builtin_elementwise_max(Dd, E));  // != 0 <=> pa[12] > max(pa[14], pa[15])
-                    const uint32_t r = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(t1, t2));
-                    if (r & 0xffffu) sm |= 1u << (2 * j);
-                    if (r >> 16) sm |= 2u << (2 * j);
+                    // (biased samples: unsigned order of the magnitudes = signed order of what the tile holds)
+                    const v2i16 A = __builtin_bit_cast(v2i16, odd[j]), B = __builtin_bit_cast(v2i16, odd[j + 3]),
+                                C = __builtin_bit_cast(v2i16, w[j + 6]), Dd = __builtin_bit_cast(v2i16, w[j + 7]),
+                                E = __builtin_bit_cast(v2i16, odd[j + 7]);
+                    const v2i16 t1 = __builtin_elementwise_sub_sat(A, B);                                 // > 0 <=> pa[1] > pa[7]
+                    const v2i16 t2 = __builtin_elementwise_sub_sat(C, __builtin_elementwise_max(Dd, E));  // > 0 <=> pa[12] > max(pa[14], pa[15])
+                    const v2i16 r = __builtin_elementwise_min(t1, t2);
+                    if (r.x > 0) sm |= 1u << (2 * j);
+                    if (r.y > 0) sm |= 2u << (2 * j);
                 }
                 {   // positions beyond the end of the stream (last tile only)
                     const int room = nvalid - p0;

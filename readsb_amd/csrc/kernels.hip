@@ -63,6 +63,20 @@ __device__ __forceinline__ int wave_excl_scan(int v, int &total) {
     return x - v;
 }
 
+// Exclusive prefix sum over the wave of a small per-lane count (< 16), bit-sliced: four ballots and
+// v_mbcnt — no cross-lane data movement, where __shfl_up costs a trip through the LDS crossbar per step.
+__device__ __forceinline__ int wave_excl_scan_small(uint32_t v, int &total) {
+    int ex = 0;
+    total = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const uint64_t m = __ballot((v >> b) & 1u);
+        ex += (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u)) << b;
+        total += __popcll(m) << b;
+    }
+    return ex;
+}
+
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
@@ -1600,7 +1614,7 @@ __global__ __launch_bounds__(kBlock, MGPU_V3_PREFETCH ? 3 : 4) void k_sweep_slic
                     const uint32_t mask = code & 7u;
                     const int np = 2 * (int) (mask & 1u) + (int) (mask & 2u) + (int) ((mask >> 2) & 1u);
                     int npairs;
-                    int off = wave_excl_scan(np, npairs);
+                    int off = wave_excl_scan_small((uint32_t) np, npairs);
                     const uint32_t pl = code & 0xfff8u;
                     if (mask & 1u) { L.pairs[off++] = (uint16_t) (pl | 0u); L.pairs[off++] = (uint16_t) (pl | 1u); }
                     if (mask & 2u) { L.pairs[off++] = (uint16_t) (pl | 2u); L.pairs[off++] = (uint16_t) (pl | 3u); }
@@ -1634,7 +1648,7 @@ __global__ __launch_bounds__(kBlock, MGPU_V3_PREFETCH ? 3 : 4) void k_sweep_slic
             // samples pa[1..18] as 9 dword pairs fetched at the survivor's own alignment
             int pqn = 0, pqh = 0;                                 // survivors waiting in L.pq[pqh .. pqn)
             auto eval_round = [&](int take) __attribute__((always_inline)) {
-                if (ccount > kWCQCap - WAVE) drain();
+                if (ccount > kWCQCap - WAVE) { const long long td0 = DBG_CLOCK(); drain(); tm[1] -= DBG_CLOCK() - td0; }
                 uint32_t m = 0;
                 int pos = 0;
                 if (lane < take) {
@@ -1711,7 +1725,7 @@ __global__ __launch_bounds__(kBlock, MGPU_V3_PREFETCH ? 3 : 4) void k_sweep_slic
                 }
                 const int cnt = __popc(sm);
                 int total;
-                int dst = pqn + wave_excl_scan(cnt, total);
+                int dst = pqn + wave_excl_scan_small((uint32_t) cnt, total);
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
                     if ((sm >> e) & 1u) L.pq[dst++] = (uint16_t) (p0 + e);

@@ -215,7 +215,8 @@ struct mgpu_ctx {
     uint64_t *d_parity = nullptr, *d_tab_long = nullptr, *d_tab_short = nullptr;
     uint16_t *d_uc8_folded = nullptr;
     int n_long = 0, n_short = 0;
-    Slot slot[2];
+    static constexpr int kSlots = 3;
+    Slot slot[kSlots];
     unsigned long long *d_win = nullptr, *h_win = nullptr;   // skip-window totals of the current feed
     uint64_t feed_cand[8] = {0, 0, 0, 0, 0, 0, 0, 0};         // C, phase[5], U, R of the current feed
     ResolveCounts feed_rc;
@@ -963,7 +964,7 @@ static void submit_slot(mgpu_ctx *c, int idx) {
 
 static int wait_all(mgpu_ctx *c) {
     std::unique_lock<std::mutex> lk(c->mu);
-    c->cv.wait(lk, [&] { return !c->slot[0].busy && !c->slot[1].busy && c->queue.empty() && c->walk_queue.empty() && c->build_queue.empty(); });
+    c->cv.wait(lk, [&] { return !c->slot[0].busy && !c->slot[1].busy && !c->slot[2].busy && c->queue.empty() && c->walk_queue.empty() && c->build_queue.empty(); });
     return c->worker_rc;
 }
 
@@ -1005,7 +1006,7 @@ static int feed_common(mgpu_ctx *c, const void *src, bool src_is_device, uint64_
     int rc = MGPU_OK;
     for (uint64_t off = 0; off < n && rc == MGPU_OK; off += c->chunk_samples) {
         const uint64_t len = n - off < c->chunk_samples ? n - off : c->chunk_samples;
-        const int k = (int) (c->chunk_seq++ & 1);
+        const int k = (int) (c->chunk_seq++ % mgpu_ctx::kSlots);
         Slot &sl = acquire_slot(c, k);
         sl.n = len;
         sl.have_mag = false;
@@ -1142,7 +1143,7 @@ int mgpu_demod_mag_buf(mgpu_ctx *c, const uint16_t *data, uint32_t length, int64
     }
     const double t_start = wall_ms();
     { int brc = feed_begin(c); if (brc != MGPU_OK) return brc; }
-    const int slot_idx = (int) (c->chunk_seq++ & 1);
+    const int slot_idx = (int) (c->chunk_seq++ % mgpu_ctx::kSlots);
     Slot &sl = acquire_slot(c, slot_idx);
     sl.n = length;
     sl.have_mag = true;

@@ -12,7 +12,9 @@ cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python $R/bench.py --steps 5 --warmup 1 > $out/bench_under_rocprof.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/pmc_write.log 2>&1
+timeout 300 rocprofv3 --kernel-trace -i $R/tools/pmc_sq.txt --output-format csv -d $out/pmc_sq -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $out/pmc_sq.log 2>&1
 cd $R
+python tools/pmc_kernels.py $out/pmc_sq > $out/pmc_sq_summary.txt 2>&1
 timeout 200 python bench.py --steps 10 --warmup 2 > $out/bench_plain.log 2>&1
 tail -1 $out/bench_plain.log | cut -c1-400
 cat $out/stats/bench_kernel_stats.csv | cut -c1-160

@@ -85,7 +85,7 @@ def main():
 
     import helpers
     import readsb_amd
-    from readsb_amd.gather import gather_messages
+    from readsb_amd.gather import MessageGatherer
     helpers.ensure_built()
 
     # ---- synthetic input: one independent stream per rank, generated on the host, staged in HBM ----
@@ -96,15 +96,23 @@ def main():
     d = readsb_amd.Demodulator(max_samples=n, device=local_rank, startup_time_ms=helpers.STARTUP_MS)
     d.upload_iq(iq)
 
+    gath = None                                 # N > 1: the aggregator role, asynchronous (readsb_amd/gather.py)
+
     def step():
         d.reset()
         d.feed_resident(n)                      # timed: everything from HBM-resident IQ to ordered messages
         d.finish()                              # ifile EOF bookkeeping (zero-length buffer on exact multiples)
-        msgs, counters = d.collect(reuse=True)   # the consumer's standing buffer
-        if world > 1:                           # aggregator role: counts + records to rank 0 over RCCL
-            gather_messages(msgs, torch.device("cuda", local_rank))
+        if gath is None:
+            return d.collect(reuse=True)        # the consumer's standing buffer
+        msgs, counters = d.collect(out=gath.staging())   # straight into pinned staging memory
+        gath.submit(len(msgs))                  # counts + records to rank 0's HBM over RCCL, overlapped with the next step
         return msgs, counters
 
+    if world > 1:
+        m0, _ = step()                          # sizes the exchange: 1.25 x the busiest rank's message count
+        cap = torch.tensor([len(m0)], dtype=torch.int64, device="cuda")
+        dist.all_reduce(cap, op=dist.ReduceOp.MAX)
+        gath = MessageGatherer(readsb_amd.MSG_DTYPE, torch.device("cuda", local_rank), int(cap.item()) * 5 // 4 + 1024)
     for _ in range(args.warmup):
         step()
     sweep_ms, conv_ms, resolve_ms, total_ms, launches = [], [], [], [], []
@@ -117,6 +125,7 @@ def main():
         tm = d.timing()
         launches.append(max(1, tm["n_chunks"])); sweep_ms.append(tm["sweep_ms"]); conv_ms.append(tm["convert_ms"]); resolve_ms.append(tm["resolve_ms"]); total_ms.append(tm["total_ms"])
     if world > 1:
+        gath.wait()                             # the last steps' exchanges are part of the job
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0

@@ -175,14 +175,18 @@ class Demodulator:
     def finish(self):
         self._chk(self.lib.mgpu_finish(self.ctx), "mgpu_finish")
 
-    def collect(self, reuse=False):
+    def collect(self, reuse=False, out=None):
         """Drain the decoded messages (stream order) and read the counters.
 
         reuse=True returns a view of a buffer the Demodulator keeps and overwrites on the next
         collect(reuse=True): a steady consumer then pays one copy and no page faults per call.
+        out=<record array> collects into the caller's buffer (e.g. pinned staging memory).
         """
         n = int(self.lib.mgpu_pending_messages(self.ctx))
-        if reuse:
+        if out is not None:
+            if out.dtype != MSG_DTYPE or not out.flags["C_CONTIGUOUS"] or out.size < n:
+                raise ValueError("collect(out=...): need a contiguous mgpu_msg array with room for %d records" % n)
+        elif reuse:
             if self._collect_buf is None or self._collect_buf.size < n:
                 self._collect_buf = np.empty(max(n, 1024) * 5 // 4, dtype=MSG_DTYPE)
             out = self._collect_buf

@@ -312,7 +312,10 @@ static void bind_near_device(std::thread *const *threads, int nthreads, int devi
         l3_of[i] = sysfs_int("/sys/devices/system/cpu/cpu" + std::to_string(cpus[i]) + "/cache/index3/id", -1);
         if (std::find(l3_ids.begin(), l3_ids.end(), l3_of[i]) == l3_ids.end()) l3_ids.push_back(l3_of[i]);
     }
-    const int want = l3_ids[(size_t) device % l3_ids.size()];
+    // ranks that each see one device as ordinal 0 (per-rank HIP_VISIBLE_DEVICES) still spread out by LOCAL_RANK
+    int ordinal = device;
+    if (const char *lr = getenv("LOCAL_RANK")) { const int v = atoi(lr); if (v >= 0) ordinal = v; }
+    const int want = l3_ids[(size_t) ordinal % l3_ids.size()];
     // one logical CPU per physical core of that group; more threads than cores share cores round-robin
     std::vector<int> pick, cores;
     for (size_t i = 0; i < cpus.size(); ++i) {

@@ -35,6 +35,86 @@ def gather_messages(msgs: np.ndarray, device: torch.device, dst: int = 0):
     return counts, out
 
 
+class MessageGatherer:
+    """The same aggregator step without a host round trip and off the critical path.
+
+    Per rank: a ring of pinned staging buffers the demodulator's messages are collected INTO
+    (`staging()`), one asynchronous H2D copy, an 8-byte `all_gather` of counts and a fixed-size `gather`
+    of the records to `dst` — all issued with `async_op=True`, so step k's exchange runs over xGMI
+    while step k+1 demodulates.  The gathered records stay in `dst`'s HBM (`wait()` returns device
+    tensors): that is where an on-GPU beast encoder / aggregator picks them up; `fetch()` copies them
+    to the host for tests.  Shapes are static (`capacity` records per rank) so nothing in `submit()`
+    waits for a count.  Backend-agnostic like gather_messages (`gloo` + CPU tensors in the tests)."""
+
+    def __init__(self, dtype, device: torch.device, capacity: int, dst: int = 0, depth: int = 2):
+        self.dtype, self.device, self.capacity, self.dst, self.depth = dtype, device, int(capacity), dst, depth
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.rec = dtype.itemsize
+        nbytes = self.capacity * self.rec
+        cuda = device.type == "cuda"
+        self.host = [torch.empty(nbytes, dtype=torch.uint8, pin_memory=cuda) for _ in range(depth)]
+        self.dev = [torch.empty(nbytes, dtype=torch.uint8, device=device) for _ in range(depth)] if cuda else self.host
+        self.recv = ([[torch.empty(nbytes, dtype=torch.uint8, device=device) for _ in range(self.world)] for _ in range(depth)]
+                     if self.rank == dst else [None] * depth)
+        self.cnt_host = [torch.zeros(1, dtype=torch.int64, pin_memory=cuda) for _ in range(depth)]
+        self.cnt = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(depth)]
+        self.counts = [[torch.zeros(1, dtype=torch.int64, device=device) for _ in range(self.world)] for _ in range(depth)]
+        self.pending = [None] * depth
+        self.copied = [torch.cuda.Event() if cuda else None for _ in range(depth)]   # H2D of the slot has read the staging buffer
+        self.seq = 0
+
+    def staging(self) -> np.ndarray:
+        """Record array (capacity entries) of the next slot; safe to overwrite once this returns."""
+        k = self.seq % self.depth
+        self._wait_slot(k)
+        return self.host[k].numpy().view(self.dtype)
+
+    def submit(self, n: int) -> int:
+        """The first n records of staging() are this rank's messages of the step.  Returns the slot."""
+        if n > self.capacity:
+            raise ValueError(f"{n} messages exceed the gatherer's capacity of {self.capacity}")
+        k = self.seq % self.depth
+        self._wait_slot(k)
+        self.cnt_host[k][0] = n
+        self.cnt[k].copy_(self.cnt_host[k], non_blocking=True)
+        if self.dev is not self.host and n:
+            self.dev[k][: n * self.rec].copy_(self.host[k][: n * self.rec], non_blocking=True)
+        if self.copied[k] is not None:
+            self.copied[k].record()
+        w1 = dist.all_gather(self.counts[k], self.cnt[k], async_op=True)
+        w2 = dist.gather(self.dev[k], self.recv[k], dst=self.dst, async_op=True)
+        self.pending[k] = (w1, w2)
+        self.seq += 1
+        return k
+
+    def _wait_slot(self, k):
+        if self.pending[k] is not None:
+            for w in self.pending[k]:
+                w.wait()                      # (NCCL: orders the current stream after the collective)
+            if self.copied[k] is not None:
+                self.copied[k].synchronize()  # the host may overwrite the staging buffer again
+            self.pending[k] = None
+
+    def wait(self, k=None):
+        """Complete slot k (default: everything outstanding).  Returns (counts, per-rank record tensors on
+        `dst` — None elsewhere) of the most recently submitted slot (or of slot k)."""
+        slots = range(self.depth) if k is None else [k]
+        for i in slots:
+            self._wait_slot(i)
+        if self.device.type == "cuda":
+            torch.cuda.current_stream(self.device).synchronize()
+        last = (self.seq - 1) % self.depth if k is None else k
+        counts = [int(c.item()) for c in self.counts[last]]
+        return counts, self.recv[last]
+
+    def fetch(self, k=None):
+        """Host copies of what wait() returned: (counts, list of per-rank record arrays on dst / None)."""
+        counts, recv = self.wait(k)
+        if recv is None:
+            return counts, None
+        return counts, [recv[r][: counts[r] * self.rec].cpu().numpy().view(self.dtype).copy() for r in range(self.world)]
+
+
 def merge_by_timestamp(per_rank):
     """Rank-0 side: one list ordered by the 12 MHz timestamp (stable for equal stamps)."""
     allm = np.concatenate(per_rank) if per_rank else np.zeros(0)

@@ -55,3 +55,58 @@ def test_gather_two_ranks_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert results == {0: True, 1: True}
+
+
+def _worker_async(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, helpers.ROOT)
+    from readsb_amd.binding import MSG_DTYPE
+    from readsb_amd.gather import MessageGatherer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = MessageGatherer(MSG_DTYPE, torch.device("cpu"), capacity=1000)
+    ok = True
+    sent = []
+    for step in range(5):                                  # more steps than ring slots: slots are reused
+        n = [700 - 100 * step, 123 + step][rank]
+        out = g.staging()
+        out[:n]["timestamp"] = np.arange(n) + 1000 * step + 7 * rank
+        out[:n]["addr"] = rank * 16 + step
+        sent.append(out[:n].copy())
+        slot = g.submit(n)
+        if step == 2:                                      # look at a step while later ones are still to come
+            counts, per_rank = g.fetch(slot)
+            ok = ok and counts == [500, 125]
+            if rank == 0:
+                ok = ok and per_rank[0].tobytes() == sent[2].tobytes() and bool((per_rank[1]["addr"] == 16 + 2).all())
+            else:
+                ok = ok and per_rank is None
+    counts, per_rank = g.fetch()
+    ok = ok and counts == [300, 127]
+    if rank == 0:
+        ok = ok and per_rank[0].tobytes() == sent[4].tobytes() and len(per_rank[1]) == 127
+        ok = ok and bool((per_rank[1]["timestamp"] == np.arange(127) + 4000 + 7).all())
+    try:
+        g.submit(1001)
+        ok = False
+    except ValueError:
+        pass
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_async_gatherer_two_ranks_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_async, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results == {0: True, 1: True}

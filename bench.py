@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--samples", type=int, default=4096 * BUF, help="samples per stream per step (multiple of 131072)")
     ap.add_argument("--msgs-per-sec", type=float, default=2000.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exercise-gather", action="store_true", help="run the N>1 aggregator exchange even with one rank (needs torchrun env)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -80,7 +81,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libmodes_gpu has no CPU path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.exercise_gather
+    if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import helpers
@@ -108,7 +110,7 @@ def main():
         gath.submit(len(msgs))                  # counts + records to rank 0's HBM over RCCL, overlapped with the next step
         return msgs, counters
 
-    if world > 1:
+    if use_dist:
         m0, _ = step()                          # sizes the exchange: 1.25 x the busiest rank's message count
         cap = torch.tensor([len(m0)], dtype=torch.int64, device="cuda")
         dist.all_reduce(cap, op=dist.ReduceOp.MAX)
@@ -116,7 +118,7 @@ def main():
     for _ in range(args.warmup):
         step()
     sweep_ms, conv_ms, resolve_ms, total_ms, launches = [], [], [], [], []
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -124,7 +126,7 @@ def main():
         msgs, counters = step()
         tm = d.timing()
         launches.append(max(1, tm["n_chunks"])); sweep_ms.append(tm["sweep_ms"]); conv_ms.append(tm["convert_ms"]); resolve_ms.append(tm["resolve_ms"]); total_ms.append(tm["total_ms"])
-    if world > 1:
+    if use_dist:
         gath.wait()                             # the last steps' exchanges are part of the job
         dist.barrier()
     torch.cuda.synchronize()
@@ -187,7 +189,7 @@ def main():
                                              f"({os.cpu_count()} cores present)",
                                    "messages": int(len(ref_msgs)), "bit_identical_to_gpu": True}
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

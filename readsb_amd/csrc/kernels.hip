@@ -819,20 +819,26 @@ __device__ __forceinline__ uint32_t slice_group_biased(const uint32_t *w32, cons
     for (int r = 0; r < 5; ++r) { a[r] = w32[g.wi[r] + gw]; b[r] = w32[g.wi[r] + gw + 1]; }
     const uint32_t c4 = w32[g.wi[4] + gw + 2];
     __builtin_amdgcn_sched_barrier(0);          // keep the loads above, the arithmetic below
-    const v2i16 k0a = {18, -15}, k0b = {-3, 0}, k1a = {14, -5}, k1b = {-9, 0}, k2a = {16, 5}, k2b = {-20, 0},
-                k3a = {7, 11}, k3b = {-18, 0}, k4a = {4, 15}, k4b = {-20, 1};
+    // NEGATED coefficients: the bit is then the sign bit of the sum — one shift and one v_lshl_or per bit instead of
+    // compare, select, shift, or.  Row 2's threshold (sum > -32768) goes into its accumulator: -(sum) - 32768 < 0.
+    const v2i16 k0a = {-18, 15}, k0b = {3, 0}, k1a = {-14, 5}, k1b = {9, 0}, k2a = {-16, -5}, k2b = {20, 0},
+                k3a = {-7, -11}, k3b = {18, 0}, k4a = {-4, -15}, k4b = {20, -1};
 #define PK01(R) __builtin_bit_cast(v2i16, __builtin_amdgcn_alignbit(b[R], a[R], g.par[R]))   /* taps 0, 1 */
 #define PK2(R) __builtin_bit_cast(v2i16, b[R] >> g.par[R])                                    /* tap 2 in the low half */
     const int s0 = __builtin_amdgcn_sdot2(PK2(0), k0b, __builtin_amdgcn_sdot2(PK01(0), k0a, 0, false), false);
     const int s1 = __builtin_amdgcn_sdot2(PK2(1), k1b, __builtin_amdgcn_sdot2(PK01(1), k1a, 0, false), false);
-    const int s2 = __builtin_amdgcn_sdot2(PK2(2), k2b, __builtin_amdgcn_sdot2(PK01(2), k2a, 0, false), false);
+    const int s2 = __builtin_amdgcn_sdot2(PK2(2), k2b, __builtin_amdgcn_sdot2(PK01(2), k2a, -32768, false), false);
     const int s3 = __builtin_amdgcn_sdot2(PK2(3), k3b, __builtin_amdgcn_sdot2(PK01(3), k3a, 0, false), false);
     const v2i16 y4 = __builtin_bit_cast(v2i16, __builtin_amdgcn_alignbit(c4, b[4], g.par[4]));   // taps 2, 3
     const int s4 = __builtin_amdgcn_sdot2(y4, k4b, __builtin_amdgcn_sdot2(PK01(4), k4a, 0, false), false);
 #undef PK01
 #undef PK2
-    return ((uint32_t) (s0 > 0) << g.sh[0]) | ((uint32_t) (s1 > 0) << g.sh[1]) | ((uint32_t) (s2 > -32768) << g.sh[2]) |
-           ((uint32_t) (s3 > 0) << g.sh[3]) | ((uint32_t) (s4 > 0) << g.sh[4]);
+    uint32_t v = ((uint32_t) s0 >> 31) << g.sh[0];
+    v |= ((uint32_t) s1 >> 31) << g.sh[1];
+    v |= ((uint32_t) s2 >> 31) << g.sh[2];
+    v |= ((uint32_t) s3 >> 31) << g.sh[3];
+    v |= ((uint32_t) s4 >> 31) << g.sh[4];
+    return v;
 }
 #undef TAPS3
 

@@ -147,6 +147,7 @@ struct Slot {
     uint32_t *h_msg_pos = nullptr, *h_msg_limit = nullptr;
     uint16_t *h_msg_len = nullptr, *h_msg_skip = nullptr;
     hipEvent_t ev[5] = {};
+    hipEvent_t ev_scan = nullptr;         // pre-screen offsets are final (main stream) -> the write pass may start (second stream)
     // the job
     uint64_t n = 0;
     bool have_mag = false, busy = false;
@@ -200,7 +201,7 @@ struct HostJob {
 
 struct mgpu_ctx {
     mgpu_config cfg{};
-    hipStream_t stream = nullptr, stream2 = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr, stream_w = nullptr;   // main | window statistics | pre-screen write pass
     std::string err;
 
     uint64_t cap_samples = 0;      // per feed call (cfg.max_samples)
@@ -241,7 +242,7 @@ struct mgpu_ctx {
     // (messages, signal / noise statistics), so that the serial walk is all the walker does
     std::thread fetcher, worker, builder;
     Team walk_team, build_team;                               // helpers of the walker / builder stage (MGPU_WALK_THREADS, MGPU_BUILD_THREADS)
-    int walk_threads = 4, build_threads = 2;
+    int walk_threads = 4, build_threads = 3;
     std::vector<SegmentWalk> segs;                            // the walker's buffer ranges
     double feed_t0 = 0;                                       // wall clock at feed start (MGPU_DEBUG_PRINT timeline)
     uint64_t spec_segments = 0, spec_batches = 0;            // ranges walked, batches it took
@@ -418,6 +419,7 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
     HIPCHK(c, hipHostMalloc(&sl.h_live, c->cap_pool * sizeof(PhaseRec)));
     HIPCHK(c, hipHostMalloc(&sl.h_live_sig, c->cap_pool * sizeof(unsigned long long)));
     HIPCHK(c, hipEventCreateWithFlags(&sl.ev_window, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&sl.ev_scan, hipEventDisableTiming));
     HIPCHK(c, hipHostMalloc(&sl.h_win, 8 * sizeof(unsigned long long)));
     HIPCHK(c, hipHostMalloc(&sl.h_sig, c->cap_msgs * sizeof(unsigned long long)));
     HIPCHK(c, hipHostMalloc(&sl.h_msg_pos, c->cap_msgs * sizeof(uint32_t)));
@@ -436,6 +438,7 @@ static void free_slot(Slot &sl) {
     for (void *p : dev)
         if (p) (void) hipFree(p);
     if (sl.ev_window) (void) hipEventDestroy(sl.ev_window);
+    if (sl.ev_scan) (void) hipEventDestroy(sl.ev_scan);
     void *host[] = {sl.h_live, sl.h_live_sig, sl.h_scratch, sl.h_win, sl.h_sig, sl.h_msg_pos,
                     sl.h_msg_limit, sl.h_msg_len, sl.h_msg_skip};
     for (void *p : host)
@@ -517,7 +520,8 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     if (const char *e = getenv("MGPU_SWEEP_VERSION")) { const int v = atoi(e); if (v >= 1 && v <= 4) c->sweep_version = v; }
     if (hipSetDevice(cfg->device) != hipSuccess) { delete c; return MGPU_E_NODEVICE; }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { mgpu_destroy(c); return MGPU_E_HIP; }
+        hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream_w, hipStreamNonBlocking) != hipSuccess) { mgpu_destroy(c); return MGPU_E_HIP; }
     // valid_df_*_bitset, init_bitsets() demod_2400.c:112-128 (ENABLE_DF24 off, readsb.h:303)
     c->valid_short = (1u << 0) | (1u << 4) | (1u << 5) | (1u << 11);
     c->valid_long = (1u << 16) | (1u << 17) | (1u << 18) | (1u << 20) | (1u << 21);
@@ -561,6 +565,7 @@ void mgpu_destroy(mgpu_ctx *c) {
     (void) hipSetDevice(c->cfg.device);
     if (c->stream) (void) hipStreamSynchronize(c->stream);
     if (c->stream2) (void) hipStreamSynchronize(c->stream2);
+    if (c->stream_w) (void) hipStreamSynchronize(c->stream_w);
     for (auto &sl : c->slot) free_slot(sl);
     if (c->h_win) (void) hipHostFree(c->h_win);
     void *dev[] = {c->d_iq, c->d_win, c->d_adder_bitmap, c->d_bit_syndrome, c->d_group_syndrome, c->d_parity,
@@ -569,6 +574,7 @@ void mgpu_destroy(mgpu_ctx *c) {
         if (p) (void) hipFree(p);
     if (c->stream) (void) hipStreamDestroy(c->stream);
     if (c->stream2) (void) hipStreamDestroy(c->stream2);
+    if (c->stream_w) (void) hipStreamDestroy(c->stream_w);
     delete c;
 }
 
@@ -643,8 +649,13 @@ static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
     q.class_final = c->sweep_version >= 3 ? sl.d_class_final : nullptr;
     q.class_words = (n + 31) / 32;
     q.d_scratch = sl.d_scratch; q.h_scratch = sl.h_scratch; q.scratch_words = (uint32_t) (sl.scratch_bytes / sizeof(unsigned long long));
-    launch_prescreen(q, s);
-    HIPCHK(c, hipEventRecord(sl.ev[3], s));
+    // Generation 3: the count pass leaves its decisions as masks in the segment headers, so the write pass does not
+    // look at the adder bitmap again.  MGPU_TWO_STREAMS=1 then moves the write pass and the publish to their own
+    // stream, beside the next chunk's convert (measured: the kernels only slow each other down, no gain end to end).
+    q.keep_masks = c->sweep_version == 3;
+    hipStream_t sw = (q.keep_masks && getenv("MGPU_TWO_STREAMS")) ? c->stream_w : s;
+    if (launch_prescreen(q, s, sw, sl.ev_scan) != 0) { c->err = "event ordering of the pre-screen passes failed"; return MGPU_E_HIP; }
+    HIPCHK(c, hipEventRecord(sl.ev[3], sw));
     return MGPU_OK;
 }
 

@@ -122,7 +122,7 @@ void launch_sweep_slice_v1(const SweepParams &p, hipStream_t s);   // first vers
 // everything between the sweep and the host: class planes -> class bitmap (+ counters, planes zeroed again),
 // pre-screen count / scan / write, scratch block to the host (and zeroed again)
 struct PostSweepParams {
-    const PhaseRec *pool;
+    PhaseRec *pool;                       // (the count pass may leave live masks in the segment headers)
     const uint32_t *unit_first;
     uint32_t nunits;
     const uint32_t *adder_bitmap;
@@ -135,8 +135,9 @@ struct PostSweepParams {
     uint64_t class_words;
     unsigned long long *d_scratch, *h_scratch;
     uint32_t scratch_words;
+    bool keep_masks;                      // generation 3 only (segments of <= 64 records)
 };
-void launch_prescreen(const PostSweepParams &q, hipStream_t s);
+int launch_prescreen(const PostSweepParams &q, hipStream_t s, hipStream_t s_write, hipEvent_t ev_scan);
 // signal power of accepted messages: sum of mag^2 over d_mag[pos+19 .. pos+19+len)
 void launch_signal_power(const uint16_t *mag, const uint32_t *pos, const uint16_t *len, uint32_t nmsg,
                          unsigned long long *out, hipStream_t s);

@@ -2186,10 +2186,17 @@ __device__ __forceinline__ bool rec_live(const PhaseRec &r, const uint32_t *bitm
 // became the accepted frame: sum of mag^2 over d_mag[pos+19 .. pos+19+len), len = 268 / 134 by the
 // DF as sliced (demod_2400.c:399,436-457).  ~5 records per real frame, 5 coalesced loads per lane
 // each — and the ordered walk then needs no second GPU round trip.
-template <bool WRITE>
-__device__ __forceinline__ void prescreen_unit(uint32_t u, const PhaseRec *pool, const uint32_t *unit_first, uint32_t nunits,
+// MODE 0: COUNT pass (decides which records live; with `keep_masks` it leaves the decision as a 64-bit mask in
+//         each segment header's spare bytes — generation 3 segments hold at most 64 records);
+// MODE 1: WRITE pass that decides again (same inputs, same stream: same answer);
+// MODE 2: WRITE pass that reads the masks — it may then run beside the next chunk's sweep, which adds bits
+//         to the adder bitmap (a second look at the bitmap could disagree with the counted offsets).
+template <int MODE>
+__device__ __forceinline__ void prescreen_unit(uint32_t u, PhaseRec *pool, const uint32_t *unit_first, uint32_t nunits,
                                                const uint32_t *bitmap, uint32_t *unit_live, PhaseRec *live,
-                                               const uint16_t *mag, unsigned long long *live_sig) {
+                                               const uint16_t *mag, unsigned long long *live_sig, bool keep_masks,
+                                               unsigned long long *counters) {
+    constexpr bool WRITE = MODE != 0;
     const int lane = lane_id();
     if (u >= nunits) return;
     uint32_t h = unit_first[u];
@@ -2200,21 +2207,31 @@ __device__ __forceinline__ void prescreen_unit(uint32_t u, const PhaseRec *pool,
         for (uint32_t i0 = 0; i0 < cnt; i0 += WAVE) {
             const uint32_t i = i0 + lane;
             bool ok = false;
-            uint32_t pos = 0, len = 0, addr = 0;
-            int sk = 0, su = 0;
-            if (i < cnt) {
-                const PhaseRec &r = pool[h + 1 + i];
-                ok = rec_live(r, bitmap);
-                pos = r.pos;
-                addr = r.addr;
-                sk = r.score_known;
-                su = r.score_unknown;
-                len = (r.msg[0] & 0x80) ? 268u : 134u;
-            }
-            // Dominated records: an earlier try-phase of the same position with the same address and scores at
-            // least as good wins every comparison the walk can make (same address = same filter answer, the
-            // best-phase test is a strict '>', demod_2400.c:246) — typically 2 of the 3 records of a clean frame.
-            {
+            uint32_t pos = 0, len = 0;
+            uint64_t m;
+            if (MODE == 2) {
+                m = ((const unsigned long long *) &pool[h])[2];
+                ok = (m >> lane) & 1;
+                if (ok) {
+                    const PhaseRec &r = pool[h + 1 + i];
+                    pos = r.pos;
+                    len = (r.msg[0] & 0x80) ? 268u : 134u;
+                }
+            } else {
+                uint32_t addr = 0;
+                int sk = 0, su = 0;
+                if (i < cnt) {
+                    const PhaseRec &r = pool[h + 1 + i];
+                    ok = rec_live(r, bitmap);
+                    pos = r.pos;
+                    addr = r.addr;
+                    sk = r.score_known;
+                    su = r.score_unknown;
+                    len = (r.msg[0] & 0x80) ? 268u : 134u;
+                }
+                // Dominated records: an earlier try-phase of the same position with the same address and scores at
+                // least as good wins every comparison the walk can make (same address = same filter answer, the
+                // best-phase test is a strict '>', demod_2400.c:246) — typically 2 of the 3 records of a clean frame.
                 const uint64_t live0 = __ballot(ok);
                 bool dom = false;
 #pragma unroll
@@ -2224,8 +2241,12 @@ __device__ __forceinline__ void prescreen_unit(uint32_t u, const PhaseRec *pool,
                     if (lane >= d && ((live0 >> (lane - d)) & 1) && pj == pos && aj == addr && kj >= sk && uj >= su) dom = true;
                 }
                 ok = ok && !dom;
+                m = __ballot(ok);
+                if (MODE == 0 && keep_masks && lane == 0) {
+                    if (cnt > (uint32_t) WAVE) atomicAdd(&counters[CNT_POOL_OVERFLOW], 1ull);   // cannot happen: one scoring pass = one segment
+                    ((unsigned long long *) &pool[h])[2] = m;
+                }
             }
-            const uint64_t m = __ballot(ok);
             if (WRITE) {
                 if (ok) {
                     const uint32_t d = dst0 + nlive + __popcll(m & ((1ull << lane) - 1));
@@ -2257,20 +2278,22 @@ __device__ __forceinline__ void prescreen_unit(uint32_t u, const PhaseRec *pool,
 
 // COUNT pass (one wave per unit) and, in the remaining workgroups of the same launch, the class-plane
 // finalize: two small latency-bound jobs that do not depend on each other.
-__global__ __launch_bounds__(kBlock) void k_count_finalize(const PhaseRec *pool, const uint32_t *unit_first, uint32_t nunits,
+__global__ __launch_bounds__(kBlock) void k_count_finalize(PhaseRec *pool, const uint32_t *unit_first, uint32_t nunits,
                                                            const uint32_t *bitmap, uint32_t *unit_live, uint32_t nb_count,
                                                            uint32_t *cond, uint32_t *uncond, uint32_t *final_bitmap, uint64_t nwords,
-                                                           unsigned long long *counters) {
+                                                           unsigned long long *counters, int keep_masks) {
     if (blockIdx.x < nb_count)
-        prescreen_unit<false>(blockIdx.x * (kBlock / WAVE) + (threadIdx.x >> 6), pool, unit_first, nunits, bitmap, unit_live, nullptr, nullptr, nullptr);
+        prescreen_unit<0>(blockIdx.x * (kBlock / WAVE) + (threadIdx.x >> 6), pool, unit_first, nunits, bitmap, unit_live, nullptr, nullptr, nullptr,
+                          keep_masks != 0, counters);
     else
         class_finalize_part(blockIdx.x - nb_count, gridDim.x - nb_count, cond, uncond, final_bitmap, nwords, counters);
 }
 
-__global__ __launch_bounds__(kBlock) void k_prescreen_write(const PhaseRec *pool, const uint32_t *unit_first, uint32_t nunits,
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_prescreen_write(PhaseRec *pool, const uint32_t *unit_first, uint32_t nunits,
                                                             const uint32_t *bitmap, uint32_t *unit_live, PhaseRec *live,
                                                             const uint16_t *mag, unsigned long long *live_sig) {
-    prescreen_unit<true>(blockIdx.x * (kBlock / WAVE) + (threadIdx.x >> 6), pool, unit_first, nunits, bitmap, unit_live, live, mag, live_sig);
+    prescreen_unit<MODE>(blockIdx.x * (kBlock / WAVE) + (threadIdx.x >> 6), pool, unit_first, nunits, bitmap, unit_live, live, mag, live_sig, false, nullptr);
 }
 
 // The chunk's scratch block (counters, pool cursor, per-buffer sums) goes to the host's pinned copy and is
@@ -2310,8 +2333,10 @@ __global__ __launch_bounds__(1024) void k_scan_units(uint32_t *unit_live, uint32
     if (threadIdx.x == 0) { unit_live[n] = s_carry; if (counters) counters[CNT_LIVE_TOTAL] = s_carry; }
 }
 
-void launch_prescreen(const PostSweepParams &q, hipStream_t s) {
-    if (q.nunits == 0) return;
+// count + finalize + scan on `s`; write + publish on `s_write` (== s, or a second stream when the segment
+// headers carry the live masks: `q.keep_masks`), ordered after the scan by `ev_scan`
+int launch_prescreen(const PostSweepParams &q, hipStream_t s, hipStream_t s_write, hipEvent_t ev_scan) {
+    if (q.nunits == 0) return 0;
     const unsigned nb_count = (q.nunits + 3) / 4;
     unsigned nb_fin = 0;
     if (q.class_final) {
@@ -2319,13 +2344,21 @@ void launch_prescreen(const PostSweepParams &q, hipStream_t s) {
         if (nb_fin > 1024) nb_fin = 1024;
     }
     hipLaunchKernelGGL(k_count_finalize, dim3(nb_count + nb_fin), dim3(kBlock), 0, s, q.pool, q.unit_first, q.nunits, q.adder_bitmap,
-                       q.unit_live, nb_count, q.class_cond, q.class_uncond, q.class_final, q.class_words, q.counters);
+                       q.unit_live, nb_count, q.class_cond, q.class_uncond, q.class_final, q.class_words, q.counters, q.keep_masks ? 1 : 0);
     hipLaunchKernelGGL(k_scan_units, dim3(1), dim3(1024), 0, s, q.unit_live, q.nunits, q.counters);
-    hipLaunchKernelGGL(k_prescreen_write, dim3(nb_count), dim3(kBlock), 0, s, q.pool, q.unit_first, q.nunits, q.adder_bitmap, q.unit_live,
-                       q.live, q.mag, q.live_sig);
+    if (s_write != s) {
+        if (hipEventRecord(ev_scan, s) != hipSuccess || hipStreamWaitEvent(s_write, ev_scan, 0) != hipSuccess) return -1;
+    }
+    if (q.keep_masks)
+        hipLaunchKernelGGL(k_prescreen_write<2>, dim3(nb_count), dim3(kBlock), 0, s_write, q.pool, q.unit_first, q.nunits, q.adder_bitmap,
+                           q.unit_live, q.live, q.mag, q.live_sig);
+    else
+        hipLaunchKernelGGL(k_prescreen_write<1>, dim3(nb_count), dim3(kBlock), 0, s_write, q.pool, q.unit_first, q.nunits, q.adder_bitmap,
+                           q.unit_live, q.live, q.mag, q.live_sig);
     unsigned pb = (q.scratch_words + kBlock - 1) / kBlock;
     if (pb > 64) pb = 64;
-    hipLaunchKernelGGL(k_publish, dim3(pb), dim3(kBlock), 0, s, q.d_scratch, q.h_scratch, q.scratch_words);
+    hipLaunchKernelGGL(k_publish, dim3(pb), dim3(kBlock), 0, s_write, q.d_scratch, q.h_scratch, q.scratch_words);
+    return 0;
 }
 
 // =============================================================================================

@@ -177,6 +177,23 @@ def main():
                          "avg_launch_ms": round(sweep / nlaunch, 4)},
             "synth_gen_s": round(t_gen, 2),
         }
+        # the boundary handing over HOST buffers (mgpu_feed_iq from page-locked memory): never `value`, see DESIGN.md §4
+        try:
+            d.host_register(iq)
+            rates = []
+            for _ in range(3):
+                d.reset()
+                t1 = time.perf_counter()
+                d.feed_iq(iq)
+                d.finish()
+                pm, _ = d.collect(reuse=True)
+                rates.append(n / (time.perf_counter() - t1) / 1e6)
+            d.host_unregister(iq)
+            out["pcie_inclusive_msamples_s"] = round(max(rates), 1)
+            assert len(pm) == total_msgs or world > 1
+        except Exception as e:                                   # the measurement is informative only
+            out["pcie_inclusive_msamples_s"] = None
+            out["pcie_inclusive_error"] = str(e)[:200]
         if not args.no_cpu_baseline:
             t0 = time.time()
             kind, ref_msgs, st = cpu_reference(iq, n)

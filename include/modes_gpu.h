@@ -142,6 +142,12 @@ int  mgpu_device_count(void);
  * Synchronous: on return the accepted messages are available to mgpu_collect(). */
 int mgpu_feed_iq(mgpu_ctx *ctx, const void *iq_host, uint64_t nsamples);
 
+/* Optional: page-lock a host buffer the caller keeps feeding from (the SDR plugin's read buffer, the
+ * ifile reader's `readbuf`, sdr_ifile.c:140) so that mgpu_feed_iq's chunked uploads run at PCIe speed
+ * and overlap the kernels.  Unregister before freeing the buffer. */
+int mgpu_host_register(mgpu_ctx *ctx, void *ptr, uint64_t bytes);
+int mgpu_host_unregister(mgpu_ctx *ctx, void *ptr);
+
 /* Same, for IQ already resident in device memory (HBM): d_iq is a device pointer to
  * nsamples samples of cfg.format.  This is the entry the benchmark times. */
 int mgpu_feed_iq_device(mgpu_ctx *ctx, const void *d_iq, uint64_t nsamples);

@@ -96,6 +96,8 @@ def load_library():
     lib.mgpu_device_count.restype = i32
     lib.mgpu_feed_iq.argtypes = [vp, vp, u64]
     lib.mgpu_feed_iq_device.argtypes = [vp, vp, u64]
+    lib.mgpu_host_register.argtypes = [vp, vp, u64]
+    lib.mgpu_host_unregister.argtypes = [vp, vp]
     lib.mgpu_upload_iq.argtypes = [vp, vp, u64]
     lib.mgpu_device_iq_buffer.argtypes = [vp]
     lib.mgpu_device_iq_buffer.restype = vp
@@ -174,6 +176,13 @@ class Demodulator:
 
     def finish(self):
         self._chk(self.lib.mgpu_finish(self.ctx), "mgpu_finish")
+
+    def host_register(self, arr):
+        """Page-lock a numpy array the caller keeps feeding from (mgpu_host_register)."""
+        self._chk(self.lib.mgpu_host_register(self.ctx, C.c_void_p(arr.ctypes.data), C.c_uint64(arr.nbytes)), "mgpu_host_register")
+
+    def host_unregister(self, arr):
+        self._chk(self.lib.mgpu_host_unregister(self.ctx, C.c_void_p(arr.ctypes.data)), "mgpu_host_unregister")
 
     def collect(self, reuse=False, out=None):
         """Drain the decoded messages (stream order) and read the counters.

@@ -147,6 +147,7 @@ struct Slot {
     uint32_t *h_msg_pos = nullptr, *h_msg_limit = nullptr;
     uint16_t *h_msg_len = nullptr, *h_msg_skip = nullptr;
     hipEvent_t ev[5] = {};
+    hipEvent_t ev_h2d = nullptr;          // the chunk's IQ samples have arrived in HBM (copy stream)
     hipEvent_t ev_scan = nullptr;         // pre-screen offsets are final (main stream) -> the write pass may start (second stream)
     // the job
     uint64_t n = 0;
@@ -420,6 +421,7 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
     HIPCHK(c, hipHostMalloc(&sl.h_live_sig, c->cap_pool * sizeof(unsigned long long)));
     HIPCHK(c, hipEventCreateWithFlags(&sl.ev_window, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&sl.ev_scan, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming));
     HIPCHK(c, hipHostMalloc(&sl.h_win, 8 * sizeof(unsigned long long)));
     HIPCHK(c, hipHostMalloc(&sl.h_sig, c->cap_msgs * sizeof(unsigned long long)));
     HIPCHK(c, hipHostMalloc(&sl.h_msg_pos, c->cap_msgs * sizeof(uint32_t)));
@@ -439,6 +441,7 @@ static void free_slot(Slot &sl) {
         if (p) (void) hipFree(p);
     if (sl.ev_window) (void) hipEventDestroy(sl.ev_window);
     if (sl.ev_scan) (void) hipEventDestroy(sl.ev_scan);
+    if (sl.ev_h2d) (void) hipEventDestroy(sl.ev_h2d);
     void *host[] = {sl.h_live, sl.h_live_sig, sl.h_scratch, sl.h_win, sl.h_sig, sl.h_msg_pos,
                     sl.h_msg_limit, sl.h_msg_len, sl.h_msg_skip};
     for (void *p : host)
@@ -1008,14 +1011,9 @@ static int feed_common(mgpu_ctx *c, const void *src, bool src_is_device, uint64_
     const double t_start = wall_ms();
     c->feed_t0 = t_start;
     { int brc = feed_begin(c); if (brc != MGPU_OK) return brc; }
-    const uint8_t *iq = (const uint8_t *) src;
-    if (!src_is_device) {
-        const double t0 = wall_ms();
-        HIPCHK(c, hipMemcpyAsync(c->d_iq, src, n * bps, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        c->acc.h2d_ms = (float) (wall_ms() - t0);
-        iq = c->d_iq;
-    }
+    // host samples go up chunk by chunk on the copy stream, each chunk's convert waits for its own piece only:
+    // the transfer of chunk i+1 overlaps the kernels of chunk i (fully so from pinned / mgpu_host_register'ed memory)
+    const uint8_t *iq = src_is_device ? (const uint8_t *) src : c->d_iq;
     // software pipeline over chunks: GPU works on chunk i+1 while the worker walks chunk i
     int rc = MGPU_OK;
     for (uint64_t off = 0; off < n && rc == MGPU_OK; off += c->chunk_samples) {
@@ -1026,7 +1024,15 @@ static int feed_common(mgpu_ctx *c, const void *src, bool src_is_device, uint64_
         sl.have_mag = false;
         sl.given_mean_power.clear();
         ifile_grid(c, c->stream_pos + off, len, sl.buffers);
-        rc = enqueue_slot(c, sl, iq + off * bps);
+        if (!src_is_device) {
+            const double t0 = wall_ms();
+            hipError_t e = hipMemcpyAsync(c->d_iq + off * bps, (const uint8_t *) src + off * bps, len * bps, hipMemcpyHostToDevice, c->stream_w);
+            if (e == hipSuccess) e = hipEventRecord(sl.ev_h2d, c->stream_w);
+            if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, sl.ev_h2d, 0);
+            if (e != hipSuccess) { c->err = std::string("H2D of the IQ samples: ") + hipGetErrorString(e); rc = MGPU_E_HIP; }
+            c->acc.h2d_ms += (float) (wall_ms() - t0);   // host time spent issuing (pageable memory: staging) the copies
+        }
+        if (rc == MGPU_OK) rc = enqueue_slot(c, sl, iq + off * bps);
         submit_slot(c, k);   // even after an enqueue error: the worker releases the slot
         if (rc != MGPU_OK) { std::lock_guard<std::mutex> lk(c->mu); if (c->worker_rc == MGPU_OK) c->worker_rc = rc; }
     }
@@ -1042,6 +1048,20 @@ static int feed_common(mgpu_ctx *c, const void *src, bool src_is_device, uint64_
 }
 
 int mgpu_feed_iq(mgpu_ctx *c, const void *iq_host, uint64_t nsamples) { return feed_common(c, iq_host, false, nsamples); }
+
+int mgpu_host_register(mgpu_ctx *c, void *ptr, uint64_t bytes) {
+    if (!c || !ptr || !bytes) return MGPU_E_INVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return MGPU_OK;
+}
+
+int mgpu_host_unregister(mgpu_ctx *c, void *ptr) {
+    if (!c || !ptr) return MGPU_E_INVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipHostUnregister(ptr));
+    return MGPU_OK;
+}
 
 int mgpu_feed_iq_device(mgpu_ctx *c, const void *d_iq, uint64_t nsamples) { return feed_common(c, d_iq, true, nsamples); }
 

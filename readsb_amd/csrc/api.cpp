@@ -245,6 +245,10 @@ struct mgpu_ctx {
     Team walk_team, build_team;                               // helpers of the walker / builder stage (MGPU_WALK_THREADS, MGPU_BUILD_THREADS)
     int walk_threads = 4, build_threads = 3;
     std::vector<SegmentWalk> segs;                            // the walker's buffer ranges
+    // experiment / debug switches, read once at creation
+    bool dbg_print = false, dbg_no_window = false, two_streams = false;
+    int dbg_stage = 0;
+    std::string dump_dir;
     double feed_t0 = 0;                                       // wall clock at feed start (MGPU_DEBUG_PRINT timeline)
     uint64_t spec_segments = 0, spec_batches = 0;            // ranges walked, batches it took
     std::mutex mu;
@@ -537,6 +541,11 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
         return rc;
     }
     c->resolver.reset(cfg->startup_time_ms);
+    c->dbg_print = getenv("MGPU_DEBUG_PRINT") != nullptr;
+    c->dbg_no_window = getenv("MGPU_DEBUG_NO_WINDOW") != nullptr;
+    c->two_streams = getenv("MGPU_TWO_STREAMS") != nullptr;
+    if (const char *e = getenv("MGPU_DEBUG_STAGE")) c->dbg_stage = atoi(e);
+    if (const char *e = getenv("MGPU_DUMP_DIR")) c->dump_dir = e;
     if (const char *e = getenv("MGPU_WALK_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) c->walk_threads = v; }
     if (const char *e = getenv("MGPU_BUILD_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) c->build_threads = v; }
     c->fetcher = std::thread(fetcher_main, c);
@@ -632,7 +641,7 @@ static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
     sp.tab_long = c->d_tab_long; sp.tab_short = c->d_tab_short; sp.n_long = c->n_long; sp.n_short = c->n_short;
     sp.pool = sl.d_pool; sp.pool_cap = (uint32_t) c->cap_pool; sp.pool_used = sl.d_pool_used;
     sp.unit_first = sl.d_unit_first; sp.unit_count = sl.d_unit_count; sp.nunits = nunits;
-    { const char *e = getenv("MGPU_DEBUG_STAGE"); sp.debug_stage = e ? atoi(e) : 0; }
+    sp.debug_stage = c->dbg_stage;
     sp.adder_bitmap = c->d_adder_bitmap; sp.class_bitmap = sl.d_class_bitmap; sp.counters = sl.d_counters;
     sp.cand = sl.d_cand; sp.cand_count = sl.d_cand_count; sp.class_uncond = sl.d_class_uncond;
     // ev[1] .. ev[4] bracket exactly one kernel: the sweep kernel of the active generation (bench.py's roofline)
@@ -656,7 +665,7 @@ static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
     // look at the adder bitmap again.  MGPU_TWO_STREAMS=1 then moves the write pass and the publish to their own
     // stream, beside the next chunk's convert (measured: the kernels only slow each other down, no gain end to end).
     q.keep_masks = c->sweep_version == 3;
-    hipStream_t sw = (q.keep_masks && getenv("MGPU_TWO_STREAMS")) ? c->stream_w : s;
+    hipStream_t sw = (q.keep_masks && c->two_streams) ? c->stream_w : s;
     if (launch_prescreen(q, s, sw, sl.ev_scan) != 0) { c->err = "event ordering of the pre-screen passes failed"; return MGPU_E_HIP; }
     HIPCHK(c, hipEventRecord(sl.ev[3], sw));
     return MGPU_OK;
@@ -666,7 +675,7 @@ static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
 static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job) {
     HIPCHK(c, hipEventSynchronize(sl.ev[3]));
     const double t_gpu_done = wall_ms();
-    if (getenv("MGPU_DEBUG_PRINT")) {
+    if (c->dbg_print) {
         const unsigned long long *h = sl.h_counters;
         fprintf(stderr, "dbg: v3 wave cycles: load %llu sweep %llu stageA %llu slice %llu score %llu total %llu | rounds B %llu passes %llu\n",
                 h[16], h[17], h[18], h[19], h[20], h[21], h[22], h[23]);
@@ -682,7 +691,8 @@ static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job) {
     if (hipEventElapsedTime(&ms, sl.ev[2], sl.ev[3]) == hipSuccess) c->acc.prescreen_ms += ms;
     const uint64_t nlive = sl.h_counters[CNT_LIVE_TOTAL];
 
-    if (const char *dd = getenv("MGPU_DUMP_DIR")) {   // replay material for tools/walk_replay.cpp
+    if (!c->dump_dir.empty()) {   // replay material for tools/walk_replay.cpp
+        const char *dd = c->dump_dir.c_str();
         static int dumped = 0;
         if (!dumped++) {
             std::string base = std::string(dd) + "/walk_";
@@ -716,7 +726,7 @@ static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job) {
     c->acc.n_live_records += nlive;
     c->acc.n_chunks += 1;
     c->acc.d2h_ms += (float) (wall_ms() - t_f0);
-    if (getenv("MGPU_DEBUG_PRINT")) fprintf(stderr, "dbg: timeline: gpu done %.3f, fetched %.3f\n", t_gpu_done - c->feed_t0, wall_ms() - c->feed_t0);
+    if (c->dbg_print) fprintf(stderr, "dbg: timeline: gpu done %.3f, fetched %.3f\n", t_gpu_done - c->feed_t0, wall_ms() - c->feed_t0);
     return MGPU_OK;
 }
 
@@ -769,7 +779,7 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
             }
             wn = (int64_t) total;
         }
-        if (getenv("MGPU_DEBUG_PRINT")) fprintf(stderr, "dbg: %d ranges in %llu batches: %.3f ms, gather %.3f ms\n", K, (unsigned long long) batches, tp2 - tp0, wall_ms() - tp2);
+        if (c->dbg_print) fprintf(stderr, "dbg: %d ranges in %llu batches: %.3f ms, gather %.3f ms\n", K, (unsigned long long) batches, tp2 - tp0, wall_ms() - tp2);
     } else {
         wn = c->resolver.decide(job.recs.data(), nlive, sl.buffers, job.acc, job.pos.data(), c->w_skip.data(),
                                 c->w_limit.data(), aux_cap, job.rc);
@@ -780,7 +790,7 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
         std::memcpy(sl.h_msg_skip, c->w_skip.data(), (size_t) wn * sizeof(uint16_t));
     }
     c->acc.resolve_ms += (float) (wall_ms() - t_res0);
-    if (getenv("MGPU_DEBUG_PRINT")) fprintf(stderr, "dbg: walk %.3f ms for %llu live records -> %lld msgs\n", wall_ms() - t_res0, (unsigned long long) nlive, (long long) wn);
+    if (c->dbg_print) fprintf(stderr, "dbg: walk %.3f ms for %llu live records -> %lld msgs\n", wall_ms() - t_res0, (unsigned long long) nlive, (long long) wn);
     if (wn < 0) { c->err = "max_messages exceeded"; return MGPU_E_OVERFLOW; }
     const uint32_t nmsg = (uint32_t) wn;
     c->feed_rc.add(job.rc);
@@ -788,7 +798,7 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
     // what the skip windows hid from the counters: asynchronous on the second stream, totals are
     // accumulated on the device and read once at the end of the feed
     const double t_sig0 = wall_ms();
-    if (nmsg && !getenv("MGPU_DEBUG_NO_WINDOW")) {
+    if (nmsg && !c->dbg_no_window) {
         hipStream_t s2 = c->stream2;
         HIPCHK(c, hipMemcpyAsync(sl.d_msg_pos, sl.h_msg_pos, nmsg * sizeof(uint32_t), hipMemcpyHostToDevice, s2));
         HIPCHK(c, hipMemcpyAsync(sl.d_msg_limit, sl.h_msg_limit, nmsg * sizeof(uint32_t), hipMemcpyHostToDevice, s2));
@@ -801,7 +811,7 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
     c->acc.sigpower_ms += (float) (wall_ms() - t_sig0);
 
     job.nmsg = nmsg;
-    if (getenv("MGPU_DEBUG_PRINT")) fprintf(stderr, "dbg: timeline: walk %.3f .. %.3f\n", t_res0 - c->feed_t0, wall_ms() - c->feed_t0);
+    if (c->dbg_print) fprintf(stderr, "dbg: timeline: walk %.3f .. %.3f\n", t_res0 - c->feed_t0, wall_ms() - c->feed_t0);
     c->acc.n_messages += nmsg;
     return MGPU_OK;
 }
@@ -859,8 +869,8 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
         k.nbuffers++;
     }
     c->acc.build_ms += (float) (wall_ms() - t0);
-    if (getenv("MGPU_DEBUG_PRINT")) fprintf(stderr, "dbg: timeline: build %.3f .. %.3f\n", t0 - c->feed_t0, wall_ms() - c->feed_t0);
-    if (getenv("MGPU_DEBUG_PRINT")) fprintf(stderr, "dbg: build: grow %.3f ms, messages %.3f ms, statistics %.3f ms for %u msgs\n", t1 - t0, t2 - t1, wall_ms() - t2, nmsg);
+    if (c->dbg_print) fprintf(stderr, "dbg: timeline: build %.3f .. %.3f\n", t0 - c->feed_t0, wall_ms() - c->feed_t0);
+    if (c->dbg_print) fprintf(stderr, "dbg: build: grow %.3f ms, messages %.3f ms, statistics %.3f ms for %u msgs\n", t1 - t0, t2 - t1, wall_ms() - t2, nmsg);
     return MGPU_OK;
 }
 

@@ -1303,8 +1303,11 @@ void launch_sweep_slice_v2(const SweepParams &p, hipStream_t s) {
         resident = per_cu * cus;
         if (resident > kSweepMaxBlocks) resident = kSweepMaxBlocks;
     }
+    static unsigned env_blocks = 0;
+    static bool env_read = false;
+    if (!env_read) { env_read = true; if (const char *e = getenv("MGPU_SWEEP_BLOCKS")) env_blocks = (unsigned) atoi(e); }
     unsigned maxb = (unsigned) resident;
-    if (const char *e = getenv("MGPU_SWEEP_BLOCKS")) { unsigned v = (unsigned) atoi(e); if (v >= 1 && v < maxb) maxb = v; }
+    if (env_blocks >= 1 && env_blocks < maxb) maxb = env_blocks;
     unsigned blocks = p.nunits < maxb ? p.nunits : maxb;
     hipLaunchKernelGGL(k_sweep_slice_v2, dim3(blocks), dim3(kBlock), (size_t) (p.n_long + p.n_short + 4) * sizeof(uint32_t), s, p);
 }
@@ -1790,8 +1793,11 @@ void launch_sweep_slice(const SweepParams &p, hipStream_t s) {
         resident = per_cu * cus;
         if (resident > kSweepMaxBlocks) resident = kSweepMaxBlocks;
     }
+    static unsigned env_blocks = 0;
+    static bool env_read = false;
+    if (!env_read) { env_read = true; if (const char *e = getenv("MGPU_SWEEP_BLOCKS")) env_blocks = (unsigned) atoi(e); }
     unsigned maxb = (unsigned) resident;
-    if (const char *e = getenv("MGPU_SWEEP_BLOCKS")) { unsigned v = (unsigned) atoi(e); if (v >= 1 && v < maxb) maxb = v; }
+    if (env_blocks >= 1 && env_blocks < maxb) maxb = env_blocks;
     const unsigned want = (p.nunits + (kBlock / WAVE) - 1) / (kBlock / WAVE);
     const unsigned blocks = want < maxb ? want : maxb;
     hipLaunchKernelGGL(k_sweep_slice, dim3(blocks), dim3(kBlock), dyn, s, p);

@@ -99,22 +99,32 @@ def main():
     d.upload_iq(iq)
 
     gath = None                                 # N > 1: the aggregator role, asynchronous (readsb_amd/gather.py)
+    outbuf = None                               # the consumer's standing message array (mgpu_set_message_buffer)
 
     def step():
         d.reset()
+        if gath is not None:
+            buf = gath.staging()                # pinned staging memory of the exchange: messages are built straight into it
+            d.set_message_buffer(buf)
+        else:
+            buf = outbuf
         d.feed_resident(n)                      # timed: everything from HBM-resident IQ to ordered messages
         d.finish()                              # ifile EOF bookkeeping (zero-length buffer on exact multiples)
-        if gath is None:
-            return d.collect(reuse=True)        # the consumer's standing buffer
-        msgs, counters = d.collect(out=gath.staging())   # straight into pinned staging memory
-        gath.submit(len(msgs))                  # counts + records to rank 0's HBM over RCCL, overlapped with the next step
+        msgs, counters = d.collect(out=buf) if buf is not None else d.collect(reuse=True)
+        if gath is not None:
+            gath.submit(len(msgs))              # counts + records to rank 0's HBM over RCCL, overlapped with the next step
         return msgs, counters
 
+    m0, _ = step()                              # sizes the consumer's buffer: 1.25 x the busiest rank's message count
+    cap = len(m0) * 5 // 4 + 1024
     if use_dist:
-        m0, _ = step()                          # sizes the exchange: 1.25 x the busiest rank's message count
-        cap = torch.tensor([len(m0)], dtype=torch.int64, device="cuda")
-        dist.all_reduce(cap, op=dist.ReduceOp.MAX)
-        gath = MessageGatherer(readsb_amd.MSG_DTYPE, torch.device("cuda", local_rank), int(cap.item()) * 5 // 4 + 1024)
+        t = torch.tensor([cap], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        cap = int(t.item())
+        gath = MessageGatherer(readsb_amd.MSG_DTYPE, torch.device("cuda", local_rank), cap)
+    else:
+        outbuf = np.empty(cap, dtype=readsb_amd.MSG_DTYPE)
+        d.set_message_buffer(outbuf)
     for _ in range(args.warmup):
         step()
     sweep_ms, conv_ms, resolve_ms, total_ms, launches = [], [], [], [], []

@@ -167,6 +167,15 @@ int mgpu_finish(mgpu_ctx *ctx);
  * via mgpu_pending_messages().  counters may be NULL. */
 int mgpu_collect(mgpu_ctx *ctx, struct mgpu_msg *out, uint64_t cap, uint64_t *n,
                  struct mgpu_counters *counters);
+/* Optional: have the messages built straight into the caller's array (capacity records) instead of an
+ * internal list.  After a feed, mgpu_collect(ctx, buf, capacity, &n, ...) with the same pointer only
+ * reports n and makes the array writable again — no copy (the builder threads have written the 64-byte
+ * records with streaming stores; 16-byte alignment of buf keeps that fast).  A feed that needs more
+ * room than capacity fails with MGPU_E_OVERFLOW.  buf = NULL returns to the internal list.  The array
+ * may be replaced between feeds (e.g. alternating staging buffers) once the pending messages are
+ * collected. */
+int mgpu_set_message_buffer(mgpu_ctx *ctx, struct mgpu_msg *buf, uint64_t capacity);
+
 uint64_t mgpu_pending_messages(mgpu_ctx *ctx);
 int mgpu_last_timing(mgpu_ctx *ctx, struct mgpu_timing *t);
 

@@ -104,6 +104,7 @@ def load_library():
     lib.mgpu_finish.argtypes = [vp]
     lib.mgpu_collect.argtypes = [vp, vp, u64, C.POINTER(u64), C.POINTER(Counters)]
     lib.mgpu_pending_messages.argtypes = [vp]
+    lib.mgpu_set_message_buffer.argtypes = [vp, vp, u64]
     lib.mgpu_pending_messages.restype = u64
     lib.mgpu_last_timing.argtypes = [vp, C.POINTER(Timing)]
     lib.mgpu_convert.argtypes = [vp, vp, vp, u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -131,6 +132,7 @@ class Demodulator:
         self.cfg = cfg
         self.fmt = fmt
         self._collect_buf = None
+        self._msgbuf = None
         self.ctx = C.c_void_p()
         rc = self.lib.mgpu_create(C.byref(cfg), C.byref(self.ctx))
         if rc != 0:
@@ -176,6 +178,18 @@ class Demodulator:
 
     def finish(self):
         self._chk(self.lib.mgpu_finish(self.ctx), "mgpu_finish")
+
+    def set_message_buffer(self, arr):
+        """Build the messages of the following feeds straight into `arr` (a contiguous mgpu_msg record array);
+        collect(out=arr) then only reports how many there are.  None returns to the internal list."""
+        if arr is None:
+            self._chk(self.lib.mgpu_set_message_buffer(self.ctx, None, 0), "mgpu_set_message_buffer")
+            self._msgbuf = None
+            return
+        if arr.dtype != MSG_DTYPE or not arr.flags["C_CONTIGUOUS"]:
+            raise ValueError("set_message_buffer: need a contiguous mgpu_msg record array")
+        self._chk(self.lib.mgpu_set_message_buffer(self.ctx, C.c_void_p(arr.ctypes.data), C.c_uint64(arr.size)), "mgpu_set_message_buffer")
+        self._msgbuf = arr                   # keep it alive
 
     def host_register(self, arr):
         """Page-lock a numpy array the caller keeps feeding from (mgpu_host_register)."""

@@ -161,12 +161,14 @@ struct Slot {
 struct MsgBuf {
     mgpu_msg *p = nullptr;
     size_t n = 0, cap = 0;
-    ~MsgBuf() { free(p); }
+    bool external = false;                            // p is the caller's buffer (mgpu_set_message_buffer): never grown, never freed
+    ~MsgBuf() { if (!external) free(p); }
     size_t size() const { return n; }
     mgpu_msg *data() { return p; }
     void clear() { n = 0; }
     bool grow_for(size_t extra) {                     // room for `extra` more messages
         if (cap - n >= extra) return true;
+        if (external) return false;
         size_t want = n + extra;
         if (want < 2 * cap) want = 2 * cap;
         void *q = nullptr;
@@ -180,6 +182,11 @@ struct MsgBuf {
     void drop_front(size_t k) {
         if (k < n) std::memmove(p, p + k, (n - k) * sizeof(mgpu_msg));
         n -= k;
+    }
+    void use_external(mgpu_msg *buf, size_t capacity) {
+        if (!external) free(p);
+        p = buf; cap = capacity; n = 0; external = buf != nullptr;
+        if (!external) { p = nullptr; cap = 0; }
     }
 };
 
@@ -823,7 +830,10 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
     const uint32_t nmsg = job.nmsg;
     const uint32_t nbuf = (uint32_t) job.buffers.size();
     const size_t first_msg = c->pending.size();
-    if (!c->pending.grow_for(nmsg)) { c->err = "out of memory for the decoded messages"; return MGPU_E_NOMEM; }
+    if (!c->pending.grow_for(nmsg)) {
+        c->err = c->pending.external ? "the caller's message buffer (mgpu_set_message_buffer) is full" : "out of memory for the decoded messages";
+        return c->pending.external ? MGPU_E_OVERFLOW : MGPU_E_NOMEM;
+    }
     const double t1 = wall_ms();
     {
         const int parts = nmsg >= 4096 ? c->build_threads : 1;
@@ -1104,10 +1114,21 @@ int mgpu_finish(mgpu_ctx *c) {
 int mgpu_collect(mgpu_ctx *c, struct mgpu_msg *out, uint64_t cap, uint64_t *n, struct mgpu_counters *counters) {
     if (!c || (!out && cap)) return MGPU_E_INVAL;
     uint64_t k = c->pending.size() < cap ? c->pending.size() : cap;
-    if (k) std::memcpy(out, c->pending.data(), k * sizeof(mgpu_msg));
-    c->pending.drop_front(k);
+    if (c->pending.external && out == c->pending.data() && k == c->pending.size()) {
+        c->pending.clear();                  // the messages already are where the caller wants them
+    } else {
+        if (k) std::memcpy(out, c->pending.data(), k * sizeof(mgpu_msg));
+        c->pending.drop_front(k);
+    }
     if (n) *n = k;
     if (counters) *counters = c->counters;
+    return MGPU_OK;
+}
+
+int mgpu_set_message_buffer(mgpu_ctx *c, struct mgpu_msg *buf, uint64_t capacity) {
+    if (!c || (buf && !capacity)) return MGPU_E_INVAL;
+    if (c->pending.size()) { c->err = "mgpu_set_message_buffer: collect the pending messages first"; return MGPU_E_INVAL; }
+    c->pending.use_external(buf, (size_t) capacity);
     return MGPU_OK;
 }
 

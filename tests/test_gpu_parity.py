@@ -78,3 +78,28 @@ def test_noise_only(built):
     got, cnt, _ = _demod(iq)
     helpers.assert_same_messages(got, want)
     helpers.assert_same_counters(cnt, wst)
+
+
+def test_caller_message_buffer(built):
+    """mgpu_set_message_buffer: the same messages, built straight into the caller's array; too small an array
+    fails loudly instead of dropping messages."""
+    import readsb_amd
+    iq = helpers.synth(seconds=3.0, seed=77)
+    want, wst = helpers.oracle_run(iq)
+    d = readsb_amd.Demodulator(startup_time_ms=helpers.STARTUP_MS, max_samples=64 * 131072)
+    try:
+        buf = np.empty(len(want) + 100, dtype=readsb_amd.MSG_DTYPE)
+        d.set_message_buffer(buf)
+        d.feed_iq(iq)
+        d.finish()
+        got, cnt = d.collect(out=buf)
+        assert got.ctypes.data == buf.ctypes.data            # no copy: a view of the caller's array
+        helpers.assert_same_messages(got, want)
+        helpers.assert_same_counters(cnt, wst)
+        small = np.empty(10, dtype=readsb_amd.MSG_DTYPE)
+        d.reset()
+        d.set_message_buffer(small)
+        with pytest.raises(readsb_amd.MgpuError):
+            d.feed_iq(iq)
+    finally:
+        d.close()

@@ -195,6 +195,23 @@ int mgpu_demod_mag_buf(mgpu_ctx *ctx, const uint16_t *data, uint32_t length,
                        int64_t sampleTimestamp, int64_t sysTimestamp,
                        double mean_power, uint32_t dropped);
 
+/* ---- one capture sharded by buffer ranges over several contexts / GPUs (BASELINE config 5) ----
+ * Buffers are independent except for the ICAO filter, and the pre-screen needs the adder addresses
+ * of the whole capture.  Per shard (a context, after mgpu_reset):
+ *   pass 1: mgpu_shard_begin(ctx, first_sample, history, 1); mgpu_feed_iq*(shard samples);
+ *           mgpu_adder_bitmap_get() -> OR over all shards (the exchange step, 2 MiB per rank)
+ *   pass 2: mgpu_reset; mgpu_adder_bitmap_set(global); mgpu_shard_begin(ctx, first_sample, history, 2);
+ *           mgpu_feed_iq*(shard samples); mgpu_shard_packets() -> the shard's live records
+ * and on ONE context, after mgpu_reset, mgpu_walk_packets() over the packets of all shards in stream
+ * order, mgpu_finish(), mgpu_collect(): the message list of the unsharded stream, bit for bit
+ * (counters: demod_accepted, demod_bestPhase, samples_processed, nbuffers, nflips only).
+ * first_sample is a multiple of buf_samples; history = the 326 IQ samples before it (NULL for 0). */
+int mgpu_shard_begin(mgpu_ctx *ctx, uint64_t first_sample, const void *history_iq, int mode);
+int mgpu_adder_bitmap_get(mgpu_ctx *ctx, uint32_t *words /* 2^19 */);
+int mgpu_adder_bitmap_set(mgpu_ctx *ctx, const uint32_t *words /* 2^19 */);
+int mgpu_shard_packets(mgpu_ctx *ctx, const void **packets, uint64_t *bytes);   /* valid until the next reset */
+int mgpu_walk_packets(mgpu_ctx *ctx, const void *packets, uint64_t bytes);
+
 /* ---- tables, for known-answer tests against crc.c --------------------------------- */
 
 /* These run on the host (they are how the device tables are built) and need no context. */

@@ -105,6 +105,11 @@ def load_library():
     lib.mgpu_collect.argtypes = [vp, vp, u64, C.POINTER(u64), C.POINTER(Counters)]
     lib.mgpu_pending_messages.argtypes = [vp]
     lib.mgpu_set_message_buffer.argtypes = [vp, vp, u64]
+    lib.mgpu_shard_begin.argtypes = [vp, u64, vp, i32]
+    lib.mgpu_adder_bitmap_get.argtypes = [vp, vp]
+    lib.mgpu_adder_bitmap_set.argtypes = [vp, vp]
+    lib.mgpu_shard_packets.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
+    lib.mgpu_walk_packets.argtypes = [vp, vp, u64]
     lib.mgpu_pending_messages.restype = u64
     lib.mgpu_last_timing.argtypes = [vp, C.POINTER(Timing)]
     lib.mgpu_convert.argtypes = [vp, vp, vp, u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -190,6 +195,34 @@ class Demodulator:
             raise ValueError("set_message_buffer: need a contiguous mgpu_msg record array")
         self._chk(self.lib.mgpu_set_message_buffer(self.ctx, C.c_void_p(arr.ctypes.data), C.c_uint64(arr.size)), "mgpu_set_message_buffer")
         self._msgbuf = arr                   # keep it alive
+
+    # ---- one capture sharded by buffer ranges (include/modes_gpu.h, "sharded" section; readsb_amd/shard.py) ----
+    def shard_begin(self, first_sample, history_iq, mode):
+        hist = None if history_iq is None else np.ascontiguousarray(history_iq, dtype=np.uint8)
+        self._hist_keep = hist
+        self._chk(self.lib.mgpu_shard_begin(self.ctx, C.c_uint64(first_sample), None if hist is None else C.c_void_p(hist.ctypes.data), mode),
+                  "mgpu_shard_begin")
+
+    def adder_bitmap(self):
+        words = np.empty(1 << 19, dtype=np.uint32)
+        self._chk(self.lib.mgpu_adder_bitmap_get(self.ctx, C.c_void_p(words.ctypes.data)), "mgpu_adder_bitmap_get")
+        return words
+
+    def set_adder_bitmap(self, words):
+        words = np.ascontiguousarray(words, dtype=np.uint32)
+        assert words.size == 1 << 19
+        self._chk(self.lib.mgpu_adder_bitmap_set(self.ctx, C.c_void_p(words.ctypes.data)), "mgpu_adder_bitmap_set")
+
+    def shard_packets(self):
+        p, n = C.c_void_p(), C.c_uint64(0)
+        self._chk(self.lib.mgpu_shard_packets(self.ctx, C.byref(p), C.byref(n)), "mgpu_shard_packets")
+        if not n.value:
+            return np.zeros(0, dtype=np.uint8)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n.value,)).copy()
+
+    def walk_packets(self, packets):
+        packets = np.ascontiguousarray(packets, dtype=np.uint8)
+        self._chk(self.lib.mgpu_walk_packets(self.ctx, C.c_void_p(packets.ctypes.data), C.c_uint64(packets.size)), "mgpu_walk_packets")
 
     def host_register(self, arr):
         """Page-lock a numpy array the caller keeps feeding from (mgpu_host_register)."""

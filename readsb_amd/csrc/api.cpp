@@ -150,7 +150,7 @@ struct Slot {
     hipEvent_t ev_h2d = nullptr;          // the chunk's IQ samples have arrived in HBM (copy stream)
     hipEvent_t ev_scan = nullptr;         // pre-screen offsets are final (main stream) -> the write pass may start (second stream)
     // the job
-    uint64_t n = 0;
+    uint64_t n = 0, stream_pos = 0;
     bool have_mag = false, busy = false;
     std::vector<BufferClock> buffers;
     std::vector<double> given_mean_power;
@@ -203,6 +203,7 @@ struct HostJob {
     ResolveCounts rc;
     uint64_t nlive = 0;
     uint32_t nmsg = 0;                       // accepted frames: acc[0..nmsg), pos[0..nmsg)
+    uint64_t stream_pos = 0;                 // stream position of the chunk's first sample
     int slot = -1;                           // the slot the chunk ran in (the walker still needs its device side)
     bool busy = false;
 };
@@ -252,6 +253,13 @@ struct mgpu_ctx {
     Team walk_team, build_team;                               // helpers of the walker / builder stage (MGPU_WALK_THREADS, MGPU_BUILD_THREADS)
     int walk_threads = 4, build_threads = 3;
     std::vector<SegmentWalk> segs;                            // the walker's buffer ranges
+    // time-sharded capture (config 5, mgpu_shard_*): 0 = normal, 1 = sweep for the adder bitmap only, 2 = keep the
+    // pre-screened records of every chunk as packets instead of walking them
+    int shard_mode = 0;
+    std::vector<uint8_t> shard_packets;
+    uint16_t *d_hist = nullptr;                               // magnitudes of the 326 samples before the shard
+    uint8_t *d_hist_iq = nullptr;
+    unsigned long long *d_hist_sums = nullptr;
     // experiment / debug switches, read once at creation
     bool dbg_print = false, dbg_no_window = false, two_streams = false;
     int dbg_stage = 0;
@@ -587,7 +595,7 @@ void mgpu_destroy(mgpu_ctx *c) {
     if (c->stream_w) (void) hipStreamSynchronize(c->stream_w);
     for (auto &sl : c->slot) free_slot(sl);
     if (c->h_win) (void) hipHostFree(c->h_win);
-    void *dev[] = {c->d_iq, c->d_win, c->d_adder_bitmap, c->d_bit_syndrome, c->d_group_syndrome, c->d_parity,
+    void *dev[] = {c->d_hist, c->d_hist_iq, c->d_hist_sums, c->d_iq, c->d_win, c->d_adder_bitmap, c->d_bit_syndrome, c->d_group_syndrome, c->d_parity,
                    c->d_tab_long, c->d_tab_short, c->d_uc8_folded};
     for (void *p : dev)
         if (p) (void) hipFree(p);
@@ -608,6 +616,8 @@ int mgpu_reset(mgpu_ctx *c) {
     c->eof = false;
     c->tail_src = nullptr;
     c->worker_rc = MGPU_OK;
+    c->shard_mode = 0;
+    c->shard_packets.clear();
     HIPCHK(c, hipMemsetAsync(c->d_adder_bitmap, 0, (1u << 24) / 8, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MGPU_OK;
@@ -713,6 +723,7 @@ static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job) {
     // but stream at tens of GB/s: copy the chunk's records into ordinary memory (0.1 ms for 70 k
     // records) and walk there.
     job.nlive = nlive;
+    job.stream_pos = sl.stream_pos;
     job.recs.resize(nlive + 1);
     job.recs[nlive].pos = 0xFFFFFFFFu;          // sentinel for the walk
     job.sig.resize(nlive);
@@ -895,6 +906,7 @@ static int feed_begin(mgpu_ctx *c) {
 }
 
 static int feed_end(mgpu_ctx *c) {
+    if (c->shard_mode != 0) return MGPU_OK;   // a shard pass produces no messages and no statistics here
     HIPCHK(c, hipMemcpyAsync(c->h_win, c->d_win, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream2));
     HIPCHK(c, hipStreamSynchronize(c->stream2));
     mgpu_counters &k = c->counters;
@@ -933,11 +945,22 @@ static void fetcher_main(mgpu_ctx *c) {
         HostJob &job = c->job[jidx];
         job.slot = idx;
         int rc = c->worker_rc == MGPU_OK ? fetch_slot(c, sl, job) : c->worker_rc;   // after an error just drain
+        if (rc == MGPU_OK && c->shard_mode == 2) {           // the chunk's records become a packet: header, records, signal powers
+            const uint64_t hdr[4] = {job.stream_pos, sl.n, job.nlive, 0};
+            const uint8_t *h8 = (const uint8_t *) hdr;
+            std::vector<uint8_t> &pk = c->shard_packets;
+            pk.insert(pk.end(), h8, h8 + sizeof(hdr));
+            const uint8_t *r8 = (const uint8_t *) job.recs.data();
+            pk.insert(pk.end(), r8, r8 + job.nlive * sizeof(PhaseRec));
+            const uint8_t *s8 = (const uint8_t *) job.sig.data();
+            pk.insert(pk.end(), s8, s8 + job.nlive * sizeof(unsigned long long));
+        }
         {
             std::lock_guard<std::mutex> lk(c->mu);
             if (rc != MGPU_OK && c->worker_rc == MGPU_OK) c->worker_rc = rc;
             c->queue.pop_front();            // popped only now: wait_all sees the chunk at every stage
-            if (rc == MGPU_OK) c->walk_queue.push_back(jidx); else { job.busy = false; sl.busy = false; }
+            if (rc == MGPU_OK && c->shard_mode == 0) c->walk_queue.push_back(jidx);
+            else { job.busy = false; sl.busy = false; }       // error, or a shard pass: nothing to walk here
         }
         c->cv.notify_all();
     }
@@ -1041,6 +1064,7 @@ static int feed_common(mgpu_ctx *c, const void *src, bool src_is_device, uint64_
         const int k = (int) (c->chunk_seq++ % mgpu_ctx::kSlots);
         Slot &sl = acquire_slot(c, k);
         sl.n = len;
+        sl.stream_pos = c->stream_pos + off;
         sl.have_mag = false;
         sl.given_mean_power.clear();
         ifile_grid(c, c->stream_pos + off, len, sl.buffers);
@@ -1231,6 +1255,111 @@ int mgpu_demod_mag_buf(mgpu_ctx *c, const uint16_t *data, uint32_t length, int64
         c->timing = c->acc;
     }
     return rc;
+}
+
+// ---- one capture sharded by buffer ranges over several contexts / GPUs (BASELINE config 5) ------------------
+// Buffers are independent except for the ICAO filter, and the pre-screen needs the adder addresses of the WHOLE
+// capture (a frame is only "conditional" with respect to adds that may lie in an earlier shard).  So a shard runs
+// twice: pass 1 (mode 1) sweeps it for its adder bitmap; the bitmaps are OR-ed across shards (the exchange step:
+// 2 MiB per rank); pass 2 (mode 2) runs convert, sweep and pre-screen against the global bitmap and keeps every
+// chunk's live records as a packet.  The packets of all shards, in stream order, go through mgpu_walk_packets on
+// one context: the ordered walk and the message build, exactly as for an unsharded stream.
+
+int mgpu_shard_begin(mgpu_ctx *c, uint64_t first_sample, const void *history_iq, int mode) {
+    if (!c || mode < 1 || mode > 2 || first_sample % c->cfg.buf_samples) return MGPU_E_INVAL;
+    if (first_sample && !history_iq) return MGPU_E_INVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    c->shard_mode = mode;
+    c->shard_packets.clear();
+    c->stream_pos = first_sample;
+    c->eof = false;
+    c->tail_src = nullptr;
+    if (first_sample) {
+        // the 326 magnitudes that precede the shard (sdr_ifile.c:209-213), from the 326 IQ samples before it
+        const size_t bps = c->cfg.format == MGPU_FMT_UC8 ? 2 : 4;
+        if (!c->d_hist) {
+            HIPCHK(c, hipMalloc(&c->d_hist, (2 * kTrailing + 64) * sizeof(uint16_t)));
+            HIPCHK(c, hipMalloc(&c->d_hist_iq, kTrailing * 4 + 64));
+            HIPCHK(c, hipMalloc(&c->d_hist_sums, 8 * sizeof(unsigned long long)));
+        }
+        hipStream_t s = c->stream;
+        HIPCHK(c, hipMemcpyAsync(c->d_hist_iq, history_iq, kTrailing * bps, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemsetAsync(c->d_hist_sums, 0, 8 * sizeof(unsigned long long), s));
+        ConvertParams cp{};
+        cp.iq = c->d_hist_iq; cp.mag = c->d_hist; cp.n = kTrailing; cp.buf_samples = 0x80000000u;
+        cp.uc8_folded = c->d_uc8_folded;
+        cp.sum_level = c->d_hist_sums; cp.sum_power = c->d_hist_sums + 1;
+        cp.fsum_level = (double *) (c->d_hist_sums + 2); cp.fsum_power = (double *) (c->d_hist_sums + 3);
+        launch_convert(c->cfg.format, cp, s);
+        HIPCHK(c, hipStreamSynchronize(s));
+        c->tail_src = c->d_hist + kTrailing;   // d_hist[326 + i] = magnitude of history sample i
+    }
+    return MGPU_OK;
+}
+
+int mgpu_adder_bitmap_get(mgpu_ctx *c, uint32_t *words) {
+    if (!c || !words) return MGPU_E_INVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipMemcpy(words, c->d_adder_bitmap, (1u << 24) / 8, hipMemcpyDeviceToHost));
+    return MGPU_OK;
+}
+
+int mgpu_adder_bitmap_set(mgpu_ctx *c, const uint32_t *words) {
+    if (!c || !words) return MGPU_E_INVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipMemcpy(c->d_adder_bitmap, words, (1u << 24) / 8, hipMemcpyHostToDevice));
+    return MGPU_OK;
+}
+
+int mgpu_shard_packets(mgpu_ctx *c, const void **packets, uint64_t *bytes) {
+    if (!c || !packets || !bytes) return MGPU_E_INVAL;
+    *packets = c->shard_packets.data();
+    *bytes = c->shard_packets.size();
+    return MGPU_OK;
+}
+
+int mgpu_walk_packets(mgpu_ctx *c, const void *packets, uint64_t bytes) {
+    if (!c || (!packets && bytes)) return MGPU_E_INVAL;
+    if (c->eof) return MGPU_E_EOF;
+    const uint8_t *p = (const uint8_t *) packets, *end = p + bytes;
+    HostJob &job = c->job[0];
+    while (p < end) {
+        uint64_t hdr[4];
+        if ((size_t) (end - p) < sizeof(hdr)) return MGPU_E_INVAL;
+        std::memcpy(hdr, p, sizeof(hdr));
+        p += sizeof(hdr);
+        const uint64_t pos = hdr[0], n = hdr[1], nrecs = hdr[2];
+        if (pos != c->stream_pos || n == 0 || (uint64_t) (end - p) < nrecs * (sizeof(PhaseRec) + 8)) {
+            c->err = "mgpu_walk_packets: packets must continue the stream in order";
+            return MGPU_E_INVAL;
+        }
+        job.recs.resize(nrecs + 1);
+        std::memcpy(job.recs.data(), p, nrecs * sizeof(PhaseRec));
+        job.recs[nrecs].pos = 0xFFFFFFFFu;
+        p += nrecs * sizeof(PhaseRec);
+        job.sig.resize(nrecs);
+        std::memcpy(job.sig.data(), p, nrecs * 8);
+        p += nrecs * 8;
+        ifile_grid(c, pos, n, job.buffers);
+        const uint64_t cap = nrecs + 1;
+        job.pos.resize(cap); c->w_limit.resize(cap); c->w_skip.resize(cap);
+        job.rc = ResolveCounts();
+        const int64_t wn = c->resolver.decide(job.recs.data(), nrecs, job.buffers, job.acc, job.pos.data(), c->w_skip.data(),
+                                              c->w_limit.data(), cap, job.rc);
+        if (wn < 0) return MGPU_E_OVERFLOW;
+        const size_t first = c->pending.size();
+        if (!c->pending.grow_for((size_t) wn)) return c->pending.external ? MGPU_E_OVERFLOW : MGPU_E_NOMEM;
+        Resolver::build_messages(job.recs.data(), job.sig.data(), job.buffers, job.acc.data(), (uint64_t) wn, c->pending.data() + first);
+        c->pending.n = first + (size_t) wn;
+        for (int i = 0; i < 3; ++i) c->counters.demod_accepted[i] += job.rc.accepted[i];
+        for (int i = 0; i < 5; ++i) c->counters.demod_bestPhase[i] += job.rc.best_phase[i];
+        c->counters.samples_processed += n;
+        c->counters.nbuffers += job.buffers.size();
+        c->counters.nflips = c->resolver.nflips();
+        c->stream_pos += n;
+        if (n % c->cfg.buf_samples) c->eof = true;
+    }
+    return MGPU_OK;
 }
 
 uint32_t mgpu_crc_checksum(const uint8_t *msg, int bits) { return crc_tables().checksum(msg, bits); }

@@ -1780,24 +1780,32 @@ __global__ __launch_bounds__(kBlock, MGPU_V3_PREFETCH ? 3 : 4) void k_sweep_slic
 }
 
 
-void launch_sweep_slice(const SweepParams &p, hipStream_t s) {
-    if (p.nunits == 0) return;
-    // persistent grid = the workgroups resident at once (occupancy x CUs)
-    static int resident = 0;
-    const size_t dyn = (size_t) (p.n_long + p.n_short + 4) * sizeof(uint32_t);
-    if (!resident) {
+// persistent grid of generation 3 = the workgroups resident at once (occupancy x CUs) for this much dynamic LDS
+// (the 2-bit syndrome keys of --aggressive take 20 KB: 2 workgroups per CU instead of 3)
+static unsigned sweep_slice_grid(size_t dyn) {
+    static size_t cached_dyn = ~(size_t) 0;
+    static unsigned cached = 0;
+    if (dyn != cached_dyn) {
         int per_cu = 0, dev = 0, cus = 256;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sweep_slice, kBlock, dyn) != hipSuccess || per_cu < 1) per_cu = 2;
-        resident = per_cu * cus;
-        if (resident > kSweepMaxBlocks) resident = kSweepMaxBlocks;
+        unsigned resident = (unsigned) (per_cu * cus);
+        if (resident > (unsigned) kSweepMaxBlocks) resident = kSweepMaxBlocks;
+        static unsigned env_blocks = 0;
+        static bool env_read = false;
+        if (!env_read) { env_read = true; if (const char *e = getenv("MGPU_SWEEP_BLOCKS")) env_blocks = (unsigned) atoi(e); }
+        if (env_blocks >= 1 && env_blocks < resident) resident = env_blocks;
+        cached = resident;
+        cached_dyn = dyn;
     }
-    static unsigned env_blocks = 0;
-    static bool env_read = false;
-    if (!env_read) { env_read = true; if (const char *e = getenv("MGPU_SWEEP_BLOCKS")) env_blocks = (unsigned) atoi(e); }
-    unsigned maxb = (unsigned) resident;
-    if (env_blocks >= 1 && env_blocks < maxb) maxb = env_blocks;
+    return cached;
+}
+
+void launch_sweep_slice(const SweepParams &p, hipStream_t s) {
+    if (p.nunits == 0) return;
+    const size_t dyn = (size_t) (p.n_long + p.n_short + 4) * sizeof(uint32_t);
+    const unsigned maxb = sweep_slice_grid(dyn);
     const unsigned want = (p.nunits + (kBlock / WAVE) - 1) / (kBlock / WAVE);
     const unsigned blocks = want < maxb ? want : maxb;
     hipLaunchKernelGGL(k_sweep_slice, dim3(blocks), dim3(kBlock), dyn, s, p);

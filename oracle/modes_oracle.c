@@ -547,6 +547,68 @@ static void demod_buffer(struct run *r, const uint16_t *m, uint32_t mlen, int64_
     r->st->noise_power_count += mlen;
 }
 
+
+/* demodulate2400AC, demod_2400.c:575-761, on one buffer (only when enabled with modes_oracle_set_mode_ac:
+ * readsb runs it after demodulate2400 on the same buffer, readsb.c:871-874).  Mode A/C bits are 1.45 us
+ * apart = 87 cycles of a virtual 60 MHz clock, one 2.4 MHz sample = 25 cycles. */
+static int g_mode_ac;
+void modes_oracle_set_mode_ac(int on) { g_mode_ac = on; }
+
+static void demod_buffer_ac(struct run *r, const uint16_t *m, uint32_t mlen, int64_t sampleTimestamp,
+                            int64_t sysTimestamp, double mean_level, double mean_power) {
+    double noise_stddev = sqrt(mean_power - mean_level * mean_level);                 /* :579 */
+    unsigned noise_level = (unsigned) ((mean_power + noise_stddev) * 65535 + 0.5);  /* :580 */
+    for (unsigned f1_sample = 1; f1_sample < mlen; ++f1_sample) {
+        if (!(m[f1_sample - 1] < m[f1_sample + 0])) continue;                        /* :639 rising edge */
+        if (m[f1_sample + 2] > m[f1_sample + 0] || m[f1_sample + 2] > m[f1_sample + 1]) continue;   /* :642 */
+        unsigned f1_level = (m[f1_sample + 0] + m[f1_sample + 1]) / 2;
+        if (noise_level * 2 > f1_level) continue;                                    /* :647, 6 dB above noise */
+        float f1a_power = (float) m[f1_sample] * m[f1_sample];                      /* :655-658: float arithmetic */
+        float f1b_power = (float) m[f1_sample + 1] * m[f1_sample + 1];
+        float fraction = f1b_power / (f1a_power + f1b_power);
+        unsigned f1_clock = (unsigned) (25 * (f1_sample + fraction * fraction) + 0.5);
+        unsigned f2_clock = f1_clock + (87 * 14);                                    /* :662, F2 is 14 bit periods later */
+        unsigned f2_sample = f2_clock / 25;
+        if (!(m[f2_sample - 1] < m[f2_sample + 0])) continue;                        /* :666-677: same tests on F2 */
+        if (m[f2_sample + 2] > m[f2_sample + 0] || m[f2_sample + 2] > m[f2_sample + 1]) continue;
+        unsigned f2_level = (m[f2_sample + 0] + m[f2_sample + 1]) / 2;
+        if (noise_level * 2 > f2_level) continue;
+        unsigned f1f2_level = (f1_level > f2_level ? f1_level : f2_level);
+        float midpoint = sqrtf(noise_level * f1f2_level);                            /* :683 (unsigned product, then float) */
+        unsigned signal_threshold = (unsigned) (midpoint * M_SQRT2 + 0.5);           /* +3 dB */
+        unsigned noise_threshold = (unsigned) (midpoint / M_SQRT2 + 0.5);            /* -3 dB */
+        unsigned uncertain_bits = 0, noisy_bits = 0, bits = 0, bit, clock;
+        for (bit = 0, clock = f1_clock; bit < 20; ++bit, clock += 87) {              /* :692-713 */
+            unsigned sample = clock / 25;
+            bits <<= 1; noisy_bits <<= 1; uncertain_bits <<= 1;
+            if (m[sample + 2] >= signal_threshold) noisy_bits |= 1;
+            if (m[sample + 0] >= signal_threshold || m[sample + 1] >= signal_threshold) bits |= 1;
+            else if (m[sample + 0] > noise_threshold && m[sample + 1] > noise_threshold) uncertain_bits |= 1;
+        }
+        if ((bits & 0x80020) != 0x80020) continue;                                   /* :716 framing bits on */
+        if ((bits & 0x0101B) != 0) continue;                                         /* :721 quiet bits off */
+        if (noisy_bits || uncertain_bits) continue;                                  /* :725 */
+        unsigned modeac =                                                            /* :731-744 */
+                ((bits & 0x40000) ? 0x0010 : 0) | ((bits & 0x20000) ? 0x1000 : 0) | ((bits & 0x10000) ? 0x0020 : 0) |
+                ((bits & 0x08000) ? 0x2000 : 0) | ((bits & 0x04000) ? 0x0040 : 0) | ((bits & 0x02000) ? 0x4000 : 0) |
+                ((bits & 0x00800) ? 0x0100 : 0) | ((bits & 0x00400) ? 0x0001 : 0) | ((bits & 0x00200) ? 0x0200 : 0) |
+                ((bits & 0x00100) ? 0x0002 : 0) | ((bits & 0x00080) ? 0x0400 : 0) | ((bits & 0x00040) ? 0x0004 : 0) |
+                ((bits & 0x00004) ? 0x0080 : 0);
+        struct oracle_msg o;
+        memset(&o, 0, sizeof(o));
+        o.timestamp = sampleTimestamp + f2_clock / 5;                                /* :755, 60 MHz -> 12 MHz, at F2 */
+        o.sys_rel_ms = sysTimestamp + (o.timestamp - sampleTimestamp) / 12000 - ORACLE_STARTUP_MS;   /* :758 */
+        o.msgtype = 77; o.msgbits = 16;                                              /* decodeModeAMessage, mode_ac.c:165-200 */
+        o.msg[0] = o.raw[0] = (uint8_t) (modeac >> 8);
+        o.msg[1] = o.raw[1] = (uint8_t) modeac;
+        o.addr = modeac & 0xFF7F;                                                    /* low 24 bits of (ModeA & 0xFF7F) | MODES_NON_ICAO_ADDRESS */
+        if (r->nout == r->cap) { r->cap = r->cap ? r->cap * 2 : 65536; r->out = realloc(r->out, r->cap * sizeof(*r->out)); }
+        r->out[r->nout++] = o;
+        f1_sample += (20 * 87 / 25);                                                 /* :765 */
+        r->st->demod_modeac++;
+    }
+}
+
 static double now_s(void) {
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -593,6 +655,7 @@ int modes_oracle_run(const struct modes_oracle_cfg *cfg, const uint8_t *iq, uint
         if (mag_dump) memcpy(mag_dump + TRAILING + sampleCounter, cur + TRAILING, slen * sizeof(uint16_t));
         sampleCounter += slen;
         demod_buffer(&r, cur, slen, sampleTimestamp, sysTimestamp, mean_power);
+        if (g_mode_ac) demod_buffer_ac(&r, cur, slen, sampleTimestamp, sysTimestamp, mean_level, mean_power);
         double t2 = now_s();
         st->t_convert_s += t1 - t0;
         st->t_demod_s += t2 - t1;

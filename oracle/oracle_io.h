@@ -51,6 +51,7 @@ struct oracle_stats {
     double   peak_signal_power;
     double   t_convert_s;    /* CLOCK_MONOTONIC around the converter calls */
     double   t_demod_s;      /* CLOCK_MONOTONIC around demodulate2400() calls */
+    uint64_t demod_modeac;   /* Mode A/C replies accepted by demodulate2400AC (stats.h:72), when enabled */
 };
 
 #endif

@@ -82,6 +82,9 @@ static double now_s(void) {
     return ts.tv_sec + ts.tv_nsec * 1e-9;
 }
 
+static int g_mode_ac;   /* --modeac: demodulate2400AC after demodulate2400 on every buffer (readsb.c:871-874) */
+void ref_set_mode_ac(int on) { g_mode_ac = on; }
+
 static struct converter_state *g_cstate;
 static iq_convert_fn g_conv;
 static int g_configured;
@@ -183,6 +186,7 @@ int ref_demod_run(int format, int nfix, int fixdf, int thr,
         sampleCounter += slen;
 
         demodulate2400(outbuf);
+        if (g_mode_ac) demodulate2400AC(outbuf);
         double t2 = now_s();
         st->t_convert_s += t1 - t0;
         st->t_demod_s += t2 - t1;
@@ -212,6 +216,7 @@ int ref_demod_run(int format, int nfix, int fixdf, int thr,
     st->signal_power_sum = s->signal_power_sum;
     st->noise_power_sum = s->noise_power_sum;
     st->peak_signal_power = s->peak_signal_power;
+    st->demod_modeac = s->demod_modeac;
     *out = g_out; *nout = g_nout;
     for (int i = 0; i < 2; i++) free(bufs[i].data);
     return 0;
@@ -261,6 +266,7 @@ int main(int argc, char **argv) {
     uint64_t n = size / (format == ORACLE_FMT_UC8 ? 2 : 4);
     struct oracle_msg *out; uint64_t nout; struct oracle_stats st;
     uint16_t *mag = argc > 8 ? malloc((n + 326) * sizeof(uint16_t)) : NULL;
+    if (getenv("ORACLE_MODE_AC")) ref_set_mode_ac(1);
     if (ref_demod_run(format, nfix, fixdf, thr, iq, n, &out, &nout, &st, mag, NULL, NULL) < 0)
         return 1;
     FILE *f = fopen(argv[6], "wb");

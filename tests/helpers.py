@@ -29,7 +29,7 @@ ORACLE_STATS = np.dtype([
     ("strong_signal_count", "<u8"), ("signal_power_count", "<u8"), ("noise_power_count", "<u8"),
     ("samples_processed", "<u8"), ("samples_lost", "<u8"), ("nbuffers", "<u8"), ("nflips", "<u8"),
     ("signal_power_sum", "<f8"), ("noise_power_sum", "<f8"), ("peak_signal_power", "<f8"),
-    ("t_convert_s", "<f8"), ("t_demod_s", "<f8"),
+    ("t_convert_s", "<f8"), ("t_demod_s", "<f8"), ("demod_modeac", "<u8"),
 ])
 COUNTER_FIELDS = ["demod_preambles", "demod_rejected_bad", "demod_rejected_unknown_icao", "demod_accepted",
                   "demod_preamblePhase", "demod_bestPhase", "strong_signal_count", "signal_power_count",
@@ -88,9 +88,10 @@ def oracle_lib():
     return _oracle
 
 
-def oracle_run(iq, fmt=0, nfix=1, fixdf=1, thr=58, want_mag=False):
+def oracle_run(iq, fmt=0, nfix=1, fixdf=1, thr=58, want_mag=False, mode_ac=0):
     """Our CPU restatement (oracle/modes_oracle.c) on an in-memory capture."""
     lib = oracle_lib()
+    lib.modes_oracle_set_mode_ac(int(mode_ac))
     iq = np.ascontiguousarray(iq).view(np.uint8).reshape(-1)
     n = iq.size // FMT_BYTES[fmt]
     cfg = OracleCfg(fmt, nfix, fixdf, thr)
@@ -120,14 +121,19 @@ def have_ref():
     return os.path.exists(REF_BIN)
 
 
-def ref_run(iq, fmt=0, nfix=1, fixdf=1, thr=58, want_mag=False):
+def ref_run(iq, fmt=0, nfix=1, fixdf=1, thr=58, want_mag=False, mode_ac=0):
     """The reference's own objects (oracle/_ref/ref_demod), one process per run."""
     iq = np.ascontiguousarray(iq).view(np.uint8).reshape(-1)
     with tempfile.TemporaryDirectory() as d:
         fin, fm, fs, fg = (os.path.join(d, x) for x in ("in.iq", "out.msgs", "out.stats", "out.mag"))
         iq.tofile(fin)
         cmd = [REF_BIN, FMT_NAMES[fmt], str(nfix), str(fixdf), str(thr), fin, fm, fs] + ([fg] if want_mag else [])
-        subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+        env = dict(os.environ)
+        if mode_ac:
+            env["ORACLE_MODE_AC"] = "1"
+        else:
+            env.pop("ORACLE_MODE_AC", None)
+        subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL, env=env)
         msgs = np.fromfile(fm, dtype=ORACLE_MSG)
         st = np.fromfile(fs, dtype=ORACLE_STATS)[0]
         if want_mag:

@@ -42,7 +42,7 @@ struct synth_cfg {
     int format;          /* SYNTH_FMT_* */
     double msgs_per_sec; /* mean frame rate */
     int naircraft;       /* ICAO pool size */
-    int dense;           /* 1: DF17-only bursts (config 5: overlapping 112-bit frames) */
+    int dense;           /* bit 0: DF17-only bursts (config 5: overlapping 112-bit frames); bit 1: add Mode A/C replies */
     double noise_lsb;    /* uniform noise amplitude, +-noise_lsb LSB of UC8 */
 };
 
@@ -93,8 +93,8 @@ static void make_frame(const struct synth_cfg *cfg, uint64_t *rng, int64_t block
     uint32_t kind = irand(rng, 100);
     uint8_t *m = f->msg;
     memset(m, 0, 14);
-    if (cfg->dense) kind = 0;
-    if (kind < 70 && silent && !cfg->dense) kind = 70 + irand(rng, 30); /* replies only */
+    if (cfg->dense & 1) kind = 0;
+    if (kind < 70 && silent && !(cfg->dense & 1)) kind = 70 + irand(rng, 30); /* replies only */
     if (kind >= 70 && irand(rng, 100) < 3) icao = 0xA00000 + irand(rng, 50); /* never squitters */
     if (kind < 57) {            /* DF17 (55 %) / DF18 (2 %) */
         m[0] = (kind < 55 ? (17 << 3) : (18 << 3)) | (kind < 55 ? 5 : irand(rng, 7));
@@ -151,18 +151,54 @@ static int block_frames(const struct synth_cfg *cfg, int64_t block, struct frame
     return n;
 }
 
-static inline void add_pulse(float *accI, float *accQ, int64_t s_lo, int64_t s_hi, int64_t p, double aI, double aQ) {
-    /* pulse occupies ticks [p, p+6); sample s covers ticks [5s, 5s+5) */
-    int64_t s0 = p / 5, s1 = (p + 5) / 5;
+static inline void add_pulse_w(float *accI, float *accQ, int64_t s_lo, int64_t s_hi, int64_t p, int width, double aI, double aQ) {
+    /* pulse occupies ticks [p, p+width); sample s covers ticks [5s, 5s+5) */
+    int64_t s0 = p / 5, s1 = (p + width - 1) / 5;
     for (int64_t s = s0; s <= s1; s++) {
         if (s < s_lo || s >= s_hi) continue;
         int64_t lo = s * 5 > p ? s * 5 : p;
-        int64_t hi = s * 5 + 5 < p + 6 ? s * 5 + 5 : p + 6;
+        int64_t hi = s * 5 + 5 < p + width ? s * 5 + 5 : p + width;
         if (hi <= lo) continue;
         float w = (float) (hi - lo) * 0.2f;
         accI[s - s_lo] += (float) aI * w;
         accQ[s - s_lo] += (float) aQ * w;
     }
+}
+
+static inline void add_pulse(float *accI, float *accQ, int64_t s_lo, int64_t s_hi, int64_t p, double aI, double aQ) {
+    add_pulse_w(accI, accQ, s_lo, s_hi, p, 6, aI, aQ);
+}
+
+/* Mode A/C replies (bit 1 of `dense`): 0.45 us pulses on a 1.45 us raster — F1, C1 A1 C2 A2 C4 A4, X, B1 D1 B2 D2 B4 D4,
+ * F2, two empty slots, SPI (demod_2400.c:588-616) — from their own random stream, so that the Mode S traffic of a
+ * seed is the same with and without them.  On the 12 MHz tick grid: 5-tick pulses at round(17.4 k). */
+struct acreply { int64_t t0; double aI, aQ; uint32_t bits; };
+
+static int block_acreplies(const struct synth_cfg *cfg, int64_t block, struct acreply **out) {
+    if (block < 0 || !(cfg->dense & 2)) { *out = NULL; return 0; }
+    uint64_t s = cfg->seed ^ (0x9E3779B97F4A7C15ULL * (uint64_t) (block + 7));
+    uint64_t rng = splitmix64(&s) | 1;
+    int n = (int) (cfg->msgs_per_sec * (0.9 + 0.2 * urand(&rng)) + 0.5);      /* as many replies as Mode S frames */
+    struct acreply *r = malloc(sizeof(*r) * (n ? n : 1));
+    for (int i = 0; i < n; i++) {
+        r[i].t0 = block * (int64_t) SYNTH_BLOCK * 5 + (int64_t) (urand(&rng) * SYNTH_BLOCK * 5);
+        double amp = 50.0 + urand(&rng) * 70.0, ph = urand(&rng) * 6.283185307179586;
+        r[i].aI = amp * cos(ph); r[i].aQ = amp * sin(ph);
+        uint32_t code = irand(&rng, 4096);                 /* C1 A1 C2 A2 C4 A4 | B1 D1 B2 D2 B4 D4 */
+        uint32_t bits = (1u << 19) | (1u << 5);            /* F1 = bit 0 (MSB of 20), F2 = bit 14 */
+        bits |= ((code >> 6) & 0x3f) << 13;                /* slots 1..6 */
+        bits |= (code & 0x3f) << 6;                        /* slots 8..13 */
+        if (irand(&rng, 100) < 5) bits |= 1u << 2;         /* SPI, slot 17 */
+        r[i].bits = bits;
+    }
+    *out = r;
+    return n;
+}
+
+static void render_acreply(const struct acreply *r, float *accI, float *accQ, int64_t s_lo, int64_t s_hi) {
+    if ((r->t0 + 20 * 18) / 5 + 2 < s_lo || r->t0 / 5 > s_hi) return;
+    for (int k = 0; k < 20; k++)
+        if ((r->bits >> (19 - k)) & 1) add_pulse_w(accI, accQ, s_lo, s_hi, r->t0 + (int64_t) (17.4 * k + 0.5), 5, r->aI, r->aQ);
 }
 
 static void render_frame(const struct frame *f, float *accI, float *accQ, int64_t s_lo, int64_t s_hi) {
@@ -190,6 +226,9 @@ static void gen_range(const struct synth_cfg *cfg, uint64_t first, uint64_t coun
             struct frame *fr; int n = block_frames(cfg, bb, &fr);
             for (int i = 0; i < n; i++) render_frame(&fr[i], accI, accQ, (int64_t) b_lo, (int64_t) b_hi);
             free(fr);
+            struct acreply *ar; int na = block_acreplies(cfg, bb, &ar);
+            for (int i = 0; i < na; i++) render_acreply(&ar[i], accI, accQ, (int64_t) b_lo, (int64_t) b_hi);
+            free(ar);
         }
         /* noise: per-block stream, skipped ahead to `lo` so sub-ranges are reproducible */
         uint64_t s = cfg->seed ^ (0xA0761D6478BD642FULL * (uint64_t) (b + 1));

@@ -49,7 +49,7 @@ struct mgpu_config {
     int32_t  preamble_threshold;  /* Modes.preambleThreshold, default 58 (readsb.c:2268) */
     uint32_t buf_samples;         /* Modes.sdr_buf_samples, default 131072 (readsb.c:2212); multiple of 4096 */
     uint32_t trailing_samples;    /* Modes.trailing_samples = 326 (readsb.c:288); must be 326 */
-    uint32_t reserved0;
+    uint32_t mode_ac;             /* Modes.mode_ac (--modeac): also run demodulate2400AC on every buffer, readsb.c:871-874 */
     uint64_t max_samples;         /* largest number of new samples one mgpu_feed_* call may carry */
     int64_t  startup_time_ms;     /* Modes.startup_time: wall clock (ms) the 12 MHz sample clock is anchored to */
     uint64_t record_pool_records; /* device pool for per-phase candidate records; 0 = max_samples/16 + 65536 */
@@ -99,6 +99,7 @@ struct mgpu_counters {
     double   signal_power_sum;
     double   noise_power_sum;
     double   peak_signal_power;
+    uint64_t demod_modeac;       /* Mode A/C replies accepted (stats.h:72), only with cfg.mode_ac */
 };
 
 /* Device time of the last feed, from HIP events on the context's stream (ms). */

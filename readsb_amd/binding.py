@@ -26,7 +26,7 @@ class Config(C.Structure):
     _fields_ = [
         ("device", C.c_int32), ("format", C.c_int32), ("nfix_crc", C.c_int32), ("fixDF", C.c_int32),
         ("preamble_threshold", C.c_int32), ("buf_samples", C.c_uint32), ("trailing_samples", C.c_uint32),
-        ("reserved0", C.c_uint32), ("max_samples", C.c_uint64), ("startup_time_ms", C.c_int64),
+        ("mode_ac", C.c_uint32), ("max_samples", C.c_uint64), ("startup_time_ms", C.c_int64),
         ("record_pool_records", C.c_uint64), ("max_messages", C.c_uint64),
     ]
 
@@ -39,7 +39,7 @@ class Counters(C.Structure):
         ("strong_signal_count", C.c_uint64), ("signal_power_count", C.c_uint64),
         ("noise_power_count", C.c_uint64), ("samples_processed", C.c_uint64), ("samples_lost", C.c_uint64),
         ("nbuffers", C.c_uint64), ("nflips", C.c_uint64), ("signal_power_sum", C.c_double),
-        ("noise_power_sum", C.c_double), ("peak_signal_power", C.c_double),
+        ("noise_power_sum", C.c_double), ("peak_signal_power", C.c_double), ("demod_modeac", C.c_uint64),
     ]
 
     def as_dict(self):
@@ -127,13 +127,14 @@ class Demodulator:
     """One SDR stream on one GPU (struct mgpu_ctx)."""
 
     def __init__(self, fmt=FMT_UC8, nfix_crc=1, fix_df=1, preamble_threshold=58, max_samples=64 * 131072,
-                 device=0, startup_time_ms=0, record_pool_records=0, max_messages=0, buf_samples=131072):
+                 device=0, startup_time_ms=0, record_pool_records=0, max_messages=0, buf_samples=131072, mode_ac=0):
         self.lib = load_library()
         cfg = Config()
         self.lib.mgpu_config_defaults(C.byref(cfg))
         cfg.device, cfg.format, cfg.nfix_crc, cfg.fixDF = device, fmt, nfix_crc, fix_df
         cfg.preamble_threshold, cfg.max_samples, cfg.startup_time_ms = preamble_threshold, max_samples, startup_time_ms
         cfg.record_pool_records, cfg.max_messages, cfg.buf_samples = record_pool_records, max_messages, buf_samples
+        cfg.mode_ac = 1 if mode_ac else 0
         self.cfg = cfg
         self.fmt = fmt
         self._collect_buf = None

@@ -147,6 +147,8 @@ struct Slot {
     uint32_t *h_msg_pos = nullptr, *h_msg_limit = nullptr;
     uint16_t *h_msg_len = nullptr, *h_msg_skip = nullptr;
     hipEvent_t ev[5] = {};
+    uint32_t *d_ac_noise = nullptr;       // Mode A/C: per-buffer noise level
+    AcCand *h_ac = nullptr;               // ... candidates, written by k_modeac straight into pinned host memory
     hipEvent_t ev_h2d = nullptr;          // the chunk's IQ samples have arrived in HBM (copy stream)
     hipEvent_t ev_scan = nullptr;         // pre-screen offsets are final (main stream) -> the write pass may start (second stream)
     // the job
@@ -200,6 +202,7 @@ struct HostJob {
     std::vector<double> given_mean_power;
     std::vector<unsigned long long> sums;    // per-buffer level / power sums of the converter
     std::vector<double> fsums;
+    std::vector<AcCand> ac;                  // Mode A/C candidates of the chunk (cfg.mode_ac)
     ResolveCounts rc;
     uint64_t nlive = 0;
     uint32_t nmsg = 0;                       // accepted frames: acc[0..nmsg), pos[0..nmsg)
@@ -215,7 +218,7 @@ struct mgpu_ctx {
 
     uint64_t cap_samples = 0;      // per feed call (cfg.max_samples)
     uint64_t chunk_samples = 0;    // per pipeline slot
-    uint64_t cap_units = 0, cap_buffers = 0, cap_pool = 0, cap_msgs = 0;   // per slot
+    uint64_t cap_units = 0, cap_buffers = 0, cap_pool = 0, cap_msgs = 0, cap_ac = 0;   // per slot
 
     uint8_t *d_iq = nullptr;
     const uint16_t *tail_src = nullptr;   // device: the 326 magnitudes before the next chunk (end of the previous chunk's d_mag)
@@ -253,6 +256,7 @@ struct mgpu_ctx {
     Team walk_team, build_team;                               // helpers of the walker / builder stage (MGPU_WALK_THREADS, MGPU_BUILD_THREADS)
     int walk_threads = 4, build_threads = 3;
     std::vector<SegmentWalk> segs;                            // the walker's buffer ranges
+    std::vector<mgpu_msg> b_stage;                            // builder scratch (Mode A/C merge)
     // time-sharded capture (config 5, mgpu_shard_*): 0 = normal, 1 = sweep for the adder bitmap only, 2 = keep the
     // pre-screened records of every chunk as packets instead of walking them
     int shard_mode = 0;
@@ -447,6 +451,10 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
     HIPCHK(c, hipHostMalloc(&sl.h_msg_limit, c->cap_msgs * sizeof(uint32_t)));
     HIPCHK(c, hipHostMalloc(&sl.h_msg_len, c->cap_msgs * sizeof(uint16_t)));
     HIPCHK(c, hipHostMalloc(&sl.h_msg_skip, c->cap_msgs * sizeof(uint16_t)));
+    if (c->cfg.mode_ac) {
+        HIPCHK(c, hipMalloc(&sl.d_ac_noise, (c->cap_buffers + 1) * sizeof(uint32_t)));
+        HIPCHK(c, hipHostMalloc(&sl.h_ac, c->cap_ac * sizeof(AcCand)));
+    }
     for (auto &e : sl.ev) HIPCHK(c, hipEventCreate(&e));
     return MGPU_OK;
 }
@@ -460,6 +468,8 @@ static void free_slot(Slot &sl) {
         if (p) (void) hipFree(p);
     if (sl.ev_window) (void) hipEventDestroy(sl.ev_window);
     if (sl.ev_scan) (void) hipEventDestroy(sl.ev_scan);
+    if (sl.d_ac_noise) (void) hipFree(sl.d_ac_noise);
+    if (sl.h_ac) (void) hipHostFree(sl.h_ac);
     if (sl.ev_h2d) (void) hipEventDestroy(sl.ev_h2d);
     void *host[] = {sl.h_live, sl.h_live_sig, sl.h_scratch, sl.h_win, sl.h_sig, sl.h_msg_pos,
                     sl.h_msg_limit, sl.h_msg_len, sl.h_msg_skip};
@@ -489,6 +499,7 @@ static int alloc_all(mgpu_ctx *c) {
     c->cap_pool = pool + reserve;
     if (c->cap_pool > 0xFFFFFFF0ull) c->cap_pool = 0xFFFFFFF0ull;
     c->cap_msgs = cfg.max_messages ? cfg.max_messages : cs / 64 + 65536;
+    c->cap_ac = cs / 256 + 65536;          // Mode A/C candidates per chunk (a reply lasts 49 samples)
     const size_t bps = cfg.format == MGPU_FMT_UC8 ? 2 : 4;
 
     HIPCHK(c, hipMalloc(&c->d_iq, n * bps + 64));
@@ -649,6 +660,9 @@ static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
     } else {
         c->tail_src = sl.d_mag + n;
     }
+    if (cfg.mode_ac && !sl.have_mag)       // Mode A/C candidates (needs the converter's per-buffer sums); a few us, streaming
+        launch_modeac(sl.d_mag, n, cfg.buf_samples, cfg.format, sl.d_sum_level, sl.d_sum_power, sl.d_fsum_level, sl.d_fsum_power,
+                      sl.d_ac_noise, sl.h_ac, (uint32_t) c->cap_ac, sl.d_counters, s);
     HIPCHK(c, hipEventRecord(sl.ev[1], s));
     SweepParams sp{};
     sp.mag = sl.d_mag; sp.n = n; sp.thr = cfg.preamble_threshold;
@@ -729,6 +743,12 @@ static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job) {
     job.sig.resize(nlive);
     std::memcpy(job.recs.data(), sl.h_live, nlive * sizeof(PhaseRec));
     std::memcpy(job.sig.data(), sl.h_live_sig, nlive * sizeof(unsigned long long));
+    job.ac.clear();
+    if (c->cfg.mode_ac && !sl.have_mag) {
+        const uint64_t nac = sl.h_counters[CNT_MODEAC];
+        if (nac > c->cap_ac) { c->err = "Mode A/C candidate buffer overflow"; return MGPU_E_OVERFLOW; }
+        job.ac.assign(sl.h_ac, sl.h_ac + nac);
+    }
     job.buffers = sl.buffers;
     job.given_mean_power = sl.given_mean_power;
     job.sums.assign(sl.h_sums, sl.h_sums + 2 * c->cap_buffers);
@@ -840,21 +860,65 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
     const double t0 = wall_ms();
     const uint32_t nmsg = job.nmsg;
     const uint32_t nbuf = (uint32_t) job.buffers.size();
+    // Mode A/C (cfg.mode_ac): candidates in position order; an accepted reply hides the next 69 positions of its
+    // buffer (f1_sample += 20 * 87 / 25, then the loop's ++, demod_2400.c:765)
+    std::vector<AcCand> &ac = job.ac;
+    std::vector<uint32_t> ac_buf;                            // buffer index of every accepted reply
+    if (!ac.empty()) {
+        std::sort(ac.begin(), ac.end(), [](const AcCand &x, const AcCand &y) { return x.pos < y.pos; });
+        size_t keep = 0, i = 0;
+        for (uint32_t b = 0; b < nbuf; ++b) {
+            const uint64_t end = (uint64_t) job.buffers[b].first + job.buffers[b].length;
+            uint64_t next_ok = 0;
+            for (; i < ac.size() && ac[i].pos < end; ++i) {
+                if (ac[i].pos < next_ok) continue;
+                next_ok = (uint64_t) ac[i].pos + 20 * 87 / 25 + 1;
+                ac[keep++] = ac[i];
+                ac_buf.push_back(b);
+            }
+        }
+        ac.resize(keep);
+    }
+    const uint32_t nac = (uint32_t) ac.size();
     const size_t first_msg = c->pending.size();
-    if (!c->pending.grow_for(nmsg)) {
+    if (!c->pending.grow_for((size_t) nmsg + nac)) {
         c->err = c->pending.external ? "the caller's message buffer (mgpu_set_message_buffer) is full" : "out of memory for the decoded messages";
         return c->pending.external ? MGPU_E_OVERFLOW : MGPU_E_NOMEM;
     }
     const double t1 = wall_ms();
+    mgpu_msg *out = c->pending.data() + first_msg;
+    std::vector<mgpu_msg> &stage = c->b_stage;               // with Mode A/C the Mode S messages are built here and merged per buffer
+    if (nac) { stage.resize(nmsg); }
     {
         const int parts = nmsg >= 4096 ? c->build_threads : 1;
-        mgpu_msg *out = c->pending.data() + first_msg;
+        mgpu_msg *dst = nac ? stage.data() : out;
         c->build_team.run(parts, [&](int i) {
             const uint64_t lo = (uint64_t) nmsg * i / parts, hi = (uint64_t) nmsg * (i + 1) / parts;
-            Resolver::build_messages(job.recs.data(), job.sig.data(), job.buffers, job.acc.data() + lo, hi - lo, out + lo);
+            Resolver::build_messages(job.recs.data(), job.sig.data(), job.buffers, job.acc.data() + lo, hi - lo, dst + lo);
         });
     }
-    c->pending.n = first_msg + nmsg;
+    if (nac) {   // netUseMessage order: per buffer the Mode S messages of demodulate2400, then the replies of demodulate2400AC
+        size_t si = 0, ai = 0, o = 0;
+        for (uint32_t b = 0; b < nbuf; ++b) {
+            const BufferClock &bc = job.buffers[b];
+            while (si < nmsg && job.acc[si].buffer == b) out[o++] = stage[si++];
+            for (; ai < nac && ac_buf[ai] == b; ++ai) {
+                mgpu_msg m;
+                std::memset(&m, 0, sizeof(m));
+                m.timestamp = bc.sampleTimestamp + ac[ai].f2_clock / 5;                               // :755, 60 MHz -> 12 MHz, at F2
+                m.sysTimestamp = bc.sysTimestamp + (m.timestamp - bc.sampleTimestamp) / 12000;        // :758
+                m.sig_len = 1;                                                                        // signalLevel stays 0
+                m.msgtype = 77;                                                                       // DFTYPE_MODEAC, decodeModeAMessage (mode_ac.c:165-200)
+                m.msgbits = 16;
+                m.msg[0] = m.raw[0] = (uint8_t) (ac[ai].modeac >> 8);
+                m.msg[1] = m.raw[1] = (uint8_t) ac[ai].modeac;
+                m.addr = ac[ai].modeac & 0xFF7Fu;                                                     // low 24 bits of (ModeA & 0xFF7F) | MODES_NON_ICAO_ADDRESS
+                out[o++] = m;
+            }
+        }
+        c->counters.demod_modeac += nac;
+    }
+    c->pending.n = first_msg + nmsg + nac;
     const double t2 = wall_ms();
 
     mgpu_counters &k = c->counters;

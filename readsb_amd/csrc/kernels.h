@@ -66,6 +66,7 @@ enum {
     CNT_CLASS_COND = 8,      // candidates whose records are all conditional (REC_COND)
     CNT_CLASS_UNCOND = 9,    // candidates with >= 1 unconditional record
     CNT_DEBUG0 = 16,         // .. 31: cycle counters of k_sweep_slice's stages (thread 0 of every workgroup)
+    CNT_MODEAC = 30,         // Mode A/C candidates written by k_modeac
     CNT_LIVE_TOTAL = 31,     // records surviving the pre-screen (written by k_scan_units)
     CNT_NUM = 32,
 };
@@ -138,6 +139,17 @@ struct PostSweepParams {
     bool keep_masks;                      // generation 3 only (segments of <= 64 records)
 };
 int launch_prescreen(const PostSweepParams &q, hipStream_t s, hipStream_t s_write, hipEvent_t ev_scan);
+// ---- Mode A/C (demodulate2400AC, demod_2400.c:575-761), only when mgpu_config.mode_ac is set ----
+// A position that passes every test of the reference's loop body: the reply is accepted unless an earlier accepted
+// reply of the same buffer hides it (f1_sample += 69, :765) — decided in order on the host.
+struct AcCand {
+    uint32_t pos;        // scan position D in the chunk (f1_sample = D - buffer start)
+    uint32_t f2_clock;   // 60 MHz cycles from the buffer start to the F2 pulse: timestamp = sampleTimestamp + f2_clock / 5 (:755)
+    uint32_t modeac;     // 00 A4 A2 A1  00 B4 B2 B1  SPI C4 C2 C1  00 D4 D2 D1 (:731-744)
+};
+void launch_modeac(const uint16_t *mag, uint64_t n, uint32_t buf_samples, int format, const unsigned long long *sum_level,
+                   const unsigned long long *sum_power, const double *fsum_level, const double *fsum_power,
+                   uint32_t *noise_level, AcCand *out, uint32_t cap, unsigned long long *counters, hipStream_t s);
 // signal power of accepted messages: sum of mag^2 over d_mag[pos+19 .. pos+19+len)
 void launch_signal_power(const uint16_t *mag, const uint32_t *pos, const uint16_t *len, uint32_t nmsg,
                          unsigned long long *out, hipStream_t s);

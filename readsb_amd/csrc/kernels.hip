@@ -2376,6 +2376,110 @@ int launch_prescreen(const PostSweepParams &q, hipStream_t s, hipStream_t s_writ
 }
 
 // =============================================================================================
+// Mode A/C replies (demodulate2400AC, demod_2400.c:575-761): F1/F2 framing pulses 20.3 us apart,
+// 20 bit slots of 1.45 us = 87 cycles of a virtual 60 MHz clock; one 2.4 MHz sample = 25 cycles.
+// Position-parallel: every position that passes all of the loop body's tests becomes a candidate;
+// the reference's skip over an accepted reply (:765) is applied in order on the host.
+// =============================================================================================
+
+// per buffer: noise_level = (mean_power + sqrt(mean_power - mean_level^2)) * 65535 + 0.5 (:579-580), from the
+// converter's sums with the converter's own divisions (convert.c:101-107)
+__global__ __launch_bounds__(kBlock) void k_modeac_noise(const unsigned long long *sum_level, const unsigned long long *sum_power,
+                                                         const double *fsum_level, const double *fsum_power, int format,
+                                                         uint64_t n, uint32_t B, uint32_t nbuf, uint32_t *noise_level) {
+#pragma clang fp contract(off)
+    const uint32_t b = blockIdx.x * kBlock + threadIdx.x;
+    if (b >= nbuf) return;
+    const uint64_t first = (uint64_t) b * B;
+    const double len = (double) (uint32_t) (n - first < B ? n - first : B);
+    double ml, mp;
+    if (format == 0) { ml = (double) sum_level[b] / 65536.0 / len; mp = (double) sum_power[b] / 65535.0 / 65535.0 / len; }
+    else { ml = fsum_level[b] / len; mp = fsum_power[b] / len; }
+    const double sd = __dsqrt_rn(mp - ml * ml);
+    noise_level[b] = (uint32_t) ((mp + sd) * 65535 + 0.5);
+}
+
+// everything after the cheap F1 edge / level tests, for the rare lanes that get here
+__device__ __noinline__ void modeac_try(const uint16_t *m /* the buffer's data[] */, uint32_t f1_sample, uint32_t m0, uint32_t m1,
+                                        uint32_t f1_level, uint32_t noise_level, uint32_t pos, AcCand *out, uint32_t cap,
+                                        unsigned long long *counters) {
+#pragma clang fp contract(off)
+    // initial clock phase from the power that ended up in the second sample (:655-658): float arithmetic, then + 0.5 in double
+    const float f1a_power = (float) m0 * (float) m0;
+    const float f1b_power = (float) m1 * (float) m1;
+    const float fraction = __fdiv_rn(f1b_power, f1a_power + f1b_power);
+    const float at = (float) f1_sample + fraction * fraction;
+    const uint32_t f1_clock = (uint32_t) ((double) (25.0f * at) + 0.5);
+    const uint32_t f2_clock = f1_clock + 87 * 14;
+    const uint32_t f2_sample = f2_clock / 25;
+    if (!(m[f2_sample - 1] < m[f2_sample + 0])) return;                                       // :666
+    if (m[f2_sample + 2] > m[f2_sample + 0] || m[f2_sample + 2] > m[f2_sample + 1]) return;  // :669
+    const uint32_t f2_level = ((uint32_t) m[f2_sample + 0] + m[f2_sample + 1]) / 2;
+    if (noise_level * 2 > f2_level) return;
+    const uint32_t f1f2_level = f1_level > f2_level ? f1_level : f2_level;
+    const float midpoint = __fsqrt_rn((float) (noise_level * f1f2_level));                      // :683: unsigned product, then float
+    const uint32_t signal_threshold = (uint32_t) ((double) midpoint * 1.41421356237309504880 + 0.5);        // +3 dB
+    const uint32_t noise_threshold = (uint32_t) (__ddiv_rn((double) midpoint, 1.41421356237309504880) + 0.5);   // -3 dB
+    uint32_t bits = 0, bad = 0, clock = f1_clock;
+    for (int bit = 0; bit < 20; ++bit, clock += 87) {                                          // :692-713
+        const uint32_t sample = clock / 25;
+        const uint32_t a = m[sample + 0], b = m[sample + 1], c = m[sample + 2];
+        bits <<= 1;
+        if (c >= signal_threshold) bad = 1;                                                    // noisy quiet period
+        if (a >= signal_threshold || b >= signal_threshold) bits |= 1;
+        else if (a > noise_threshold && b > noise_threshold) bad = 1;                          // uncertain
+    }
+    if ((bits & 0x80020u) != 0x80020u || (bits & 0x0101Bu) != 0 || bad) return;               // :716-727
+    const uint32_t modeac =
+        ((bits & 0x40000) ? 0x0010 : 0) | ((bits & 0x20000) ? 0x1000 : 0) | ((bits & 0x10000) ? 0x0020 : 0) |
+        ((bits & 0x08000) ? 0x2000 : 0) | ((bits & 0x04000) ? 0x0040 : 0) | ((bits & 0x02000) ? 0x4000 : 0) |
+        ((bits & 0x00800) ? 0x0100 : 0) | ((bits & 0x00400) ? 0x0001 : 0) | ((bits & 0x00200) ? 0x0200 : 0) |
+        ((bits & 0x00100) ? 0x0002 : 0) | ((bits & 0x00080) ? 0x0400 : 0) | ((bits & 0x00040) ? 0x0004 : 0) |
+        ((bits & 0x00004) ? 0x0080 : 0);
+    const unsigned long long idx = atomicAdd(&counters[CNT_MODEAC], 1ull);
+    if (idx < cap) { AcCand c; c.pos = pos; c.f2_clock = f2_clock; c.modeac = modeac; out[idx] = c; }
+}
+
+// 8 positions per thread from one 16-byte load and its two neighbour dwords
+__global__ __launch_bounds__(kBlock) void k_modeac(const uint16_t *mag, uint64_t n, uint32_t B, const uint32_t *noise_level,
+                                                   AcCand *out, uint32_t cap, unsigned long long *counters) {
+    const uint64_t p0 = ((uint64_t) blockIdx.x * kBlock + threadIdx.x) * 8;
+    if (p0 >= n) return;
+    const u32x4 x = *(const u32x4 *) &mag[p0];
+    const uint32_t prev = p0 ? *(const uint32_t *) &mag[p0 - 2] : 0u, next = *(const uint32_t *) &mag[p0 + 8];
+    const uint32_t w[6] = {prev, x.x, x.y, x.z, x.w, next};                  // samples p0-2 .. p0+9
+    const uint32_t b = (uint32_t) (p0 / B);                                   // 8 | B: the thread's positions share a buffer
+    const uint64_t first = (uint64_t) b * B;
+    const uint32_t nl = noise_level[b];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#define SMP(i) ((w[((e) + (i) + 2) >> 1] >> ((((e) + (i)) & 1) * 16)) & 0xffffu)
+        const uint32_t m_1 = SMP(-1), m0 = SMP(0), m1 = SMP(1), m2 = SMP(2);
+#undef SMP
+        const uint64_t D = p0 + e;
+        const uint32_t f1_sample = (uint32_t) (D - first);
+        if (D >= n || f1_sample == 0) continue;                               // the loop starts at f1_sample = 1 (:582)
+        if (!(m_1 < m0)) continue;                                            // not a rising edge (:639)
+        if (m2 > m0 || m2 > m1) continue;                                     // quiet part not quiet (:642)
+        const uint32_t f1_level = (m0 + m1) / 2;
+        if (nl * 2 > f1_level) continue;                                      // 6 dB above noise (:647)
+        modeac_try(mag + first, f1_sample, m0, m1, f1_level, nl, (uint32_t) D, out, cap, counters);
+    }
+}
+
+void launch_modeac(const uint16_t *mag, uint64_t n, uint32_t buf_samples, int format, const unsigned long long *sum_level,
+                   const unsigned long long *sum_power, const double *fsum_level, const double *fsum_power,
+                   uint32_t *noise_level, AcCand *out, uint32_t cap, unsigned long long *counters, hipStream_t s) {
+    if (n == 0) return;
+    const uint32_t nbuf = (uint32_t) ((n + buf_samples - 1) / buf_samples);
+    hipLaunchKernelGGL(k_modeac_noise, dim3((nbuf + kBlock - 1) / kBlock), dim3(kBlock), 0, s, sum_level, sum_power, fsum_level, fsum_power,
+                       format, n, buf_samples, nbuf, noise_level);
+    const uint64_t threads = (n + 7) / 8;
+    hipLaunchKernelGGL(k_modeac, dim3((unsigned) ((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, mag, n, buf_samples, noise_level,
+                       out, cap, counters);
+}
+
+// =============================================================================================
 // per accepted message: signal power, and what its skip-ahead window hid from the counters
 // =============================================================================================
 

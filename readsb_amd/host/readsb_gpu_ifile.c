@@ -36,6 +36,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--no-fix")) cfg.nfix_crc = 0;
         else if (!strcmp(argv[i], "--aggressive")) cfg.nfix_crc = 2;
         else if (!strcmp(argv[i], "--no-fix-df")) cfg.fixDF = 0;
+        else if (!strcmp(argv[i], "--modeac")) cfg.mode_ac = 1;        /* Modes.mode_ac, readsb.c:1479 */
         else if (!strcmp(argv[i], "--preamble-threshold") && i + 1 < argc) cfg.preamble_threshold = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--gpu-device") && i + 1 < argc) cfg.device = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--gpu-chunk-buffers") && i + 1 < argc) chunk = (unsigned) atoi(argv[++i]);

@@ -419,7 +419,7 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
     HIPCHK(c, hipMalloc(&sl.d_cand, (c->cap_units * (size_t) kUnit + 64) * sizeof(uint16_t)));
     HIPCHK(c, hipMalloc(&sl.d_cand_count, (c->cap_units + 1) * sizeof(uint32_t)));
     {
-        const size_t nb = c->cap_buffers, words = CNT_NUM + 1 + 4 * nb;
+        const size_t nb = c->cap_buffers, words = CNT_NUM + 1 + 4 * nb + kAcLists;   // ... + Mode A/C list counters
         sl.scratch_bytes = words * sizeof(unsigned long long);
         HIPCHK(c, hipMalloc(&sl.d_scratch, sl.scratch_bytes));
         HIPCHK(c, hipMemsetAsync(sl.d_scratch, 0, sl.scratch_bytes, c->stream));
@@ -662,7 +662,7 @@ static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
     }
     if (cfg.mode_ac && !sl.have_mag)       // Mode A/C candidates (needs the converter's per-buffer sums); a few us, streaming
         launch_modeac(sl.d_mag, n, cfg.buf_samples, cfg.format, sl.d_sum_level, sl.d_sum_power, sl.d_fsum_level, sl.d_fsum_power,
-                      sl.d_ac_noise, sl.h_ac, (uint32_t) c->cap_ac, sl.d_counters, s);
+                      sl.d_ac_noise, sl.h_ac, (uint32_t) c->cap_ac, sl.d_scratch + CNT_NUM + 1 + 4 * c->cap_buffers, sl.d_counters, s);
     HIPCHK(c, hipEventRecord(sl.ev[1], s));
     SweepParams sp{};
     sp.mag = sl.d_mag; sp.n = n; sp.thr = cfg.preamble_threshold;
@@ -745,9 +745,12 @@ static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job) {
     std::memcpy(job.sig.data(), sl.h_live_sig, nlive * sizeof(unsigned long long));
     job.ac.clear();
     if (c->cfg.mode_ac && !sl.have_mag) {
-        const uint64_t nac = sl.h_counters[CNT_MODEAC];
-        if (nac > c->cap_ac) { c->err = "Mode A/C candidate buffer overflow"; return MGPU_E_OVERFLOW; }
-        job.ac.assign(sl.h_ac, sl.h_ac + nac);
+        const unsigned long long *counts = sl.h_scratch + CNT_NUM + 1 + 4 * c->cap_buffers;   // k_modeac's kAcLists lists
+        const uint64_t cap_l = c->cap_ac / kAcLists;
+        for (int l = 0; l < kAcLists; ++l) {
+            if (counts[l] > cap_l) { c->err = "Mode A/C candidate buffer overflow"; return MGPU_E_OVERFLOW; }
+            job.ac.insert(job.ac.end(), sl.h_ac + (size_t) l * cap_l, sl.h_ac + (size_t) l * cap_l + counts[l]);
+        }
     }
     job.buffers = sl.buffers;
     job.given_mean_power = sl.given_mean_power;

@@ -66,7 +66,6 @@ enum {
     CNT_CLASS_COND = 8,      // candidates whose records are all conditional (REC_COND)
     CNT_CLASS_UNCOND = 9,    // candidates with >= 1 unconditional record
     CNT_DEBUG0 = 16,         // .. 31: cycle counters of k_sweep_slice's stages (thread 0 of every workgroup)
-    CNT_MODEAC = 30,         // Mode A/C candidates written by k_modeac
     CNT_LIVE_TOTAL = 31,     // records surviving the pre-screen (written by k_scan_units)
     CNT_NUM = 32,
 };
@@ -142,6 +141,7 @@ int launch_prescreen(const PostSweepParams &q, hipStream_t s, hipStream_t s_writ
 // ---- Mode A/C (demodulate2400AC, demod_2400.c:575-761), only when mgpu_config.mode_ac is set ----
 // A position that passes every test of the reference's loop body: the reply is accepted unless an earlier accepted
 // reply of the same buffer hides it (f1_sample += 69, :765) — decided in order on the host.
+constexpr int kAcLists = 64;   // k_modeac appends to one of 64 lists (own counter word, own slice of the output)
 struct AcCand {
     uint32_t pos;        // scan position D in the chunk (f1_sample = D - buffer start)
     uint32_t f2_clock;   // 60 MHz cycles from the buffer start to the F2 pulse: timestamp = sampleTimestamp + f2_clock / 5 (:755)
@@ -149,7 +149,8 @@ struct AcCand {
 };
 void launch_modeac(const uint16_t *mag, uint64_t n, uint32_t buf_samples, int format, const unsigned long long *sum_level,
                    const unsigned long long *sum_power, const double *fsum_level, const double *fsum_power,
-                   uint32_t *noise_level, AcCand *out, uint32_t cap, unsigned long long *counters, hipStream_t s);
+                   uint32_t *noise_level, AcCand *out, uint32_t cap, unsigned long long *list_counts /* [kAcLists], zero */,
+                   unsigned long long *counters, hipStream_t s);
 // signal power of accepted messages: sum of mag^2 over d_mag[pos+19 .. pos+19+len)
 void launch_signal_power(const uint16_t *mag, const uint32_t *pos, const uint16_t *len, uint32_t nmsg,
                          unsigned long long *out, hipStream_t s);

@@ -2400,9 +2400,8 @@ __global__ __launch_bounds__(kBlock) void k_modeac_noise(const unsigned long lon
 }
 
 // everything after the cheap F1 edge / level tests, for the rare lanes that get here
-__device__ __noinline__ void modeac_try(const uint16_t *m /* the buffer's data[] */, uint32_t f1_sample, uint32_t m0, uint32_t m1,
-                                        uint32_t f1_level, uint32_t noise_level, uint32_t pos, AcCand *out, uint32_t cap,
-                                        unsigned long long *counters) {
+__device__ __forceinline__ bool modeac_try(const uint16_t *m /* the buffer's data[] */, uint32_t f1_sample, uint32_t m0, uint32_t m1,
+                                           uint32_t f1_level, uint32_t noise_level, uint32_t pos, AcCand &cand) {
 #pragma clang fp contract(off)
     // initial clock phase from the power that ended up in the second sample (:655-658): float arithmetic, then + 0.5 in double
     const float f1a_power = (float) m0 * (float) m0;
@@ -2412,10 +2411,10 @@ __device__ __noinline__ void modeac_try(const uint16_t *m /* the buffer's data[]
     const uint32_t f1_clock = (uint32_t) ((double) (25.0f * at) + 0.5);
     const uint32_t f2_clock = f1_clock + 87 * 14;
     const uint32_t f2_sample = f2_clock / 25;
-    if (!(m[f2_sample - 1] < m[f2_sample + 0])) return;                                       // :666
-    if (m[f2_sample + 2] > m[f2_sample + 0] || m[f2_sample + 2] > m[f2_sample + 1]) return;  // :669
+    if (!(m[f2_sample - 1] < m[f2_sample + 0])) return false;                                       // :666
+    if (m[f2_sample + 2] > m[f2_sample + 0] || m[f2_sample + 2] > m[f2_sample + 1]) return false;  // :669
     const uint32_t f2_level = ((uint32_t) m[f2_sample + 0] + m[f2_sample + 1]) / 2;
-    if (noise_level * 2 > f2_level) return;
+    if (noise_level * 2 > f2_level) return false;
     const uint32_t f1f2_level = f1_level > f2_level ? f1_level : f2_level;
     const float midpoint = __fsqrt_rn((float) (noise_level * f1f2_level));                      // :683: unsigned product, then float
     const uint32_t signal_threshold = (uint32_t) ((double) midpoint * 1.41421356237309504880 + 0.5);        // +3 dB
@@ -2429,54 +2428,103 @@ __device__ __noinline__ void modeac_try(const uint16_t *m /* the buffer's data[]
         if (a >= signal_threshold || b >= signal_threshold) bits |= 1;
         else if (a > noise_threshold && b > noise_threshold) bad = 1;                          // uncertain
     }
-    if ((bits & 0x80020u) != 0x80020u || (bits & 0x0101Bu) != 0 || bad) return;               // :716-727
+    if ((bits & 0x80020u) != 0x80020u || (bits & 0x0101Bu) != 0 || bad) return false;               // :716-727
     const uint32_t modeac =
         ((bits & 0x40000) ? 0x0010 : 0) | ((bits & 0x20000) ? 0x1000 : 0) | ((bits & 0x10000) ? 0x0020 : 0) |
         ((bits & 0x08000) ? 0x2000 : 0) | ((bits & 0x04000) ? 0x0040 : 0) | ((bits & 0x02000) ? 0x4000 : 0) |
         ((bits & 0x00800) ? 0x0100 : 0) | ((bits & 0x00400) ? 0x0001 : 0) | ((bits & 0x00200) ? 0x0200 : 0) |
         ((bits & 0x00100) ? 0x0002 : 0) | ((bits & 0x00080) ? 0x0400 : 0) | ((bits & 0x00040) ? 0x0004 : 0) |
         ((bits & 0x00004) ? 0x0080 : 0);
-    const unsigned long long idx = atomicAdd(&counters[CNT_MODEAC], 1ull);
-    if (idx < cap) { AcCand c; c.pos = pos; c.f2_clock = f2_clock; c.modeac = modeac; out[idx] = c; }
+    cand.pos = pos; cand.f2_clock = f2_clock; cand.modeac = modeac;
+    return true;
 }
 
-// 8 positions per thread from one 16-byte load and its two neighbour dwords
+// A workgroup covers 2048 positions; its samples (+ 80 of look-ahead: F2 is 48.7 samples after F1, the last bit slot
+// 66) are staged in LDS once.  The cheap F1 tests leave a few dozen positions per workgroup (mostly pulses of Mode S
+// frames); they are gathered in LDS and then tried one per lane, so that the long slow path — some 60 dependent,
+// scattered sample reads — runs converged and out of LDS.
+constexpr int kAcTile = kBlock * 8, kAcHalo = 80, kAcQueue = 1024;
 __global__ __launch_bounds__(kBlock) void k_modeac(const uint16_t *mag, uint64_t n, uint32_t B, const uint32_t *noise_level,
-                                                   AcCand *out, uint32_t cap, unsigned long long *counters) {
-    const uint64_t p0 = ((uint64_t) blockIdx.x * kBlock + threadIdx.x) * 8;
-    if (p0 >= n) return;
-    const u32x4 x = *(const u32x4 *) &mag[p0];
-    const uint32_t prev = p0 ? *(const uint32_t *) &mag[p0 - 2] : 0u, next = *(const uint32_t *) &mag[p0 + 8];
-    const uint32_t w[6] = {prev, x.x, x.y, x.z, x.w, next};                  // samples p0-2 .. p0+9
-    const uint32_t b = (uint32_t) (p0 / B);                                   // 8 | B: the thread's positions share a buffer
+                                                   AcCand *out, uint32_t cap, unsigned long long *list_counts, unsigned long long *counters) {
+    __shared__ __attribute__((aligned(16))) uint16_t s_m[8 + kAcTile + kAcHalo];    // s_m[8 + i] = sample blk0 + i
+    __shared__ uint32_t s_n;
+    __shared__ uint16_t s_pos[kAcQueue];
+    const uint64_t blk0 = (uint64_t) blockIdx.x * kAcTile;
+    if (threadIdx.x == 0) s_n = 0;
+    for (int i = threadIdx.x; i < (8 + kAcTile + kAcHalo) / 8; i += kBlock) {
+        const int64_t g = (int64_t) blk0 - 8 + 8 * i;                          // d_mag is padded beyond n + 326 (api.cpp: alloc_slot)
+        u32x4 v = {0, 0, 0, 0};
+        if (g >= 0) v = *(const u32x4 *) &mag[g];
+        *(u32x4 *) &s_m[8 * i] = v;
+    }
+    __syncthreads();
+    const uint32_t b = (uint32_t) (blk0 / B);                                 // 2048 | B: the workgroup's positions share a buffer
     const uint64_t first = (uint64_t) b * B;
     const uint32_t nl = noise_level[b];
+    const int l0 = 8 + threadIdx.x * 8;                                       // index of the thread's first position in s_m
+    const uint64_t p0 = blk0 + (uint64_t) threadIdx.x * 8;
+    if (p0 < n) {
+        const u32x4 x = *(const u32x4 *) &s_m[l0];
+        const uint32_t prev = *(const uint32_t *) &s_m[l0 - 2], next = *(const uint32_t *) &s_m[l0 + 8];
+        const uint32_t w[6] = {prev, x.x, x.y, x.z, x.w, next};              // samples p0-2 .. p0+9
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < 8; ++e) {
 #define SMP(i) ((w[((e) + (i) + 2) >> 1] >> ((((e) + (i)) & 1) * 16)) & 0xffffu)
-        const uint32_t m_1 = SMP(-1), m0 = SMP(0), m1 = SMP(1), m2 = SMP(2);
+            const uint32_t m_1 = SMP(-1), m0 = SMP(0), m1 = SMP(1), m2 = SMP(2);
 #undef SMP
-        const uint64_t D = p0 + e;
-        const uint32_t f1_sample = (uint32_t) (D - first);
-        if (D >= n || f1_sample == 0) continue;                               // the loop starts at f1_sample = 1 (:582)
-        if (!(m_1 < m0)) continue;                                            // not a rising edge (:639)
-        if (m2 > m0 || m2 > m1) continue;                                     // quiet part not quiet (:642)
-        const uint32_t f1_level = (m0 + m1) / 2;
-        if (nl * 2 > f1_level) continue;                                      // 6 dB above noise (:647)
-        modeac_try(mag + first, f1_sample, m0, m1, f1_level, nl, (uint32_t) D, out, cap, counters);
+            const uint64_t D = p0 + e;
+            const uint32_t f1_sample = (uint32_t) (D - first);
+            if (D >= n || f1_sample == 0) continue;                           // the loop starts at f1_sample = 1 (:582)
+            if (!(m_1 < m0)) continue;                                        // not a rising edge (:639)
+            if (m2 > m0 || m2 > m1) continue;                                 // quiet part not quiet (:642)
+            if (nl * 2 > (m0 + m1) / 2) continue;                             // 6 dB above noise (:647)
+            const uint32_t slot = atomicAdd(&s_n, 1u);
+            if (slot < (uint32_t) kAcQueue) s_pos[slot] = (uint16_t) (threadIdx.x * 8 + e);
+        }
     }
+    __syncthreads();
+    const uint32_t cnt = s_n;
+    if (cnt > (uint32_t) kAcQueue) {              // half the positions passing is not a real signal; say so rather than drop any
+        if (threadIdx.x == 0) atomicAdd(&counters[CNT_POOL_OVERFLOW], 1ull);
+        return;
+    }
+    // the buffer's data[] as the slow path indexes it (f1_sample-relative), served from the LDS window
+    const uint16_t *m_rel = s_m + 8 - (int64_t) (blk0 - first);
+    __shared__ uint32_t s_nacc, s_base;
+    __shared__ AcCand s_acc[kAcQueue];
+    if (threadIdx.x == 0) s_nacc = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < cnt; i += kBlock) {
+        const uint32_t q = s_pos[i];
+        const uint32_t m0 = s_m[8 + q], m1 = s_m[8 + q + 1];
+        AcCand c;
+        if (modeac_try(m_rel, (uint32_t) (blk0 - first) + q, m0, m1, (m0 + m1) / 2, nl, (uint32_t) (blk0 + q), c)) s_acc[atomicAdd(&s_nacc, 1u)] = c;
+    }
+    __syncthreads();
+    // one returning device atomic per workgroup that found something (one per candidate on a single word costs 11 ns
+    // each, serialised: more than the whole scan)
+    const uint32_t nacc = s_nacc;
+    if (nacc == 0) return;
+    // ... and spread over kAcLists lists, each with its own counter word and its own slice of the output
+    const uint32_t list = blockIdx.x % kAcLists, cap_l = cap / kAcLists;
+    if (threadIdx.x == 0) s_base = (uint32_t) atomicAdd(&list_counts[list], (unsigned long long) nacc);
+    __syncthreads();
+    const uint32_t base = s_base;
+    for (uint32_t i = threadIdx.x; i < nacc; i += kBlock)
+        if (base + i < cap_l) out[(size_t) list * cap_l + base + i] = s_acc[i];
 }
 
 void launch_modeac(const uint16_t *mag, uint64_t n, uint32_t buf_samples, int format, const unsigned long long *sum_level,
                    const unsigned long long *sum_power, const double *fsum_level, const double *fsum_power,
-                   uint32_t *noise_level, AcCand *out, uint32_t cap, unsigned long long *counters, hipStream_t s) {
+                   uint32_t *noise_level, AcCand *out, uint32_t cap, unsigned long long *list_counts, unsigned long long *counters,
+                   hipStream_t s) {
     if (n == 0) return;
     const uint32_t nbuf = (uint32_t) ((n + buf_samples - 1) / buf_samples);
     hipLaunchKernelGGL(k_modeac_noise, dim3((nbuf + kBlock - 1) / kBlock), dim3(kBlock), 0, s, sum_level, sum_power, fsum_level, fsum_power,
                        format, n, buf_samples, nbuf, noise_level);
     const uint64_t threads = (n + 7) / 8;
     hipLaunchKernelGGL(k_modeac, dim3((unsigned) ((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, mag, n, buf_samples, noise_level,
-                       out, cap, counters);
+                       out, cap, list_counts, counters);
 }
 
 // =============================================================================================

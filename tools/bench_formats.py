@@ -6,9 +6,9 @@ import numpy as np
 import helpers, readsb_amd
 helpers.ensure_built()
 N = 2048 * 131072
-for name, fmt, nfix in [("UC8 nfix=1", 0, 1), ("UC8 nfix=2", 0, 2), ("SC16 nfix=1", 1, 1), ("SC16Q11 nfix=2 (config 3)", 2, 2)]:
-    iq = helpers.synth(nsamples=N, fmt=fmt, seed=11, threads=32)
-    d = readsb_amd.Demodulator(fmt=fmt, nfix_crc=nfix, max_samples=N, startup_time_ms=helpers.STARTUP_MS)
+for name, fmt, nfix, ac in [("UC8 nfix=1", 0, 1, 0), ("UC8 nfix=1 + Mode A/C", 0, 1, 1), ("UC8 nfix=2", 0, 2, 0), ("SC16 nfix=1", 1, 1, 0), ("SC16Q11 nfix=2 (config 3)", 2, 2, 0)]:
+    iq = helpers.synth(nsamples=N, fmt=fmt, seed=11, threads=32, dense=2 if ac else 0, rate=800.0 if ac else 2000.0)
+    d = readsb_amd.Demodulator(fmt=fmt, nfix_crc=nfix, max_samples=N, startup_time_ms=helpers.STARTUP_MS, mode_ac=ac)
     d.upload_iq(iq)
     best = 1e9
     for _ in range(5):

@@ -2355,7 +2355,7 @@ int launch_prescreen(const PostSweepParams &q, hipStream_t s, hipStream_t s_writ
     unsigned nb_fin = 0;
     if (q.class_final) {
         nb_fin = (unsigned) ((q.class_words / 4 + kBlock) / kBlock);
-        if (nb_fin > 1024) nb_fin = 1024;
+        if (nb_fin > 256) nb_fin = 256;          // every workgroup ends with two device atomics on the same two words
     }
     hipLaunchKernelGGL(k_count_finalize, dim3(nb_count + nb_fin), dim3(kBlock), 0, s, q.pool, q.unit_first, q.nunits, q.adder_bitmap,
                        q.unit_live, nb_count, q.class_cond, q.class_uncond, q.class_final, q.class_words, q.counters, q.keep_masks ? 1 : 0);

@@ -408,7 +408,7 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
     HIPCHK(c, hipMalloc(&sl.d_pool, c->cap_pool * sizeof(PhaseRec)));
     HIPCHK(c, hipMalloc(&sl.d_unit_first, (c->cap_units + 1) * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc(&sl.d_unit_count, (c->cap_units + 1) * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc(&sl.d_unit_live, (c->cap_units + 2) * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(&sl.d_unit_live, (c->cap_units + 2 + c->cap_units / 4 + 2) * sizeof(uint32_t)));   // per unit, then per count-pass workgroup
     sl.class_bytes = (mag_len / 32 + 64) * sizeof(uint32_t);
     HIPCHK(c, hipMalloc(&sl.d_class_bitmap, sl.class_bytes));
     HIPCHK(c, hipMalloc(&sl.d_class_uncond, sl.class_bytes));
@@ -687,7 +687,7 @@ static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
     // pinned host memory), counters and per-buffer sums to the host
     PostSweepParams q{};
     q.pool = sl.d_pool; q.unit_first = sl.d_unit_first; q.nunits = nunits; q.adder_bitmap = c->d_adder_bitmap;
-    q.unit_live = sl.d_unit_live; q.live = sl.h_live; q.mag = sl.d_mag; q.live_sig = sl.h_live_sig; q.counters = sl.d_counters;
+    q.unit_live = sl.d_unit_live; q.block_live = sl.d_unit_live + c->cap_units + 2; q.live = sl.h_live; q.mag = sl.d_mag; q.live_sig = sl.h_live_sig; q.counters = sl.d_counters;
     q.class_cond = sl.d_class_bitmap; q.class_uncond = sl.d_class_uncond;
     q.class_final = c->sweep_version >= 3 ? sl.d_class_final : nullptr;
     q.class_words = (n + 31) / 32;

@@ -126,7 +126,8 @@ struct PostSweepParams {
     const uint32_t *unit_first;
     uint32_t nunits;
     const uint32_t *adder_bitmap;
-    uint32_t *unit_live;
+    uint32_t *unit_live;                  // live records per unit (count pass)
+    uint32_t *block_live;                 // ... per count-pass workgroup (4 units)
     PhaseRec *live;                       // pinned host memory
     const uint16_t *mag;
     unsigned long long *live_sig;         // pinned host memory

@@ -2206,16 +2206,15 @@ __device__ __forceinline__ bool rec_live(const PhaseRec &r, const uint32_t *bitm
 // MODE 2: WRITE pass that reads the masks — it may then run beside the next chunk's sweep, which adds bits
 //         to the adder bitmap (a second look at the bitmap could disagree with the counted offsets).
 template <int MODE>
-__device__ __forceinline__ void prescreen_unit(uint32_t u, PhaseRec *pool, const uint32_t *unit_first, uint32_t nunits,
-                                               const uint32_t *bitmap, uint32_t *unit_live, PhaseRec *live,
-                                               const uint16_t *mag, unsigned long long *live_sig, bool keep_masks,
-                                               unsigned long long *counters) {
+__device__ __forceinline__ uint32_t prescreen_unit(uint32_t u, PhaseRec *pool, const uint32_t *unit_first, uint32_t nunits,
+                                                   const uint32_t *bitmap, uint32_t dst0, PhaseRec *live,
+                                                   const uint16_t *mag, unsigned long long *live_sig, bool keep_masks,
+                                                   unsigned long long *counters) {
     constexpr bool WRITE = MODE != 0;
     const int lane = lane_id();
-    if (u >= nunits) return;
+    if (u >= nunits) return 0;
     uint32_t h = unit_first[u];
     uint32_t nlive = 0;
-    const uint32_t dst0 = WRITE ? unit_live[u] : 0;
     while (h != kNone) {
         const uint32_t cnt = pool[h].pos, next = pool[h].addr;
         for (uint32_t i0 = 0; i0 < cnt; i0 += WAVE) {
@@ -2287,27 +2286,46 @@ __device__ __forceinline__ void prescreen_unit(uint32_t u, PhaseRec *pool, const
         }
         h = next;
     }
-    if (!WRITE && lane == 0) unit_live[u] = nlive;
+    return nlive;
 }
 
 // COUNT pass (one wave per unit) and, in the remaining workgroups of the same launch, the class-plane
 // finalize: two small latency-bound jobs that do not depend on each other.
 __global__ __launch_bounds__(kBlock) void k_count_finalize(PhaseRec *pool, const uint32_t *unit_first, uint32_t nunits,
-                                                           const uint32_t *bitmap, uint32_t *unit_live, uint32_t nb_count,
+                                                           const uint32_t *bitmap, uint32_t *unit_live, uint32_t *block_live, uint32_t nb_count,
                                                            uint32_t *cond, uint32_t *uncond, uint32_t *final_bitmap, uint64_t nwords,
                                                            unsigned long long *counters, int keep_masks) {
-    if (blockIdx.x < nb_count)
-        prescreen_unit<0>(blockIdx.x * (kBlock / WAVE) + (threadIdx.x >> 6), pool, unit_first, nunits, bitmap, unit_live, nullptr, nullptr, nullptr,
-                          keep_masks != 0, counters);
-    else
+    if (blockIdx.x < nb_count) {
+        __shared__ uint32_t s_live[kBlock / WAVE];
+        const uint32_t wv = threadIdx.x >> 6, u = blockIdx.x * (kBlock / WAVE) + wv;
+        const uint32_t nlive = prescreen_unit<0>(u, pool, unit_first, nunits, bitmap, 0, nullptr, nullptr, nullptr, keep_masks != 0, counters);
+        if (lane_id() == 0) { s_live[wv] = nlive; if (u < nunits) unit_live[u] = nlive; }
+        __syncthreads();
+        if (threadIdx.x == 0) block_live[blockIdx.x] = s_live[0] + s_live[1] + s_live[2] + s_live[3];   // the write pass sums these: no scan kernel
+    } else {
         class_finalize_part(blockIdx.x - nb_count, gridDim.x - nb_count, cond, uncond, final_bitmap, nwords, counters);
+    }
 }
 
+// WRITE pass.  A workgroup's output offset = the live counts of all workgroups before it (block_live, at most a few
+// thousand words out of L2, summed cooperatively) + those of the earlier units of its own four.
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_prescreen_write(PhaseRec *pool, const uint32_t *unit_first, uint32_t nunits,
-                                                            const uint32_t *bitmap, uint32_t *unit_live, PhaseRec *live,
-                                                            const uint16_t *mag, unsigned long long *live_sig) {
-    prescreen_unit<MODE>(blockIdx.x * (kBlock / WAVE) + (threadIdx.x >> 6), pool, unit_first, nunits, bitmap, unit_live, live, mag, live_sig, false, nullptr);
+                                                            const uint32_t *bitmap, const uint32_t *unit_live, const uint32_t *block_live,
+                                                            PhaseRec *live, const uint16_t *mag, unsigned long long *live_sig,
+                                                            unsigned long long *counters) {
+    __shared__ uint32_t s_part[kBlock / WAVE];
+    uint32_t acc = 0;
+    for (uint32_t i = threadIdx.x; i < blockIdx.x; i += kBlock) acc += block_live[i];
+    acc = (uint32_t) wave_sum_u64(acc);
+    const uint32_t wv = threadIdx.x >> 6;
+    if (lane_id() == 0) s_part[wv] = acc;
+    __syncthreads();
+    uint32_t dst0 = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    const uint32_t u = blockIdx.x * (kBlock / WAVE) + wv;
+    for (uint32_t v = blockIdx.x * (kBlock / WAVE); v < u && v < nunits; ++v) dst0 += unit_live[v];
+    const uint32_t nlive = prescreen_unit<MODE>(u, pool, unit_first, nunits, bitmap, dst0, live, mag, live_sig, false, nullptr);
+    if (u == nunits - 1 && lane_id() == 0) counters[CNT_LIVE_TOTAL] = dst0 + nlive;
 }
 
 // The chunk's scratch block (counters, pool cursor, per-buffer sums) goes to the host's pinned copy and is
@@ -2319,36 +2337,8 @@ __global__ __launch_bounds__(kBlock) void k_publish(unsigned long long *d_scratc
     }
 }
 
-// exclusive scan of unit_live[0..n) in place; unit_live[n] = total.  One workgroup.
-__global__ __launch_bounds__(1024) void k_scan_units(uint32_t *unit_live, uint32_t n, unsigned long long *counters) {
-    __shared__ uint32_t s_wave[16];
-    __shared__ uint32_t s_carry;
-    const int lane = lane_id(), wv = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < n; base += 1024) {
-        const uint32_t i = base + threadIdx.x;
-        const int v = i < n ? (int) unit_live[i] : 0;
-        int total;
-        const int ex = wave_excl_scan(v, total);
-        if (lane == 0) s_wave[wv] = total;
-        __syncthreads();
-        uint32_t off = s_carry;
-        for (int k = 0; k < wv; ++k) off += s_wave[k];
-        if (i < n) unit_live[i] = off + ex;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t t = 0;
-            for (int k = 0; k < 16; ++k) t += s_wave[k];
-            s_carry += t;
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { unit_live[n] = s_carry; if (counters) counters[CNT_LIVE_TOTAL] = s_carry; }
-}
-
-// count + finalize + scan on `s`; write + publish on `s_write` (== s, or a second stream when the segment
-// headers carry the live masks: `q.keep_masks`), ordered after the scan by `ev_scan`
+// count + finalize on `s`; write + publish on `s_write` (== s, or a second stream when the segment headers carry
+// the live masks: `q.keep_masks`), ordered after the count pass by `ev_scan`
 int launch_prescreen(const PostSweepParams &q, hipStream_t s, hipStream_t s_write, hipEvent_t ev_scan) {
     if (q.nunits == 0) return 0;
     const unsigned nb_count = (q.nunits + 3) / 4;
@@ -2358,17 +2348,17 @@ int launch_prescreen(const PostSweepParams &q, hipStream_t s, hipStream_t s_writ
         if (nb_fin > 256) nb_fin = 256;          // every workgroup ends with two device atomics on the same two words
     }
     hipLaunchKernelGGL(k_count_finalize, dim3(nb_count + nb_fin), dim3(kBlock), 0, s, q.pool, q.unit_first, q.nunits, q.adder_bitmap,
-                       q.unit_live, nb_count, q.class_cond, q.class_uncond, q.class_final, q.class_words, q.counters, q.keep_masks ? 1 : 0);
-    hipLaunchKernelGGL(k_scan_units, dim3(1), dim3(1024), 0, s, q.unit_live, q.nunits, q.counters);
+                       q.unit_live, q.block_live, nb_count, q.class_cond, q.class_uncond, q.class_final, q.class_words, q.counters,
+                       q.keep_masks ? 1 : 0);
     if (s_write != s) {
         if (hipEventRecord(ev_scan, s) != hipSuccess || hipStreamWaitEvent(s_write, ev_scan, 0) != hipSuccess) return -1;
     }
     if (q.keep_masks)
         hipLaunchKernelGGL(k_prescreen_write<2>, dim3(nb_count), dim3(kBlock), 0, s_write, q.pool, q.unit_first, q.nunits, q.adder_bitmap,
-                           q.unit_live, q.live, q.mag, q.live_sig);
+                           q.unit_live, q.block_live, q.live, q.mag, q.live_sig, q.counters);
     else
         hipLaunchKernelGGL(k_prescreen_write<1>, dim3(nb_count), dim3(kBlock), 0, s_write, q.pool, q.unit_first, q.nunits, q.adder_bitmap,
-                           q.unit_live, q.live, q.mag, q.live_sig);
+                           q.unit_live, q.block_live, q.live, q.mag, q.live_sig, q.counters);
     unsigned pb = (q.scratch_words + kBlock - 1) / kBlock;
     if (pb > 64) pb = 64;
     hipLaunchKernelGGL(k_publish, dim3(pb), dim3(kBlock), 0, s_write, q.d_scratch, q.h_scratch, q.scratch_words);

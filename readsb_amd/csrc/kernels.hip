@@ -1460,7 +1460,9 @@ __global__ __launch_bounds__(kBlock, MGPU_V3_PREFETCH ? 3 : 4) void k_sweep_slic
     long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // MGPU_KERNEL_TIMERS: load, sweep, stage A, slice, score, total, rounds B, passes
     const long long tm_start = DBG_CLOCK();
     (void) tm_start;
-    uint32_t chunk_base = 0, chunk_left = 0;     // wave-uniform: reserved pool space
+    // wave-uniform: reserved pool space.  The first slice is the wave's by position — a returning atomic on the shared
+    // cursor costs ~11 ns serialised, and every wave of the grid asks for its first slice within the same few microseconds
+    uint32_t chunk_base = wave_global * (uint32_t) kPoolChunkRecords, chunk_left = kPoolChunkRecords;
     u32x4 pre[kWPre];
     bool have_pre = false;
 
@@ -1503,7 +1505,7 @@ __global__ __launch_bounds__(kBlock, MGPU_V3_PREFETCH ? 3 : 4) void k_sweep_slic
                 if (chunk_left < (uint32_t) cnt + 1u) {
                     uint32_t b = 0;
                     if (lane == 0) b = atomicAdd(p.pool_used, (uint32_t) kPoolChunkRecords);
-                    chunk_base = rfl(b);
+                    chunk_base = nwaves * (uint32_t) kPoolChunkRecords + rfl(b);     // the cursor counts from behind the waves' first slices
                     chunk_left = kPoolChunkRecords;
                 }
                 const uint32_t base = chunk_base;

@@ -77,6 +77,8 @@ int gpu_ifile_run(struct gpu_demod *g, int fd, input_format_t format, unsigned c
     const size_t chunk = (size_t) chunk_buffers * buf_samples;
     uint8_t *readbuf = malloc(chunk * bps);
     if (!readbuf) return MGPU_E_NOMEM;
+    /* page-locked, the chunked uploads of mgpu_feed_iq run at PCIe speed beside the kernels (optional: ignore failure) */
+    const int pinned = mgpu_host_register(g->ctx, readbuf, chunk * bps) == MGPU_OK;
     int rc = MGPU_OK, eof = 0;
     while (!eof) {
         size_t have = 0, want = chunk * bps;
@@ -95,6 +97,7 @@ int gpu_ifile_run(struct gpu_demod *g, int fd, input_format_t format, unsigned c
     }
     if (rc == MGPU_OK) rc = mgpu_finish(g->ctx);    /* zero-length EOF buffer on exact multiples */
     if (rc == MGPU_OK) mgpu_collect(g->ctx, g->scratch, 0, NULL, &g->counters);
+    if (pinned) mgpu_host_unregister(g->ctx, readbuf);
     free(readbuf);
     return rc;
 }

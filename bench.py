@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--samples", type=int, default=4096 * BUF, help="samples per stream per step (multiple of 131072)")
     ap.add_argument("--msgs-per-sec", type=float, default=2000.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--main-cpu", type=int, default=-1, help="experiment: pin the calling thread to this CPU after the context exists")
     ap.add_argument("--exercise-gather", action="store_true", help="run the N>1 aggregator exchange even with one rank (needs torchrun env)")
     args = ap.parse_args()
 
@@ -97,6 +98,9 @@ def main():
     t_gen = time.time() - t0
     d = readsb_amd.Demodulator(max_samples=n, device=local_rank, startup_time_ms=helpers.STARTUP_MS)
     d.upload_iq(iq)
+    d.keep_other_threads_away()         # the application's threads (this one, the HIP runtime's) stay off the pipeline's CCD cores
+    if args.main_cpu >= 0:
+        os.sched_setaffinity(0, {args.main_cpu})
 
     gath = None                                 # N > 1: the aggregator role, asynchronous (readsb_amd/gather.py)
     outbuf = None                               # the consumer's standing message array (mgpu_set_message_buffer)

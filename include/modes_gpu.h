@@ -143,6 +143,11 @@ int  mgpu_device_count(void);
  * Synchronous: on return the accepted messages are available to mgpu_collect(). */
 int mgpu_feed_iq(mgpu_ctx *ctx, const void *iq_host, uint64_t nsamples);
 
+/* The CPUs the context pinned its host threads to (one physical core each, one L3; 0 = not pinned, e.g. with
+ * MGPU_NO_AFFINITY=1).  An application that wants the full speed keeps its own busy threads off these cores and
+ * their SMT siblings: a thread of the application sharing a core with a pipeline stage costs up to 30 %. */
+int mgpu_host_cpus(mgpu_ctx *ctx, int32_t *cpus, int32_t cap);
+
 /* Optional: page-lock a host buffer the caller keeps feeding from (the SDR plugin's read buffer, the
  * ifile reader's `readbuf`, sdr_ifile.c:140) so that mgpu_feed_iq's chunked uploads run at PCIe speed
  * and overlap the kernels.  Unregister before freeing the buffer. */

@@ -96,6 +96,7 @@ def load_library():
     lib.mgpu_device_count.restype = i32
     lib.mgpu_feed_iq.argtypes = [vp, vp, u64]
     lib.mgpu_feed_iq_device.argtypes = [vp, vp, u64]
+    lib.mgpu_host_cpus.argtypes = [vp, vp, i32]
     lib.mgpu_host_register.argtypes = [vp, vp, u64]
     lib.mgpu_host_unregister.argtypes = [vp, vp]
     lib.mgpu_upload_iq.argtypes = [vp, vp, u64]
@@ -224,6 +225,41 @@ class Demodulator:
     def walk_packets(self, packets):
         packets = np.ascontiguousarray(packets, dtype=np.uint8)
         self._chk(self.lib.mgpu_walk_packets(self.ctx, C.c_void_p(packets.ctypes.data), C.c_uint64(packets.size)), "mgpu_walk_packets")
+
+    def host_cpus(self):
+        """CPUs the context's host threads are pinned to (empty list: not pinned)."""
+        buf = (C.c_int32 * 64)()
+        n = int(self.lib.mgpu_host_cpus(self.ctx, buf, 64))
+        return [int(buf[i]) for i in range(max(0, min(n, 64)))]
+
+    def keep_other_threads_away(self):
+        """Move every thread of this process that is not one of the context's pinned threads off the pinned cores and
+        their SMT siblings (the application side of mgpu_host_cpus' advice; Linux only, best effort)."""
+        cpus = self.host_cpus()
+        if not cpus:
+            return 0
+        taken = set()
+        for c in cpus:
+            try:
+                txt = open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip()
+                for part in txt.split(","):
+                    lo, _, hi = part.partition("-")
+                    taken.update(range(int(lo), int(hi or lo) + 1))
+            except OSError:
+                taken.add(c)
+        moved = 0
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                cur = os.sched_getaffinity(int(tid))
+                if len(cur) == 1 and next(iter(cur)) in cpus:
+                    continue                       # one of the pipeline's own threads
+                target = cur - taken
+                if target and target != cur:
+                    os.sched_setaffinity(int(tid), target)
+                    moved += 1
+            except OSError:
+                pass
+        return moved
 
     def host_register(self, arr):
         """Page-lock a numpy array the caller keeps feeding from (mgpu_host_register)."""

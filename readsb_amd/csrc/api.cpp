@@ -96,7 +96,12 @@ class Team {
     void loop() {
         uint64_t seen = wake_.load(std::memory_order_acquire);
         for (;;) {
-            for (int spin = 0; spin < 20000 && wake_.load(std::memory_order_acquire) == seen; ++spin) __builtin_ia32_pause();
+            // spin briefly (the forks come every few hundred microseconds while a feed runs), giving the core away in between:
+            // a helper that spins through its time slice starves whatever else the scheduler put on this core
+            for (int spin = 0; spin < 4000 && wake_.load(std::memory_order_acquire) == seen; ++spin) {
+                __builtin_ia32_pause();
+                if ((spin & 63) == 63) sched_yield();
+            }
             const std::function<void(int)> *fn;
             int n;
             uint32_t g;
@@ -255,6 +260,7 @@ struct mgpu_ctx {
     std::thread fetcher, worker, builder;
     Team walk_team, build_team;                               // helpers of the walker / builder stage (MGPU_WALK_THREADS, MGPU_BUILD_THREADS)
     int walk_threads = 4, build_threads = 3;
+    std::vector<int> host_cpus;                               // the CPUs the host threads were pinned to (empty: not pinned)
     std::vector<SegmentWalk> segs;                            // the walker's buffer ranges
     std::vector<mgpu_msg> b_stage;                            // builder scratch (Mode A/C merge)
     // time-sharded capture (config 5, mgpu_shard_*): 0 = normal, 1 = sweep for the adder bitmap only, 2 = keep the
@@ -307,7 +313,7 @@ static int sysfs_int(const std::string &path, int dflt) {
     return v;
 }
 
-static void bind_near_device(std::thread *const *threads, int nthreads, int device) {
+static void bind_near_device(std::thread *const *threads, int nthreads, int device, std::vector<int> *pinned) {
     if (getenv("MGPU_NO_AFFINITY")) return;
     char bus[64] = {0};
     if (hipDeviceGetPCIBusId(bus, (int) sizeof(bus), device) != hipSuccess) return;
@@ -356,6 +362,7 @@ static void bind_near_device(std::thread *const *threads, int nthreads, int devi
             CPU_ZERO(&set); CPU_SET(pick[(size_t) t % pick.size()], &set);
             (void) pthread_setaffinity_np(threads[t]->native_handle(), sizeof(set), &set);
         }
+        if (pinned) pinned->assign(pick.begin(), pick.begin() + (nthreads < (int) pick.size() ? nthreads : (int) pick.size()));
     } else {                               // no cache topology in sysfs: the whole node
         CPU_ZERO(&set);
         for (int k : cpus) CPU_SET(k, &set);
@@ -583,7 +590,7 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
         std::vector<std::thread *> th = {&c->worker, &c->builder, &c->fetcher};
         for (auto &t : c->walk_team.threads) th.push_back(&t);
         for (auto &t : c->build_team.threads) th.push_back(&t);
-        bind_near_device(th.data(), (int) th.size(), cfg->device);
+        bind_near_device(th.data(), (int) th.size(), cfg->device, &c->host_cpus);
     }
     *out = c;
     return MGPU_OK;
@@ -1159,6 +1166,13 @@ static int feed_common(mgpu_ctx *c, const void *src, bool src_is_device, uint64_
 }
 
 int mgpu_feed_iq(mgpu_ctx *c, const void *iq_host, uint64_t nsamples) { return feed_common(c, iq_host, false, nsamples); }
+
+int mgpu_host_cpus(mgpu_ctx *c, int32_t *cpus, int32_t cap) {
+    if (!c || (!cpus && cap)) return MGPU_E_INVAL;
+    const int n = (int) c->host_cpus.size();
+    for (int i = 0; i < n && i < cap; ++i) cpus[i] = c->host_cpus[i];
+    return n;
+}
 
 int mgpu_host_register(mgpu_ctx *c, void *ptr, uint64_t bytes) {
     if (!c || !ptr || !bytes) return MGPU_E_INVAL;

@@ -98,7 +98,9 @@ def main():
     t_gen = time.time() - t0
     d = readsb_amd.Demodulator(max_samples=n, device=local_rank, startup_time_ms=helpers.STARTUP_MS)
     d.upload_iq(iq)
-    d.keep_other_threads_away()         # the application's threads (this one, the HIP runtime's) stay off the pipeline's CCD cores
+    # the application's threads (this one, the HIP / RCCL runtime's) stay off the pipeline's cores; with several ranks on the
+    # node they stay inside the rank's own CCD, on the SMT siblings the pipeline leaves free
+    d.keep_other_threads_away(confine_to_own_l3=world > 1)
     if args.main_cpu >= 0:
         os.sched_setaffinity(0, {args.main_cpu})
 

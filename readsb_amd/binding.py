@@ -232,28 +232,36 @@ class Demodulator:
         n = int(self.lib.mgpu_host_cpus(self.ctx, buf, 64))
         return [int(buf[i]) for i in range(max(0, min(n, 64)))]
 
-    def keep_other_threads_away(self):
+    def keep_other_threads_away(self, confine_to_own_l3=False):
         """Move every thread of this process that is not one of the context's pinned threads off the pinned cores and
-        their SMT siblings (the application side of mgpu_host_cpus' advice; Linux only, best effort)."""
+        their SMT siblings (the application side of mgpu_host_cpus' advice; Linux only, best effort).
+        confine_to_own_l3=True (several ranks on one node): the other threads go to the free SMT siblings of the
+        context's own L3 group instead, so that they cannot wander onto another rank's pipeline cores either."""
         cpus = self.host_cpus()
         if not cpus:
             return 0
-        taken = set()
-        for c in cpus:
+
+        def cpulist(path):
+            out = set()
             try:
-                txt = open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip()
-                for part in txt.split(","):
+                for part in open(path).read().strip().split(","):
                     lo, _, hi = part.partition("-")
-                    taken.update(range(int(lo), int(hi or lo) + 1))
-            except OSError:
-                taken.add(c)
+                    out.update(range(int(lo), int(hi or lo) + 1))
+            except (OSError, ValueError):
+                pass
+            return out
+
+        siblings, l3 = set(), set()
+        for c in cpus:
+            siblings |= cpulist(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") or {c}
+            l3 |= cpulist(f"/sys/devices/system/cpu/cpu{c}/cache/index3/shared_cpu_list")
         moved = 0
         for tid in os.listdir("/proc/self/task"):
             try:
                 cur = os.sched_getaffinity(int(tid))
                 if len(cur) == 1 and next(iter(cur)) in cpus:
                     continue                       # one of the pipeline's own threads
-                target = cur - taken
+                target = ((l3 - set(cpus)) & cur) if confine_to_own_l3 else (cur - siblings)
                 if target and target != cur:
                     os.sched_setaffinity(int(tid), target)
                     moved += 1

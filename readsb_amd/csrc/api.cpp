@@ -45,7 +45,11 @@ double wall_ms() {
 class Team {
   public:
     ~Team() { stop(); }
-    void start(int helpers) {
+    // while *hot is set (a feed is running) idle helpers never block: a core that sleeps between two forks a few hundred
+    // microseconds apart drops into a deep C-state, and the wake-up latency then costs more than the work (seen as a
+    // 2.4x slower walker stage in the first run on an idle box)
+    void start(int helpers, const std::atomic<bool> *hot = nullptr) {
+        hot_ = hot;
         for (int i = 0; i < helpers; ++i) threads.emplace_back([this] { loop(); });
     }
     void stop() {
@@ -96,11 +100,12 @@ class Team {
     void loop() {
         uint64_t seen = wake_.load(std::memory_order_acquire);
         for (;;) {
-            // spin briefly (the forks come every few hundred microseconds while a feed runs), giving the core away in between:
-            // a helper that spins through its time slice starves whatever else the scheduler put on this core
-            for (int spin = 0; spin < 4000 && wake_.load(std::memory_order_acquire) == seen; ++spin) {
+            // spin (giving the core away in between: a helper that spins through its time slice starves whatever else the
+            // scheduler put on this core); block only when no feed is running
+            for (int spin = 0; wake_.load(std::memory_order_acquire) == seen; ++spin) {
                 __builtin_ia32_pause();
                 if ((spin & 63) == 63) sched_yield();
+                if (spin >= 4000 && !(hot_ && hot_->load(std::memory_order_relaxed))) break;
             }
             const std::function<void(int)> *fn;
             int n;
@@ -122,6 +127,7 @@ class Team {
     uint32_t gen_ = 0;
     std::atomic<uint64_t> ticket_{0}, wake_{0};
     std::atomic<int> pending_{0};
+    const std::atomic<bool> *hot_ = nullptr;
     bool quit_ = false;
 };
 
@@ -260,6 +266,7 @@ struct mgpu_ctx {
     std::thread fetcher, worker, builder;
     Team walk_team, build_team;                               // helpers of the walker / builder stage (MGPU_WALK_THREADS, MGPU_BUILD_THREADS)
     int walk_threads = 4, build_threads = 3;
+    std::atomic<bool> hot{false};                             // a feed is running: the stage threads and helpers poll instead of sleeping
     std::vector<int> host_cpus;                               // the CPUs the host threads were pinned to (empty: not pinned)
     std::vector<SegmentWalk> segs;                            // the walker's buffer ranges
     std::vector<mgpu_msg> b_stage;                            // builder scratch (Mode A/C merge)
@@ -291,6 +298,22 @@ struct mgpu_ctx {
             return e_ == hipErrorOutOfMemory ? MGPU_E_NOMEM : MGPU_E_HIP;                          \
         }                                                                                          \
     } while (0)
+
+// Wait for `pred` (evaluated under c->mu).  During a feed: poll with the lock released and the core offered to others;
+// otherwise block on the condition variable.
+template <class Pred>
+static void stage_wait(mgpu_ctx *c, std::unique_lock<std::mutex> &lk, Pred pred) {
+    while (!pred()) {
+        if (c->hot.load(std::memory_order_relaxed)) {
+            lk.unlock();
+            for (int i = 0; i < 32; ++i) __builtin_ia32_pause();
+            sched_yield();
+            lk.lock();
+        } else {
+            c->cv.wait(lk);                      // (feed_begin notifies after raising `hot`)
+        }
+    }
+}
 
 static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job);
 static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job);
@@ -584,8 +607,8 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     c->fetcher = std::thread(fetcher_main, c);
     c->worker = std::thread(worker_main, c);
     c->builder = std::thread(builder_main, c);
-    c->walk_team.start(c->walk_threads - 1);
-    c->build_team.start(c->build_threads - 1);
+    c->walk_team.start(c->walk_threads - 1, &c->hot);
+    c->build_team.start(c->build_threads - 1, &c->hot);
     {
         std::vector<std::thread *> th = {&c->worker, &c->builder, &c->fetcher};
         for (auto &t : c->walk_team.threads) th.push_back(&t);
@@ -972,6 +995,8 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
 // Start / end of one API call that runs chunks: reset and then apply the skip-window corrections of
 // the demod counters (see DESIGN.md §1 "Statistics without a candidate log").
 static int feed_begin(mgpu_ctx *c) {
+    { std::lock_guard<std::mutex> lk(c->mu); c->hot.store(true, std::memory_order_relaxed); }
+    c->cv.notify_all();                      // the stage threads switch from sleeping to polling
     std::memset(&c->acc, 0, sizeof(c->acc));
     std::memset(c->feed_cand, 0, sizeof(c->feed_cand));
     c->feed_rc = ResolveCounts();
@@ -1008,11 +1033,11 @@ static void fetcher_main(mgpu_ctx *c) {
         int idx, jidx;
         {
             std::unique_lock<std::mutex> lk(c->mu);
-            c->cv.wait(lk, [&] { return c->stop || !c->queue.empty(); });
+            stage_wait(c, lk, [&] { return c->stop || !c->queue.empty(); });
             if (c->queue.empty()) return;   // stop requested and nothing left
             idx = c->queue.front();
             jidx = (int) (c->job_seq++ % 4);
-            c->cv.wait(lk, [&] { return !c->job[jidx].busy; });
+            stage_wait(c, lk, [&] { return !c->job[jidx].busy; });
             c->job[jidx].busy = true;
         }
         Slot &sl = c->slot[idx];
@@ -1046,7 +1071,7 @@ static void worker_main(mgpu_ctx *c) {
         int jidx;
         {
             std::unique_lock<std::mutex> lk(c->mu);
-            c->cv.wait(lk, [&] { return c->stop || !c->walk_queue.empty(); });
+            stage_wait(c, lk, [&] { return c->stop || !c->walk_queue.empty(); });
             if (c->walk_queue.empty()) return;
             jidx = c->walk_queue.front();
         }
@@ -1069,7 +1094,7 @@ static void builder_main(mgpu_ctx *c) {
         int jidx;
         {
             std::unique_lock<std::mutex> lk(c->mu);
-            c->cv.wait(lk, [&] { return c->stop || !c->build_queue.empty(); });
+            stage_wait(c, lk, [&] { return c->stop || !c->build_queue.empty(); });
             if (c->build_queue.empty()) return;
             jidx = c->build_queue.front();
         }
@@ -1155,6 +1180,7 @@ static int feed_common(mgpu_ctx *c, const void *src, bool src_is_device, uint64_
         if (rc != MGPU_OK) { std::lock_guard<std::mutex> lk(c->mu); if (c->worker_rc == MGPU_OK) c->worker_rc = rc; }
     }
     const int wrc = wait_all(c);
+    c->hot.store(false, std::memory_order_relaxed);
     if (rc == MGPU_OK) rc = wrc;
     if (rc == MGPU_OK) rc = feed_end(c);
     if (rc != MGPU_OK) return rc;
@@ -1328,6 +1354,7 @@ int mgpu_demod_mag_buf(mgpu_ctx *c, const uint16_t *data, uint32_t length, int64
     submit_slot(c, slot_idx);
     if (rc != MGPU_OK) { std::lock_guard<std::mutex> lk(c->mu); if (c->worker_rc == MGPU_OK) c->worker_rc = rc; }
     const int wrc = wait_all(c);
+    c->hot.store(false, std::memory_order_relaxed);
     if (rc == MGPU_OK) rc = wrc;
     if (rc == MGPU_OK) rc = feed_end(c);
     if (rc == MGPU_OK) {

@@ -7,8 +7,9 @@
  *
  * Everything here is `extern "C"`, plain pointers and sizes; the caller owns all host
  * memory, the library owns all device memory.  One context = one SDR stream on one GPU;
- * a context is not thread-safe (the reference calls demodulate2400 from one decode thread
- * only, readsb.c:871).  Each entry point names the reference interface it replaces
+ * calls into a context must come from one thread at a time (the reference calls demodulate2400
+ * from one decode thread only, readsb.c:871); inside, a context runs its own host threads
+ * (mgpu_host_cpus).  Each entry point names the reference interface it replaces
  * (file:line under the reference tree).
  *
  * The reference-side binding a maintainer would add is shown in INTEGRATION.md.
@@ -143,6 +144,16 @@ int  mgpu_device_count(void);
  * Synchronous: on return the accepted messages are available to mgpu_collect(). */
 int mgpu_feed_iq(mgpu_ctx *ctx, const void *iq_host, uint64_t nsamples);
 
+/* Same, for IQ already resident in device memory (HBM): d_iq is a device pointer to
+ * nsamples samples of cfg.format.  This is the entry the benchmark times. */
+int mgpu_feed_iq_device(mgpu_ctx *ctx, const void *d_iq, uint64_t nsamples);
+
+/* Host -> HBM copy only (no processing): stages nsamples IQ samples in the context's device
+ * input buffer, whose address mgpu_device_iq_buffer() returns; follow with
+ * mgpu_feed_iq_device(ctx, mgpu_device_iq_buffer(ctx), nsamples) to demodulate them in place. */
+int   mgpu_upload_iq(mgpu_ctx *ctx, const void *iq_host, uint64_t nsamples);
+void *mgpu_device_iq_buffer(mgpu_ctx *ctx);
+
 /* The CPUs the context pinned its host threads to (one physical core each, one L3; 0 = not pinned, e.g. with
  * MGPU_NO_AFFINITY=1).  An application that wants the full speed keeps its own busy threads off these cores and
  * their SMT siblings: a thread of the application sharing a core with a pipeline stage costs up to 30 %. */
@@ -153,16 +164,6 @@ int mgpu_host_cpus(mgpu_ctx *ctx, int32_t *cpus, int32_t cap);
  * and overlap the kernels.  Unregister before freeing the buffer. */
 int mgpu_host_register(mgpu_ctx *ctx, void *ptr, uint64_t bytes);
 int mgpu_host_unregister(mgpu_ctx *ctx, void *ptr);
-
-/* Same, for IQ already resident in device memory (HBM): d_iq is a device pointer to
- * nsamples samples of cfg.format.  This is the entry the benchmark times. */
-int mgpu_feed_iq_device(mgpu_ctx *ctx, const void *d_iq, uint64_t nsamples);
-
-/* Host -> HBM copy only (no processing): stages nsamples IQ samples in the context's device
- * input buffer, whose address mgpu_device_iq_buffer() returns; follow with
- * mgpu_feed_iq_device(ctx, mgpu_device_iq_buffer(ctx), nsamples) to demodulate them in place. */
-int   mgpu_upload_iq(mgpu_ctx *ctx, const void *iq_host, uint64_t nsamples);
-void *mgpu_device_iq_buffer(mgpu_ctx *ctx);
 
 /* EOF handling of ifileRun: when the stream length is an exact multiple of buf_samples the
  * reference pushes one more zero-length buffer (sdr_ifile.c:223-237).  Call once at end. */

@@ -674,6 +674,36 @@ int modes_oracle_run(const struct modes_oracle_cfg *cfg, const uint8_t *iq, uint
     return 0;
 }
 
+/* Beast wire format of one accepted message: modesSendBeastOutput, net_io.c:1655-1714 (the frame part; the 0x1a 0xe3
+ * receiverId prefix is only sent with --net-receiver-id).  0x1a, type '2' (7 bytes) / '3' (14) / '1' (Mode A/C, 2),
+ * the 12 MHz timestamp as 6 bytes big-endian (netTimestamp :1620-1648), one byte of signal level, the message
+ * bytes; every 0x1a payload byte doubled.  Returns the number of bytes written (at most 2 + 2 * 21), 0 for a
+ * length the format does not carry. */
+size_t modes_oracle_beast_frame(const struct oracle_msg *m, uint8_t *out) {
+    uint8_t *p = out;
+    int msgLen = m->msgbits / 8;
+    *p++ = 0x1a;
+    if (msgLen == 7) *p++ = '2';
+    else if (msgLen == 14) *p++ = '3';
+    else if (msgLen == 2) *p++ = '1';
+    else return 0;
+    for (int sh = 40; sh >= 0; sh -= 8) {                       /* netTimestamp */
+        uint8_t ch = (uint8_t) (m->timestamp >> sh);
+        *p++ = ch;
+        if (ch == 0x1a) *p++ = ch;
+    }
+    int sig = (int) nearbyint(sqrt(m->signalLevel) * 255);      /* :1696-1700 */
+    if (m->signalLevel > 0 && sig < 1) sig = 1;
+    if (sig > 255) sig = 255;
+    { uint8_t ch = (uint8_t) sig; *p++ = ch; if (ch == 0x1a) *p++ = ch; }
+    for (int j = 0; j < msgLen; j++) {                          /* mm->msg: the corrected bytes (no --net-verbatim) */
+        uint8_t ch = m->msg[j];
+        *p++ = ch;
+        if (ch == 0x1a) *p++ = ch;
+    }
+    return (size_t) (p - out);
+}
+
 void modes_oracle_free(void *p) { free(p); }
 
 #ifdef MODES_ORACLE_MAIN

@@ -219,6 +219,15 @@ int mgpu_adder_bitmap_set(mgpu_ctx *ctx, const uint32_t *words /* 2^19 */);
 int mgpu_shard_packets(mgpu_ctx *ctx, const void **packets, uint64_t *bytes);   /* valid until the next reset */
 int mgpu_walk_packets(mgpu_ctx *ctx, const void *packets, uint64_t bytes);
 
+/* ---- beast wire output (modesSendBeastOutput, net_io.c:1655-1714) ------------------------------------
+ * Per message: 0x1a, type '2' (56-bit) / '3' (112-bit) / '1' (Mode A/C), the 12 MHz timestamp as 6 bytes
+ * big-endian, one signal byte clamp(nearbyint(sqrt(signalLevel) * 255), 1..255), the (corrected) message
+ * bytes; every 0x1a payload byte doubled; no 0x1a 0xe3 receiverId prefix.  Encoded on the GPU.
+ * _device: d_msgs / d_out are device pointers (e.g. the records an aggregator gathered into its HBM);
+ * *bytes = size of the stream; MGPU_E_OVERFLOW (with *bytes set) if it does not fit cap. */
+int mgpu_beast_encode_device(mgpu_ctx *ctx, const struct mgpu_msg *d_msgs, uint64_t n, uint8_t *d_out, uint64_t cap, uint64_t *bytes);
+int mgpu_beast_encode(mgpu_ctx *ctx, const struct mgpu_msg *msgs, uint64_t n, uint8_t *out, uint64_t cap, uint64_t *bytes);
+
 /* ---- tables, for known-answer tests against crc.c --------------------------------- */
 
 /* These run on the host (they are how the device tables are built) and need no context. */

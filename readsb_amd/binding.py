@@ -106,6 +106,8 @@ def load_library():
     lib.mgpu_collect.argtypes = [vp, vp, u64, C.POINTER(u64), C.POINTER(Counters)]
     lib.mgpu_pending_messages.argtypes = [vp]
     lib.mgpu_set_message_buffer.argtypes = [vp, vp, u64]
+    lib.mgpu_beast_encode.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64)]
+    lib.mgpu_beast_encode_device.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64)]
     lib.mgpu_shard_begin.argtypes = [vp, u64, vp, i32]
     lib.mgpu_adder_bitmap_get.argtypes = [vp, vp]
     lib.mgpu_adder_bitmap_set.argtypes = [vp, vp]
@@ -225,6 +227,22 @@ class Demodulator:
     def walk_packets(self, packets):
         packets = np.ascontiguousarray(packets, dtype=np.uint8)
         self._chk(self.lib.mgpu_walk_packets(self.ctx, C.c_void_p(packets.ctypes.data), C.c_uint64(packets.size)), "mgpu_walk_packets")
+
+    def beast_encode(self, msgs):
+        """Beast wire stream (bytes) of a record array (host memory in, host memory out, encoded on the GPU)."""
+        msgs = np.ascontiguousarray(msgs)
+        assert msgs.dtype == MSG_DTYPE
+        out = np.empty(len(msgs) * 44 + 64, dtype=np.uint8)
+        nb = C.c_uint64(0)
+        self._chk(self.lib.mgpu_beast_encode(self.ctx, C.c_void_p(msgs.ctypes.data), len(msgs), C.c_void_p(out.ctypes.data), out.size, C.byref(nb)),
+                  "mgpu_beast_encode")
+        return out[: nb.value].tobytes()
+
+    def beast_encode_device(self, d_msgs_ptr, n, d_out_ptr, cap):
+        """Same on device pointers (ints, e.g. torch tensor.data_ptr()); returns the stream's size in bytes."""
+        nb = C.c_uint64(0)
+        self._chk(self.lib.mgpu_beast_encode_device(self.ctx, C.c_void_p(d_msgs_ptr), n, C.c_void_p(d_out_ptr), cap, C.byref(nb)), "mgpu_beast_encode_device")
+        return int(nb.value)
 
     def host_cpus(self):
         """CPUs the context's host threads are pinned to (empty list: not pinned)."""

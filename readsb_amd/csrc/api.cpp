@@ -274,6 +274,11 @@ struct mgpu_ctx {
     // pre-screened records of every chunk as packets instead of walking them
     int shard_mode = 0;
     std::vector<uint8_t> shard_packets;
+    // beast encoder scratch (mgpu_beast_encode*): grown on demand
+    uint8_t *d_beast_len = nullptr, *d_beast_in = nullptr, *d_beast_out = nullptr;
+    uint32_t *d_beast_blocks = nullptr;
+    unsigned long long *d_beast_total = nullptr;
+    uint64_t beast_cap_msgs = 0, beast_cap_in = 0, beast_cap_out = 0;
     uint16_t *d_hist = nullptr;                               // magnitudes of the 326 samples before the shard
     uint8_t *d_hist_iq = nullptr;
     unsigned long long *d_hist_sums = nullptr;
@@ -636,7 +641,7 @@ void mgpu_destroy(mgpu_ctx *c) {
     if (c->stream_w) (void) hipStreamSynchronize(c->stream_w);
     for (auto &sl : c->slot) free_slot(sl);
     if (c->h_win) (void) hipHostFree(c->h_win);
-    void *dev[] = {c->d_hist, c->d_hist_iq, c->d_hist_sums, c->d_iq, c->d_win, c->d_adder_bitmap, c->d_bit_syndrome, c->d_group_syndrome, c->d_parity,
+    void *dev[] = {c->d_beast_len, c->d_beast_in, c->d_beast_out, c->d_beast_blocks, c->d_beast_total, c->d_hist, c->d_hist_iq, c->d_hist_sums, c->d_iq, c->d_win, c->d_adder_bitmap, c->d_bit_syndrome, c->d_group_syndrome, c->d_parity,
                    c->d_tab_long, c->d_tab_short, c->d_uc8_folded};
     for (void *p : dev)
         if (p) (void) hipFree(p);
@@ -1467,6 +1472,57 @@ int mgpu_walk_packets(mgpu_ctx *c, const void *packets, uint64_t bytes) {
         c->stream_pos += n;
         if (n % c->cfg.buf_samples) c->eof = true;
     }
+    return MGPU_OK;
+}
+
+// ---- beast wire format (net_io.c:1655-1714) for message records that already are in HBM -----------------------
+
+int mgpu_beast_encode_device(mgpu_ctx *c, const struct mgpu_msg *d_msgs, uint64_t n, uint8_t *d_out, uint64_t cap, uint64_t *bytes) {
+    if (!c || !bytes || (n && (!d_msgs || !d_out))) return MGPU_E_INVAL;
+    *bytes = 0;
+    if (n == 0) return MGPU_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (n > c->beast_cap_msgs) {
+        if (c->d_beast_len) (void) hipFree(c->d_beast_len);
+        if (c->d_beast_blocks) (void) hipFree(c->d_beast_blocks);
+        c->d_beast_len = nullptr; c->d_beast_blocks = nullptr; c->beast_cap_msgs = 0;
+        const uint64_t want = n + n / 4 + 1024;
+        HIPCHK(c, hipMalloc(&c->d_beast_len, want));
+        HIPCHK(c, hipMalloc(&c->d_beast_blocks, (want / kBlock + 2) * sizeof(uint32_t)));
+        c->beast_cap_msgs = want;
+    }
+    if (!c->d_beast_total) HIPCHK(c, hipMalloc(&c->d_beast_total, sizeof(unsigned long long)));
+    launch_beast_encode(d_msgs, n, c->d_beast_len, c->d_beast_blocks, d_out, cap, c->d_beast_total, c->stream);
+    unsigned long long total = 0;
+    HIPCHK(c, hipMemcpyAsync(&total, c->d_beast_total, sizeof(total), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *bytes = total;
+    if (total > cap) { c->err = "mgpu_beast_encode: output buffer too small"; return MGPU_E_OVERFLOW; }
+    return MGPU_OK;
+}
+
+int mgpu_beast_encode(mgpu_ctx *c, const struct mgpu_msg *msgs, uint64_t n, uint8_t *out, uint64_t cap, uint64_t *bytes) {
+    if (!c || !bytes || (n && (!msgs || !out))) return MGPU_E_INVAL;
+    *bytes = 0;
+    if (n == 0) return MGPU_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (n * sizeof(mgpu_msg) > c->beast_cap_in) {
+        if (c->d_beast_in) (void) hipFree(c->d_beast_in);
+        c->d_beast_in = nullptr; c->beast_cap_in = 0;
+        const uint64_t want = (n + n / 4 + 1024) * sizeof(mgpu_msg);
+        HIPCHK(c, hipMalloc(&c->d_beast_in, want));
+        c->beast_cap_in = want;
+    }
+    if (cap > c->beast_cap_out) {
+        if (c->d_beast_out) (void) hipFree(c->d_beast_out);
+        c->d_beast_out = nullptr; c->beast_cap_out = 0;
+        HIPCHK(c, hipMalloc(&c->d_beast_out, cap + 64));
+        c->beast_cap_out = cap;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_beast_in, msgs, n * sizeof(mgpu_msg), hipMemcpyHostToDevice, c->stream));
+    const int rc = mgpu_beast_encode_device(c, (const mgpu_msg *) c->d_beast_in, n, c->d_beast_out, cap, bytes);
+    if (rc != MGPU_OK) return rc;
+    HIPCHK(c, hipMemcpy(out, c->d_beast_out, *bytes, hipMemcpyDeviceToHost));
     return MGPU_OK;
 }
 

@@ -87,8 +87,11 @@ struct einfo { uint32_t syndrome; int errors; int bit[2]; };
 static struct einfo *tab_short, *tab_long;
 static int n_short, n_long;
 
+static void crc_lookup_init(void);
+
 /* modesChecksum, crc.c:67-82 */
 uint32_t modes_oracle_checksum(const uint8_t *msg, int bits) {
+    if (!crc_ready) crc_lookup_init();
     uint32_t rem = 0;
     int n = bits / 8;
     for (int i = 0; i < n - 3; ++i) {

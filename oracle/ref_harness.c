@@ -224,6 +224,99 @@ int ref_demod_run(int format, int nfix, int fixdf, int thr,
 
 /* CRC KATs (the reference's only pinned numbers for crc.c are the table sizes printed by
  * `crctests`): expose checksum + diagnose so tests can compare tables. */
+/* ---- field decode: decodeModesMessage / decodeModeAMessage on one frame, struct modesMessage -> oracle_fields ---- */
+
+static int g_fields_ready;
+
+/* modesInit's order for what the decode needs: CRC tables, ICAO filter, the Mode A -> Mode C table. */
+int ref_fields_init(int nfix) {
+    if (g_fields_ready) return 0;
+    if (!g_configured) {
+        if (ref_configure(ORACLE_FMT_UC8, nfix, 1, 58) != 0) return -1;
+    }
+    modeACInit();
+    g_fields_ready = 1;
+    return 0;
+}
+
+static void fields_from_mm(const struct modesMessage *mm, struct oracle_fields *f) {
+    memset(f, 0, sizeof(*f));
+    f->addr = mm->addr; f->AA = mm->AA;
+    f->flags = (mm->baro_alt_valid ? ORACLE_F_BARO_ALT_VALID : 0) | (mm->geom_alt_valid ? ORACLE_F_GEOM_ALT_VALID : 0)
+        | (mm->heading_valid ? ORACLE_F_HEADING_VALID : 0) | (mm->gs_valid ? ORACLE_F_GS_VALID : 0)
+        | (mm->ias_valid ? ORACLE_F_IAS_VALID : 0) | (mm->tas_valid ? ORACLE_F_TAS_VALID : 0)
+        | (mm->baro_rate_valid ? ORACLE_F_BARO_RATE_VALID : 0) | (mm->geom_rate_valid ? ORACLE_F_GEOM_RATE_VALID : 0)
+        | (mm->squawk_valid ? ORACLE_F_SQUAWK_VALID : 0) | (mm->callsign_valid ? ORACLE_F_CALLSIGN_VALID : 0)
+        | (mm->cpr_valid ? ORACLE_F_CPR_VALID : 0) | (mm->cpr_odd ? ORACLE_F_CPR_ODD : 0)
+        | (mm->category_valid ? ORACLE_F_CATEGORY_VALID : 0) | (mm->geom_delta_valid ? ORACLE_F_GEOM_DELTA_VALID : 0)
+        | (mm->spi_valid ? ORACLE_F_SPI_VALID : 0) | (mm->spi ? ORACLE_F_SPI : 0)
+        | (mm->alert_valid ? ORACLE_F_ALERT_VALID : 0) | (mm->alert ? ORACLE_F_ALERT : 0)
+        | (mm->emergency_valid ? ORACLE_F_EMERGENCY_VALID : 0) | (mm->alt_q_bit ? ORACLE_F_ALT_Q_BIT : 0)
+        | (mm->acas_ra_valid ? ORACLE_F_ACAS_RA_VALID : 0);
+    f->acc_flags = (mm->accuracy.nic_a_valid ? ORACLE_ACC_NIC_A_VALID : 0) | (mm->accuracy.nic_b_valid ? ORACLE_ACC_NIC_B_VALID : 0)
+        | (mm->accuracy.nic_c_valid ? ORACLE_ACC_NIC_C_VALID : 0) | (mm->accuracy.nic_baro_valid ? ORACLE_ACC_NIC_BARO_VALID : 0)
+        | (mm->accuracy.nac_p_valid ? ORACLE_ACC_NAC_P_VALID : 0) | (mm->accuracy.nac_v_valid ? ORACLE_ACC_NAC_V_VALID : 0)
+        | (mm->accuracy.gva_valid ? ORACLE_ACC_GVA_VALID : 0) | (mm->accuracy.sda_valid ? ORACLE_ACC_SDA_VALID : 0)
+        | (mm->accuracy.nic_a ? ORACLE_ACC_NIC_A : 0) | (mm->accuracy.nic_b ? ORACLE_ACC_NIC_B : 0)
+        | (mm->accuracy.nic_c ? ORACLE_ACC_NIC_C : 0) | (mm->accuracy.nic_baro ? ORACLE_ACC_NIC_BARO : 0);
+    f->nav_flags = (mm->nav.heading_valid ? ORACLE_NAV_HEADING_VALID : 0) | (mm->nav.fms_altitude_valid ? ORACLE_NAV_FMS_ALT_VALID : 0)
+        | (mm->nav.mcp_altitude_valid ? ORACLE_NAV_MCP_ALT_VALID : 0) | (mm->nav.qnh_valid ? ORACLE_NAV_QNH_VALID : 0)
+        | (mm->nav.modes_valid ? ORACLE_NAV_MODES_VALID : 0);
+    f->msgtype = mm->msgtype; f->addrtype = mm->addrtype; f->source = mm->source; f->airground = mm->airground;
+    f->metype = mm->metype; f->mesub = mm->mesub; f->CA = mm->CA; f->CC = mm->CC; f->CF = mm->CF;
+    f->DR = mm->DR; f->FS = mm->FS; f->KE = mm->KE; f->ND = mm->ND; f->RI = mm->RI; f->SL = mm->SL; f->UM = mm->UM; f->VS = mm->VS;
+    f->IID = mm->IID; f->category = mm->category; f->emergency = mm->emergency; f->cpr_type = mm->cpr_type;
+    f->AC = mm->AC; f->ID = mm->ID; f->squawkHex = mm->squawkHex; f->squawkDec = mm->squawkDec;
+    f->baro_alt = mm->baro_alt; f->geom_alt = mm->geom_alt; f->geom_delta = mm->geom_delta;
+    f->baro_rate = mm->baro_rate; f->geom_rate = mm->geom_rate; f->ias = mm->ias; f->tas = mm->tas;
+    f->heading = mm->heading; f->gs_v0 = mm->gs.v0; f->gs_v2 = mm->gs.v2; f->gs_selected = mm->gs.selected;
+    f->cpr_lat = mm->cpr_lat; f->cpr_lon = mm->cpr_lon;
+    memcpy(f->callsign, mm->callsign, 8);
+    f->baro_alt_unit = mm->baro_alt_unit; f->geom_alt_unit = mm->geom_alt_unit; f->heading_type = mm->heading_type;
+    f->sil_type = mm->accuracy.sil_type; f->nac_p = mm->accuracy.nac_p; f->nac_v = mm->accuracy.nac_v;
+    f->sil = mm->accuracy.sil; f->gva = mm->accuracy.gva; f->sda = mm->accuracy.sda;
+    f->op_version = mm->opstatus.version; f->op_hrd = mm->opstatus.hrd; f->op_tah = mm->opstatus.tah;
+    f->op_flags = (mm->opstatus.valid ? ORACLE_OP_VALID : 0) | (mm->opstatus.om_acas_ra ? ORACLE_OP_OM_ACAS_RA : 0)
+        | (mm->opstatus.om_ident ? ORACLE_OP_OM_IDENT : 0) | (mm->opstatus.om_atc ? ORACLE_OP_OM_ATC : 0)
+        | (mm->opstatus.om_saf ? ORACLE_OP_OM_SAF : 0) | (mm->opstatus.cc_acas ? ORACLE_OP_CC_ACAS : 0)
+        | (mm->opstatus.cc_cdti ? ORACLE_OP_CC_CDTI : 0) | (mm->opstatus.cc_1090_in ? ORACLE_OP_CC_1090_IN : 0)
+        | (mm->opstatus.cc_arv ? ORACLE_OP_CC_ARV : 0) | (mm->opstatus.cc_ts ? ORACLE_OP_CC_TS : 0)
+        | (mm->opstatus.cc_uat_in ? ORACLE_OP_CC_UAT_IN : 0) | (mm->opstatus.cc_poa ? ORACLE_OP_CC_POA : 0)
+        | (mm->opstatus.cc_b2_low ? ORACLE_OP_CC_B2_LOW : 0) | (mm->opstatus.cc_lw_valid ? ORACLE_OP_CC_LW_VALID : 0);
+    f->op_cc_lw = mm->opstatus.cc_lw; f->op_cc_antenna_offset = mm->opstatus.cc_antenna_offset; f->op_cc_tc = mm->opstatus.cc_tc;
+    f->nav_heading_type = mm->nav.heading_type; f->nav_altitude_source = mm->nav.altitude_source; f->nav_modes = mm->nav.modes;
+    f->nav_fms_altitude = mm->nav.fms_altitude; f->nav_mcp_altitude = mm->nav.mcp_altitude;
+    f->nav_qnh = mm->nav.qnh; f->nav_heading = mm->nav.heading;
+}
+
+/* One frame (corrected bytes, as netUseMessage sees mm->msg): msgbits 56/112 -> decodeModesMessage, 16 -> the
+ * Mode A/C reply decodeModeAMessage builds.  Address/Parity formats need their address in the ICAO filter to get
+ * past the CRC stage (mode_s.c:477-482,572-581): it is added first, as it was when the frame was accepted in-stream.
+ * Returns decodeResult (0 = decoded). */
+int ref_decode_fields(const uint8_t *msg, int msgbits, struct oracle_fields *out) {
+    static struct modesMessage mm;
+    memset(&mm, 0, sizeof(mm));
+    if (msgbits == 16) {
+        decodeModeAMessage(&mm, (msg[0] << 8) | msg[1]);
+        fields_from_mm(&mm, out);
+        return 0;
+    }
+    memcpy(mm.msg, msg, 14);
+    const int df = msg[0] >> 3;
+    if (df != 11 && df != 17 && df != 18) icaoFilterAdd(modesChecksum((uint8_t *) msg, modesMessageLenByType(df)));
+    const int rc = decodeModesMessage(&mm);
+    fields_from_mm(&mm, out);
+    return rc;
+}
+
+/* n frames of 14 bytes each; rc[i] = decodeResult.  The filter is flipped regularly so it does not fill up. */
+void ref_decode_fields_batch(const uint8_t *msgs, const int32_t *msgbits, uint64_t n, struct oracle_fields *out, int32_t *rc) {
+    for (uint64_t i = 0; i < n; ++i) {
+        if ((i & 0xffff) == 0xffff) { icaoFilterExpire(); icaoFilterExpire(); }
+        rc[i] = ref_decode_fields(msgs + 14 * i, msgbits[i], &out[i]);
+    }
+}
+
 uint32_t ref_modesChecksum(const uint8_t *msg, int bits) { return modesChecksum((uint8_t *) msg, bits); }
 
 /* returns number of error bits (0..2) or -1 when uncorrectable; bit positions in b0/b1 */

@@ -228,6 +228,107 @@ int mgpu_walk_packets(mgpu_ctx *ctx, const void *packets, uint64_t bytes);
 int mgpu_beast_encode_device(mgpu_ctx *ctx, const struct mgpu_msg *d_msgs, uint64_t n, uint8_t *d_out, uint64_t cap, uint64_t *bytes);
 int mgpu_beast_encode(mgpu_ctx *ctx, const struct mgpu_msg *msgs, uint64_t n, uint8_t *out, uint64_t cap, uint64_t *bytes);
 
+/* ---- per-message field decode (decodeModesMessage behind the CRC stage, mode_s.c:598-760; decodeExtendedSquitter and
+ * its ME decoders, mode_s.c:806-1555; decodeModeAMessage, mode_ac.c:171-200) ---------------------------------------
+ * One record per message, same index, decoded on the GPU from the corrected frame: the raw Annex-10 fields, altitude,
+ * squawk, callsign, velocity, CPR words, the accuracy / operational-status / target-state groups — the members of
+ * struct modesMessage (readsb.h:887-1143) under the same names; enums carry the reference's numeric values
+ * (addrtype_t readsb.h:178, datasource_t :159, airground_t :216, heading_type_t :239, sil_type_t :224, cpr_type_t :229,
+ * nav_modes_t :263, nav_altitude_source_t :287, emergency_t :275, altitude_unit_t :204).  What a memset-0 modesMessage
+ * would hold stays 0.  MB/MD/ME/MV are msg[4..10] / msg[1..10] of the message record and are not repeated.
+ * Not decoded: the Comm-B payload of DF20/21 (decodeCommB, comm_b.c).  144 bytes. */
+struct mgpu_fields {
+    uint32_t addr;              /* mm->addr (with MODES_NON_ICAO_ADDRESS = 1<<24 where the ME decode says so) */
+    uint32_t AA;
+    uint32_t flags;             /* MGPU_F_* */
+    uint16_t acc_flags;         /* MGPU_ACC_* */
+    uint8_t  nav_flags;         /* MGPU_NAV_* */
+    uint8_t  msgtype;           /* DF, 77 = Mode A/C */
+    uint8_t  addrtype, source, airground, metype;
+    uint8_t  mesub, CA, CC, CF;
+    uint8_t  DR, FS, KE, ND;
+    uint8_t  RI, SL, UM, VS;
+    uint8_t  IID, category, emergency, cpr_type;
+    uint16_t AC, ID;
+    uint16_t squawkHex, squawkDec;
+    int32_t  baro_alt, geom_alt;
+    int32_t  geom_delta, baro_rate, geom_rate;
+    uint16_t ias, tas;
+    float    heading, gs_v0, gs_v2, gs_selected;
+    uint32_t cpr_lat, cpr_lon;
+    char     callsign[8];
+    uint8_t  baro_alt_unit, geom_alt_unit, heading_type, sil_type;
+    uint8_t  nac_p, nac_v, sil, gva;
+    uint8_t  sda, op_version, op_hrd, op_tah;
+    uint16_t op_flags;          /* MGPU_OP_* */
+    uint8_t  op_cc_lw, op_cc_antenna_offset;
+    uint8_t  op_cc_tc, nav_heading_type, nav_altitude_source, nav_modes;
+    uint32_t nav_fms_altitude, nav_mcp_altitude;
+    float    nav_qnh, nav_heading;
+    uint8_t  reserved[8];
+};
+
+/* flags: the bools of struct modesMessage (readsb.h:954-993) */
+#define MGPU_F_BARO_ALT_VALID   (1u << 0)
+#define MGPU_F_GEOM_ALT_VALID   (1u << 1)
+#define MGPU_F_HEADING_VALID    (1u << 2)
+#define MGPU_F_GS_VALID         (1u << 3)
+#define MGPU_F_IAS_VALID        (1u << 4)
+#define MGPU_F_TAS_VALID        (1u << 5)
+#define MGPU_F_BARO_RATE_VALID  (1u << 6)
+#define MGPU_F_GEOM_RATE_VALID  (1u << 7)
+#define MGPU_F_SQUAWK_VALID     (1u << 8)
+#define MGPU_F_CALLSIGN_VALID   (1u << 9)
+#define MGPU_F_CPR_VALID        (1u << 10)
+#define MGPU_F_CPR_ODD          (1u << 11)
+#define MGPU_F_CATEGORY_VALID   (1u << 12)
+#define MGPU_F_GEOM_DELTA_VALID (1u << 13)
+#define MGPU_F_SPI_VALID        (1u << 14)
+#define MGPU_F_SPI              (1u << 15)
+#define MGPU_F_ALERT_VALID      (1u << 16)
+#define MGPU_F_ALERT            (1u << 17)
+#define MGPU_F_EMERGENCY_VALID  (1u << 18)
+#define MGPU_F_ALT_Q_BIT        (1u << 19)
+#define MGPU_F_ACAS_RA_VALID    (1u << 20)
+/* acc_flags: mm->accuracy (readsb.h:1061-1086) */
+#define MGPU_ACC_NIC_A_VALID    (1u << 0)
+#define MGPU_ACC_NIC_B_VALID    (1u << 1)
+#define MGPU_ACC_NIC_C_VALID    (1u << 2)
+#define MGPU_ACC_NIC_BARO_VALID (1u << 3)
+#define MGPU_ACC_NAC_P_VALID    (1u << 4)
+#define MGPU_ACC_NAC_V_VALID    (1u << 5)
+#define MGPU_ACC_GVA_VALID      (1u << 6)
+#define MGPU_ACC_SDA_VALID      (1u << 7)
+#define MGPU_ACC_NIC_A          (1u << 8)
+#define MGPU_ACC_NIC_B          (1u << 9)
+#define MGPU_ACC_NIC_C          (1u << 10)
+#define MGPU_ACC_NIC_BARO       (1u << 11)
+/* nav_flags: mm->nav (readsb.h:1127-1142) */
+#define MGPU_NAV_HEADING_VALID  (1u << 0)
+#define MGPU_NAV_FMS_ALT_VALID  (1u << 1)
+#define MGPU_NAV_MCP_ALT_VALID  (1u << 2)
+#define MGPU_NAV_QNH_VALID      (1u << 3)
+#define MGPU_NAV_MODES_VALID    (1u << 4)
+/* op_flags: the one-bit members of mm->opstatus (readsb.h:1103-1120) */
+#define MGPU_OP_VALID       (1u << 0)
+#define MGPU_OP_OM_ACAS_RA  (1u << 1)
+#define MGPU_OP_OM_IDENT    (1u << 2)
+#define MGPU_OP_OM_ATC      (1u << 3)
+#define MGPU_OP_OM_SAF      (1u << 4)
+#define MGPU_OP_CC_ACAS     (1u << 5)
+#define MGPU_OP_CC_CDTI     (1u << 6)
+#define MGPU_OP_CC_1090_IN  (1u << 7)
+#define MGPU_OP_CC_ARV      (1u << 8)
+#define MGPU_OP_CC_TS       (1u << 9)
+#define MGPU_OP_CC_UAT_IN   (1u << 10)
+#define MGPU_OP_CC_POA      (1u << 11)
+#define MGPU_OP_CC_B2_LOW   (1u << 12)
+#define MGPU_OP_CC_LW_VALID (1u << 13)
+
+/* msgs / out in host memory (copied through the context's device scratch), or both in device memory. */
+int mgpu_decode_fields(mgpu_ctx *ctx, const struct mgpu_msg *msgs, uint64_t n, struct mgpu_fields *out);
+int mgpu_decode_fields_device(mgpu_ctx *ctx, const struct mgpu_msg *d_msgs, uint64_t n, struct mgpu_fields *d_out);
+
 /* ---- tables, for known-answer tests against crc.c --------------------------------- */
 
 /* These run on the host (they are how the device tables are built) and need no context. */

@@ -21,6 +21,29 @@ MSG_DTYPE = np.dtype([
 ])
 assert MSG_DTYPE.itemsize == 64
 
+# struct mgpu_fields (include/modes_gpu.h): the per-message field decode
+FIELDS_DTYPE = np.dtype([
+    ("addr", "<u4"), ("AA", "<u4"), ("flags", "<u4"), ("acc_flags", "<u2"), ("nav_flags", "u1"), ("msgtype", "u1"),
+    ("addrtype", "u1"), ("source", "u1"), ("airground", "u1"), ("metype", "u1"),
+    ("mesub", "u1"), ("CA", "u1"), ("CC", "u1"), ("CF", "u1"),
+    ("DR", "u1"), ("FS", "u1"), ("KE", "u1"), ("ND", "u1"),
+    ("RI", "u1"), ("SL", "u1"), ("UM", "u1"), ("VS", "u1"),
+    ("IID", "u1"), ("category", "u1"), ("emergency", "u1"), ("cpr_type", "u1"),
+    ("AC", "<u2"), ("ID", "<u2"), ("squawkHex", "<u2"), ("squawkDec", "<u2"),
+    ("baro_alt", "<i4"), ("geom_alt", "<i4"), ("geom_delta", "<i4"), ("baro_rate", "<i4"), ("geom_rate", "<i4"),
+    ("ias", "<u2"), ("tas", "<u2"),
+    ("heading", "<f4"), ("gs_v0", "<f4"), ("gs_v2", "<f4"), ("gs_selected", "<f4"),
+    ("cpr_lat", "<u4"), ("cpr_lon", "<u4"), ("callsign", "S8"),
+    ("baro_alt_unit", "u1"), ("geom_alt_unit", "u1"), ("heading_type", "u1"), ("sil_type", "u1"),
+    ("nac_p", "u1"), ("nac_v", "u1"), ("sil", "u1"), ("gva", "u1"),
+    ("sda", "u1"), ("op_version", "u1"), ("op_hrd", "u1"), ("op_tah", "u1"),
+    ("op_flags", "<u2"), ("op_cc_lw", "u1"), ("op_cc_antenna_offset", "u1"),
+    ("op_cc_tc", "u1"), ("nav_heading_type", "u1"), ("nav_altitude_source", "u1"), ("nav_modes", "u1"),
+    ("nav_fms_altitude", "<u4"), ("nav_mcp_altitude", "<u4"), ("nav_qnh", "<f4"), ("nav_heading", "<f4"),
+    ("reserved", "u1", 8),
+])
+assert FIELDS_DTYPE.itemsize == 144
+
 
 class Config(C.Structure):
     _fields_ = [
@@ -106,6 +129,8 @@ def load_library():
     lib.mgpu_collect.argtypes = [vp, vp, u64, C.POINTER(u64), C.POINTER(Counters)]
     lib.mgpu_pending_messages.argtypes = [vp]
     lib.mgpu_set_message_buffer.argtypes = [vp, vp, u64]
+    lib.mgpu_decode_fields.argtypes = [vp, vp, u64, vp]
+    lib.mgpu_decode_fields_device.argtypes = [vp, vp, u64, vp]
     lib.mgpu_beast_encode.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64)]
     lib.mgpu_beast_encode_device.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64)]
     lib.mgpu_shard_begin.argtypes = [vp, u64, vp, i32]
@@ -227,6 +252,17 @@ class Demodulator:
     def walk_packets(self, packets):
         packets = np.ascontiguousarray(packets, dtype=np.uint8)
         self._chk(self.lib.mgpu_walk_packets(self.ctx, C.c_void_p(packets.ctypes.data), C.c_uint64(packets.size)), "mgpu_walk_packets")
+
+    def decode_fields(self, msgs):
+        """Per-message field records (FIELDS_DTYPE) of a message record array, decoded on the GPU."""
+        msgs = np.ascontiguousarray(msgs)
+        assert msgs.dtype == MSG_DTYPE
+        out = np.empty(len(msgs), dtype=FIELDS_DTYPE)
+        self._chk(self.lib.mgpu_decode_fields(self.ctx, C.c_void_p(msgs.ctypes.data), len(msgs), C.c_void_p(out.ctypes.data)), "mgpu_decode_fields")
+        return out
+
+    def decode_fields_device(self, d_msgs_ptr, n, d_out_ptr):
+        self._chk(self.lib.mgpu_decode_fields_device(self.ctx, C.c_void_p(d_msgs_ptr), n, C.c_void_p(d_out_ptr)), "mgpu_decode_fields_device")
 
     def beast_encode(self, msgs):
         """Beast wire stream (bytes) of a record array (host memory in, host memory out, encoded on the GPU)."""

@@ -276,6 +276,8 @@ struct mgpu_ctx {
     std::vector<uint8_t> shard_packets;
     // beast encoder scratch (mgpu_beast_encode*): grown on demand
     uint8_t *d_beast_len = nullptr, *d_beast_in = nullptr, *d_beast_out = nullptr;
+    mgpu_fields *d_fields = nullptr;
+    uint64_t fields_cap = 0;
     uint32_t *d_beast_blocks = nullptr;
     unsigned long long *d_beast_total = nullptr;
     uint64_t beast_cap_msgs = 0, beast_cap_in = 0, beast_cap_out = 0;
@@ -641,7 +643,7 @@ void mgpu_destroy(mgpu_ctx *c) {
     if (c->stream_w) (void) hipStreamSynchronize(c->stream_w);
     for (auto &sl : c->slot) free_slot(sl);
     if (c->h_win) (void) hipHostFree(c->h_win);
-    void *dev[] = {c->d_beast_len, c->d_beast_in, c->d_beast_out, c->d_beast_blocks, c->d_beast_total, c->d_hist, c->d_hist_iq, c->d_hist_sums, c->d_iq, c->d_win, c->d_adder_bitmap, c->d_bit_syndrome, c->d_group_syndrome, c->d_parity,
+    void *dev[] = {c->d_fields, c->d_beast_len, c->d_beast_in, c->d_beast_out, c->d_beast_blocks, c->d_beast_total, c->d_hist, c->d_hist_iq, c->d_hist_sums, c->d_iq, c->d_win, c->d_adder_bitmap, c->d_bit_syndrome, c->d_group_syndrome, c->d_parity,
                    c->d_tab_long, c->d_tab_short, c->d_uc8_folded};
     for (void *p : dev)
         if (p) (void) hipFree(p);
@@ -1523,6 +1525,44 @@ int mgpu_beast_encode(mgpu_ctx *c, const struct mgpu_msg *msgs, uint64_t n, uint
     const int rc = mgpu_beast_encode_device(c, (const mgpu_msg *) c->d_beast_in, n, c->d_beast_out, cap, bytes);
     if (rc != MGPU_OK) return rc;
     HIPCHK(c, hipMemcpy(out, c->d_beast_out, *bytes, hipMemcpyDeviceToHost));
+    return MGPU_OK;
+}
+
+// ---- per-message field decode (mode_s.c:598-760, 806-1555; mode_ac.c:171-200) --------------------------------------
+
+int mgpu_decode_fields_device(mgpu_ctx *c, const struct mgpu_msg *d_msgs, uint64_t n, struct mgpu_fields *d_out) {
+    if (!c || (n && (!d_msgs || !d_out))) return MGPU_E_INVAL;
+    if (n == 0) return MGPU_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    launch_decode_fields(d_msgs, n, d_out, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MGPU_OK;
+}
+
+int mgpu_decode_fields(mgpu_ctx *c, const struct mgpu_msg *msgs, uint64_t n, struct mgpu_fields *out) {
+    if (!c || (n && (!msgs || !out))) return MGPU_E_INVAL;
+    if (n == 0) return MGPU_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (n * sizeof(mgpu_msg) > c->beast_cap_in) {
+        if (c->d_beast_in) (void) hipFree(c->d_beast_in);
+        c->d_beast_in = nullptr; c->beast_cap_in = 0;
+        const uint64_t want = (n + n / 4 + 1024) * sizeof(mgpu_msg);
+        HIPCHK(c, hipMalloc(&c->d_beast_in, want));
+        c->beast_cap_in = want;
+    }
+    if (n > c->fields_cap) {
+        if (c->d_fields) (void) hipFree(c->d_fields);
+        c->d_fields = nullptr; c->fields_cap = 0;
+        const uint64_t want = n + n / 4 + 1024;
+        HIPCHK(c, hipMalloc(&c->d_fields, want * sizeof(mgpu_fields)));
+        c->fields_cap = want;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_beast_in, msgs, n * sizeof(mgpu_msg), hipMemcpyHostToDevice, c->stream));
+    launch_decode_fields((const mgpu_msg *) c->d_beast_in, n, c->d_fields, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, c->d_fields, n * sizeof(mgpu_fields), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return MGPU_OK;
 }
 

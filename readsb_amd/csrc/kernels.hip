@@ -16,7 +16,7 @@
 // ops with contraction disabled and a correctly rounded sqrt.
 // One translation unit, in parts (kernels/*.inc, included below in dependency order):
 //   convert | sweep_gen1, slicer, sweep_gen2 (earlier generations, MGPU_SWEEP_VERSION=1|2) | sweep_slice (generation 3,
-//   the default) | sweep_gen4 (split experiment) | class_finalize, prescreen (post-sweep stage) | modeac | window_stats | beast (wire encoder)
+//   the default) | sweep_gen4 (split experiment) | class_finalize, prescreen (post-sweep stage) | modeac | window_stats | beast (wire encoder) | fields (per-message field decode)
 #include "kernels.h"
 #include "tables.h"
 
@@ -98,5 +98,6 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 #include "kernels/modeac.inc"
 #include "kernels/window_stats.inc"
 #include "kernels/beast.inc"
+#include "kernels/fields.inc"
 
 }  // namespace mgpu

@@ -275,7 +275,9 @@ struct mgpu_ctx {
     int shard_mode = 0;
     std::vector<uint8_t> shard_packets;
     // beast encoder scratch (mgpu_beast_encode*): grown on demand
-    uint8_t *d_beast_len = nullptr, *d_beast_in = nullptr, *d_beast_out = nullptr;
+    uint16_t *d_beast_len = nullptr;        // per message: frame length | signal byte << 8
+    uint8_t *d_beast_in = nullptr, *d_beast_out = nullptr;
+    unsigned long long *d_beast_off = nullptr;
     mgpu_fields *d_fields = nullptr;
     uint64_t fields_cap = 0;
     uint32_t *d_beast_blocks = nullptr;
@@ -643,7 +645,7 @@ void mgpu_destroy(mgpu_ctx *c) {
     if (c->stream_w) (void) hipStreamSynchronize(c->stream_w);
     for (auto &sl : c->slot) free_slot(sl);
     if (c->h_win) (void) hipHostFree(c->h_win);
-    void *dev[] = {c->d_fields, c->d_beast_len, c->d_beast_in, c->d_beast_out, c->d_beast_blocks, c->d_beast_total, c->d_hist, c->d_hist_iq, c->d_hist_sums, c->d_iq, c->d_win, c->d_adder_bitmap, c->d_bit_syndrome, c->d_group_syndrome, c->d_parity,
+    void *dev[] = {c->d_fields, c->d_beast_off, c->d_beast_len, c->d_beast_in, c->d_beast_out, c->d_beast_blocks, c->d_beast_total, c->d_hist, c->d_hist_iq, c->d_hist_sums, c->d_iq, c->d_win, c->d_adder_bitmap, c->d_bit_syndrome, c->d_group_syndrome, c->d_parity,
                    c->d_tab_long, c->d_tab_short, c->d_uc8_folded};
     for (void *p : dev)
         if (p) (void) hipFree(p);
@@ -1487,14 +1489,16 @@ int mgpu_beast_encode_device(mgpu_ctx *c, const struct mgpu_msg *d_msgs, uint64_
     if (n > c->beast_cap_msgs) {
         if (c->d_beast_len) (void) hipFree(c->d_beast_len);
         if (c->d_beast_blocks) (void) hipFree(c->d_beast_blocks);
-        c->d_beast_len = nullptr; c->d_beast_blocks = nullptr; c->beast_cap_msgs = 0;
+        if (c->d_beast_off) (void) hipFree(c->d_beast_off);
+        c->d_beast_len = nullptr; c->d_beast_blocks = nullptr; c->d_beast_off = nullptr; c->beast_cap_msgs = 0;
         const uint64_t want = n + n / 4 + 1024;
-        HIPCHK(c, hipMalloc(&c->d_beast_len, want));
+        HIPCHK(c, hipMalloc(&c->d_beast_len, want * sizeof(uint16_t)));
         HIPCHK(c, hipMalloc(&c->d_beast_blocks, (want / kBlock + 2) * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(&c->d_beast_off, (want / kBlock + 2) * sizeof(unsigned long long)));
         c->beast_cap_msgs = want;
     }
     if (!c->d_beast_total) HIPCHK(c, hipMalloc(&c->d_beast_total, sizeof(unsigned long long)));
-    launch_beast_encode(d_msgs, n, c->d_beast_len, c->d_beast_blocks, d_out, cap, c->d_beast_total, c->stream);
+    launch_beast_encode(d_msgs, n, c->d_beast_len, c->d_beast_blocks, c->d_beast_off, d_out, cap, c->d_beast_total, c->stream);
     unsigned long long total = 0;
     HIPCHK(c, hipMemcpyAsync(&total, c->d_beast_total, sizeof(total), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

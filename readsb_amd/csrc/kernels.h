@@ -158,8 +158,8 @@ void launch_modeac(const uint16_t *mag, uint64_t n, uint32_t buf_samples, int fo
 // beast wire frames (modesSendBeastOutput, net_io.c:1655-1714) of n message records in device memory; len [n] and
 // block_bytes [ceil(n/256)] are scratch; *total (device) receives the number of bytes the frames take
 void launch_decode_fields(const mgpu_msg *msgs, uint64_t n, mgpu_fields *out, hipStream_t s);
-void launch_beast_encode(const mgpu_msg *msgs, uint64_t n, uint8_t *len, uint32_t *block_bytes, uint8_t *out, uint64_t cap,
-                         unsigned long long *total, hipStream_t s);
+void launch_beast_encode(const mgpu_msg *msgs, uint64_t n, uint16_t *meta, uint32_t *block_bytes, unsigned long long *block_off, uint8_t *out,
+                         uint64_t cap, unsigned long long *total, hipStream_t s);
 // signal power of accepted messages: sum of mag^2 over d_mag[pos+19 .. pos+19+len)
 void launch_signal_power(const uint16_t *mag, const uint32_t *pos, const uint16_t *len, uint32_t nmsg,
                          unsigned long long *out, hipStream_t s);

@@ -7,12 +7,13 @@
  *   decodeAC13Field/decodeAC12Field/decodeID13Field/decodeMovementFieldV0/V2  mode_s.c:82-241
  *   modeAToModeC / internalModeAToModeC  mode_ac.c:80-170, modeAToIndex track.h:724
  *   decodeModeAMessage  mode_ac.c:171-200 (msgbits == 16)
- * Not restated: decodeCommB (comm_b.c) — the MB payload of DF20/21 is left undecoded.
+ *   decodeCommB and its nine register hypotheses  comm_b.c:52-961 (DF20/21)
  * Pinned against the reference's own decodeModesMessage (oracle/_ref, ref_decode_fields) by tests/test_oracle_fields.py.
  *
  * Written around one 56-bit integer per field group (the first 32 bits of the frame, the ME block) and a
  * "bits first..last, 1-based, MSB first" extractor — the numbering the reference's comments and Annex 10 use. */
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include "modes_oracle.h"
 
@@ -408,6 +409,218 @@ static void extended_squitter(struct oracle_fields *f, uint64_t me) {   /* decod
     else if (t == 31) es_opstatus(f, me, check_imf);
 }
 
+/* ------------------------------------------------------------------------------------------------ comm_b.c
+ * decodeCommB (comm_b.c:52-86): the requested register is not known, so every register hypothesis is scored on the
+ * 56-bit MB field and the single best one (score > 0) is decoded; two hypotheses sharing the best score -> AMBIGUOUS.
+ * One function per hypothesis, `f` NULL = score only.  Formats: commb_format_t, readsb.h:249. */
+enum { CB_UNKNOWN, CB_AMBIGUOUS, CB_EMPTY, CB_DATALINK_CAPS, CB_GICB_CAPS, CB_IDENT, CB_ACAS_RA, CB_VERTICAL_INTENT, CB_TRACK_TURN,
+       CB_HEADING_SPEED, CB_MET_ROUTINE };
+
+#define MBF(a, b) bits_of(mb, 56, (a), (b))
+
+/* "status bit + value" subfield rule used all over BDS4,0/5,0/6,0: a set status bit needs a non-zero value (checked by the
+ * caller), a clear one needs a zero value — anything else disqualifies the hypothesis.  Returns 1 (+1 score) or -1 (reject). */
+static int idle_field(unsigned valid, unsigned raw) { return (!valid && raw == 0) ? 1 : -1; }
+
+static int cb_empty(uint64_t mb, struct oracle_fields *f) {            /* comm_b.c:88-100 */
+    if (mb) return 0;
+    if (f) f->commb_format = CB_EMPTY;
+    return 56;
+}
+
+static int cb_bds10(uint64_t mb, struct oracle_fields *f) {            /* comm_b.c:104-124 */
+    if (MBF(1, 8) != 0x10 || MBF(10, 14)) return 0;
+    if (f) f->commb_format = CB_DATALINK_CAPS;
+    return 56;
+}
+
+static int cb_bds17(uint64_t mb, struct oracle_fields *f) {            /* comm_b.c:128-205 */
+    if (MBF(25, 56)) return 0;
+    int score = MBF(7, 7) ? 1 : -2;                                     /* BDS2,0 is on almost everything */
+    static const int unlikely[8] = {10, 11, 12, 13, 14, 20, 21, 22};
+    for (int k = 0; k < 8; ++k) if (MBF(unlikely[k], unlikely[k])) score -= 2;
+    const unsigned es = MBF(1, 6);
+    if ((es >> 1) == 0x1f) score += 5 + (int) (es & 1);                 /* ES capable (+ EDI) */
+    else if (es == 0) score += 1;
+    else score -= 12;
+    const unsigned tt = MBF(16, 16), hs = MBF(24, 24), vi = MBF(9, 9);
+    if (tt && hs) score += 2 + (int) vi;
+    else if (!tt && !hs && !vi) score += 1;
+    else score -= 6;
+    if (f) f->commb_format = CB_GICB_CAPS;
+    return score;
+}
+
+static int cb_bds20(uint64_t mb, struct oracle_fields *f) {            /* comm_b.c:209-259 */
+    if (MBF(1, 8) != 0x20) return 0;
+    char cs[8];
+    for (int k = 0; k < 8; ++k) {
+        const char c = kAis[MBF(9 + 6 * k, 14 + 6 * k)];
+        if (!((c >= 'A' && c <= 'Z') || (c >= '-' && c <= '9') || c == ' ' || c == '@')) return 0;
+        cs[k] = c;
+    }
+    if (f) { f->commb_format = CB_IDENT; memcpy(f->callsign, cs, 8); f->flags |= ORACLE_F_CALLSIGN_VALID; }
+    return 8 + 8 * 6;
+}
+
+static int cb_bds30(uint64_t mb, struct oracle_fields *f) {            /* comm_b.c:333-348 */
+    if (MBF(1, 8) != 0x30) return 0;
+    if (f) { f->commb_format = CB_ACAS_RA; f->flags |= ORACLE_F_ACAS_RA_VALID; }
+    return 56;
+}
+
+static int cb_bds40(uint64_t mb, struct oracle_fields *f) {            /* comm_b.c:352-514 */
+    const unsigned mcp_v = MBF(1, 1), mcp = MBF(2, 13), fms_v = MBF(14, 14), fms = MBF(15, 26), baro_v = MBF(27, 27), baro = MBF(28, 39);
+    const unsigned mode_v = MBF(48, 48), mode = MBF(49, 51), src_v = MBF(54, 54), src = MBF(55, 56);
+    if (!(mcp_v | fms_v | baro_v | mode_v | src_v)) return 0;
+    int score = 0, r;
+    unsigned alt[2] = {0, 0};
+    const unsigned av[2] = {mcp_v, fms_v}, araw[2] = {mcp, fms};
+    for (int k = 0; k < 2; ++k) {
+        if (av[k] && araw[k]) {
+            alt[k] = araw[k] * 16;
+            if (alt[k] < 1000 || alt[k] > 50000) return 0;
+            score += 13;
+        } else if ((r = idle_field(av[k], araw[k])) < 0) return 0;
+        else score += r;
+    }
+    float qnh = 0;
+    if (baro_v && baro) {
+        qnh = (float) (800 + baro * 0.1);
+        if (!(qnh >= 900 && qnh <= 1100)) return 0;
+        score += 13;
+    } else if ((r = idle_field(baro_v, baro)) < 0) return 0;
+    else score += r;
+    if (MBF(40, 47)) return 0;
+    if (mode_v) score += 4; else if (mode == 0) score += 1; else return 0;
+    if (MBF(52, 53)) return 0;
+    if (src_v) score += 3; else if (src == 0) score += 1; else return 0;
+    if (mcp_v && fms_v && alt[0] != alt[1]) score -= 4;
+    for (int k = 0; k < 2; ++k) {
+        const unsigned rem = alt[k] % 500;
+        if (av[k] && !(rem < 16 || rem > 484)) score -= 4;             /* selected altitudes are multiples of 500 ft */
+    }
+    if (f) {
+        f->commb_format = CB_VERTICAL_INTENT;
+        if (mcp_v) { f->nav_flags |= ORACLE_NAV_MCP_ALT_VALID; f->nav_mcp_altitude = alt[0]; }
+        if (fms_v) { f->nav_flags |= ORACLE_NAV_FMS_ALT_VALID; f->nav_fms_altitude = alt[1]; }
+        if (baro_v) { f->nav_flags |= ORACLE_NAV_QNH_VALID; f->nav_qnh = qnh; }
+        if (mode_v) {
+            f->nav_flags |= ORACLE_NAV_MODES_VALID;
+            f->nav_modes = (uint8_t) (((mode & 4) ? NM_VNAV : 0) | ((mode & 2) ? NM_ALT_HOLD : 0) | ((mode & 1) ? NM_APPROACH : 0));
+        }
+        f->nav_altitude_source = (uint8_t) (src_v ? src + 1 : 0);     /* UNKNOWN AIRCRAFT MCP FMS = 1..4, readsb.h:287 */
+    }
+    return score;
+}
+
+static int cb_bds50(uint64_t mb, struct oracle_fields *f) {            /* comm_b.c:518-672 */
+    const unsigned roll_s = MBF(2, 2), roll_raw = MBF(3, 11), trk_s = MBF(13, 13), trk_raw = MBF(14, 23), gs_raw = MBF(25, 34);
+    const unsigned rate_v = MBF(35, 35), rate_s = MBF(36, 36), rate_raw = MBF(37, 45), tas_raw = MBF(47, 56);
+    if (!MBF(1, 1) || !MBF(12, 12) || !MBF(24, 24) || !MBF(46, 46)) return 0;    /* roll, track, gs, tas must all be present */
+    float roll = (float) (roll_raw * 45.0 / 256.0);
+    if (roll_s) roll = (float) (roll - 90.0);
+    if (!(roll >= -40 && roll < 40)) return 0;
+    float track = (float) (trk_raw * 90.0 / 512.0);
+    if (trk_s) track = (float) (track + 180.0);
+    const unsigned gs = gs_raw * 2, tas = tas_raw * 2;
+    if (gs < 50 || gs > 700 || tas < 50 || tas > 700) return 0;          /* (a zero raw value fails the same test) */
+    int score = 11 + 12 + 11 + 11;
+    float rate = 0;
+    if (rate_v) {
+        rate = (float) (rate_raw * 8.0 / 256.0);
+        if (rate_s) rate = (float) (rate - 16);
+        if (!(rate >= -10.0 && rate <= 10.0)) return 0;
+        score += 11;
+        /* coordinated-turn rate for this roll and airspeed against the reported one (comm_b.c:631-637) */
+        const double turn = 68625 * tan(roll * M_PI / 180.0) / (tas * 20 * M_PI);
+        if (fabs(turn - rate) > 2.0) score -= 6;
+    } else if (rate_raw == 0 && !rate_s) score += 1;
+    else return 0;
+    if (f) {
+        f->commb_format = CB_TRACK_TURN;
+        f->flags |= ORACLE_F_ROLL_VALID | ORACLE_F_HEADING_VALID | ORACLE_F_GS_VALID | ORACLE_F_TAS_VALID;
+        f->roll = roll;
+        f->heading = track; f->heading_type = HD_GROUND_TRACK;
+        f->gs_v0 = f->gs_v2 = f->gs_selected = (float) gs;
+        if (rate_v) { f->flags |= ORACLE_F_TRACK_RATE_VALID; f->track_rate = rate; }
+        f->tas = (uint16_t) tas;
+    }
+    return score;
+}
+
+static int cb_bds60(uint64_t mb, struct oracle_fields *f) {            /* comm_b.c:676-824 */
+    const unsigned hdg_s = MBF(2, 2), hdg_raw = MBF(3, 12), ias = MBF(14, 23), mach_raw = MBF(25, 34);
+    const unsigned rv[2] = {MBF(35, 35), MBF(46, 46)}, rs[2] = {MBF(36, 36), MBF(47, 47)}, rr[2] = {MBF(37, 45), MBF(48, 56)};
+    if (!MBF(1, 1) || !MBF(13, 13) || !MBF(24, 24) || !(rv[0] | rv[1])) return 0;
+    float heading = (float) (hdg_raw * 90.0 / 512.0);
+    if (hdg_s) heading = (float) (heading + 180.0);
+    if (ias < 50 || ias > 700 || mach_raw == 0) return 0;
+    const float mach = (float) (mach_raw * 2.048 / 512);
+    if (!(mach >= 0.1 && mach <= 0.9)) return 0;
+    int score = 12 + 11 + 11, rate[2] = {0, 0};
+    for (int k = 0; k < 2; ++k) {                                       /* barometric, then inertial vertical rate */
+        if (rv[k]) {
+            rate[k] = (int) rr[k] * 32 - (rs[k] ? 16384 : 0);
+            if (rate[k] < -6000 || rate[k] > 6000) return 0;
+            score += 11;
+        } else if (rr[k] == 0) score += 1;
+        else return 0;
+    }
+    if (rv[0] && rv[1] && abs(rate[0] - rate[1]) > 2000) score -= 12;
+    if (f) {
+        f->commb_format = CB_HEADING_SPEED;
+        f->flags |= ORACLE_F_HEADING_VALID | ORACLE_F_IAS_VALID | ORACLE_F_MACH_VALID;
+        f->heading = heading; f->heading_type = HD_MAGNETIC;
+        f->ias = (uint16_t) ias;
+        f->mach = mach;
+        if (rv[0]) { f->flags |= ORACLE_F_BARO_RATE_VALID; f->baro_rate = rate[0]; }
+        if (rv[1]) { f->flags |= ORACLE_F_GEOM_RATE_VALID; f->geom_rate = rate[1]; }
+    }
+    return score;
+}
+
+/* BDS4,4 as the reference scores it (comm_b.c:828-961), including what its arithmetic really does: the wind direction
+ * factor 180/256 is an integer division (direction is always 0), and a set static-pressure status bit always ends in
+ * `return 0` (the 11-bit value cannot exceed 2048), so only reports without pressure can win. */
+static int cb_bds44(uint64_t mb, struct oracle_fields *f) {
+    const unsigned source = MBF(1, 4), wind_v = MBF(5, 5), wind = MBF(6, 14), t_raw = MBF(25, 34);
+    const unsigned turb_v = MBF(47, 47), hum_v = MBF(50, 50);
+    if (source > 6) return 0;
+    if (MBF(35, 35)) return 0;
+    const float oat = (float) (MBF(24, 24) ? (t_raw - 1024.0) * 0.25 : t_raw * 0.25);
+    if (!(oat >= -128 && oat <= 128)) return 0;
+    const int score = 4 + (wind_v ? 18 : 2) + 10 + 1 + (turb_v ? 2 : 1) + (hum_v ? 6 : 1);
+    if (f) {
+        f->commb_format = CB_MET_ROUTINE;
+        f->flags |= ORACLE_F_MET_SOURCE_VALID | ORACLE_F_OAT_VALID;
+        f->met_source = (uint8_t) source;
+        if (wind_v) { f->flags |= ORACLE_F_WIND_VALID; f->wind_speed = (uint16_t) wind; f->wind_direction = 0; }
+        f->oat = oat;
+        if (turb_v) { f->flags |= ORACLE_F_TURBULENCE_VALID; f->turbulence = (uint8_t) MBF(48, 49); }
+        if (hum_v) { f->flags |= ORACLE_F_HUMIDITY_VALID; f->humidity = MBF(51, 56) * (100.0f / 64); }
+    }
+    return score;
+}
+
+static void comm_b(struct oracle_fields *f, uint64_t mb) {
+    typedef int (*hyp_fn)(uint64_t, struct oracle_fields *);
+    static const hyp_fn hyp[9] = {cb_empty, cb_bds10, cb_bds20, cb_bds30, cb_bds17, cb_bds40, cb_bds50, cb_bds60, cb_bds44};
+    f->commb_format = CB_UNKNOWN;
+    /* comm_b.c:58 also tests mm->UM and mm->correctedbits, but decodeModesMessage extracts UM only AFTER it has called
+     * decodeCommB (mode_s.c:713-716 vs :755-757), so UM is still 0 there, and DF20/21 never carry corrected bits */
+    if (f->DR) return;
+    int best = 0, winner = -1, ties = 0;
+    for (int k = 0; k < 9; ++k) {
+        const int sc = hyp[k](mb, NULL);
+        if (sc > best) { best = sc; winner = k; ties = 0; }
+        else if (sc == best) ++ties;
+    }
+    if (winner < 0) return;
+    if (ties) f->commb_format = CB_AMBIGUOUS;
+    else hyp[winner](mb, f);
+}
+
 void modes_oracle_decode_fields(const uint8_t *msg, int msgbits, struct oracle_fields *f) {
     memset(f, 0, sizeof(*f));
     if (msgbits == 16) {                                         /* decodeModeAMessage, mode_ac.c:171-200 */
@@ -471,6 +684,11 @@ void modes_oracle_decode_fields(const uint8_t *msg, int msgbits, struct oracle_f
         if (f->ID) set_squawk(f, f->ID);
     }
     if (df >= 24) { f->KE = (uint8_t) HD(4, 4); f->ND = (uint8_t) HD(5, 8); }
+    if (df == 20 || df == 21) {
+        uint64_t mb = 0;
+        for (int k = 4; k < 11; ++k) mb = (mb << 8) | msg[k];
+        comm_b(f, mb);
+    }
     if (df == 17 || df == 18) {
         uint64_t me = 0;
         for (int k = 4; k < 11; ++k) me = (me << 8) | msg[k];

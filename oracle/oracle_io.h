@@ -57,10 +57,8 @@ struct oracle_stats {
 /* Per-message fields decodeModesMessage() leaves in struct modesMessage behind the CRC stage
  * (mode_s.c:598-803: AA AC CA CC CF DR FS ID KE ND RI SL UM VS; decodeExtendedSquitter and its eight
  * ME decoders, mode_s.c:806-1555), and what decodeModeAMessage (mode_ac.c:171-200) sets for a
- * Mode A/C reply.  Everything a memset-0 modesMessage would hold stays 0.  NOT covered: decodeCommB
- * (comm_b.c) — for DF20/21 only the fields mode_s.c itself sets are filled by the restatement, and
- * ref_decode_fields() reports the reference's values after decodeCommB, so tests compare DF20/21
- * through ORACLE_FIELDS_DF20_MASK-style subsets.  144 bytes, same layout as struct mgpu_fields. */
+ * Mode A/C reply, and what decodeCommB (comm_b.c:52-961) infers from the MB field of DF20/21.
+ * Everything a memset-0 modesMessage would hold stays 0.  176 bytes, same layout as struct mgpu_fields. */
 struct oracle_fields {
     uint32_t addr;              /* mm->addr (with MODES_NON_ICAO_ADDRESS = 1<<24 where the ME decode says so) */
     uint32_t AA;
@@ -89,6 +87,10 @@ struct oracle_fields {
     uint8_t  op_cc_tc, nav_heading_type, nav_altitude_source, nav_modes;
     uint32_t nav_fms_altitude, nav_mcp_altitude;
     float    nav_qnh, nav_heading;
+    float    roll, track_rate, mach;          /* Comm-B BDS5,0 / 6,0 (mm->mach is a double holding this float) */
+    float    oat, humidity, wind_direction;   /* Comm-B BDS4,4 */
+    uint16_t wind_speed, static_pressure;
+    uint8_t  commb_format, met_source, turbulence, pad0;
     uint8_t  reserved[8];
 };
 
@@ -114,6 +116,15 @@ struct oracle_fields {
 #define ORACLE_F_EMERGENCY_VALID  (1u << 18)
 #define ORACLE_F_ALT_Q_BIT        (1u << 19)
 #define ORACLE_F_ACAS_RA_VALID    (1u << 20)
+#define ORACLE_F_ROLL_VALID       (1u << 21)
+#define ORACLE_F_TRACK_RATE_VALID (1u << 22)
+#define ORACLE_F_MACH_VALID       (1u << 23)
+#define ORACLE_F_WIND_VALID       (1u << 24)
+#define ORACLE_F_OAT_VALID        (1u << 25)
+#define ORACLE_F_STATIC_PRESSURE_VALID (1u << 26)
+#define ORACLE_F_TURBULENCE_VALID (1u << 27)
+#define ORACLE_F_HUMIDITY_VALID   (1u << 28)
+#define ORACLE_F_MET_SOURCE_VALID (1u << 29)
 /* acc_flags: mm->accuracy (readsb.h:1061-1086) */
 #define ORACLE_ACC_NIC_A_VALID    (1u << 0)
 #define ORACLE_ACC_NIC_B_VALID    (1u << 1)

@@ -252,7 +252,12 @@ static void fields_from_mm(const struct modesMessage *mm, struct oracle_fields *
         | (mm->spi_valid ? ORACLE_F_SPI_VALID : 0) | (mm->spi ? ORACLE_F_SPI : 0)
         | (mm->alert_valid ? ORACLE_F_ALERT_VALID : 0) | (mm->alert ? ORACLE_F_ALERT : 0)
         | (mm->emergency_valid ? ORACLE_F_EMERGENCY_VALID : 0) | (mm->alt_q_bit ? ORACLE_F_ALT_Q_BIT : 0)
-        | (mm->acas_ra_valid ? ORACLE_F_ACAS_RA_VALID : 0);
+        | (mm->acas_ra_valid ? ORACLE_F_ACAS_RA_VALID : 0)
+        | (mm->roll_valid ? ORACLE_F_ROLL_VALID : 0) | (mm->track_rate_valid ? ORACLE_F_TRACK_RATE_VALID : 0)
+        | (mm->mach_valid ? ORACLE_F_MACH_VALID : 0) | (mm->wind_valid ? ORACLE_F_WIND_VALID : 0)
+        | (mm->oat_valid ? ORACLE_F_OAT_VALID : 0) | (mm->static_pressure_valid ? ORACLE_F_STATIC_PRESSURE_VALID : 0)
+        | (mm->turbulence_valid ? ORACLE_F_TURBULENCE_VALID : 0) | (mm->humidity_valid ? ORACLE_F_HUMIDITY_VALID : 0)
+        | (mm->met_source_valid ? ORACLE_F_MET_SOURCE_VALID : 0);
     f->acc_flags = (mm->accuracy.nic_a_valid ? ORACLE_ACC_NIC_A_VALID : 0) | (mm->accuracy.nic_b_valid ? ORACLE_ACC_NIC_B_VALID : 0)
         | (mm->accuracy.nic_c_valid ? ORACLE_ACC_NIC_C_VALID : 0) | (mm->accuracy.nic_baro_valid ? ORACLE_ACC_NIC_BARO_VALID : 0)
         | (mm->accuracy.nac_p_valid ? ORACLE_ACC_NAC_P_VALID : 0) | (mm->accuracy.nac_v_valid ? ORACLE_ACC_NAC_V_VALID : 0)
@@ -287,6 +292,11 @@ static void fields_from_mm(const struct modesMessage *mm, struct oracle_fields *
     f->nav_heading_type = mm->nav.heading_type; f->nav_altitude_source = mm->nav.altitude_source; f->nav_modes = mm->nav.modes;
     f->nav_fms_altitude = mm->nav.fms_altitude; f->nav_mcp_altitude = mm->nav.mcp_altitude;
     f->nav_qnh = mm->nav.qnh; f->nav_heading = mm->nav.heading;
+    f->roll = mm->roll; f->track_rate = mm->track_rate; f->mach = (float) mm->mach;
+    if ((double) f->mach != mm->mach) { fprintf(stderr, "ref_harness: mach is not a float value\n"); exit(1); }
+    f->oat = mm->oat; f->humidity = mm->humidity; f->wind_direction = mm->wind_direction;
+    f->wind_speed = mm->wind_speed; f->static_pressure = mm->static_pressure;
+    f->commb_format = mm->commb_format; f->met_source = mm->met_source; f->turbulence = mm->turbulence;
 }
 
 /* One frame (corrected bytes, as netUseMessage sees mm->msg): msgbits 56/112 -> decodeModesMessage, 16 -> the

@@ -40,9 +40,11 @@ FIELDS_DTYPE = np.dtype([
     ("op_flags", "<u2"), ("op_cc_lw", "u1"), ("op_cc_antenna_offset", "u1"),
     ("op_cc_tc", "u1"), ("nav_heading_type", "u1"), ("nav_altitude_source", "u1"), ("nav_modes", "u1"),
     ("nav_fms_altitude", "<u4"), ("nav_mcp_altitude", "<u4"), ("nav_qnh", "<f4"), ("nav_heading", "<f4"),
+    ("roll", "<f4"), ("track_rate", "<f4"), ("mach", "<f4"), ("oat", "<f4"), ("humidity", "<f4"), ("wind_direction", "<f4"),
+    ("wind_speed", "<u2"), ("static_pressure", "<u2"), ("commb_format", "u1"), ("met_source", "u1"), ("turbulence", "u1"), ("pad0", "u1"),
     ("reserved", "u1", 8),
 ])
-assert FIELDS_DTYPE.itemsize == 144
+assert FIELDS_DTYPE.itemsize == 176
 
 
 class Config(C.Structure):

@@ -9,7 +9,9 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import fields_util as fu  # noqa: E402
 
-frames, bits = fu.fuzz_frames(1800, 20240917)
+frames, bits = fu.fuzz_frames(1200, 20240917)
+fc, bc = fu.commb_frames(600, 20240918)
+frames, bits = np.concatenate([frames, fc]), np.concatenate([bits, bc])
 rng = np.random.default_rng(5)
 modea = rng.integers(0, 65536, size=200)
 fa = np.zeros((200, 14), dtype=np.uint8)

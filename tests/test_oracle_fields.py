@@ -13,7 +13,7 @@ GOLDEN = os.path.join(helpers.GOLDEN_DIR, "fields_fuzz_2000.npz")
 
 
 def test_struct_sizes():
-    assert fu.FIELDS.itemsize == 144
+    assert fu.FIELDS.itemsize == 176
 
 
 def test_vector_crc_is_the_oracle_crc():
@@ -34,6 +34,25 @@ def test_fuzz_every_format_against_reference():
     es = want[(want["msgtype"] == 17)]
     assert set(np.unique(es["metype"])) == set(range(32))
     assert (es["flags"] & (1 << 9)).any() and (es["nav_flags"] != 0).any() and (es["op_flags"] != 0).any()
+
+
+@needs_ref
+def test_comm_b_registers_against_reference():
+    frames, bits = fu.commb_frames(600000, 23)
+    want, rc = fu.ref_fields(frames, bits)
+    assert (rc == 0).all()
+    fu.assert_same_fields(fu.oracle_fields(frames, bits), want, frames, "comm-b")
+    # every register hypothesis wins somewhere, and so do "ambiguous" and "unknown" (commb_format_t, readsb.h:249)
+    assert set(np.unique(want["commb_format"])) == set(range(11))
+
+
+@needs_ref
+def test_comm_b_turn_rate_threshold_against_reference():
+    frames, bits = fu.turn_rate_frames()
+    want, rc = fu.ref_fields(frames, bits)
+    assert (rc == 0).all()
+    fu.assert_same_fields(fu.oracle_fields(frames, bits), want, frames, "bds5,0 turn rate")
+    assert (want["commb_format"] == 8).sum() > 1000000
 
 
 @needs_ref

@@ -229,14 +229,17 @@ int mgpu_beast_encode_device(mgpu_ctx *ctx, const struct mgpu_msg *d_msgs, uint6
 int mgpu_beast_encode(mgpu_ctx *ctx, const struct mgpu_msg *msgs, uint64_t n, uint8_t *out, uint64_t cap, uint64_t *bytes);
 
 /* ---- per-message field decode (decodeModesMessage behind the CRC stage, mode_s.c:598-760; decodeExtendedSquitter and
- * its ME decoders, mode_s.c:806-1555; decodeModeAMessage, mode_ac.c:171-200) ---------------------------------------
+ * its ME decoders, mode_s.c:806-1555; decodeCommB, comm_b.c; decodeModeAMessage, mode_ac.c:171-200) ---------------------------------------
  * One record per message, same index, decoded on the GPU from the corrected frame: the raw Annex-10 fields, altitude,
  * squawk, callsign, velocity, CPR words, the accuracy / operational-status / target-state groups — the members of
  * struct modesMessage (readsb.h:887-1143) under the same names; enums carry the reference's numeric values
  * (addrtype_t readsb.h:178, datasource_t :159, airground_t :216, heading_type_t :239, sil_type_t :224, cpr_type_t :229,
  * nav_modes_t :263, nav_altitude_source_t :287, emergency_t :275, altitude_unit_t :204).  What a memset-0 modesMessage
  * would hold stays 0.  MB/MD/ME/MV are msg[4..10] / msg[1..10] of the message record and are not repeated.
- * Not decoded: the Comm-B payload of DF20/21 (decodeCommB, comm_b.c).  144 bytes. */
+ * DF20/21: decodeCommB's register inference (comm_b.c:52-961) fills commb_format (commb_format_t, readsb.h:249) and the
+ * fields of the register it settles on (callsign; selected altitude / QNH / modes; roll, track, ground speed, track
+ * rate, TAS; heading, IAS, Mach, vertical rates; the BDS4,4 weather group).  mach is the float the reference stores
+ * into its double.  176 bytes. */
 struct mgpu_fields {
     uint32_t addr;              /* mm->addr (with MODES_NON_ICAO_ADDRESS = 1<<24 where the ME decode says so) */
     uint32_t AA;
@@ -265,6 +268,10 @@ struct mgpu_fields {
     uint8_t  op_cc_tc, nav_heading_type, nav_altitude_source, nav_modes;
     uint32_t nav_fms_altitude, nav_mcp_altitude;
     float    nav_qnh, nav_heading;
+    float    roll, track_rate, mach;          /* Comm-B BDS5,0 / 6,0 (mm->mach is a double holding this float) */
+    float    oat, humidity, wind_direction;   /* Comm-B BDS4,4 */
+    uint16_t wind_speed, static_pressure;
+    uint8_t  commb_format, met_source, turbulence, pad0;
     uint8_t  reserved[8];
 };
 
@@ -290,6 +297,15 @@ struct mgpu_fields {
 #define MGPU_F_EMERGENCY_VALID  (1u << 18)
 #define MGPU_F_ALT_Q_BIT        (1u << 19)
 #define MGPU_F_ACAS_RA_VALID    (1u << 20)
+#define MGPU_F_ROLL_VALID       (1u << 21)
+#define MGPU_F_TRACK_RATE_VALID (1u << 22)
+#define MGPU_F_MACH_VALID       (1u << 23)
+#define MGPU_F_WIND_VALID       (1u << 24)
+#define MGPU_F_OAT_VALID        (1u << 25)
+#define MGPU_F_STATIC_PRESSURE_VALID (1u << 26)
+#define MGPU_F_TURBULENCE_VALID (1u << 27)
+#define MGPU_F_HUMIDITY_VALID   (1u << 28)
+#define MGPU_F_MET_SOURCE_VALID (1u << 29)
 /* acc_flags: mm->accuracy (readsb.h:1061-1086) */
 #define MGPU_ACC_NIC_A_VALID    (1u << 0)
 #define MGPU_ACC_NIC_B_VALID    (1u << 1)

@@ -280,6 +280,7 @@ struct mgpu_ctx {
     unsigned long long *d_beast_off = nullptr;
     mgpu_fields *d_fields = nullptr;
     uint64_t fields_cap = 0;
+    double *d_roll_tan = nullptr;                             // tables.h build_roll_tangent_table(), uploaded on first use
     uint32_t *d_beast_blocks = nullptr;
     unsigned long long *d_beast_total = nullptr;
     uint64_t beast_cap_msgs = 0, beast_cap_in = 0, beast_cap_out = 0;
@@ -645,7 +646,7 @@ void mgpu_destroy(mgpu_ctx *c) {
     if (c->stream_w) (void) hipStreamSynchronize(c->stream_w);
     for (auto &sl : c->slot) free_slot(sl);
     if (c->h_win) (void) hipHostFree(c->h_win);
-    void *dev[] = {c->d_fields, c->d_beast_off, c->d_beast_len, c->d_beast_in, c->d_beast_out, c->d_beast_blocks, c->d_beast_total, c->d_hist, c->d_hist_iq, c->d_hist_sums, c->d_iq, c->d_win, c->d_adder_bitmap, c->d_bit_syndrome, c->d_group_syndrome, c->d_parity,
+    void *dev[] = {c->d_roll_tan, c->d_fields, c->d_beast_off, c->d_beast_len, c->d_beast_in, c->d_beast_out, c->d_beast_blocks, c->d_beast_total, c->d_hist, c->d_hist_iq, c->d_hist_sums, c->d_iq, c->d_win, c->d_adder_bitmap, c->d_bit_syndrome, c->d_group_syndrome, c->d_parity,
                    c->d_tab_long, c->d_tab_short, c->d_uc8_folded};
     for (void *p : dev)
         if (p) (void) hipFree(p);
@@ -1534,11 +1535,20 @@ int mgpu_beast_encode(mgpu_ctx *c, const struct mgpu_msg *msgs, uint64_t n, uint
 
 // ---- per-message field decode (mode_s.c:598-760, 806-1555; mode_ac.c:171-200) --------------------------------------
 
+static int fields_tables(mgpu_ctx *c) {
+    if (c->d_roll_tan) return MGPU_OK;
+    const std::vector<double> t = build_roll_tangent_table();
+    HIPCHK(c, hipMalloc(&c->d_roll_tan, t.size() * sizeof(double)));
+    HIPCHK(c, hipMemcpy(c->d_roll_tan, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    return MGPU_OK;
+}
+
 int mgpu_decode_fields_device(mgpu_ctx *c, const struct mgpu_msg *d_msgs, uint64_t n, struct mgpu_fields *d_out) {
     if (!c || (n && (!d_msgs || !d_out))) return MGPU_E_INVAL;
     if (n == 0) return MGPU_OK;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    launch_decode_fields(d_msgs, n, d_out, c->stream);
+    if (int rc = fields_tables(c)) return rc;
+    launch_decode_fields(d_msgs, n, d_out, c->d_roll_tan, c->stream);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MGPU_OK;
@@ -1562,8 +1572,9 @@ int mgpu_decode_fields(mgpu_ctx *c, const struct mgpu_msg *msgs, uint64_t n, str
         HIPCHK(c, hipMalloc(&c->d_fields, want * sizeof(mgpu_fields)));
         c->fields_cap = want;
     }
+    if (int rc = fields_tables(c)) return rc;
     HIPCHK(c, hipMemcpyAsync(c->d_beast_in, msgs, n * sizeof(mgpu_msg), hipMemcpyHostToDevice, c->stream));
-    launch_decode_fields((const mgpu_msg *) c->d_beast_in, n, c->d_fields, c->stream);
+    launch_decode_fields((const mgpu_msg *) c->d_beast_in, n, c->d_fields, c->d_roll_tan, c->stream);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(out, c->d_fields, n * sizeof(mgpu_fields), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -170,4 +170,14 @@ std::vector<uint16_t> uc8_folded_table() {
     return f;
 }
 
+std::vector<double> build_roll_tangent_table() {
+    std::vector<double> t(1024);
+    for (unsigned code = 0; code < 1024; ++code) {
+        float roll = (float) ((code & 511u) * 45.0 / 256.0);
+        if (code & 512u) roll = (float) (roll - 90.0);
+        t[code] = std::tan(roll * M_PI / 180.0);
+    }
+    return t;
+}
+
 }  // namespace mgpu

@@ -56,4 +56,9 @@ const uint16_t *uc8_table();
 constexpr int UC8_FOLD_STRIDE = 130;   // row stride chosen so a column walk changes LDS bank
 std::vector<uint16_t> uc8_folded_table();
 
+// tan(roll) for the 1024 roll codes of BDS5,0 (index = sign << 9 | 9-bit magnitude, roll = magnitude * 45/256 - 90 * sign as
+// the float comm_b.c:541-545 forms), evaluated as comm_b.c:632 does — tan(roll * M_PI / 180.0) in the host's libm, the same
+// library the reference links — so the field decoder's turn-rate consistency test compares the reference's own doubles.
+std::vector<double> build_roll_tangent_table();
+
 }  // namespace mgpu

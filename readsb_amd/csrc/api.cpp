@@ -278,6 +278,7 @@ struct mgpu_ctx {
     uint16_t *d_beast_len = nullptr;        // per message: frame length | signal byte << 8
     uint8_t *d_beast_in = nullptr, *d_beast_out = nullptr;
     unsigned long long *d_beast_off = nullptr;
+    int device_slot = -1;                                     // which of the device's pipeline core groups this context pinned to
     mgpu_fields *d_fields = nullptr;
     uint64_t fields_cap = 0;
     double *d_roll_tan = nullptr;                             // tables.h build_roll_tangent_table(), uploaded on first use
@@ -346,7 +347,25 @@ static int sysfs_int(const std::string &path, int dflt) {
     return v;
 }
 
-static void bind_near_device(std::thread *const *threads, int nthreads, int device, std::vector<int> *pinned) {
+// Several contexts of one process on the same device (fan-in: one context per sample stream) must not pin their pipelines
+// onto the same cores: the k-th live context of a device takes another L3 group (below).
+static std::mutex g_slot_mu;
+static uint32_t g_device_slots[64];          // bit k set = the device's k-th pipeline slot is taken
+
+static int take_device_slot(int device) {
+    std::lock_guard<std::mutex> lk(g_slot_mu);
+    uint32_t &m = g_device_slots[device & 63];
+    for (int k = 0; k < 32; ++k)
+        if (!(m & (1u << k))) { m |= 1u << k; return k; }
+    return 0;
+}
+
+static void release_device_slot(int device, int slot) {
+    std::lock_guard<std::mutex> lk(g_slot_mu);
+    g_device_slots[device & 63] &= ~(1u << slot);
+}
+
+static void bind_near_device(std::thread *const *threads, int nthreads, int device, int device_slot, std::vector<int> *pinned) {
     if (getenv("MGPU_NO_AFFINITY")) return;
     char bus[64] = {0};
     if (hipDeviceGetPCIBusId(bus, (int) sizeof(bus), device) != hipSuccess) return;
@@ -379,7 +398,9 @@ static void bind_near_device(std::thread *const *threads, int nthreads, int devi
     // ranks that each see one device as ordinal 0 (per-rank HIP_VISIBLE_DEVICES) still spread out by LOCAL_RANK
     int ordinal = device;
     if (const char *lr = getenv("LOCAL_RANK")) { const int v = atoi(lr); if (v >= 0) ordinal = v; }
-    const int want = l3_ids[(size_t) ordinal % l3_ids.size()];
+    // further contexts of the same device: half the node's groups away, where an 8-GPU node's other devices do not sit
+    const size_t stride = l3_ids.size() >= 2 ? l3_ids.size() / 2 : 1;
+    const int want = l3_ids[((size_t) ordinal + (size_t) device_slot * stride + (size_t) (device_slot / 2)) % l3_ids.size()];
     // one logical CPU per physical core of that group; more threads than cores share cores round-robin
     std::vector<int> pick, cores;
     for (size_t i = 0; i < cpus.size(); ++i) {
@@ -623,7 +644,8 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
         std::vector<std::thread *> th = {&c->worker, &c->builder, &c->fetcher};
         for (auto &t : c->walk_team.threads) th.push_back(&t);
         for (auto &t : c->build_team.threads) th.push_back(&t);
-        bind_near_device(th.data(), (int) th.size(), cfg->device, &c->host_cpus);
+        c->device_slot = take_device_slot(cfg->device);
+        bind_near_device(th.data(), (int) th.size(), cfg->device, c->device_slot, &c->host_cpus);
     }
     *out = c;
     return MGPU_OK;
@@ -640,6 +662,7 @@ void mgpu_destroy(mgpu_ctx *c) {
     }
     c->walk_team.stop();
     c->build_team.stop();
+    if (c->device_slot >= 0) release_device_slot(c->cfg.device, c->device_slot);
     (void) hipSetDevice(c->cfg.device);
     if (c->stream) (void) hipStreamSynchronize(c->stream);
     if (c->stream2) (void) hipStreamSynchronize(c->stream2);

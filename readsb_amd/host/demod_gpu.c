@@ -72,6 +72,10 @@ void demodulate2400_gpu(struct gpu_demod *g, struct mag_buf *mag) {
 }
 
 int gpu_ifile_run(struct gpu_demod *g, int fd, input_format_t format, unsigned chunk_buffers) {
+    return gpu_ifile_run_until(g, fd, format, chunk_buffers, NULL, NULL);
+}
+
+int gpu_ifile_run_until(struct gpu_demod *g, int fd, input_format_t format, unsigned chunk_buffers, const volatile int *stop, uint64_t *samples) {
     const size_t bps = format == INPUT_UC8 ? 2 : 4;
     const size_t buf_samples = 131072;
     const size_t chunk = (size_t) chunk_buffers * buf_samples;
@@ -80,7 +84,7 @@ int gpu_ifile_run(struct gpu_demod *g, int fd, input_format_t format, unsigned c
     /* page-locked, the chunked uploads of mgpu_feed_iq run at PCIe speed beside the kernels (optional: ignore failure) */
     const int pinned = mgpu_host_register(g->ctx, readbuf, chunk * bps) == MGPU_OK;
     int rc = MGPU_OK, eof = 0;
-    while (!eof) {
+    while (!eof && !(stop && *stop)) {         /* while (!Modes.exit && !eof), sdr_ifile.c:197 */
         size_t have = 0, want = chunk * bps;
         while (have < want) {                       /* sdr_ifile.c:221-235 */
             ssize_t r = read(fd, readbuf + have, want - have);
@@ -92,6 +96,7 @@ int gpu_ifile_run(struct gpu_demod *g, int fd, input_format_t format, unsigned c
         if (nsamples) {
             rc = mgpu_feed_iq(g->ctx, readbuf, nsamples);
             if (rc != MGPU_OK) break;
+            if (samples) *samples += nsamples;
             deliver(g);
         }
     }

@@ -70,6 +70,57 @@ void demodulate2400_gpu(struct gpu_demod *g, struct mag_buf *mag);
  * reads `fd` to EOF in chunks of `chunk_buffers` 131072-sample buffers, converts and demodulates
  * on the GPU, delivers messages in stream order.  Returns 0 or a negative MGPU_E_* code. */
 int gpu_ifile_run(struct gpu_demod *g, int fd, input_format_t format, unsigned chunk_buffers);
+/* the same with the reader loop's exit flag (Modes.exit, sdr_ifile.c:197) and a running sample count; both may be NULL */
+int gpu_ifile_run_until(struct gpu_demod *g, int fd, input_format_t format, unsigned chunk_buffers, const volatile int *stop, uint64_t *samples);
+
+/* ---- fan-in: many sample streams, one demodulator context each -------------------------------
+ * The aggregator's input side (README.md:40-51: several receivers feeding one readsb): an sdr_handler-shaped row
+ * (sdr.c:94-122: initConfig / handleOption / open / run / cancel / close) that takes any number of `--ifile`s.  Every
+ * stream gets its own context — its own sample clock, ICAO filter and counters, exactly one readsb process's worth —
+ * on GPU `stream index % devices`; each stream's reader thread reads into its own page-locked buffer and feeds its
+ * context, so one stream's file reads and uploads run under the others' kernels.  Messages arrive per stream, in that
+ * stream's order, on the stream's thread. */
+typedef void (*gpu_stream_sink)(unsigned stream, const struct gpu_modes_message *mm, void *user);
+
+struct gpu_fanin;
+struct gpu_fanin_stream {
+    char *path;
+    int fd;
+    input_format_t format;
+    int device;
+    struct gpu_demod demod;
+    struct gpu_fanin *owner;
+    unsigned index;
+    int started;                 /* thread exists */
+    int rc;                      /* MGPU_OK or the code that ended the stream */
+    uint64_t samples;            /* samples demodulated */
+    unsigned long thread;        /* pthread_t */
+};
+
+struct gpu_fanin {
+    struct gpu_fanin_stream *streams;
+    unsigned nstreams, cap;
+    struct mgpu_config cfg;      /* options common to all streams (--fix, --modeac, threshold, …) */
+    input_format_t next_format;  /* --iformat applies to the --ifile arguments that follow it */
+    unsigned chunk_buffers;      /* 131072-sample buffers per feed */
+    int devices;                 /* GPUs to spread the streams over; 0 = all visible */
+    gpu_stream_sink sink;
+    void *user;
+    volatile int exit;           /* Modes.exit's role for the reader loops (sdr_ifile.c:197) */
+};
+
+void gpuFaninInitConfig(struct gpu_fanin *f);
+/* `--ifile PATH` (repeatable), `--iformat UC8|SC16|SC16Q11`, `--gpu-devices N`, `--gpu-chunk-buffers N`,
+ * `--fix` `--no-fix` `--aggressive` `--no-fix-df` `--modeac` `--preamble-threshold N` `--startup-time-ms T`.
+ * Returns 1 if the option was consumed (2 if it also consumed `arg`), 0 if it is not one of ours. */
+int gpuFaninHandleOption(struct gpu_fanin *f, const char *opt, const char *arg);
+/* opens every file and creates the contexts; 0 or a negative MGPU_E_* code (loud: there is no CPU fallback) */
+int gpuFaninOpen(struct gpu_fanin *f, gpu_stream_sink sink, void *user);
+/* one reader thread per stream; returns when every stream reached EOF, failed, or gpuFaninCancel() was called.
+ * 0 if every stream ended with MGPU_OK, else the first failing stream's code. */
+int gpuFaninRun(struct gpu_fanin *f);
+void gpuFaninCancel(struct gpu_fanin *f);
+void gpuFaninClose(struct gpu_fanin *f);
 
 #ifdef __cplusplus
 }

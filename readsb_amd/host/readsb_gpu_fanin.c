@@ -14,12 +14,19 @@
 
 struct outputs { FILE **out; unsigned n; };
 
+static void print_raw_line(FILE *out, const struct gpu_modes_message *mm) {
+    static const char hexl[] = "0123456789abcdef", hexu[] = "0123456789ABCDEF";
+    char line[1 + 12 + 28 + 2], *p = line;
+    *p++ = '@';
+    for (int sh = 44; sh >= 0; sh -= 4) *p++ = hexu[((uint64_t) mm->timestamp >> sh) & 15];     /* %012 PRIX64 */
+    for (int j = 0; j < mm->msgbits / 8; j++) { *p++ = hexl[mm->msg[j] >> 4]; *p++ = hexl[mm->msg[j] & 15]; }
+    *p++ = ';'; *p++ = '\n';
+    fwrite(line, 1, (size_t) (p - line), out);
+}
+
 static void print_raw(unsigned stream, const struct gpu_modes_message *mm, void *user) {
     struct outputs *o = user;
-    FILE *out = o->out[stream];                 /* one file per stream, written only by that stream's thread */
-    fprintf(out, "@%012" PRIX64, (uint64_t) mm->timestamp);
-    for (int j = 0; j < mm->msgbits / 8; j++) fprintf(out, "%02x", mm->msg[j]);
-    fputs(";\n", out);
+    print_raw_line(o->out[stream], mm);         /* one file per stream, written only by that stream's thread */
 }
 
 int main(int argc, char **argv) {

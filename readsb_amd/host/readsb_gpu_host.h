@@ -57,11 +57,16 @@ struct gpu_demod {
     struct mgpu_msg *scratch;
     uint64_t scratch_cap;
     struct mgpu_counters counters;   /* mirrors Modes.stats_current's demod counters */
+    uint8_t *readbuf[2];             /* the file reader's two page-locked chunk buffers (gpu_demod_reserve_input) */
+    size_t readbuf_bytes;
+    int readbuf_pinned[2];
 };
 
 /* modesInit()'s hot-path part (readsb.c:285-310) + init_converter (sdr_ifile.c:156) */
 int gpu_demod_open(struct gpu_demod *g, const struct mgpu_config *cfg, gpu_message_sink sink, void *user);
 void gpu_demod_close(struct gpu_demod *g);
+/* optional: allocate and page-lock the file reader's buffers now (else the first gpu_ifile_run does it) */
+int gpu_demod_reserve_input(struct gpu_demod *g, size_t bytes);
 
 /* void demodulate2400(struct mag_buf *mag) (demod_2400.h:38): same call shape, decode thread only */
 void demodulate2400_gpu(struct gpu_demod *g, struct mag_buf *mag);

@@ -13,12 +13,17 @@
 
 #include "readsb_gpu_host.h"
 
-static void print_raw(const struct gpu_modes_message *mm, void *user) {
-    FILE *out = user;
-    fprintf(out, "@%012" PRIX64, (uint64_t) mm->timestamp);
-    for (int j = 0; j < mm->msgbits / 8; j++) fprintf(out, "%02x", mm->msg[j]);
-    fputs(";\n", out);
+static void print_raw_line(FILE *out, const struct gpu_modes_message *mm) {
+    static const char hexl[] = "0123456789abcdef", hexu[] = "0123456789ABCDEF";
+    char line[1 + 12 + 28 + 2], *p = line;
+    *p++ = '@';
+    for (int sh = 44; sh >= 0; sh -= 4) *p++ = hexu[((uint64_t) mm->timestamp >> sh) & 15];     /* %012 PRIX64 */
+    for (int j = 0; j < mm->msgbits / 8; j++) { *p++ = hexl[mm->msg[j] >> 4]; *p++ = hexl[mm->msg[j] & 15]; }
+    *p++ = ';'; *p++ = '\n';
+    fwrite(line, 1, (size_t) (p - line), out);
 }
+
+static void print_raw(const struct gpu_modes_message *mm, void *user) { print_raw_line(user, mm); }
 
 int main(int argc, char **argv) {
     struct mgpu_config cfg;

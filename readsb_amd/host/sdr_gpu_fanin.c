@@ -102,6 +102,8 @@ int gpuFaninOpen(struct gpu_fanin *f, gpu_stream_sink sink, void *user) {
         s->device = cfg.device;
         const int rc = gpu_demod_open(&s->demod, &cfg, stream_sink, s);
         if (rc != MGPU_OK) return rc;
+        const size_t bps = s->format == INPUT_UC8 ? 2 : 4;
+        if (gpu_demod_reserve_input(&s->demod, (size_t) f->chunk_buffers * 131072 * bps) != MGPU_OK) return MGPU_E_NOMEM;
     }
     return MGPU_OK;
 }

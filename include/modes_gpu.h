@@ -201,6 +201,12 @@ int mgpu_convert(mgpu_ctx *ctx, const void *iq_host, uint16_t *mag_host, uint32_
 int mgpu_demod_mag_buf(mgpu_ctx *ctx, const uint16_t *data, uint32_t length,
                        int64_t sampleTimestamp, int64_t sysTimestamp,
                        double mean_power, uint32_t dropped);
+/* The same when cfg.mode_ac is set — demodulate2400(buf) followed by demodulate2400AC(buf) (readsb.c:871-874): the Mode A/C
+ * demodulator derives its noise floor from mag_buf.mean_level and mean_power (demod_2400.c:579-580), so the caller passes
+ * both.  (mgpu_demod_mag_buf on a mode_ac context is refused with MGPU_E_INVAL rather than decoded without Mode A/C.) */
+int mgpu_demod_mag_buf_ac(mgpu_ctx *ctx, const uint16_t *data, uint32_t length,
+                          int64_t sampleTimestamp, int64_t sysTimestamp,
+                          double mean_level, double mean_power, uint32_t dropped);
 
 /* ---- one capture sharded by buffer ranges over several contexts / GPUs (BASELINE config 5) ----
  * Buffers are independent except for the ICAO filter, and the pre-screen needs the adder addresses

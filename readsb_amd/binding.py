@@ -144,6 +144,7 @@ def load_library():
     lib.mgpu_last_timing.argtypes = [vp, C.POINTER(Timing)]
     lib.mgpu_convert.argtypes = [vp, vp, vp, u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.mgpu_demod_mag_buf.argtypes = [vp, vp, u32, i64, i64, C.c_double, u32]
+    lib.mgpu_demod_mag_buf_ac.argtypes = [vp, vp, u32, i64, i64, C.c_double, C.c_double, u32]
     lib.mgpu_crc_checksum.argtypes = [vp, i32]
     lib.mgpu_crc_checksum.restype = u32
     lib.mgpu_crc_diagnose.argtypes = [i32, u32, i32, C.POINTER(i32), C.POINTER(i32)]
@@ -373,6 +374,13 @@ class Demodulator:
         assert data.size >= 326 + length
         self._chk(self.lib.mgpu_demod_mag_buf(self.ctx, data.ctypes.data, length, sample_timestamp, sys_timestamp,
                                               float(mean_power), dropped), "mgpu_demod_mag_buf")
+
+    def demod_mag_buf_ac(self, data, length, sample_timestamp, sys_timestamp, mean_level, mean_power, dropped=0):
+        """demodulate2400 + demodulate2400AC on one struct mag_buf (cfg.mode_ac)."""
+        data = np.ascontiguousarray(data, dtype=np.uint16)
+        assert data.size >= 326 + length
+        self._chk(self.lib.mgpu_demod_mag_buf_ac(self.ctx, data.ctypes.data, length, sample_timestamp, sys_timestamp,
+                                                 float(mean_level), float(mean_power), dropped), "mgpu_demod_mag_buf_ac")
 
     def demodulate_capture(self, iq, chunk_samples=None):
         """Whole capture: feed in chunks that are multiples of the buffer size, finish, collect."""

@@ -165,6 +165,8 @@ struct Slot {
     // the job
     uint64_t n = 0, stream_pos = 0;
     bool have_mag = false, busy = false;
+    bool have_noise = false;              // mag_buf entry with the caller's mean_level: Mode A/C noise level computed on the host
+    uint32_t given_noise = 0;
     std::vector<BufferClock> buffers;
     std::vector<double> given_mean_power;
 };
@@ -723,6 +725,11 @@ static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
     } else {
         c->tail_src = sl.d_mag + n;
     }
+    if (cfg.mode_ac && sl.have_mag && sl.have_noise) {   // struct mag_buf entry: one buffer, noise level from the caller's means
+        HIPCHK(c, hipMemcpyAsync(sl.d_ac_noise, &sl.given_noise, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        launch_modeac_scan(sl.d_mag, n, cfg.buf_samples, sl.d_ac_noise, sl.h_ac, (uint32_t) c->cap_ac,
+                           sl.d_scratch + CNT_NUM + 1 + 4 * c->cap_buffers, sl.d_counters, s);
+    }
     if (cfg.mode_ac && !sl.have_mag)       // Mode A/C candidates (needs the converter's per-buffer sums); a few us, streaming
         launch_modeac(sl.d_mag, n, cfg.buf_samples, cfg.format, sl.d_sum_level, sl.d_sum_power, sl.d_fsum_level, sl.d_fsum_power,
                       sl.d_ac_noise, sl.h_ac, (uint32_t) c->cap_ac, sl.d_scratch + CNT_NUM + 1 + 4 * c->cap_buffers, sl.d_counters, s);
@@ -807,7 +814,7 @@ static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job) {
     std::memcpy(job.recs.data(), sl.h_live, nlive * sizeof(PhaseRec));
     std::memcpy(job.sig.data(), sl.h_live_sig, nlive * sizeof(unsigned long long));
     job.ac.clear();
-    if (c->cfg.mode_ac && !sl.have_mag) {
+    if (c->cfg.mode_ac && (!sl.have_mag || sl.have_noise)) {
         const unsigned long long *counts = sl.h_scratch + CNT_NUM + 1 + 4 * c->cap_buffers;   // k_modeac's kAcLists lists
         const uint64_t cap_l = c->cap_ac / kAcLists;
         for (int l = 0; l < kAcLists; ++l) {
@@ -1198,6 +1205,7 @@ static int feed_common(mgpu_ctx *c, const void *src, bool src_is_device, uint64_
         sl.n = len;
         sl.stream_pos = c->stream_pos + off;
         sl.have_mag = false;
+        sl.have_noise = false;
         sl.given_mean_power.clear();
         ifile_grid(c, c->stream_pos + off, len, sl.buffers);
         if (!src_is_device) {
@@ -1355,8 +1363,22 @@ int mgpu_convert(mgpu_ctx *c, const void *iq_host, uint16_t *mag_host, uint32_t 
     return MGPU_OK;
 }
 
+static int demod_mag_buf(mgpu_ctx *c, const uint16_t *data, uint32_t length, int64_t sampleTimestamp, int64_t sysTimestamp,
+                         const double *mean_level, double mean_power, uint32_t dropped);
+
 int mgpu_demod_mag_buf(mgpu_ctx *c, const uint16_t *data, uint32_t length, int64_t sampleTimestamp, int64_t sysTimestamp,
                        double mean_power, uint32_t dropped) {
+    if (c && c->cfg.mode_ac) { c->err = "mode_ac needs the buffer's mean_level: use mgpu_demod_mag_buf_ac"; return MGPU_E_INVAL; }
+    return demod_mag_buf(c, data, length, sampleTimestamp, sysTimestamp, nullptr, mean_power, dropped);
+}
+
+int mgpu_demod_mag_buf_ac(mgpu_ctx *c, const uint16_t *data, uint32_t length, int64_t sampleTimestamp, int64_t sysTimestamp,
+                          double mean_level, double mean_power, uint32_t dropped) {
+    return demod_mag_buf(c, data, length, sampleTimestamp, sysTimestamp, &mean_level, mean_power, dropped);
+}
+
+static int demod_mag_buf(mgpu_ctx *c, const uint16_t *data, uint32_t length, int64_t sampleTimestamp, int64_t sysTimestamp,
+                         const double *mean_level, double mean_power, uint32_t dropped) {
     if (!c || !data) return MGPU_E_INVAL;
     (void) dropped;   // raising the threshold after drops (demod_2400.c:335-338) is the caller's cfg.preamble_threshold
     if (length > c->chunk_samples) return MGPU_E_CAPACITY;
@@ -1376,6 +1398,12 @@ int mgpu_demod_mag_buf(mgpu_ctx *c, const uint16_t *data, uint32_t length, int64
     Slot &sl = acquire_slot(c, slot_idx);
     sl.n = length;
     sl.have_mag = true;
+    sl.have_noise = c->cfg.mode_ac && mean_level;
+    if (sl.have_noise) {
+        // demodulate2400AC, demod_2400.c:579-580: noise_stddev = sqrt(mean_power - mean_level^2); noise_level = (power + stddev) * 65535 + 0.5
+        const double sd = std::sqrt(mean_power - *mean_level * *mean_level);
+        sl.given_noise = (uint32_t) ((mean_power + sd) * 65535 + 0.5);
+    }
     sl.given_mean_power.assign(1, mean_power);
     sl.buffers.assign(1, BufferClock{sampleTimestamp, sysTimestamp, 0u, length});
     int rc = MGPU_OK;

@@ -157,6 +157,8 @@ void launch_modeac(const uint16_t *mag, uint64_t n, uint32_t buf_samples, int fo
                    unsigned long long *counters, hipStream_t s);
 // beast wire frames (modesSendBeastOutput, net_io.c:1655-1714) of n message records in device memory; len [n] and
 // block_bytes [ceil(n/256)] are scratch; *total (device) receives the number of bytes the frames take
+void launch_modeac_scan(const uint16_t *mag, uint64_t n, uint32_t buf_samples, const uint32_t *noise_level, AcCand *out, uint32_t cap,
+                        unsigned long long *list_counts, unsigned long long *counters, hipStream_t s);
 void launch_decode_fields(const mgpu_msg *msgs, uint64_t n, mgpu_fields *out, const double *roll_tan, hipStream_t s);
 void launch_beast_encode(const mgpu_msg *msgs, uint64_t n, uint16_t *meta, uint32_t *block_bytes, unsigned long long *block_off, uint8_t *out,
                          uint64_t cap, unsigned long long *total, hipStream_t s);

@@ -22,6 +22,7 @@ int gpu_demod_open(struct gpu_demod *g, const struct mgpu_config *cfg, gpu_messa
     memset(g, 0, sizeof(*g));
     g->sink = sink;
     g->user = user;
+    g->mode_ac = cfg->mode_ac != 0;
     int rc = mgpu_create(cfg, &g->ctx);
     if (rc != MGPU_OK) {
         fprintf(stderr, "gpu demodulator: %s\n", mgpu_strerror(rc));   /* loud: there is no CPU fallback */
@@ -91,8 +92,11 @@ static void deliver(struct gpu_demod *g) {
 }
 
 void demodulate2400_gpu(struct gpu_demod *g, struct mag_buf *mag) {
-    int rc = mgpu_demod_mag_buf(g->ctx, mag->data, mag->length, mag->sampleTimestamp, mag->sysTimestamp,
-                                mag->mean_power, mag->dropped);
+    /* with --modeac the decode thread runs demodulate2400AC(buf) right after demodulate2400(buf) (readsb.c:871-874) */
+    int rc = g->mode_ac ? mgpu_demod_mag_buf_ac(g->ctx, mag->data, mag->length, mag->sampleTimestamp, mag->sysTimestamp,
+                                                mag->mean_level, mag->mean_power, mag->dropped)
+                        : mgpu_demod_mag_buf(g->ctx, mag->data, mag->length, mag->sampleTimestamp, mag->sysTimestamp,
+                                             mag->mean_power, mag->dropped);
     if (rc != MGPU_OK) {
         fprintf(stderr, "demodulate2400_gpu: %s (%s)\n", mgpu_strerror(rc), mgpu_last_error(g->ctx));
         abort();   /* the reference's demodulate2400 cannot fail; silently dropping a buffer would be worse */

@@ -60,6 +60,7 @@ struct gpu_demod {
     uint8_t *readbuf[2];             /* the file reader's two page-locked chunk buffers (gpu_demod_reserve_input) */
     size_t readbuf_bytes;
     int readbuf_pinned[2];
+    int mode_ac;                     /* Modes.mode_ac: demodulate2400_gpu also runs the Mode A/C demodulator */
 };
 
 /* modesInit()'s hot-path part (readsb.c:285-310) + init_converter (sdr_ifile.c:156) */

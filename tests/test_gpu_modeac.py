@@ -39,3 +39,36 @@ def test_mode_ac_off_is_the_default(built):
     d.close()
     helpers.assert_same_messages(got, want)
     assert int(cnt["demod_modeac"]) == 0
+
+
+def test_mag_buf_entry_with_mode_ac(built):
+    """demodulate2400(buf) + demodulate2400AC(buf) on host-provided struct mag_buf contents (readsb.c:871-874): the caller
+    hands over mean_level and mean_power, the Mode A/C noise floor comes from them (demod_2400.c:579-580)."""
+    import numpy as np
+    import readsb_amd
+    B, TR = 131072, 326
+    iq = helpers.synth(nsamples=6 * B + 50000, seed=97, rate=700.0, dense=2)
+    want, wst, mag = helpers.oracle_run(iq, 0, 1, 1, 58, want_mag=True, mode_ac=1)
+    assert (want["msgbits"] == 16).sum() > 20
+    n = iq.size // 2
+    d = readsb_amd.Demodulator(mode_ac=1, startup_time_ms=helpers.STARTUP_MS, max_samples=B)
+    try:
+        with pytest.raises(readsb_amd.MgpuError):          # without mean_level the Mode A/C half cannot run: refused, not skipped
+            d.demod_mag_buf(mag[: TR + B], B, 0, helpers.STARTUP_MS, 0.01)
+        k = 0
+        while True:
+            length = min(B, n - k * B)
+            data = mag[k * B: k * B + TR + length]
+            new = data[TR:].astype(np.uint64)
+            mean_level = float(new.sum()) / 65536.0 / length                        # convert_uc8_nodc, convert.c:101-107
+            mean_power = float((new * new).sum()) / 65535.0 / 65535.0 / length
+            st = k * B * 5
+            d.demod_mag_buf_ac(data, length, st, st // 12000 + helpers.STARTUP_MS, mean_level, mean_power)
+            k += 1
+            if length < B:
+                break
+        got, cnt = d.collect()
+    finally:
+        d.close()
+    helpers.assert_same_messages(got, want)
+    helpers.assert_same_counters(cnt, wst)

@@ -566,8 +566,8 @@ static int alloc_all(mgpu_ctx *c) {
     const size_t bps = cfg.format == MGPU_FMT_UC8 ? 2 : 4;
 
     HIPCHK(c, hipMalloc(&c->d_iq, n * bps + 64));
-    HIPCHK(c, hipMalloc(&c->d_win, 8 * sizeof(unsigned long long)));
-    HIPCHK(c, hipHostMalloc(&c->h_win, 8 * sizeof(unsigned long long)));
+    HIPCHK(c, hipMalloc(&c->d_win, kWinWords * sizeof(unsigned long long)));
+    HIPCHK(c, hipHostMalloc(&c->h_win, kWinWords * sizeof(unsigned long long)));
     HIPCHK(c, hipMalloc(&c->d_adder_bitmap, (1u << 24) / 8));
     HIPCHK(c, hipMemsetAsync(c->d_adder_bitmap, 0, (1u << 24) / 8, c->stream));
     for (auto &sl : c->slot) {
@@ -1040,14 +1040,15 @@ static int feed_begin(mgpu_ctx *c) {
     std::memset(&c->acc, 0, sizeof(c->acc));
     std::memset(c->feed_cand, 0, sizeof(c->feed_cand));
     c->feed_rc = ResolveCounts();
-    HIPCHK(c, hipMemsetAsync(c->d_win, 0, 8 * sizeof(unsigned long long), c->stream2));
+    HIPCHK(c, hipMemsetAsync(c->d_win, 0, kWinWords * sizeof(unsigned long long), c->stream2));
     return MGPU_OK;
 }
 
 static int feed_end(mgpu_ctx *c) {
     if (c->shard_mode != 0) return MGPU_OK;   // a shard pass produces no messages and no statistics here
-    HIPCHK(c, hipMemcpyAsync(c->h_win, c->d_win, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream2));
+    HIPCHK(c, hipMemcpyAsync(c->h_win, c->d_win, kWinWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream2));
     HIPCHK(c, hipStreamSynchronize(c->stream2));
+    for (int k = 8; k < kWinWords; ++k) c->h_win[k & 7] += c->h_win[k];    // k_window_stats spreads its totals over 16 copies
     mgpu_counters &k = c->counters;
     k.nflips = c->resolver.nflips();
     const unsigned long long *hw = c->h_win;

@@ -18,6 +18,7 @@
 
 namespace mgpu {
 
+constexpr int kWinWords = 16 * 8;       // k_window_stats: 16 copies of its 8 result words (fewer atomics per word)
 constexpr int kTrailing = 326;          // Modes.trailing_samples (readsb.c:288)
 constexpr int kTile = 4096;             // scan positions per LDS tile
 constexpr int kHalo = 304;              // >= 290 samples of look-ahead (demod reads pa[0..289]), multiple of 8

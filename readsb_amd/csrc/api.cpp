@@ -145,6 +145,7 @@ struct Slot {
     unsigned long long *d_scratch = nullptr, *h_scratch = nullptr;
     size_t scratch_bytes = 0;
     unsigned long long *d_counters = nullptr, *d_sum_level = nullptr, *d_sum_power = nullptr, *d_win = nullptr, *d_msg_sig = nullptr;
+    unsigned long long *d_win_part = nullptr;   // k_window_stats: per-workgroup totals of the chunk's skip windows
     double *d_fsum_level = nullptr, *d_fsum_power = nullptr;
     uint32_t *d_msg_pos = nullptr, *d_msg_limit = nullptr;
     uint16_t *d_msg_len = nullptr, *d_msg_skip = nullptr;
@@ -498,6 +499,7 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
         sl.h_fsums = (double *) (sl.h_scratch + CNT_NUM + 1 + 2 * nb);   // level[nb] then power[nb]
     }
     HIPCHK(c, hipMalloc(&sl.d_win, 8 * sizeof(unsigned long long)));
+    HIPCHK(c, hipMalloc(&sl.d_win_part, kWinPartWords * sizeof(unsigned long long)));
     HIPCHK(c, hipMalloc(&sl.d_msg_pos, c->cap_msgs * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc(&sl.d_msg_limit, c->cap_msgs * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc(&sl.d_msg_len, c->cap_msgs * sizeof(uint16_t)));
@@ -525,7 +527,7 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
 static void free_slot(Slot &sl) {
     void *dev[] = {sl.d_mag, sl.d_pool, sl.d_scratch, sl.d_unit_first, sl.d_unit_count, sl.d_unit_live, sl.d_class_bitmap,
                    sl.d_class_uncond, sl.d_class_final, sl.d_cand, sl.d_cand_count,
-                   sl.d_win, sl.d_msg_pos,
+                   sl.d_win, sl.d_win_part, sl.d_msg_pos,
                    sl.d_msg_limit, sl.d_msg_len, sl.d_msg_skip, sl.d_msg_sig};
     for (void *p : dev)
         if (p) (void) hipFree(p);
@@ -566,8 +568,8 @@ static int alloc_all(mgpu_ctx *c) {
     const size_t bps = cfg.format == MGPU_FMT_UC8 ? 2 : 4;
 
     HIPCHK(c, hipMalloc(&c->d_iq, n * bps + 64));
-    HIPCHK(c, hipMalloc(&c->d_win, kWinWords * sizeof(unsigned long long)));
-    HIPCHK(c, hipHostMalloc(&c->h_win, kWinWords * sizeof(unsigned long long)));
+    HIPCHK(c, hipMalloc(&c->d_win, 8 * sizeof(unsigned long long)));
+    HIPCHK(c, hipHostMalloc(&c->h_win, 8 * sizeof(unsigned long long)));
     HIPCHK(c, hipMalloc(&c->d_adder_bitmap, (1u << 24) / 8));
     HIPCHK(c, hipMemsetAsync(c->d_adder_bitmap, 0, (1u << 24) / 8, c->stream));
     for (auto &sl : c->slot) {
@@ -915,7 +917,7 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
         HIPCHK(c, hipMemcpyAsync(sl.d_msg_limit, sl.h_msg_limit, nmsg * sizeof(uint32_t), hipMemcpyHostToDevice, s2));
         HIPCHK(c, hipMemcpyAsync(sl.d_msg_skip, sl.h_msg_skip, nmsg * sizeof(uint16_t), hipMemcpyHostToDevice, s2));
         launch_window_stats(sl.d_mag, n, cfg.preamble_threshold, c->sweep_version >= 3 ? sl.d_class_final : sl.d_class_bitmap, sl.d_msg_pos, sl.d_msg_skip,
-                            sl.d_msg_limit, nmsg, c->d_win, s2);
+                            sl.d_msg_limit, nmsg, sl.d_win_part, c->d_win, s2);
         HIPCHK(c, hipEventRecord(sl.ev_window, s2));
         sl.window_pending = true;
     }
@@ -1040,15 +1042,14 @@ static int feed_begin(mgpu_ctx *c) {
     std::memset(&c->acc, 0, sizeof(c->acc));
     std::memset(c->feed_cand, 0, sizeof(c->feed_cand));
     c->feed_rc = ResolveCounts();
-    HIPCHK(c, hipMemsetAsync(c->d_win, 0, kWinWords * sizeof(unsigned long long), c->stream2));
+    HIPCHK(c, hipMemsetAsync(c->d_win, 0, 8 * sizeof(unsigned long long), c->stream2));
     return MGPU_OK;
 }
 
 static int feed_end(mgpu_ctx *c) {
     if (c->shard_mode != 0) return MGPU_OK;   // a shard pass produces no messages and no statistics here
-    HIPCHK(c, hipMemcpyAsync(c->h_win, c->d_win, kWinWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream2));
+    HIPCHK(c, hipMemcpyAsync(c->h_win, c->d_win, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream2));
     HIPCHK(c, hipStreamSynchronize(c->stream2));
-    for (int k = 8; k < kWinWords; ++k) c->h_win[k & 7] += c->h_win[k];    // k_window_stats spreads its totals over 16 copies
     mgpu_counters &k = c->counters;
     k.nflips = c->resolver.nflips();
     const unsigned long long *hw = c->h_win;

@@ -18,7 +18,7 @@
 
 namespace mgpu {
 
-constexpr int kWinWords = 16 * 8;       // k_window_stats: 16 copies of its 8 result words (fewer atomics per word)
+constexpr int kWinPartWords = 8192 * 8;  // k_window_stats: one row of 8 words per workgroup (kWinMaxBlocks rows)
 constexpr int kTrailing = 326;          // Modes.trailing_samples (readsb.c:288)
 constexpr int kTile = 4096;             // scan positions per LDS tile
 constexpr int kHalo = 304;              // >= 290 samples of look-ahead (demod reads pa[0..289]), multiple of 8
@@ -168,8 +168,8 @@ void launch_signal_power(const uint16_t *mag, const uint32_t *pos, const uint16_
                          unsigned long long *out, hipStream_t s);
 // candidates / tried phases / conditional-class candidates inside the skip-ahead window of
 // each accepted message (positions pos+1 .. pos+skip, clipped to `limit`), for the stats fix-up
-void launch_window_stats(const uint16_t *mag, uint64_t n, int thr, const uint32_t *class_bitmap,
-                         const uint32_t *pos, const uint16_t *skip, const uint32_t *limit, uint32_t nmsg,
-                         unsigned long long *out /*[8]: cand, ph0..4, cond*/, hipStream_t s);
+void launch_window_stats(const uint16_t *mag, uint64_t n, int thr, const uint32_t *class_bitmap, const uint32_t *pos,
+                         const uint16_t *skip, const uint32_t *limit, uint32_t nmsg, unsigned long long *part, unsigned long long *out,
+                         hipStream_t s);
 
 }  // namespace mgpu

@@ -1,6 +1,6 @@
 """Throughput of the two kernels behind the message list — k_decode_fields and k_beast_size/k_beast_write — on records
 resident in HBM (python tools/bench_behind.py [--messages N]).  Prints one JSON line per kernel: messages/s, algorithmic
-GB/s (208 B per message for the field decode; 64 B in + the frame bytes out for the encoder) against the
+GB/s (64 + 176 B per message for the field decode; 64 B in + the frame bytes out for the encoder) against the
 8 TB/s HBM peak.  Wall clock around the C-ABI `_device` calls (launch + stream sync included), so run it under
 `rocprofv3 --kernel-trace --stats` for the kernels' own durations (profiles/r01_behind_*)."""
 import argparse
@@ -38,7 +38,7 @@ def main():
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     d = readsb_amd.Demodulator(max_samples=1 << 20)
     d_in, d_f, d_b = C.c_void_p(), C.c_void_p(), C.c_void_p()
-    assert hip.hipMalloc(C.byref(d_in), n * 64) == 0 and hip.hipMalloc(C.byref(d_f), n * 144) == 0 and hip.hipMalloc(C.byref(d_b), n * 44) == 0
+    assert hip.hipMalloc(C.byref(d_in), n * 64) == 0 and hip.hipMalloc(C.byref(d_f), n * readsb_amd.FIELDS_DTYPE.itemsize) == 0 and hip.hipMalloc(C.byref(d_b), n * 44) == 0
     for k in range(reps_in):
         assert hip.hipMemcpy(C.c_void_p(d_in.value + k * m.nbytes), m.ctypes.data, m.nbytes, 1) == 0
     for _ in range(3):
@@ -52,7 +52,7 @@ def main():
     for _ in range(a.reps):
         d.beast_encode_device(d_in.value, n, d_b.value, n * 44)
     t_b = (time.perf_counter() - t0) / a.reps
-    for name, t, algo in (("k_decode_fields", t_f, n * 208), ("k_beast_size+k_beast_write", t_b, n * 64 + nbytes)):
+    for name, t, algo in (("k_decode_fields", t_f, n * (64 + readsb_amd.FIELDS_DTYPE.itemsize)), ("k_beast_size+k_beast_write", t_b, n * 64 + nbytes)):
         print(json.dumps({"kernel": name, "messages": n, "ms": round(t * 1e3, 4), "messages_per_s": round(n / t),
                           "algorithmic_GBps": round(algo / t / 1e9, 1), "frac_of_hbm_peak": round(algo / t / 8e12, 4),
                           "timing": "wall clock around the C-ABI call, launch + sync included"}))

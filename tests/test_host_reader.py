@@ -1,0 +1,66 @@
+"""CPU: the host adapter's file reader (readsb_amd/host/demod_gpu.c — read-ahead thread, parallel pread slices, the two
+page-locked chunk buffers, EOF rules of ifileRun, sdr_ifile.c:194-241) driven against a stand-in for the library that only
+records what it is fed (tests/host_stub/reader_check.c).  What reaches mgpu_feed_iq must be the file, in order, in feeds of
+at most cfg.max_samples, straight out of the registered buffers, followed by exactly one mgpu_finish."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers
+
+SRC = os.path.join(helpers.ROOT, "tests", "host_stub", "reader_check.c")
+HOST = os.path.join(helpers.ROOT, "readsb_amd", "host")
+B = 131072
+
+
+@pytest.fixture(scope="module")
+def checker(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("hoststub") / "reader_check")
+    subprocess.run(["gcc", "-std=gnu11", "-O1", "-Wall", "-o", exe, SRC, os.path.join(HOST, "demod_gpu.c"), "-lpthread", "-lm"], check=True)
+    return exe
+
+
+def _stats(line):
+    return {k: int(v) for k, v in (kv.split("=") for kv in line.split())}
+
+
+@pytest.mark.parametrize("fmt,bps", [("UC8", 2), ("SC16", 4)])
+@pytest.mark.parametrize("nbytes_of", [lambda c, bps: 0, lambda c, bps: 2 * bps, lambda c, bps: c * bps - 2, lambda c, bps: c * bps,
+                                       lambda c, bps: c * bps + bps, lambda c, bps: 3 * c * bps, lambda c, bps: 3 * c * bps + 12345 * bps + 1,
+                                       lambda c, bps: 7 * c * bps + 4096 * 3])
+def test_file_reaches_the_demodulator_unchanged(checker, tmp_path, fmt, bps, nbytes_of):
+    chunk_buffers = 3
+    chunk_samples = chunk_buffers * B
+    nbytes = nbytes_of(chunk_samples, bps)
+    data = np.random.default_rng(nbytes).integers(0, 256, size=nbytes, dtype=np.uint8)
+    src, out = tmp_path / "in.iq", tmp_path / "out.iq"
+    data.tofile(src)
+    r = subprocess.run([checker, str(src), fmt, str(chunk_buffers), str(out)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    st = _stats(r.stdout.strip())
+    whole = nbytes // bps * bps                                  # a trailing partial sample is dropped (have / bytes_per_sample)
+    # only the LAST feed may be cut short to whole samples: a partial sample can only sit at the end of the file
+    assert np.array_equal(np.fromfile(out, dtype=np.uint8), data[:whole])
+    assert st["samples"] == st["counted"] == whole // bps
+    assert st["feeds"] == -(-(whole // bps) // chunk_samples)
+    assert st["finish"] == 1 and st["bad"] == 0 and st["rc"] == 0
+    assert st["registered"] == 2 and st["unregistered"] == 2      # two chunk buffers, page-locked once
+
+
+def test_pipe_input(checker, tmp_path):
+    """`--ifile -`: not seekable, sequential reads with short read() returns (sdr_ifile.c:221-235)."""
+    nbytes = 5 * B * 2 + 777 * 2
+    data = np.random.default_rng(5).integers(0, 256, size=nbytes, dtype=np.uint8)
+    out = tmp_path / "out.iq"
+    p = subprocess.Popen([checker, "-", "UC8", "2", str(out)], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=False)
+    raw = data.tobytes()
+    for off in range(0, len(raw), 100003):                      # odd-sized writes
+        p.stdin.write(raw[off:off + 100003])
+    p.stdin.close()
+    line = p.stdout.read().decode().strip()
+    assert p.wait(timeout=120) == 0
+    st = _stats(line)
+    assert np.array_equal(np.fromfile(out, dtype=np.uint8), data)
+    assert st["samples"] == nbytes // 2 and st["finish"] == 1 and st["bad"] == 0

@@ -64,3 +64,50 @@ def test_pipe_input(checker, tmp_path):
     st = _stats(line)
     assert np.array_equal(np.fromfile(out, dtype=np.uint8), data)
     assert st["samples"] == nbytes // 2 and st["finish"] == 1 and st["bad"] == 0
+
+
+@pytest.fixture(scope="module")
+def fanin_checker(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("hoststub") / "fanin_check")
+    subprocess.run(["gcc", "-std=gnu11", "-O1", "-Wall", "-o", exe, os.path.join(helpers.ROOT, "tests", "host_stub", "fanin_check.c"),
+                    os.path.join(HOST, "sdr_gpu_fanin.c"), os.path.join(HOST, "demod_gpu.c"), "-lpthread", "-lm"], check=True)
+    return exe
+
+
+def test_fanin_streams_options_and_devices(fanin_checker, tmp_path):
+    """Seven files of two formats: `--iformat` applies to the `--ifile`s after it, every stream gets its own context on device
+    index % devices (the stand-in reports three; `--gpu-devices 2` narrows that), common options reach every context,
+    every context is fed exactly its own file and finished once."""
+    rng = np.random.default_rng(1)
+    sizes = [5 * B * 2 + 10, 0, 2 * B * 4, 3 * B * 2, B * 4 + 8, 12, 9 * B * 2]
+    fmts = ["UC8", "UC8", "SC16", "UC8", "SC16Q11", "SC16Q11", "UC8"]
+    args, datas, last = [], [], None
+    for k, (n, f) in enumerate(zip(sizes, fmts)):
+        d = rng.integers(0, 256, size=n, dtype=np.uint8)
+        p = tmp_path / f"s{k}.iq"
+        d.tofile(p)
+        datas.append(d)
+        if f != last:
+            args += ["--iformat", f]
+            last = f
+        args += ["--ifile", str(p)]
+    prefix = tmp_path / "fed"
+    r = subprocess.run([fanin_checker, str(prefix)] + args + ["--aggressive", "--modeac", "--preamble-threshold", "40", "--gpu-devices", "2",
+                                                              "--gpu-chunk-buffers", "2"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().splitlines()
+    head = _stats(lines[0])
+    assert head == {"run": 0, "streams": 7, "finish": 7, "nfix": 2, "mode_ac": 1, "thr": 40}
+    code = {"UC8": 0, "SC16": 1, "SC16Q11": 2}
+    for k, ln in enumerate(lines[1:]):
+        st = _stats(ln)
+        bps = 2 if fmts[k] == "UC8" else 4
+        assert st["stream"] == k and st["device"] == k % 2 and st["format"] == code[fmts[k]]
+        assert st["samples"] == st["processed"] == sizes[k] // bps
+        fed = np.fromfile(f"{prefix}.{st['ctx']}", dtype=np.uint8)
+        assert np.array_equal(fed, datas[k][: sizes[k] // bps * bps]), f"stream {k}"
+
+
+def test_fanin_needs_an_input(fanin_checker, tmp_path):
+    r = subprocess.run([fanin_checker, str(tmp_path / "x"), "--fix"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "requires an --ifile argument" in r.stderr

@@ -677,6 +677,52 @@ int modes_oracle_run(const struct modes_oracle_cfg *cfg, const uint8_t *iq, uint
     return 0;
 }
 
+/* ---- the same, one struct mag_buf at a time: what the decode thread does per buffer (readsb.c:869-902): demodulate2400(buf),
+ * with mode_ac demodulate2400AC(buf), then backgroundTasks' filter flip.  One stream per process (the file's statics). ---- */
+static struct run g_stream;
+static struct oracle_stats g_stream_stats;
+static int64_t g_stream_next_flip;
+
+void modes_oracle_stream_begin(const struct modes_oracle_cfg *cfg, int64_t synthetic_now) {
+    g_nfix = cfg->nfix_crc; g_fixDF = cfg->fixDF;
+    modes_oracle_crc_init(cfg->nfix_crc);
+    filter_init();
+    filter_add(BADDR);
+    init_bitsets();
+    free(g_stream.out);
+    memset(&g_stream, 0, sizeof(g_stream));
+    memset(&g_stream_stats, 0, sizeof(g_stream_stats));
+    g_stream.st = &g_stream_stats;
+    g_stream.thr = cfg->preamble_threshold;
+    g_stream.synthetic_now = synthetic_now;
+    g_stream_next_flip = 0;
+}
+
+/* data = trailing samples then `length` new ones (struct mag_buf.data); sysTimestamp absolute (oracle_msg.sys_rel_ms comes
+ * back relative to ORACLE_STARTUP_MS like everywhere else) */
+void modes_oracle_stream_mag_buf(const uint16_t *data, uint32_t length, int64_t sampleTimestamp, int64_t sysTimestamp,
+                                 double mean_level, double mean_power) {
+    demod_buffer(&g_stream, data, length, sampleTimestamp, sysTimestamp, mean_power);
+    if (g_mode_ac) demod_buffer_ac(&g_stream, data, length, sampleTimestamp, sysTimestamp, mean_level, mean_power);
+    g_stream_stats.samples_processed += length;
+    g_stream_stats.samples_lost += BUF_SAMPLES - length;
+    if (g_stream.synthetic_now >= g_stream_next_flip) {       /* readsb.c:1227-1231 */
+        filter_expire();
+        g_stream_next_flip = g_stream.synthetic_now + FILTER_TTL_MS;
+        g_stream_stats.nflips++;
+    }
+    g_stream_stats.nbuffers++;
+}
+
+/* messages accumulated since the last take (caller frees with modes_oracle_free); *st = running counters */
+uint64_t modes_oracle_stream_take(struct oracle_msg **out, struct oracle_stats *st) {
+    const uint64_t n = g_stream.nout;
+    *out = g_stream.out;
+    g_stream.out = NULL; g_stream.nout = 0; g_stream.cap = 0;
+    if (st) *st = g_stream_stats;
+    return n;
+}
+
 /* Beast wire format of one accepted message: modesSendBeastOutput, net_io.c:1655-1714 (the frame part; the 0x1a 0xe3
  * receiverId prefix is only sent with --net-receiver-id).  0x1a, type '2' (7 bytes) / '3' (14) / '1' (Mode A/C, 2),
  * the 12 MHz timestamp as 6 bytes big-endian (netTimestamp :1620-1648), one byte of signal level, the message

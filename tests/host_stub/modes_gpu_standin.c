@@ -1,7 +1,7 @@
-/* modes_gpu_standin.c — TEST INFRASTRUCTURE: a CPU stand-in with libmodes_gpu.so's C ABI (the struct mag_buf entry only),
- * implemented by the restated oracle, so that the link-time drop-in of the whole reference program
- * (readsb_amd/host/readsb_tree/demod_gpu_wrap.c, `make -C oracle full_standin`) can be exercised without a GPU:
- * what is under test is the ADAPTER inside the reference program, not the demodulator.  Never shipped, never linked
+/* modes_gpu_standin.c — TEST INFRASTRUCTURE: a CPU stand-in with libmodes_gpu.so's C ABI (the struct mag_buf and host-IQ entries, one stream per process),
+ * implemented by the restated oracle, so that the HOST code above the C ABI can be exercised without a GPU: the link-time
+ * drop-in of the whole reference program (readsb_amd/host/readsb_tree/demod_gpu_wrap.c, `make -C oracle full_standin`) and the
+ * stand-alone CLI (readsb_amd/host/readsb_gpu_ifile.c).  What is under test is the adapter, not the demodulator.  Never shipped, never linked
  * into the product; the product library has no CPU path. */
 #include <stdlib.h>
 #include <string.h>
@@ -9,7 +9,13 @@
 #include "../../include/modes_gpu.h"
 #include "../../oracle/modes_oracle.h"
 
-struct mgpu_ctx { struct mgpu_config cfg; struct oracle_msg *pending; uint64_t npending, next; struct oracle_stats st; };
+struct mgpu_ctx {
+    struct mgpu_config cfg;
+    struct oracle_msg *pending; uint64_t npending, next, cap;
+    struct oracle_stats st;
+    /* IQ entry: the buffer grid of ifileRun (sdr_ifile.c:194-241) */
+    uint16_t *buf[2]; uint32_t len[2]; uint64_t k, sample_counter; int saw_short;
+};
 
 void mgpu_config_defaults(struct mgpu_config *cfg) {
     memset(cfg, 0, sizeof(*cfg));
@@ -18,24 +24,71 @@ void mgpu_config_defaults(struct mgpu_config *cfg) {
 int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     mgpu_ctx *c = calloc(1, sizeof(*c));
     c->cfg = *cfg;
-    const struct modes_oracle_cfg oc = {0, cfg->nfix_crc, cfg->fixDF, cfg->preamble_threshold};
+    const struct modes_oracle_cfg oc = {cfg->format, cfg->nfix_crc, cfg->fixDF, cfg->preamble_threshold};
     modes_oracle_set_mode_ac((int) cfg->mode_ac);
     modes_oracle_stream_begin(&oc, cfg->startup_time_ms);
     *out = c;
     return MGPU_OK;
 }
-void mgpu_destroy(mgpu_ctx *c) { if (c) { modes_oracle_free(c->pending); free(c); } }
+void mgpu_destroy(mgpu_ctx *c) { if (c) { modes_oracle_free(c->pending); free(c->buf[0]); free(c->buf[1]); free(c); } }
 const char *mgpu_strerror(int rc) { (void) rc; return "stand-in"; }
 const char *mgpu_last_error(mgpu_ctx *c) { (void) c; return ""; }
 
-static int run(mgpu_ctx *c, const uint16_t *data, uint32_t length, int64_t st, int64_t sys, double ml, double mp) {
-    if (c->next < c->npending) return MGPU_E_INVAL;          /* collect first */
-    modes_oracle_free(c->pending);
+/* one buffer through the oracle; its messages are appended to what mgpu_collect has not handed out yet */
+static void one_buffer(mgpu_ctx *c, const uint16_t *data, uint32_t length, int64_t st, int64_t sys, double ml, double mp) {
     modes_oracle_stream_mag_buf(data, length, st, sys, ml, mp);
-    c->npending = modes_oracle_stream_take(&c->pending, &c->st);
-    c->next = 0;
+    struct oracle_msg *m = NULL;
+    const uint64_t n = modes_oracle_stream_take(&m, &c->st);
+    if (c->next == c->npending) c->next = c->npending = 0;
+    if (c->npending + n > c->cap) {
+        c->cap = (c->npending + n) * 2 + 1024;
+        c->pending = realloc(c->pending, c->cap * sizeof(*c->pending));
+    }
+    if (n) memcpy(c->pending + c->npending, m, n * sizeof(*m));
+    c->npending += n;
+    modes_oracle_free(m);
+}
+
+static int run(mgpu_ctx *c, const uint16_t *data, uint32_t length, int64_t st, int64_t sys, double ml, double mp) {
+    one_buffer(c, data, length, st, sys, ml, mp);
     return MGPU_OK;
 }
+
+/* ifileRun's grid on a block of IQ samples: 131072-sample buffers, 326 samples of overlap from the previous buffer,
+ * sampleTimestamp = sampleCounter * 5, sysTimestamp = sampleTimestamp / 12000 + startup (sdr_ifile.c:194-241) */
+static void iq_buffer(mgpu_ctx *c, const uint8_t *iq, uint32_t slen) {
+    const uint32_t B = c->cfg.buf_samples, TR = c->cfg.trailing_samples;
+    if (!c->buf[0]) { c->buf[0] = calloc(B + TR, 2); c->buf[1] = calloc(B + TR, 2); }
+    uint16_t *cur = c->buf[c->k & 1], *last = c->buf[(c->k + 1) & 1];
+    const uint32_t lastlen = c->len[(c->k + 1) & 1];
+    if (c->k > 0 && lastlen >= TR) memcpy(cur, last + lastlen, TR * sizeof(uint16_t));
+    else memset(cur, 0, TR * sizeof(uint16_t));
+    double ml = 0, mp = 0;
+    modes_oracle_convert(c->cfg.format, iq, cur + TR, slen, &ml, &mp);
+    c->len[c->k & 1] = slen;
+    const int64_t st = (int64_t) c->sample_counter * 5;
+    one_buffer(c, cur, slen, st, st / 12000 + c->cfg.startup_time_ms, ml, mp);
+    c->sample_counter += slen;
+    c->k++;
+    if (slen < B) c->saw_short = 1;
+}
+
+int mgpu_feed_iq(mgpu_ctx *c, const void *iq_host, uint64_t nsamples) {
+    if (nsamples > c->cfg.max_samples) return MGPU_E_CAPACITY;
+    const uint32_t B = c->cfg.buf_samples, bps = c->cfg.format == 0 ? 2 : 4;
+    const uint8_t *p = iq_host;
+    for (uint64_t off = 0; off < nsamples; off += B) {
+        const uint32_t slen = (uint32_t) (nsamples - off < B ? nsamples - off : B);
+        iq_buffer(c, p + off * bps, slen);
+    }
+    return MGPU_OK;
+}
+int mgpu_finish(mgpu_ctx *c) {                      /* the zero-length buffer ifileRun pushes at EOF on an exact multiple */
+    if (!c->saw_short) iq_buffer(c, (const uint8_t *) "", 0);
+    return MGPU_OK;
+}
+int mgpu_host_register(mgpu_ctx *c, void *p, uint64_t bytes) { (void) c; (void) p; (void) bytes; return MGPU_OK; }
+int mgpu_host_unregister(mgpu_ctx *c, void *p) { (void) c; (void) p; return MGPU_OK; }
 int mgpu_demod_mag_buf(mgpu_ctx *c, const uint16_t *data, uint32_t length, int64_t st, int64_t sys, double mp, uint32_t dropped) {
     (void) dropped;
     if (c->cfg.mode_ac) return MGPU_E_INVAL;

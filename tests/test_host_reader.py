@@ -111,3 +111,39 @@ def test_fanin_streams_options_and_devices(fanin_checker, tmp_path):
 def test_fanin_needs_an_input(fanin_checker, tmp_path):
     r = subprocess.run([fanin_checker, str(tmp_path / "x"), "--fix"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "requires an --ifile argument" in r.stderr
+
+
+@pytest.fixture(scope="module")
+def cli_standin(tmp_path_factory):
+    """readsb_gpu_ifile (the stand-alone CLI) linked against the oracle stand-in instead of libmodes_gpu.so."""
+    exe = str(tmp_path_factory.mktemp("hoststub") / "readsb_gpu_ifile_standin")
+    subprocess.run(["gcc", "-std=gnu11", "-O1", "-Wall", "-ffp-contract=off", "-o", exe, os.path.join(HOST, "readsb_gpu_ifile.c"),
+                    os.path.join(HOST, "demod_gpu.c"), os.path.join(helpers.ROOT, "tests", "host_stub", "modes_gpu_standin.c"),
+                    os.path.join(helpers.ORACLE_DIR, "modes_oracle.c"), os.path.join(helpers.ORACLE_DIR, "modes_oracle_fields.c"),
+                    "-lpthread", "-lm"], check=True)
+    return exe
+
+
+@pytest.mark.parametrize("fmt,flag,nfix,nsamples,extra", [
+    (0, "--fix", 1, 9 * B + 4321, []),
+    (0, "--fix", 1, 6 * B, []),                               # exact multiple: the zero-length EOF buffer (sdr_ifile.c:223-237)
+    (2, "--aggressive", 2, 7 * B + 99, []),
+    (0, "--fix", 1, 8 * B + 17, ["--modeac"]),
+])
+def test_cli_host_code_on_the_standin(cli_standin, tmp_path, fmt, flag, nfix, nsamples, extra):
+    """Option parsing, the chunked reader, per-message delivery, --raw line format and the --stats block of the C host side,
+    end to end on the CPU: the output must be the oracle's message list (which the goldens pin to the reference)."""
+    mode_ac = 1 if extra else 0
+    iq = helpers.synth(nsamples=nsamples, seed=1000 + nsamples % 97, fmt=fmt, rate=900.0 if mode_ac else 2000.0, dense=2 if mode_ac else 0)
+    path = tmp_path / "cap.iq"
+    iq.tofile(path)
+    want, wst = helpers.oracle_run(iq, fmt, nfix, 1, 58, mode_ac=mode_ac)
+    r = subprocess.run([cli_standin, "--device-type", "ifile", "--ifile", str(path), "--iformat", helpers.FMT_NAMES[fmt], flag, "--raw", "--mlat",
+                        "--stats", "--gpu-chunk-buffers", "4", "--startup-time-ms", str(helpers.STARTUP_MS)] + extra,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = ["@%012X%s;" % (int(m["timestamp"]), bytes(m["msg"][: int(m["msgbits"]) // 8]).hex()) for m in want]
+    assert len(lines) > 50 and r.stdout.strip().splitlines() == lines
+    assert f"{int(wst['demod_preambles'])} Mode-S message preambles received" in r.stderr
+    assert f"{int(wst['demod_accepted'][0])} accepted with correct CRC" in r.stderr
+    assert f"{int(wst['samples_processed'])} samples processed" in r.stderr

@@ -22,8 +22,8 @@ pytestmark = [pytest.mark.gpu,
 
 @pytest.mark.parametrize("kw,opts", [
     (dict(seconds=4.0, seed=301, rate=1800.0), []),
-    (dict(seconds=3.0, seed=302, rate=700.0, dense=2), ["--aggressive"]),
-    (dict(seconds=3.0, seed=302, rate=700.0, dense=2), ["--fix", "--modeac"]),
+    (dict(seconds=3.0, seed=302, rate=700.0, dense=2, naircraft=24), ["--aggressive"]),
+    (dict(seconds=3.0, seed=302, rate=700.0, dense=2, naircraft=24), ["--aggressive", "--modeac"]),
 ])
 def test_reference_program_on_the_gpu_library(built, tmp_path, kw, opts):
     iq = helpers.synth(**kw)

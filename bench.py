@@ -32,6 +32,30 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achi
 SWEEP_BYTES_PER_SAMPLE = 2.0   # k_preamble_sweep reads one u16 magnitude per position
 
 
+VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12     # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-ops/s
+
+
+def valu_issue(avg_launch_ms, path=None):
+    """What actually bounds k_sweep_slice: VALU wave-instructions of one launch from the committed SQ counter
+    pass of this same command (profiles/r01_final_pmc_sq_summary.txt, SQ_INSTS_VALU) over the launch time measured live.
+    Informative; None if the summary is missing or does not parse."""
+    try:
+        path = path or os.path.join(ROOT, "profiles", "r01_final_pmc_sq_summary.txt")
+        insts, inside = None, False
+        for ln in open(path):
+            if not ln.startswith(" "):
+                inside = ln.strip() == "k_sweep_slice"
+            elif inside and ln.split()[0] == "SQ_INSTS_VALU":
+                insts = int(ln.split()[1])
+        if not insts or avg_launch_ms <= 0:
+            return None
+        tl = insts * 64 / (avg_launch_ms * 1e-3) / 1e12
+        return {"wave_insts_per_launch": insts, "achieved_Tlaneops_s": round(tl, 2), "peak_Tlaneops_s": round(VALU_PEAK_TLANEOPS, 1),
+                "frac": round(tl / VALU_PEAK_TLANEOPS, 3), "source": "SQ_INSTS_VALU, profiles/r01_final_pmc_sq_summary.txt"}
+    except Exception:
+        return None
+
+
 def cpu_reference(iq, nsamples):
     """oracle/_ref (the reference's own convert.c + demodulate2400 + ...) on the host, 1 core."""
     import helpers
@@ -190,7 +214,8 @@ def main():
             "roofline": {"kernel": "k_sweep_slice", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "launches_per_step": nlaunch, "algorithmic_bytes_per_launch": int(n * SWEEP_BYTES_PER_SAMPLE / nlaunch),
-                         "avg_launch_ms": round(sweep / nlaunch, 4)},
+                         "avg_launch_ms": round(sweep / nlaunch, 4),
+                         "valu_issue": valu_issue(sweep / nlaunch) if int(n * SWEEP_BYTES_PER_SAMPLE / nlaunch) == 134217728 else None},
             "synth_gen_s": round(t_gen, 2),
         }
         # the boundary handing over HOST buffers (mgpu_feed_iq from page-locked memory): never `value`, see DESIGN.md §4

@@ -114,3 +114,11 @@ def test_parallel_walk_equals_serial_walk(built):
         held.append(pm.value)
     # permille of chunks whose ranges all committed in the first batch: some did, some needed a restart
     assert any(h > 500 for h in held) and any(h < 1000 for h in held), held
+
+
+def test_bench_roofline_helpers():
+    """bench.py's informative VALU-issue figure parses the committed SQ counter summary (and degrades to None, never raises)."""
+    import bench
+    v = bench.valu_issue(0.19)
+    assert v and v["wave_insts_per_launch"] > 10_000_000 and 0.3 < v["frac"] < 1.0 and v["peak_Tlaneops_s"] == 39.3
+    assert bench.valu_issue(0.19, "/nonexistent/file") is None and bench.valu_issue(0.0) is None

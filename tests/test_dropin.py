@@ -23,12 +23,12 @@ DEMOD_STATS = re.compile(r"samples processed|samples lost|Mode-S message preambl
                          r"Mode A/C messages|strong signals|mean signal power|peak signal power|noise power")
 
 
-def run_program(exe, path, fmt, opts, workdir):
+def run_program(exe, path, fmt, opts, workdir, timeout=600):
     import make_beast_golden as g
     dump = os.path.join(workdir, "dump_" + os.path.basename(exe))
     os.mkdir(dump)
     r = subprocess.run([exe, "--device-type", "ifile", "--ifile", path, "--iformat", fmt, "--quiet", "--stats", "--dump-beast", dump + ",3600"] + opts,
-                       cwd=workdir, capture_output=True, text=True, timeout=600)
+                       cwd=workdir, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stderr[-2000:]
     raw = b"".join(open(os.path.join(dump, f), "rb").read() for f in sorted(os.listdir(dump)))
     frames = g.strip_clock_records(g.zstd_decompress_stream(raw))

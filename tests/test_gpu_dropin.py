@@ -29,12 +29,12 @@ def test_reference_program_on_the_gpu_library(built, tmp_path, kw, opts):
     iq = helpers.synth(**kw)
     path = str(tmp_path / "in.iq")
     iq.tofile(path)
-    got_frames, got_stats = td.run_program(GPU_EXE, path, "UC8", opts, str(tmp_path))
+    got_frames, got_stats = td.run_program(GPU_EXE, path, "UC8", opts, str(tmp_path), timeout=90)
     assert len(got_frames) > 10000
     for attempt in range(6):                                   # the reference's own start-up race, see tests/test_dropin.py
         work = tmp_path / f"ref{attempt}"
         work.mkdir()
-        want_frames, want_stats = td.run_program(td.FULL, path, "UC8", opts, str(work))
+        want_frames, want_stats = td.run_program(td.FULL, path, "UC8", opts, str(work), timeout=90)
         if got_frames == want_frames and got_stats == want_stats:
             return
     assert got_frames == want_frames

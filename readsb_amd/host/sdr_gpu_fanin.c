@@ -66,8 +66,6 @@ int gpuFaninHandleOption(struct gpu_fanin *f, const char *opt, const char *arg) 
     return 0;
 }
 
-struct stream_sink_ctx { struct gpu_fanin_stream *s; };
-
 static void stream_sink(const struct gpu_modes_message *mm, void *user) {
     struct gpu_fanin_stream *s = user;
     if (s->owner->sink) s->owner->sink(s->index, mm, s->owner->user);

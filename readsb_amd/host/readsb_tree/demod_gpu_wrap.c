@@ -20,6 +20,11 @@ static mgpu_ctx *gpu;
 static struct mgpu_counters seen;          /* the library's counters are cumulative: remember what was already added */
 static int failed;
 
+static void gpu_close(void) {                               /* at exit: stop the library's pipeline threads before the runtime unloads */
+    if (gpu) mgpu_destroy(gpu);
+    gpu = NULL;
+}
+
 static void gpu_open(void) {
     struct mgpu_config cfg;
     mgpu_config_defaults(&cfg);
@@ -39,7 +44,9 @@ static void gpu_open(void) {
         gpu = NULL;
         failed = 1;
         setExit(2);
+        return;
     }
+    atexit(gpu_close);
 }
 
 static void add_counter_deltas(const struct mgpu_counters *c) {

@@ -117,3 +117,50 @@ void __wrap_demodulate2400(struct mag_buf *mag) {
 /* demodulate2400AC(buf) follows demodulate2400(buf) when Modes.mode_ac is set (readsb.c:872-874): the call above already
  * delivered the buffer's Mode A/C replies behind its Mode S messages, in the reference's order */
 void __wrap_demodulate2400AC(struct mag_buf *mag) { (void) mag; }
+
+/* ---- the converter side of the boundary: iq_convert_fn (convert.h:34-39) ------------------------------------------------
+ * With READSB_GPU_CONVERT=1 in the environment and `-Wl,--wrap=init_converter`, the SDR reader thread's converter
+ * (sdr_ifile.c:156,238; sdr_rtlsdr.c:271) is mgpu_convert() on its own context: IQ block up, magnitudes and the two means
+ * back.  A round trip over PCIe per buffer — there for the completeness of the drop-in (the bulk path hands the library IQ
+ * and never brings magnitudes back), off by default. */
+iq_convert_fn __real_init_converter(input_format_t format, double sample_rate, int filter_dc, struct converter_state **out_state);
+
+static mgpu_ctx *conv_gpu;
+
+static void gpu_convert_close(void) {
+    if (conv_gpu) mgpu_destroy(conv_gpu);
+    conv_gpu = NULL;
+}
+
+static void gpu_convert(void *iq_data, uint16_t *mag_data, unsigned nsamples, struct converter_state *state,
+                        double *out_mean_level, double *out_mean_power) {
+    (void) state;
+    const int rc = mgpu_convert(conv_gpu, iq_data, mag_data, nsamples, out_mean_level, out_mean_power);
+    if (rc != MGPU_OK) {
+        fprintf(stderr, "<3>GPU converter: %s (%s)\n", mgpu_strerror(rc), mgpu_last_error(conv_gpu));
+        setExit(2);
+    }
+}
+
+iq_convert_fn __wrap_init_converter(input_format_t format, double sample_rate, int filter_dc, struct converter_state **out_state) {
+    const char *on = getenv("READSB_GPU_CONVERT");
+    if (!on || !atoi(on) || filter_dc)                       /* the --dcfilter converters are a serial IIR: not offered */
+        return __real_init_converter(format, sample_rate, filter_dc, out_state);
+    struct mgpu_config cfg;
+    mgpu_config_defaults(&cfg);
+    const char *dev = getenv("READSB_GPU_DEVICE");
+    cfg.device = dev ? atoi(dev) : 0;
+    cfg.format = format == INPUT_UC8 ? MGPU_FMT_UC8 : format == INPUT_SC16 ? MGPU_FMT_SC16 : MGPU_FMT_SC16Q11;
+    cfg.max_samples = Modes.sdr_buf_samples ? Modes.sdr_buf_samples : 131072;   /* one buffer per call (sdr_ifile.c:238) */
+    const int rc = mgpu_create(&cfg, &conv_gpu);
+    if (rc != MGPU_OK) {
+        fprintf(stderr, "<3>GPU converter: %s\n", mgpu_strerror(rc));
+        conv_gpu = NULL;
+        return NULL;                                        /* init_converter's own failure value: the plugin's open() fails */
+    }
+    atexit(gpu_convert_close);
+    *out_state = NULL;
+    fprintf(stderr, "init_converter: using the GPU library\n");
+    return gpu_convert;
+}
+

@@ -14,7 +14,7 @@ struct mgpu_ctx {
     struct oracle_msg *pending; uint64_t npending, next, cap;
     struct oracle_stats st;
     /* IQ entry: the buffer grid of ifileRun (sdr_ifile.c:194-241) */
-    uint16_t *buf[2]; uint32_t len[2]; uint64_t k, sample_counter; int saw_short;
+    uint16_t *buf[2]; uint32_t len[2]; uint64_t k, sample_counter; int saw_short, streaming;
 };
 
 void mgpu_config_defaults(struct mgpu_config *cfg) {
@@ -24,9 +24,6 @@ void mgpu_config_defaults(struct mgpu_config *cfg) {
 int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     mgpu_ctx *c = calloc(1, sizeof(*c));
     c->cfg = *cfg;
-    const struct modes_oracle_cfg oc = {cfg->format, cfg->nfix_crc, cfg->fixDF, cfg->preamble_threshold};
-    modes_oracle_set_mode_ac((int) cfg->mode_ac);
-    modes_oracle_stream_begin(&oc, cfg->startup_time_ms);
     *out = c;
     return MGPU_OK;
 }
@@ -36,6 +33,12 @@ const char *mgpu_last_error(mgpu_ctx *c) { (void) c; return ""; }
 
 /* one buffer through the oracle; its messages are appended to what mgpu_collect has not handed out yet */
 static void one_buffer(mgpu_ctx *c, const uint16_t *data, uint32_t length, int64_t st, int64_t sys, double ml, double mp) {
+    if (!c->streaming) {                                     /* the process's one demodulator stream belongs to the first context that demodulates */
+        const struct modes_oracle_cfg oc = {c->cfg.format, c->cfg.nfix_crc, c->cfg.fixDF, c->cfg.preamble_threshold};
+        modes_oracle_set_mode_ac((int) c->cfg.mode_ac);
+        modes_oracle_stream_begin(&oc, c->cfg.startup_time_ms);
+        c->streaming = 1;
+    }
     modes_oracle_stream_mag_buf(data, length, st, sys, ml, mp);
     struct oracle_msg *m = NULL;
     const uint64_t n = modes_oracle_stream_take(&m, &c->st);
@@ -85,6 +88,15 @@ int mgpu_feed_iq(mgpu_ctx *c, const void *iq_host, uint64_t nsamples) {
 }
 int mgpu_finish(mgpu_ctx *c) {                      /* the zero-length buffer ifileRun pushes at EOF on an exact multiple */
     if (!c->saw_short) iq_buffer(c, (const uint8_t *) "", 0);
+    return MGPU_OK;
+}
+/* iq_convert_fn on its own (a context that only converts does not touch the oracle's one demodulator stream) */
+int mgpu_convert(mgpu_ctx *c, const void *iq_host, uint16_t *mag_host, uint32_t nsamples, double *out_mean_level, double *out_mean_power) {
+    double ml = 0, mp = 0;
+    if (nsamples > c->cfg.max_samples) return MGPU_E_CAPACITY;
+    modes_oracle_convert(c->cfg.format, iq_host, mag_host, nsamples, &ml, &mp);
+    if (out_mean_level) *out_mean_level = ml;
+    if (out_mean_power) *out_mean_power = mp;
     return MGPU_OK;
 }
 int mgpu_host_register(mgpu_ctx *c, void *p, uint64_t bytes) { (void) c; (void) p; (void) bytes; return MGPU_OK; }

@@ -23,13 +23,14 @@ DEMOD_STATS = re.compile(r"samples processed|samples lost|Mode-S message preambl
                          r"Mode A/C messages|strong signals|mean signal power|peak signal power|noise power")
 
 
-def run_program(exe, path, fmt, opts, workdir, timeout=600):
+def run_program(exe, path, fmt, opts, workdir, timeout=600, env=None):
     import make_beast_golden as g
     dump = os.path.join(workdir, "dump_" + os.path.basename(exe))
     os.mkdir(dump)
     r = subprocess.run([exe, "--device-type", "ifile", "--ifile", path, "--iformat", fmt, "--quiet", "--stats", "--dump-beast", dump + ",3600"] + opts,
-                       cwd=workdir, capture_output=True, text=True, timeout=timeout)
+                       cwd=workdir, capture_output=True, text=True, timeout=timeout, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
+    run_program.last_output = r.stdout + r.stderr
     raw = b"".join(open(os.path.join(dump, f), "rb").read() for f in sorted(os.listdir(dump)))
     frames = g.strip_clock_records(g.zstd_decompress_stream(raw))
     stats = [ln.strip() for ln in (r.stdout + r.stderr).splitlines() if DEMOD_STATS.search(ln)]
@@ -63,3 +64,24 @@ def test_wrapped_program_equals_reference(tmp_path, kw, opts):
             return
     assert got_frames == want_frames
     assert got_stats == want_stats
+
+
+@pytest.mark.parametrize("fmt,fmt_id,opts", [("UC8", 0, []), ("SC16Q11", 2, ["--aggressive"])])
+def test_wrapped_converter_too(tmp_path, fmt, fmt_id, opts):
+    """READSB_GPU_CONVERT=1: the reader thread's iq_convert_fn (init_converter, convert.h:34-44) is the library's too
+    (`--wrap=init_converter`); magnitudes and the two means come back through mgpu_convert()."""
+    iq = helpers.synth(seconds=3.0, seed=305, rate=1500.0, fmt=fmt_id, naircraft=24)
+    path = str(tmp_path / "in.iq")
+    iq.tofile(path)
+    env = dict(os.environ, READSB_GPU_CONVERT="1")
+    got_frames, got_stats = run_program(STANDIN, path, fmt, opts, str(tmp_path), env=env)
+    assert len(got_frames) > 10000 and "init_converter: using the GPU library" in run_program.last_output
+    for attempt in range(6):
+        work = tmp_path / f"ref{attempt}"
+        work.mkdir()
+        want_frames, want_stats = run_program(FULL, path, fmt, opts, str(work))
+        if got_frames == want_frames and got_stats == want_stats:
+            return
+    assert got_frames == want_frames
+    assert got_stats == want_stats
+

@@ -39,3 +39,22 @@ def test_reference_program_on_the_gpu_library(built, tmp_path, kw, opts):
             return
     assert got_frames == want_frames
     assert got_stats == want_stats
+
+
+def test_reference_program_with_the_gpu_converter_too(built, tmp_path):
+    """READSB_GPU_CONVERT=1: the reader thread's iq_convert_fn is mgpu_convert() as well (`--wrap=init_converter`)."""
+    iq = helpers.synth(seconds=3.0, seed=305, rate=1500.0, fmt=2, naircraft=24)
+    path = str(tmp_path / "in.iq")
+    iq.tofile(path)
+    env = dict(os.environ, READSB_GPU_CONVERT="1")
+    got_frames, got_stats = td.run_program(GPU_EXE, path, "SC16Q11", ["--aggressive"], str(tmp_path), timeout=90, env=env)
+    assert len(got_frames) > 10000 and "init_converter: using the GPU library" in td.run_program.last_output
+    for attempt in range(6):
+        work = tmp_path / f"ref{attempt}"
+        work.mkdir()
+        want_frames, want_stats = td.run_program(td.FULL, path, "SC16Q11", ["--aggressive"], str(work), timeout=90)
+        if got_frames == want_frames and got_stats == want_stats:
+            return
+    assert got_frames == want_frames
+    assert got_stats == want_stats
+

@@ -29,12 +29,12 @@ def test_reference_program_on_the_gpu_library(built, tmp_path, kw, opts):
     iq = helpers.synth(**kw)
     path = str(tmp_path / "in.iq")
     iq.tofile(path)
-    got_frames, got_stats = td.run_program(GPU_EXE, path, "UC8", opts, str(tmp_path), timeout=90)
+    got_frames, got_stats = td.run_program(GPU_EXE, path, "UC8", opts, str(tmp_path), timeout=45)
     assert len(got_frames) > 10000
-    for attempt in range(6):                                   # the reference's own start-up race, see tests/test_dropin.py
+    for attempt in range(3):                                   # the reference's own start-up race, see tests/test_dropin.py
         work = tmp_path / f"ref{attempt}"
         work.mkdir()
-        want_frames, want_stats = td.run_program(td.FULL, path, "UC8", opts, str(work), timeout=90)
+        want_frames, want_stats = td.run_program(td.FULL, path, "UC8", opts, str(work), timeout=45)
         if got_frames == want_frames and got_stats == want_stats:
             return
     assert got_frames == want_frames
@@ -47,12 +47,12 @@ def test_reference_program_with_the_gpu_converter_too(built, tmp_path):
     path = str(tmp_path / "in.iq")
     iq.tofile(path)
     env = dict(os.environ, READSB_GPU_CONVERT="1")
-    got_frames, got_stats = td.run_program(GPU_EXE, path, "SC16Q11", ["--aggressive"], str(tmp_path), timeout=90, env=env)
+    got_frames, got_stats = td.run_program(GPU_EXE, path, "SC16Q11", ["--aggressive"], str(tmp_path), timeout=45, env=env)
     assert len(got_frames) > 10000 and "init_converter: using the GPU library" in td.run_program.last_output
-    for attempt in range(6):
+    for attempt in range(3):
         work = tmp_path / f"ref{attempt}"
         work.mkdir()
-        want_frames, want_stats = td.run_program(td.FULL, path, "SC16Q11", ["--aggressive"], str(work), timeout=90)
+        want_frames, want_stats = td.run_program(td.FULL, path, "SC16Q11", ["--aggressive"], str(work), timeout=45)
         if got_frames == want_frames and got_stats == want_stats:
             return
     assert got_frames == want_frames

@@ -55,7 +55,27 @@ struct mgpu_config {
     int64_t  startup_time_ms;     /* Modes.startup_time: wall clock (ms) the 12 MHz sample clock is anchored to */
     uint64_t record_pool_records; /* device pool for per-phase candidate records; 0 = max_samples/16 + 65536 */
     uint64_t max_messages;        /* cap on accepted messages kept per feed; 0 = max_samples/64 + 65536 */
+    uint32_t filter_clock;        /* MGPU_FILTER_CLOCK_*: who runs icaoFilterExpire (readsb.c:1227-1231), see below */
+    uint32_t reserved0;
 };
+
+/* The ICAO filter's 60 s expiry (backgroundTasks, readsb.c:1227-1231: `static next_flip = 0`, so the first
+ * icaoFilterExpire() runs at the first backgroundTasks call).  The reference program itself has two start-up orders:
+ * its decode thread either finds the first buffer waiting (flip AFTER buffer 0, next one 60 s after the clock at the end
+ * of buffer 0) or does not (flip BEFORE buffer 0, on the still empty filter, next one 60 s after start-up) — thread
+ * scheduling decides (readsb.c:857-902).  The orders differ in which filter generation buffer 0's addresses land in, and
+ * therefore in what the next table resize drops (icao_filter.c:65-93).
+ *   AFTER_FIRST   the library runs the clock on the buffers' sysTimestamp, first expiry after buffer 0 (default; what the
+ *                 oracle, the goldens and a reference run with a slow decode-thread start do)
+ *   BEFORE_FIRST  the same clock, first expiry before buffer 0 (anchored to startup_time_ms)
+ *   EXTERNAL      the library never expires on its own: the host forwards every icaoFilterExpire() it performs with
+ *                 mgpu_filter_expire() (and foreign icaoFilterAdd()s, e.g. from network input, with mgpu_filter_add())
+ *                 between two feed calls.  This is what a readsb process linked against the library uses
+ *                 (readsb_amd/host/readsb_tree/demod_gpu_wrap.c wraps icaoFilterExpire): its own filter and the
+ *                 library's then flip at the same buffer boundaries whatever clock the host runs (synthetic or wall). */
+#define MGPU_FILTER_CLOCK_AFTER_FIRST  0
+#define MGPU_FILTER_CLOCK_BEFORE_FIRST 1
+#define MGPU_FILTER_CLOCK_EXTERNAL     2
 
 /* Fills cfg with the reference defaults (configSetDefaults, readsb.c:150-228). */
 void mgpu_config_defaults(struct mgpu_config *cfg);
@@ -184,6 +204,14 @@ int mgpu_collect(mgpu_ctx *ctx, struct mgpu_msg *out, uint64_t cap, uint64_t *n,
 int mgpu_set_message_buffer(mgpu_ctx *ctx, struct mgpu_msg *buf, uint64_t capacity);
 
 uint64_t mgpu_pending_messages(mgpu_ctx *ctx);
+
+/* icaoFilterExpire() (icao_filter.c:96-110) / icaoFilterAdd() (:112-130) on the context's filter, between two feed
+ * calls.  mgpu_filter_expire is how a host drives the filter with cfg.filter_clock = MGPU_FILTER_CLOCK_EXTERNAL (it is
+ * refused with MGPU_E_INVAL in the other modes: two clocks would double-flip); mgpu_filter_add mirrors adds the host
+ * makes outside the demodulator (decodeModesMessage on network input, mode_s.c:766-779) and is allowed in every mode. */
+int mgpu_filter_expire(mgpu_ctx *ctx);
+int mgpu_filter_add(mgpu_ctx *ctx, uint32_t addr);
+
 int mgpu_last_timing(mgpu_ctx *ctx, struct mgpu_timing *t);
 
 /* ---- the two plugin-surface pieces on their own ----------------------------------- */
@@ -197,7 +225,10 @@ int mgpu_convert(mgpu_ctx *ctx, const void *iq_host, uint16_t *mag_host, uint32_
 /* demodulate2400(struct mag_buf *) (demod_2400.h:38) on one magnitude buffer laid out as
  * struct mag_buf.data (readsb.h:450-464): trailing_samples of overlap then `length` new
  * samples.  The caller passes the struct's scalar fields; messages come back through
- * mgpu_collect().  The stream position / filter clock advance exactly as for mgpu_feed_iq. */
+ * mgpu_collect().  The stream position / filter clock advance exactly as for mgpu_feed_iq.
+ * dropped: nonzero = the host has recently dropped samples (what demod_2400.c:335-338 reads from
+ * Modes.stats_15min.samples_dropped): this buffer is swept with max(PREAMBLE_THRESHOLD_PIZERO = 75,
+ * cfg.preamble_threshold), as the reference does. */
 int mgpu_demod_mag_buf(mgpu_ctx *ctx, const uint16_t *data, uint32_t length,
                        int64_t sampleTimestamp, int64_t sysTimestamp,
                        double mean_power, uint32_t dropped);

@@ -556,6 +556,10 @@ static void demod_buffer(struct run *r, const uint16_t *m, uint32_t mlen, int64_
  * apart = 87 cycles of a virtual 60 MHz clock, one 2.4 MHz sample = 25 cycles. */
 static int g_mode_ac;
 void modes_oracle_set_mode_ac(int on) { g_mode_ac = on; }
+/* who flips the ICAO filter: 0 = first flip after buffer 0 (default), 1 = before buffer 0 (the reference program's other
+ * start-up order), 2 = only modes_oracle_stream_filter_expire() (same values as mgpu_config.filter_clock) */
+static int g_filter_clock;
+void modes_oracle_set_filter_clock(int mode) { g_filter_clock = mode; }
 
 static void demod_buffer_ac(struct run *r, const uint16_t *m, uint32_t mlen, int64_t sampleTimestamp,
                             int64_t sysTimestamp, double mean_level, double mean_power) {
@@ -639,6 +643,11 @@ int modes_oracle_run(const struct modes_oracle_cfg *cfg, const uint8_t *iq, uint
     int64_t next_flip = 0;
     uint64_t sampleCounter = 0, k = 0;
     int eof = 0;
+    if (g_filter_clock == 1) {                             /* first backgroundTasks before buffer 0 (readsb.c:857-902) */
+        filter_expire();
+        next_flip = r.synthetic_now + FILTER_TTL_MS;
+        st->nflips++;
+    }
     while (!eof) {
         uint16_t *cur = bufs[k & 1], *last = bufs[(k + 1) & 1];
         uint64_t remain = nsamples - sampleCounter;
@@ -664,7 +673,7 @@ int modes_oracle_run(const struct modes_oracle_cfg *cfg, const uint8_t *iq, uint
         st->t_demod_s += t2 - t1;
         st->samples_processed += slen;
         st->samples_lost += BUF_SAMPLES - slen;            /* readsb.c:886 */
-        if (r.synthetic_now >= next_flip) {                /* readsb.c:1227-1231 */
+        if (g_filter_clock != 2 && r.synthetic_now >= next_flip) {   /* readsb.c:1227-1231 */
             filter_expire();
             next_flip = r.synthetic_now + FILTER_TTL_MS;
             st->nflips++;
@@ -696,7 +705,16 @@ void modes_oracle_stream_begin(const struct modes_oracle_cfg *cfg, int64_t synth
     g_stream.thr = cfg->preamble_threshold;
     g_stream.synthetic_now = synthetic_now;
     g_stream_next_flip = 0;
+    if (g_filter_clock == 1) {
+        filter_expire();
+        g_stream_next_flip = synthetic_now + FILTER_TTL_MS;
+        g_stream_stats.nflips++;
+    }
 }
+
+/* the host's own icaoFilterExpire() / icaoFilterAdd() forwarded (filter clock 2 = external) */
+void modes_oracle_stream_filter_expire(void) { filter_expire(); g_stream_stats.nflips++; }
+void modes_oracle_stream_filter_add(uint32_t addr) { filter_add(addr); }
 
 /* data = trailing samples then `length` new ones (struct mag_buf.data); sysTimestamp absolute (oracle_msg.sys_rel_ms comes
  * back relative to ORACLE_STARTUP_MS like everywhere else) */
@@ -706,7 +724,7 @@ void modes_oracle_stream_mag_buf(const uint16_t *data, uint32_t length, int64_t 
     if (g_mode_ac) demod_buffer_ac(&g_stream, data, length, sampleTimestamp, sysTimestamp, mean_level, mean_power);
     g_stream_stats.samples_processed += length;
     g_stream_stats.samples_lost += BUF_SAMPLES - length;
-    if (g_stream.synthetic_now >= g_stream_next_flip) {       /* readsb.c:1227-1231 */
+    if (g_filter_clock != 2 && g_stream.synthetic_now >= g_stream_next_flip) {   /* readsb.c:1227-1231 */
         filter_expire();
         g_stream_next_flip = g_stream.synthetic_now + FILTER_TTL_MS;
         g_stream_stats.nflips++;

@@ -84,6 +84,8 @@ static double now_s(void) {
 
 static int g_mode_ac;   /* --modeac: demodulate2400AC after demodulate2400 on every buffer (readsb.c:871-874) */
 void ref_set_mode_ac(int on) { g_mode_ac = on; }
+static int g_flip_before;   /* the reference program's other start-up order: first icaoFilterExpire() before buffer 0 */
+void ref_set_flip_before(int on) { g_flip_before = on; }
 
 static struct converter_state *g_cstate;
 static iq_convert_fn g_conv;
@@ -161,6 +163,12 @@ int ref_demod_run(int format, int nfix, int fixdf, int thr,
     uint64_t sampleCounter = 0;
     uint64_t k = 0;
     int eof = 0;
+    if (g_flip_before) {                        /* the decode thread found no buffer waiting on its first pass: backgroundTasks
+                                                   (and the first filter flip) ran before buffer 0, readsb.c:857-902 */
+        icaoFilterExpire();
+        next_flip = Modes.synthetic_now + MODES_ICAO_FILTER_TTL;
+        st->nflips++;
+    }
     while (!eof) {
         struct mag_buf *outbuf = &bufs[k & 1], *lastbuf = &bufs[(k + 1) & 1];
         uint64_t remain = nsamples - sampleCounter;
@@ -370,6 +378,7 @@ int main(int argc, char **argv) {
     struct oracle_msg *out; uint64_t nout; struct oracle_stats st;
     uint16_t *mag = argc > 8 ? malloc((n + 326) * sizeof(uint16_t)) : NULL;
     if (getenv("ORACLE_MODE_AC")) ref_set_mode_ac(1);
+    if (getenv("ORACLE_FLIP_BEFORE")) ref_set_flip_before(1);
     if (ref_demod_run(format, nfix, fixdf, thr, iq, n, &out, &nout, &st, mag, NULL, NULL) < 0)
         return 1;
     FILE *f = fopen(argv[6], "wb");

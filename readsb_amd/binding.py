@@ -47,12 +47,16 @@ FIELDS_DTYPE = np.dtype([
 assert FIELDS_DTYPE.itemsize == 176
 
 
+FILTER_CLOCK_AFTER_FIRST, FILTER_CLOCK_BEFORE_FIRST, FILTER_CLOCK_EXTERNAL = 0, 1, 2
+
+
 class Config(C.Structure):
     _fields_ = [
         ("device", C.c_int32), ("format", C.c_int32), ("nfix_crc", C.c_int32), ("fixDF", C.c_int32),
         ("preamble_threshold", C.c_int32), ("buf_samples", C.c_uint32), ("trailing_samples", C.c_uint32),
         ("mode_ac", C.c_uint32), ("max_samples", C.c_uint64), ("startup_time_ms", C.c_int64),
         ("record_pool_records", C.c_uint64), ("max_messages", C.c_uint64),
+        ("filter_clock", C.c_uint32), ("reserved0", C.c_uint32),
     ]
 
 
@@ -130,6 +134,8 @@ def load_library():
     lib.mgpu_finish.argtypes = [vp]
     lib.mgpu_collect.argtypes = [vp, vp, u64, C.POINTER(u64), C.POINTER(Counters)]
     lib.mgpu_pending_messages.argtypes = [vp]
+    lib.mgpu_filter_expire.argtypes = [vp]
+    lib.mgpu_filter_add.argtypes = [vp, u32]
     lib.mgpu_set_message_buffer.argtypes = [vp, vp, u64]
     lib.mgpu_decode_fields.argtypes = [vp, vp, u64, vp]
     lib.mgpu_decode_fields_device.argtypes = [vp, vp, u64, vp]
@@ -158,7 +164,8 @@ class Demodulator:
     """One SDR stream on one GPU (struct mgpu_ctx)."""
 
     def __init__(self, fmt=FMT_UC8, nfix_crc=1, fix_df=1, preamble_threshold=58, max_samples=64 * 131072,
-                 device=0, startup_time_ms=0, record_pool_records=0, max_messages=0, buf_samples=131072, mode_ac=0):
+                 device=0, startup_time_ms=0, record_pool_records=0, max_messages=0, buf_samples=131072, mode_ac=0,
+                 filter_clock=0):
         self.lib = load_library()
         cfg = Config()
         self.lib.mgpu_config_defaults(C.byref(cfg))
@@ -166,6 +173,7 @@ class Demodulator:
         cfg.preamble_threshold, cfg.max_samples, cfg.startup_time_ms = preamble_threshold, max_samples, startup_time_ms
         cfg.record_pool_records, cfg.max_messages, cfg.buf_samples = record_pool_records, max_messages, buf_samples
         cfg.mode_ac = 1 if mode_ac else 0
+        cfg.filter_clock = filter_clock          # FILTER_CLOCK_*: who runs icaoFilterExpire (modes_gpu.h)
         self.cfg = cfg
         self.fmt = fmt
         self._collect_buf = None
@@ -196,6 +204,14 @@ class Demodulator:
 
     def reset(self):
         self._chk(self.lib.mgpu_reset(self.ctx), "mgpu_reset")
+
+    def filter_expire(self):
+        """icaoFilterExpire() forwarded by the host (filter_clock=FILTER_CLOCK_EXTERNAL only)."""
+        self._chk(self.lib.mgpu_filter_expire(self.ctx), "mgpu_filter_expire")
+
+    def filter_add(self, addr):
+        """icaoFilterAdd(addr) made by the host outside the demodulator."""
+        self._chk(self.lib.mgpu_filter_add(self.ctx, int(addr)), "mgpu_filter_add")
 
     def feed_iq(self, iq):
         iq, n = self._nsamples(iq)

@@ -165,6 +165,7 @@ struct Slot {
     hipEvent_t ev_scan = nullptr;         // pre-screen offsets are final (main stream) -> the write pass may start (second stream)
     // the job
     uint64_t n = 0, stream_pos = 0;
+    int32_t thr = 58;                     // preamble threshold of this chunk (raised after drops, demod_2400.c:335-338)
     bool have_mag = false, busy = false;
     bool have_noise = false;              // mag_buf entry with the caller's mean_level: Mode A/C noise level computed on the host
     uint32_t given_noise = 0;
@@ -608,7 +609,8 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     if (!cfg || !out) return MGPU_E_INVAL;
     *out = nullptr;
     if (cfg->trailing_samples != (uint32_t) kTrailing || cfg->buf_samples == 0 || cfg->buf_samples % kTile != 0 ||
-        cfg->max_samples == 0 || cfg->format < 0 || cfg->format > 2 || cfg->nfix_crc < 0 || cfg->nfix_crc > 2)
+        cfg->max_samples == 0 || cfg->format < 0 || cfg->format > 2 || cfg->nfix_crc < 0 || cfg->nfix_crc > 2 ||
+        cfg->filter_clock > MGPU_FILTER_CLOCK_EXTERNAL)
         return MGPU_E_INVAL;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device >= ndev) return MGPU_E_NODEVICE;
@@ -631,7 +633,7 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
         mgpu_destroy(c);
         return rc;
     }
-    c->resolver.reset(cfg->startup_time_ms);
+    c->resolver.reset(cfg->startup_time_ms, (int) cfg->filter_clock);
     c->dbg_print = getenv("MGPU_DEBUG_PRINT") != nullptr;
     c->dbg_no_window = getenv("MGPU_DEBUG_NO_WINDOW") != nullptr;
     c->two_streams = getenv("MGPU_TWO_STREAMS") != nullptr;
@@ -686,7 +688,7 @@ void mgpu_destroy(mgpu_ctx *c) {
 int mgpu_reset(mgpu_ctx *c) {
     if (!c) return MGPU_E_INVAL;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    c->resolver.reset(c->cfg.startup_time_ms);
+    c->resolver.reset(c->cfg.startup_time_ms, (int) c->cfg.filter_clock);
     c->pending.clear();
     std::memset(&c->counters, 0, sizeof(c->counters));
     std::memset(&c->timing, 0, sizeof(c->timing));
@@ -737,7 +739,7 @@ static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
                       sl.d_ac_noise, sl.h_ac, (uint32_t) c->cap_ac, sl.d_scratch + CNT_NUM + 1 + 4 * c->cap_buffers, sl.d_counters, s);
     HIPCHK(c, hipEventRecord(sl.ev[1], s));
     SweepParams sp{};
-    sp.mag = sl.d_mag; sp.n = n; sp.thr = cfg.preamble_threshold;
+    sp.mag = sl.d_mag; sp.n = n; sp.thr = sl.thr;
     sp.valid_long = c->valid_long; sp.valid_short = c->valid_short;
     sp.fix_df = (cfg.fixDF && cfg.nfix_crc) ? 1 : 0;
     sp.bit_syndrome = c->d_bit_syndrome; sp.parity = c->d_parity; sp.group_syndrome = c->d_group_syndrome;
@@ -845,7 +847,6 @@ static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job) {
 
 // ---- part 2 (walker thread): the ordered accept walk, then the window statistics of what it hid ----
 static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
-    const mgpu_config &cfg = c->cfg;
     const uint64_t n = sl.n;
     const uint64_t nlive = job.nlive;
     const double t_res0 = wall_ms();
@@ -916,7 +917,7 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
         HIPCHK(c, hipMemcpyAsync(sl.d_msg_pos, sl.h_msg_pos, nmsg * sizeof(uint32_t), hipMemcpyHostToDevice, s2));
         HIPCHK(c, hipMemcpyAsync(sl.d_msg_limit, sl.h_msg_limit, nmsg * sizeof(uint32_t), hipMemcpyHostToDevice, s2));
         HIPCHK(c, hipMemcpyAsync(sl.d_msg_skip, sl.h_msg_skip, nmsg * sizeof(uint16_t), hipMemcpyHostToDevice, s2));
-        launch_window_stats(sl.d_mag, n, cfg.preamble_threshold, c->sweep_version >= 3 ? sl.d_class_final : sl.d_class_bitmap, sl.d_msg_pos, sl.d_msg_skip,
+        launch_window_stats(sl.d_mag, n, sl.thr, c->sweep_version >= 3 ? sl.d_class_final : sl.d_class_bitmap, sl.d_msg_pos, sl.d_msg_skip,
                             sl.d_msg_limit, nmsg, sl.d_win_part, c->d_win, s2);
         HIPCHK(c, hipEventRecord(sl.ev_window, s2));
         sl.window_pending = true;
@@ -1208,6 +1209,7 @@ static int feed_common(mgpu_ctx *c, const void *src, bool src_is_device, uint64_
         sl.stream_pos = c->stream_pos + off;
         sl.have_mag = false;
         sl.have_noise = false;
+        sl.thr = c->cfg.preamble_threshold;
         sl.given_mean_power.clear();
         ifile_grid(c, c->stream_pos + off, len, sl.buffers);
         if (!src_is_device) {
@@ -1308,6 +1310,23 @@ int mgpu_set_message_buffer(mgpu_ctx *c, struct mgpu_msg *buf, uint64_t capacity
 
 uint64_t mgpu_pending_messages(mgpu_ctx *c) { return c ? c->pending.size() : 0; }
 
+int mgpu_filter_expire(mgpu_ctx *c) {
+    if (!c) return MGPU_E_INVAL;
+    if (c->cfg.filter_clock != MGPU_FILTER_CLOCK_EXTERNAL) {
+        c->err = "mgpu_filter_expire: the context runs its own filter clock (cfg.filter_clock)";
+        return MGPU_E_INVAL;
+    }
+    c->resolver.external_expire();
+    c->counters.nflips = c->resolver.nflips();
+    return MGPU_OK;
+}
+
+int mgpu_filter_add(mgpu_ctx *c, uint32_t addr) {
+    if (!c) return MGPU_E_INVAL;
+    c->resolver.filter().add(addr);
+    return MGPU_OK;
+}
+
 int mgpu_last_timing(mgpu_ctx *c, struct mgpu_timing *t) {
     if (!c || !t) return MGPU_E_INVAL;
     *t = c->timing;
@@ -1382,7 +1401,6 @@ int mgpu_demod_mag_buf_ac(mgpu_ctx *c, const uint16_t *data, uint32_t length, in
 static int demod_mag_buf(mgpu_ctx *c, const uint16_t *data, uint32_t length, int64_t sampleTimestamp, int64_t sysTimestamp,
                          const double *mean_level, double mean_power, uint32_t dropped) {
     if (!c || !data) return MGPU_E_INVAL;
-    (void) dropped;   // raising the threshold after drops (demod_2400.c:335-338) is the caller's cfg.preamble_threshold
     if (length > c->chunk_samples) return MGPU_E_CAPACITY;
     if (c->worker_rc != MGPU_OK) return c->worker_rc;
     HIPCHK(c, hipSetDevice(c->cfg.device));
@@ -1399,6 +1417,8 @@ static int demod_mag_buf(mgpu_ctx *c, const uint16_t *data, uint32_t length, int
     const int slot_idx = (int) (c->chunk_seq++ % mgpu_ctx::kSlots);
     Slot &sl = acquire_slot(c, slot_idx);
     sl.n = length;
+    // demod_2400.c:335-338: after dropped samples the reference raises the threshold to at least PREAMBLE_THRESHOLD_PIZERO
+    sl.thr = dropped && c->cfg.preamble_threshold < 75 ? 75 : c->cfg.preamble_threshold;
     sl.have_mag = true;
     sl.have_noise = c->cfg.mode_ac && mean_level;
     if (sl.have_noise) {

@@ -100,12 +100,17 @@ void IcaoFilter::union_sorted(std::vector<uint32_t> &out) const {
     out.erase(std::unique(out.begin(), out.end()), out.end());
 }
 
-void Resolver::reset(int64_t startup_ms) {
+void Resolver::reset(int64_t startup_ms, int clock_mode) {
     filter_.init();
     filter_.add(kShowOnlyDefault);
     synthetic_now_ = startup_ms;   // Modes.synthetic_now armed by ifileOpen (sdr_ifile.c:131-133)
     next_flip_ = 0;                // static next_flip = 0 (readsb.c:1227)
     nflips_ = 0;
+    // The decode thread's first backgroundTasks() call comes before or after its first buffer (readsb.c:857-902):
+    // before = the first expiry hits the filter while it only holds show_only, the next is due 60 s after start-up.
+    if (clock_mode == 1) after_buffer();
+    // external clock: the host forwards its own icaoFilterExpire() calls; nothing is ever due here
+    if (clock_mode == 2) next_flip_ = std::numeric_limits<int64_t>::max();
 }
 
 void Resolver::after_buffer() {

@@ -136,7 +136,9 @@ struct SegmentWalk {
 
 class Resolver {
   public:
-    void reset(int64_t startup_ms);
+    // clock_mode = mgpu_config.filter_clock: 0 first expiry after buffer 0, 1 before it, 2 never (external_expire only)
+    void reset(int64_t startup_ms, int clock_mode = 0);
+    void external_expire() { filter_.expire(); ++nflips_; }   // the host's icaoFilterExpire(), forwarded
     // The serial part: walk the ordered live records of one chunk and decide which frames the
     // reference accepts (best phase, ICAO filter, skip-ahead, filter clock).  Fills acc[0..return) (the
     // vector is only ever grown, to aux_cap entries) and

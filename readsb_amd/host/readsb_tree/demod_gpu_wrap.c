@@ -1,6 +1,6 @@
 /* demod_gpu_wrap.c — the adapter of INTEGRATION.md §2 as a real file that compiles against the reference's own headers,
  * in the form that needs NO change to the reference's sources: linked with
- *     -Wl,--wrap=demodulate2400 -Wl,--wrap=demodulate2400AC
+ *     -Wl,--wrap=demodulate2400 -Wl,--wrap=demodulate2400AC -Wl,--wrap=icaoFilterExpire -Wl,--wrap=icaoFilterAdd
  * every call the decode thread makes (readsb.c:871-874) lands here instead of in demod_2400.c, and the GPU library does the
  * work.  (Inside a readsb tree one would rename the two functions and switch on a --gpu option instead; the body is the same.)
  *
@@ -11,6 +11,12 @@
  * (tracking, beast / raw / SBS output, statistics) sees what it always saw.  The demodulator counters of struct stats are
  * advanced by the library's counter deltas.
  *
+ * The ICAO filter clock stays the host's: the library runs with MGPU_FILTER_CLOCK_EXTERNAL and every icaoFilterExpire() /
+ * icaoFilterAdd() the program performs (backgroundTasks, readsb.c:1227-1231; decodeModesMessage on any input,
+ * mode_s.c:766-779) is forwarded, so the two filters flip between the same two buffers whichever of the program's two
+ * start-up orders occurs (first flip before or after buffer 0, readsb.c:857-902) and whatever clock drives it (synthetic
+ * for ifile, wall clock for a live SDR).
+ *
  * Built by `make -C oracle full_gpu` against /root/reference's headers and objects (outputs under oracle/_ref/full/).
  */
 #include "readsb.h"
@@ -19,6 +25,36 @@
 static mgpu_ctx *gpu;
 static struct mgpu_counters seen;          /* the library's counters are cumulative: remember what was already added */
 static int failed;
+
+/* filter operations the program performed before the library context existed (modesInit's icaoFilterAdd(show_only), a
+ * first backgroundTasks pass that found no buffer): replayed in order when the context is created */
+static struct early_op { uint32_t addr; int expire; } *early;
+static size_t n_early, cap_early;
+
+static void early_push(int expire, uint32_t addr) {
+    if (n_early == cap_early) {
+        cap_early = cap_early ? 2 * cap_early : 64;
+        early = realloc(early, cap_early * sizeof(*early));
+        if (!early) { fprintf(stderr, "<3>GPU demodulator: out of memory\n"); exit(1); }
+    }
+    early[n_early].expire = expire;
+    early[n_early++].addr = addr;
+}
+
+void __real_icaoFilterExpire(void);
+void __real_icaoFilterAdd(uint32_t addr);
+
+void __wrap_icaoFilterExpire(void) {
+    __real_icaoFilterExpire();
+    if (gpu) (void) mgpu_filter_expire(gpu);
+    else if (!failed) early_push(1, 0);
+}
+
+void __wrap_icaoFilterAdd(uint32_t addr) {
+    __real_icaoFilterAdd(addr);
+    if (gpu) (void) mgpu_filter_add(gpu, addr);
+    else if (!failed) early_push(0, addr);
+}
 
 static void gpu_close(void) {                               /* at exit: stop the library's pipeline threads before the runtime unloads */
     if (gpu) mgpu_destroy(gpu);
@@ -38,6 +74,7 @@ static void gpu_open(void) {
     cfg.trailing_samples = Modes.trailing_samples;
     cfg.max_samples = Modes.sdr_buf_samples;                /* one struct mag_buf per call */
     cfg.startup_time_ms = Modes.startup_time;
+    cfg.filter_clock = MGPU_FILTER_CLOCK_EXTERNAL;          /* the program's own backgroundTasks decides, see above */
     const int rc = mgpu_create(&cfg, &gpu);
     if (rc != MGPU_OK) {                                    /* loud, like a failing sdrOpen() (readsb.c:501-506): no CPU fallback */
         fprintf(stderr, "<3>GPU demodulator: %s\n", mgpu_strerror(rc));
@@ -47,6 +84,15 @@ static void gpu_open(void) {
         return;
     }
     atexit(gpu_close);
+    int flips = 0;
+    for (size_t i = 0; i < n_early; i++) {
+        if (early[i].expire) { (void) mgpu_filter_expire(gpu); flips++; }
+        else (void) mgpu_filter_add(gpu, early[i].addr);
+    }
+    fprintf(stderr, "GPU demodulator: following the program's ICAO filter clock (first flip %s buffer 0)\n", flips ? "before" : "after");
+    free(early);
+    early = NULL;
+    n_early = cap_early = 0;
 }
 
 static void add_counter_deltas(const struct mgpu_counters *c) {
@@ -74,9 +120,10 @@ void __wrap_demodulate2400(struct mag_buf *mag) {
     if (!gpu) return;
     if (Modes.sdr_type == SDR_IFILE && Modes.synthetic_now)
         Modes.synthetic_now = mag->sysTimestamp;                                   /* demod_2400.c:283-285 */
+    const uint32_t dropped = Modes.stats_15min.samples_dropped ? 1 : 0;            /* what demod_2400.c:335-338 looks at */
     const int rc = Modes.mode_ac
-        ? mgpu_demod_mag_buf_ac(gpu, mag->data, mag->length, mag->sampleTimestamp, mag->sysTimestamp, mag->mean_level, mag->mean_power, mag->dropped)
-        : mgpu_demod_mag_buf(gpu, mag->data, mag->length, mag->sampleTimestamp, mag->sysTimestamp, mag->mean_power, mag->dropped);
+        ? mgpu_demod_mag_buf_ac(gpu, mag->data, mag->length, mag->sampleTimestamp, mag->sysTimestamp, mag->mean_level, mag->mean_power, dropped)
+        : mgpu_demod_mag_buf(gpu, mag->data, mag->length, mag->sampleTimestamp, mag->sysTimestamp, mag->mean_power, dropped);
     if (rc != MGPU_OK) {
         fprintf(stderr, "<3>GPU demodulator: %s (%s)\n", mgpu_strerror(rc), mgpu_last_error(gpu));
         failed = 1;
@@ -84,10 +131,10 @@ void __wrap_demodulate2400(struct mag_buf *mag) {
         return;
     }
     static struct mgpu_msg batch[4096];
-    struct mgpu_counters c;
+    struct mgpu_counters c = seen;                                                 /* a failing first collect adds nothing */
     uint64_t n = 0;
     do {
-        if (mgpu_collect(gpu, batch, 4096, &n, &c) != MGPU_OK) break;
+        if (mgpu_collect(gpu, batch, 4096, &n, &c) != MGPU_OK) { c = seen; break; }
         for (uint64_t i = 0; i < n; i++) {
             const struct mgpu_msg *m = &batch[i];
             struct modesMessage *mm = netGetMM(&Modes.netMessageBuffer[0]);

@@ -88,10 +88,12 @@ def oracle_lib():
     return _oracle
 
 
-def oracle_run(iq, fmt=0, nfix=1, fixdf=1, thr=58, want_mag=False, mode_ac=0):
-    """Our CPU restatement (oracle/modes_oracle.c) on an in-memory capture."""
+def oracle_run(iq, fmt=0, nfix=1, fixdf=1, thr=58, want_mag=False, mode_ac=0, filter_clock=0):
+    """Our CPU restatement (oracle/modes_oracle.c) on an in-memory capture.  filter_clock 1 = the reference program's other
+    start-up order (first ICAO filter flip before buffer 0)."""
     lib = oracle_lib()
     lib.modes_oracle_set_mode_ac(int(mode_ac))
+    lib.modes_oracle_set_filter_clock(int(filter_clock))
     iq = np.ascontiguousarray(iq).view(np.uint8).reshape(-1)
     n = iq.size // FMT_BYTES[fmt]
     cfg = OracleCfg(fmt, nfix, fixdf, thr)
@@ -121,7 +123,7 @@ def have_ref():
     return os.path.exists(REF_BIN)
 
 
-def ref_run(iq, fmt=0, nfix=1, fixdf=1, thr=58, want_mag=False, mode_ac=0):
+def ref_run(iq, fmt=0, nfix=1, fixdf=1, thr=58, want_mag=False, mode_ac=0, flip_before=False):
     """The reference's own objects (oracle/_ref/ref_demod), one process per run."""
     iq = np.ascontiguousarray(iq).view(np.uint8).reshape(-1)
     with tempfile.TemporaryDirectory() as d:
@@ -133,6 +135,9 @@ def ref_run(iq, fmt=0, nfix=1, fixdf=1, thr=58, want_mag=False, mode_ac=0):
             env["ORACLE_MODE_AC"] = "1"
         else:
             env.pop("ORACLE_MODE_AC", None)
+        env.pop("ORACLE_FLIP_BEFORE", None)
+        if flip_before:
+            env["ORACLE_FLIP_BEFORE"] = "1"
         subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL, env=env)
         msgs = np.fromfile(fm, dtype=ORACLE_MSG)
         st = np.fromfile(fs, dtype=ORACLE_STATS)[0]

@@ -31,14 +31,19 @@ void mgpu_destroy(mgpu_ctx *c) { if (c) { modes_oracle_free(c->pending); free(c-
 const char *mgpu_strerror(int rc) { (void) rc; return "stand-in"; }
 const char *mgpu_last_error(mgpu_ctx *c) { (void) c; return ""; }
 
-/* one buffer through the oracle; its messages are appended to what mgpu_collect has not handed out yet */
-static void one_buffer(mgpu_ctx *c, const uint16_t *data, uint32_t length, int64_t st, int64_t sys, double ml, double mp) {
+static void begin_stream(mgpu_ctx *c) {
     if (!c->streaming) {                                     /* the process's one demodulator stream belongs to the first context that demodulates */
         const struct modes_oracle_cfg oc = {c->cfg.format, c->cfg.nfix_crc, c->cfg.fixDF, c->cfg.preamble_threshold};
         modes_oracle_set_mode_ac((int) c->cfg.mode_ac);
+        modes_oracle_set_filter_clock((int) c->cfg.filter_clock);
         modes_oracle_stream_begin(&oc, c->cfg.startup_time_ms);
         c->streaming = 1;
     }
+}
+
+/* one buffer through the oracle; its messages are appended to what mgpu_collect has not handed out yet */
+static void one_buffer(mgpu_ctx *c, const uint16_t *data, uint32_t length, int64_t st, int64_t sys, double ml, double mp) {
+    begin_stream(c);
     modes_oracle_stream_mag_buf(data, length, st, sys, ml, mp);
     struct oracle_msg *m = NULL;
     const uint64_t n = modes_oracle_stream_take(&m, &c->st);
@@ -110,6 +115,13 @@ int mgpu_demod_mag_buf_ac(mgpu_ctx *c, const uint16_t *data, uint32_t length, in
     (void) dropped;
     return run(c, data, length, st, sys, ml, mp);
 }
+int mgpu_filter_expire(mgpu_ctx *c) {
+    if (c->cfg.filter_clock != MGPU_FILTER_CLOCK_EXTERNAL) return MGPU_E_INVAL;
+    begin_stream(c);
+    modes_oracle_stream_filter_expire();
+    return MGPU_OK;
+}
+int mgpu_filter_add(mgpu_ctx *c, uint32_t addr) { begin_stream(c); modes_oracle_stream_filter_add(addr); return MGPU_OK; }
 int mgpu_collect(mgpu_ctx *c, struct mgpu_msg *out, uint64_t cap, uint64_t *n, struct mgpu_counters *k) {
     uint64_t m = 0;
     while (m < cap && c->next < c->npending) {

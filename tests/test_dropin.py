@@ -37,51 +37,156 @@ def run_program(exe, path, fmt, opts, workdir, timeout=600, env=None):
     return frames, stats
 
 
-# The reference program itself has a start-up race: backgroundTasks' first ICAO-filter flip (readsb.c:1227-1231, next_flip = 0)
-# runs either before the decode thread sees its first buffer or after it, depending on thread scheduling.  After it, the
-# addresses learnt in buffer 0 sit in the inactive generation and are lost at the filter's next resize (icao_filter.c:65-93)
-# — seen with `--aggressive --modeac` on a dense capture: 1033 or 1041 accepted frames from run to run of the same binary on
-# the same file.  The library (and the oracle) implement the "after the first buffer" order, which is also what the wrapped
-# program does every time; the cases below keep to 24 aircraft, where the filter never resizes and both orders give the same
-# output (one distinct stream in ten reference runs each); a mismatch is still retried against fresh reference runs.
-@pytest.mark.parametrize("kw,opts", [
-    (dict(seconds=4.0, seed=301, rate=1800.0), []),
-    (dict(seconds=3.0, seed=302, rate=700.0, dense=2, naircraft=24), ["--aggressive"]),
-    (dict(seconds=3.0, seed=302, rate=700.0, dense=2, naircraft=24), ["--aggressive", "--modeac"]),
-    (dict(seconds=2.0, seed=303, rate=2500.0, dense=1, naircraft=24), ["--no-fix"]),
-])
-def test_wrapped_program_equals_reference(tmp_path, kw, opts):
-    iq = helpers.synth(**kw)
+# ---- the reference program's two start-up orders -------------------------------------------------------------------------
+# backgroundTasks' first ICAO-filter flip (readsb.c:1227-1231, next_flip = 0) runs either before the decode thread sees its
+# first buffer or after it, depending on thread scheduling (readsb.c:857-902).  After an "after" flip the addresses learnt in
+# buffer 0 sit in the inactive generation and are lost at the filter's next resize (icao_filter.c:65-93) — with more than 85
+# aircraft the two orders accept different frames (e.g. 1033 or 1041 from run to run of the same binary on the same file).
+# The adapter forwards the program's own icaoFilterExpire() calls to the library (MGPU_FILTER_CLOCK_EXTERNAL), so a wrapped run
+# follows whichever order ITS decode thread took, and says which.  A run's order is also visible in its statistics: the
+# reference's own objects under the harness (oracle/_ref/ref_demod, ORACLE_FLIP_BEFORE) give the demodulator counters of both.
+
+COUNTER_LINES = [("demod_preambles", r"(\d+) Mode-S message preambles received"),
+                 ("demod_rejected_bad", r"(\d+) with bad message format or invalid CRC"),
+                 ("demod_rejected_unknown_icao", r"(\d+) with unrecognized ICAO address"),
+                 ("accepted0", r"(\d+) accepted with correct CRC"),
+                 ("accepted1", r"(\d+) accepted with 1-bit error repaired"),
+                 ("accepted2", r"(\d+) accepted with 2-bit error repaired")]
+
+
+def stats_counters(stats):
+    out = {}
+    for name, pat in COUNTER_LINES:
+        for ln in stats:
+            m = re.search(pat, ln)
+            if m:
+                out[name] = int(m.group(1))     # the first block is the local receiver's (the network block repeats some lines)
+                break
+    return out
+
+
+def harness_counters(iq, fmt, nfix, mode_ac, flip_before):
+    _, st = helpers.ref_run(iq, fmt=fmt, nfix=nfix, mode_ac=mode_ac, flip_before=flip_before)
+    out = {"demod_preambles": int(st["demod_preambles"]), "demod_rejected_bad": int(st["demod_rejected_bad"]),
+           "demod_rejected_unknown_icao": int(st["demod_rejected_unknown_icao"]), "accepted0": int(st["demod_accepted"][0])}
+    for j in range(1, nfix + 1):
+        out[f"accepted{j}"] = int(st["demod_accepted"][j])
+    return out
+
+
+def order_of(stats, expected):
+    """'after' / 'before' / 'either' (the orders agree on this capture), or None when the run matches neither."""
+    got = stats_counters(stats)
+    hits = [o for o in ("after", "before") if expected[o] == got]
+    return "either" if len(hits) == 2 else hits[0] if hits else None
+
+
+def logged_order(output):
+    m = re.search(r"following the program's ICAO filter clock \(first flip (before|after) buffer 0\)", output)
+    return m.group(1) if m else None
+
+
+def split_frames(stream):
+    """Beast frames of a stream: 0x1a <type> then the escaped payload up to the next unescaped 0x1a."""
+    frames, i = [], 0
+    while i < len(stream):
+        j = i + 2
+        while j < len(stream):
+            if stream[j] == 0x1A:
+                if j + 1 < len(stream) and stream[j + 1] == 0x1A:
+                    j += 2
+                    continue
+                break
+            j += 1
+        frames.append(stream[i:j])
+        i = j
+    return frames
+
+
+def first_difference(a, b):
+    """Human-readable position of the first differing beast frame of two streams (for assertion messages)."""
+    fa, fb = split_frames(a), split_frames(b)
+    for i, (x, y) in enumerate(zip(fa, fb)):
+        if x != y:
+            return f"frame {i}: {x.hex()} vs {y.hex()} (of {len(fa)} / {len(fb)} frames)"
+    return f"one stream is a prefix of the other: {len(fa)} vs {len(fb)} frames"
+
+
+def check_wrapped_against_reference(wrapped_exe, iq, fmt_name, fmt_id, opts, tmp_path, nfix, env=None, timeout=600, tries=6):
+    """Runs the wrapped program; its output must equal the unmodified program's for the same start-up order.  Both programs'
+    statistics must be those of one of the two orders (harness on the reference's own objects), the wrapped run's must be
+    the order its adapter logged."""
     path = str(tmp_path / "in.iq")
     iq.tofile(path)
-    got_frames, got_stats = run_program(STANDIN, path, "UC8", opts, str(tmp_path))
-    assert len(got_frames) > 10000 and any("preambles" in s for s in got_stats)
-    for attempt in range(6):
-        work = tmp_path / f"ref{attempt}"
+    mode_ac = 1 if "--modeac" in opts else 0
+    expected = {"after": harness_counters(iq, fmt_id, nfix, mode_ac, False), "before": harness_counters(iq, fmt_id, nfix, mode_ac, True)}
+    seen_ref = {}
+    last = None
+    for attempt in range(tries):
+        work = tmp_path / f"w{attempt}"
         work.mkdir()
-        want_frames, want_stats = run_program(FULL, path, "UC8", opts, str(work))
-        if got_frames == want_frames and got_stats == want_stats:
-            return
-    assert got_frames == want_frames
-    assert got_stats == want_stats
+        got_frames, got_stats = run_program(wrapped_exe, path, fmt_name, opts, str(work), timeout=timeout, env=env)
+        out = check_wrapped_against_reference.wrapped_output = run_program.last_output
+        assert "filters out of step" not in out, out[-2000:]
+        assert len(got_frames) > 10000 and any("preambles" in s for s in got_stats)
+        order = order_of(got_stats, expected)
+        assert order is not None, f"wrapped run matches neither start-up order: {stats_counters(got_stats)} vs {expected}"
+        said = logged_order(out)
+        assert said is not None, "the adapter did not report the filter clock it follows"
+        assert order in ("either", said), f"adapter followed '{said}' but the counters are those of '{order}'"
+        for rattempt in range(tries):
+            if said in seen_ref or "either" in seen_ref:
+                break
+            rwork = tmp_path / f"r{attempt}_{rattempt}"
+            rwork.mkdir()
+            want_frames, want_stats = run_program(FULL, path, fmt_name, opts, str(rwork), timeout=timeout)
+            rorder = order_of(want_stats, expected)
+            assert rorder is not None, f"reference run matches neither start-up order: {stats_counters(want_stats)} vs {expected}"
+            seen_ref[rorder] = (want_frames, want_stats)
+        ref = seen_ref.get("either") or seen_ref.get(said)
+        if ref is None:
+            last = (said, sorted(seen_ref))
+            continue                     # the reference never took this order here: let the wrapped program race again
+        want_frames, want_stats = ref
+        assert got_frames == want_frames, first_difference(got_frames, want_frames)
+        assert got_stats == want_stats, f"{got_stats}\n!=\n{want_stats}"
+        return order
+    pytest.fail(f"no reference run with the wrapped program's start-up order in {tries} x {tries} runs: {last}")
 
 
-@pytest.mark.parametrize("fmt,fmt_id,opts", [("UC8", 0, []), ("SC16Q11", 2, ["--aggressive"])])
-def test_wrapped_converter_too(tmp_path, fmt, fmt_id, opts):
+@pytest.mark.parametrize("kw,opts,nfix", [
+    (dict(seconds=4.0, seed=301, rate=1800.0, naircraft=24), [], 1),
+    (dict(seconds=3.0, seed=302, rate=700.0, dense=2, naircraft=24), ["--aggressive"], 2),
+    (dict(seconds=3.0, seed=302, rate=700.0, dense=2, naircraft=24), ["--aggressive", "--modeac"], 2),
+    (dict(seconds=2.0, seed=303, rate=2500.0, dense=1, naircraft=24), ["--no-fix"], 0),
+    # 200 aircraft: the filter resizes, the two start-up orders give different outputs
+    (dict(seconds=4.0, seed=301, rate=1800.0, naircraft=200), [], 1),
+])
+def test_wrapped_program_equals_reference(tmp_path, kw, opts, nfix):
+    iq = helpers.synth(**kw)
+    check_wrapped_against_reference(STANDIN, iq, "UC8", 0, opts, tmp_path, nfix)
+
+
+def test_the_two_startup_orders_differ_on_the_200_aircraft_capture():
+    """What makes the last case above a test of the filter clock: the orders accept different frames."""
+    iq = helpers.synth(seconds=4.0, seed=301, rate=1800.0, naircraft=200)
+    a = harness_counters(iq, 0, 1, 0, False)
+    b = harness_counters(iq, 0, 1, 0, True)
+    assert a != b
+    # ... and the restated oracle follows both (filter_clock 0 / 1)
+    for clock, want in ((0, a), (1, b)):
+        _, st = helpers.oracle_run(iq, filter_clock=clock)
+        got = {"demod_preambles": int(st["demod_preambles"]), "demod_rejected_bad": int(st["demod_rejected_bad"]),
+               "demod_rejected_unknown_icao": int(st["demod_rejected_unknown_icao"]), "accepted0": int(st["demod_accepted"][0]),
+               "accepted1": int(st["demod_accepted"][1])}
+        assert got == want
+
+
+@pytest.mark.parametrize("fmt,fmt_id,opts,nfix", [("UC8", 0, [], 1), ("SC16Q11", 2, ["--aggressive"], 2)])
+def test_wrapped_converter_too(tmp_path, fmt, fmt_id, opts, nfix):
     """READSB_GPU_CONVERT=1: the reader thread's iq_convert_fn (init_converter, convert.h:34-44) is the library's too
     (`--wrap=init_converter`); magnitudes and the two means come back through mgpu_convert()."""
     iq = helpers.synth(seconds=3.0, seed=305, rate=1500.0, fmt=fmt_id, naircraft=24)
-    path = str(tmp_path / "in.iq")
-    iq.tofile(path)
     env = dict(os.environ, READSB_GPU_CONVERT="1")
-    got_frames, got_stats = run_program(STANDIN, path, fmt, opts, str(tmp_path), env=env)
-    assert len(got_frames) > 10000 and "init_converter: using the GPU library" in run_program.last_output
-    for attempt in range(6):
-        work = tmp_path / f"ref{attempt}"
-        work.mkdir()
-        want_frames, want_stats = run_program(FULL, path, fmt, opts, str(work))
-        if got_frames == want_frames and got_stats == want_stats:
-            return
-    assert got_frames == want_frames
-    assert got_stats == want_stats
-
+    check_wrapped_against_reference(STANDIN, iq, fmt, fmt_id, opts, tmp_path, nfix, env=env)
+    assert "init_converter: using the GPU library" in check_wrapped_against_reference.wrapped_output

@@ -10,7 +10,8 @@ resident in HBM when the timed region starts (BASELINE.json configs[1]: single U
 decoded message counts/records are gathered over RCCL inside the timed step.
 
 Prints ONE JSON line (rank 0): metric/value/unit as BASELINE.json, plus
-  roofline     — k_sweep_slice: algorithmic bytes (2 B per magnitude sample) / its HIP-event time
+  roofline     — k_sweep (the preamble-sweep kernel): algorithmic bytes (2 B per magnitude sample) / its HIP-event time;
+                 `kernels` carries the same figure for k_slice (slicer + CRC + scoring, the longer of the two)
   cpu_baseline — the reference's own C files (oracle/_ref) timed on this host on the same stream,
                  whose message list must be bit-identical to the GPU's (checked in the same run).
 """
@@ -32,26 +33,29 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achi
 SWEEP_BYTES_PER_SAMPLE = 2.0   # k_preamble_sweep reads one u16 magnitude per position
 
 
-VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12     # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-ops/s
+# VALU issue rate measured on this chip (tools/micro/valu_issue.hip, profiles/r02_valu_issue.txt): three-operand / packed /
+# dot2 instructions — what these kernels are made of — sustain 36 T lane-ops/s chip-wide (v_add/v_xor: ~60)
+VALU_PEAK_TLANEOPS = 36.4
+PMC_SQ_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_sq_summary.txt")
 
 
-def valu_issue(avg_launch_ms, path=None):
-    """What actually bounds k_sweep_slice: VALU wave-instructions of one launch from the committed SQ counter
-    pass of this same command (profiles/r01_final_pmc_sq_summary.txt, SQ_INSTS_VALU) over the launch time measured live.
+def valu_issue(kernel, avg_launch_ms, samples_per_launch, path=PMC_SQ_SUMMARY):
+    """How busy the vector ALUs are (these kernels are integer-VALU work): VALU wave-instructions of one launch
+    from the committed SQ counter pass of this same command (SQ_INSTS_VALU) over the launch time measured live.
     Informative; None if the summary is missing or does not parse."""
     try:
-        path = path or os.path.join(ROOT, "profiles", "r01_final_pmc_sq_summary.txt")
         insts, inside = None, False
         for ln in open(path):
             if not ln.startswith(" "):
-                inside = ln.strip() == "k_sweep_slice"
+                inside = ln.strip() == kernel
             elif inside and ln.split()[0] == "SQ_INSTS_VALU":
                 insts = int(ln.split()[1])
         if not insts or avg_launch_ms <= 0:
             return None
         tl = insts * 64 / (avg_launch_ms * 1e-3) / 1e12
-        return {"wave_insts_per_launch": insts, "achieved_Tlaneops_s": round(tl, 2), "peak_Tlaneops_s": round(VALU_PEAK_TLANEOPS, 1),
-                "frac": round(tl / VALU_PEAK_TLANEOPS, 3), "source": "SQ_INSTS_VALU, profiles/r01_final_pmc_sq_summary.txt"}
+        return {"wave_insts_per_launch": insts, "lane_ops_per_sample": round(insts * 64 / samples_per_launch, 1),
+                "achieved_Tlaneops_s": round(tl, 2), "peak_Tlaneops_s": VALU_PEAK_TLANEOPS,
+                "frac": round(tl / VALU_PEAK_TLANEOPS, 3), "source": "SQ_INSTS_VALU, " + os.path.relpath(path, ROOT)}
     except Exception:
         return None
 
@@ -157,7 +161,7 @@ def main():
         d.set_message_buffer(outbuf)
     for _ in range(args.warmup):
         step()
-    sweep_ms, conv_ms, resolve_ms, total_ms, launches = [], [], [], [], []
+    sweep_ms, slice_ms, conv_ms, resolve_ms, total_ms, launches = [], [], [], [], [], []
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -165,7 +169,7 @@ def main():
     for _ in range(args.steps):
         msgs, counters = step()
         tm = d.timing()
-        launches.append(max(1, tm["n_chunks"])); sweep_ms.append(tm["sweep_ms"]); conv_ms.append(tm["convert_ms"]); resolve_ms.append(tm["resolve_ms"]); total_ms.append(tm["total_ms"])
+        launches.append(max(1, tm["n_chunks"])); sweep_ms.append(tm["sweep_ms"]); slice_ms.append(tm["slice_ms"]); conv_ms.append(tm["convert_ms"]); resolve_ms.append(tm["resolve_ms"]); total_ms.append(tm["total_ms"])
     if use_dist:
         gath.wait()                             # the last steps' exchanges are part of the job
         dist.barrier()
@@ -187,15 +191,18 @@ def main():
         sweep = float(np.mean(sweep_ms))                  # per step: sum over the step's launches
         nlaunch = int(np.mean(launches))
         achieved = n * SWEEP_BYTES_PER_SAMPLE / (sweep * 1e-3) / 1e9
-        # HBM traffic of one k_sweep_slice launch from the committed rocprofv3 PMC passes of this same
-        # command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, tools/pmc_summary.py); null if the launch size differs
-        traffic = None
+        slice_ = float(np.mean(slice_ms))
+        per_launch = int(n * SWEEP_BYTES_PER_SAMPLE / nlaunch)
+        # HBM traffic of one launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x2 on
+        # gfx950 + WRITE_SIZE, tools/pmc_summary.py); null if the launch size differs
+        traffic, traffic_slice = None, None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_final_pmc_hbm.json")))
-            if int(n * SWEEP_BYTES_PER_SAMPLE / nlaunch) == 134217728:
-                traffic = round(pm["mgpu::k_sweep_slice"]["hbm_bytes"])
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_hbm.json")))
+            if per_launch == 134217728:
+                traffic = round(pm["mgpu::k_sweep"]["hbm_bytes"])
+                traffic_slice = round(pm["mgpu::k_slice"]["hbm_bytes"])
         except Exception:
-            traffic = None
+            pass
         out = {
             "metric": "IQ Msamples/s demodulated (UC8 2.4 MSps stream, --fix), whole job",
             "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -207,15 +214,22 @@ def main():
             "x_realtime_per_gpu": round(value / world / 2.4, 1),
             "msgs_per_s": round(total_msgs * args.steps / elapsed, 1),
             "messages_per_step": total_msgs,
-            "stage_ms": {"convert": round(float(np.mean(conv_ms)), 3), "sweep": round(sweep, 3), "slice": round(tm.get("slice_ms", 0.0), 3),
+            "stage_ms": {"convert": round(float(np.mean(conv_ms)), 3), "sweep": round(sweep, 3), "slice": round(slice_, 3),
                          "prescreen": round(tm["prescreen_ms"], 3), "d2h": round(tm["d2h_ms"], 3),
                          "resolve_host": round(float(np.mean(resolve_ms)), 3), "build_host": round(tm.get("build_ms", 0.0), 3), "sigpower": round(tm["sigpower_ms"], 3),
                          "feed_total": round(float(np.mean(total_ms)), 3)},
-            "roofline": {"kernel": "k_sweep_slice", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "roofline": {"kernel": "k_sweep", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "launches_per_step": nlaunch, "algorithmic_bytes_per_launch": int(n * SWEEP_BYTES_PER_SAMPLE / nlaunch),
+                         "launches_per_step": nlaunch, "algorithmic_bytes_per_launch": per_launch,
                          "avg_launch_ms": round(sweep / nlaunch, 4),
-                         "valu_issue": valu_issue(sweep / nlaunch) if int(n * SWEEP_BYTES_PER_SAMPLE / nlaunch) == 134217728 else None},
+                         "valu_issue": valu_issue("k_sweep", sweep / nlaunch, n / nlaunch) if per_launch == 134217728 else None},
+            # the other half of what used to be one kernel: slicer + CRC + scoring over k_sweep's candidate lists.  It reads the
+            # same 2 B per sample again (tile staging), so the same algorithmic bytes; its work is per candidate, not per byte.
+            "kernels": {"k_slice": {"avg_launch_ms": round(slice_ / nlaunch, 4), "algorithmic_bytes_per_launch": per_launch,
+                                    "achieved": round(n * SWEEP_BYTES_PER_SAMPLE / (slice_ * 1e-3) / 1e9, 1) if slice_ > 0 else None,
+                                    "frac": round(n * SWEEP_BYTES_PER_SAMPLE / (slice_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if slice_ > 0 else None,
+                                    "unit": "GB/s", "traffic": traffic_slice,
+                                    "valu_issue": valu_issue("k_slice", slice_ / nlaunch, n / nlaunch) if per_launch == 134217728 else None}},
             "synth_gen_s": round(t_gen, 2),
         }
         # the boundary handing over HOST buffers (mgpu_feed_iq from page-locked memory): never `value`, see DESIGN.md §4

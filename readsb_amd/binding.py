@@ -96,7 +96,10 @@ class MgpuError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmodes_gpu.so")
+    """The product library; MGPU_LIBRARY=libmodes_gpu_exp.so selects the cross-check build (`make -C readsb_amd/csrc exp`:
+    the same library plus the superseded fused sweep kernel) — tests and tools only."""
+    name = os.path.basename(os.environ.get("MGPU_LIBRARY", "libmodes_gpu.so"))
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", name)
 
 
 _lib = None

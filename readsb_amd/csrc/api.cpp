@@ -138,7 +138,7 @@ struct Slot {
     uint16_t *d_mag = nullptr;
     PhaseRec *d_pool = nullptr;
     uint32_t *d_pool_used = nullptr, *d_unit_first = nullptr, *d_unit_count = nullptr, *d_unit_live = nullptr, *d_class_bitmap = nullptr;
-    uint32_t *d_class_uncond = nullptr, *d_class_final = nullptr, *d_cand_count = nullptr;
+    uint32_t *d_class_uncond = nullptr, *d_class_final = nullptr, *d_cand_count = nullptr, *d_sweep_part = nullptr;
     uint16_t *d_cand = nullptr;
     size_t class_bytes = 0;
     // one zero-initialised scratch block per chunk: counters | pool_used | per-buffer sums (1 memset, 1 copy back)
@@ -262,7 +262,7 @@ struct mgpu_ctx {
     mgpu_timing timing{}, acc{};
     uint64_t stream_pos = 0;
     bool eof = false;
-    int sweep_version = 3;     // MGPU_SWEEP_VERSION=1|2|3: earlier (fused) generations of the sweep/slice stage (A/B measurements)
+    int sweep_version = 5;     // 5 = k_sweep + k_slice; the experiments build (make exp) also has 3 = the fused k_sweep_slice (MGPU_SWEEP_VERSION=3)
 
     // host pipeline behind the GPU: the walker thread takes the slots in submission order (record copy,
     // ordered accept walk, window-statistics launch) and hands a HostJob to the builder thread
@@ -482,7 +482,8 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
     HIPCHK(c, hipMemsetAsync(sl.d_class_bitmap, 0, sl.class_bytes, c->stream));
     HIPCHK(c, hipMemsetAsync(sl.d_class_uncond, 0, sl.class_bytes, c->stream));
     HIPCHK(c, hipMalloc(&sl.d_cand, (c->cap_units * (size_t) kUnit + 64) * sizeof(uint16_t)));
-    HIPCHK(c, hipMalloc(&sl.d_cand_count, (c->cap_units + 1) * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(&sl.d_cand_count, (c->cap_units * (size_t) (kUnit / kSweepTile) + 1) * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(&sl.d_sweep_part, (size_t) kSweepGridMax * 4 * sizeof(uint32_t)));
     {
         const size_t nb = c->cap_buffers, words = CNT_NUM + 1 + 4 * nb + kAcLists;   // ... + Mode A/C list counters
         sl.scratch_bytes = words * sizeof(unsigned long long);
@@ -527,7 +528,7 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
 
 static void free_slot(Slot &sl) {
     void *dev[] = {sl.d_mag, sl.d_pool, sl.d_scratch, sl.d_unit_first, sl.d_unit_count, sl.d_unit_live, sl.d_class_bitmap,
-                   sl.d_class_uncond, sl.d_class_final, sl.d_cand, sl.d_cand_count,
+                   sl.d_class_uncond, sl.d_class_final, sl.d_cand, sl.d_cand_count, sl.d_sweep_part,
                    sl.d_win, sl.d_win_part, sl.d_msg_pos,
                    sl.d_msg_limit, sl.d_msg_len, sl.d_msg_skip, sl.d_msg_sig};
     for (void *p : dev)
@@ -617,7 +618,9 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     mgpu_ctx *c = new (std::nothrow) mgpu_ctx();
     if (!c) return MGPU_E_NOMEM;
     c->cfg = *cfg;
-    if (const char *e = getenv("MGPU_SWEEP_VERSION")) { const int v = atoi(e); if (v >= 1 && v <= 4) c->sweep_version = v; }
+#if MGPU_EXPERIMENTS
+    if (const char *e = getenv("MGPU_SWEEP_VERSION")) { const int v = atoi(e); if (v == 3 || v == 5) c->sweep_version = v; }
+#endif
     if (hipSetDevice(cfg->device) != hipSuccess) { delete c; return MGPU_E_NODEVICE; }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
@@ -746,16 +749,21 @@ static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
     sp.tab_long = c->d_tab_long; sp.tab_short = c->d_tab_short; sp.n_long = c->n_long; sp.n_short = c->n_short;
     sp.pool = sl.d_pool; sp.pool_cap = (uint32_t) c->cap_pool; sp.pool_used = sl.d_pool_used;
     sp.unit_first = sl.d_unit_first; sp.unit_count = sl.d_unit_count; sp.nunits = nunits;
-    sp.debug_stage = c->dbg_stage;
     sp.adder_bitmap = c->d_adder_bitmap; sp.class_bitmap = sl.d_class_bitmap; sp.counters = sl.d_counters;
-    sp.cand = sl.d_cand; sp.cand_count = sl.d_cand_count; sp.class_uncond = sl.d_class_uncond;
-    // ev[1] .. ev[4] bracket exactly one kernel: the sweep kernel of the active generation (bench.py's roofline)
-    if (c->sweep_version == 1) launch_sweep_slice_v1(sp, s);
-    else if (c->sweep_version == 2) launch_sweep_slice_v2(sp, s);
-    else if (c->sweep_version == 3) launch_sweep_slice(sp, s);
-    else launch_sweep(sp, s);
-    HIPCHK(c, hipEventRecord(sl.ev[4], s));
-    if (c->sweep_version == 4) launch_slice(sp, s);
+    sp.cand = sl.d_cand; sp.cand_count = sl.d_cand_count; sp.class_uncond = sl.d_class_uncond; sp.sweep_part = sl.d_sweep_part;
+    // ev[1] .. ev[4] bracket exactly one kernel: k_sweep (bench.py's roofline); ev[4] .. ev[2]: k_slice
+#if MGPU_EXPERIMENTS
+    sp.debug_stage = c->dbg_stage;
+    if (c->sweep_version == 3) {
+        launch_sweep_slice(sp, s);
+        HIPCHK(c, hipEventRecord(sl.ev[4], s));
+    } else
+#endif
+    {
+        sp.sweep_blocks = launch_sweep(sp, s);
+        HIPCHK(c, hipEventRecord(sl.ev[4], s));
+        launch_slice(sp, s);
+    }
     HIPCHK(c, hipEventRecord(sl.ev[2], s));
     // class planes -> class bitmap, pre-screen (the surviving records are written by the kernel straight into
     // pinned host memory), counters and per-buffer sums to the host
@@ -763,13 +771,13 @@ static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
     q.pool = sl.d_pool; q.unit_first = sl.d_unit_first; q.nunits = nunits; q.adder_bitmap = c->d_adder_bitmap;
     q.unit_live = sl.d_unit_live; q.block_live = sl.d_unit_live + c->cap_units + 2; q.live = sl.h_live; q.mag = sl.d_mag; q.live_sig = sl.h_live_sig; q.counters = sl.d_counters;
     q.class_cond = sl.d_class_bitmap; q.class_uncond = sl.d_class_uncond;
-    q.class_final = c->sweep_version >= 3 ? sl.d_class_final : nullptr;
+    q.class_final = sl.d_class_final;
     q.class_words = (n + 31) / 32;
     q.d_scratch = sl.d_scratch; q.h_scratch = sl.h_scratch; q.scratch_words = (uint32_t) (sl.scratch_bytes / sizeof(unsigned long long));
     // Generation 3: the count pass leaves its decisions as masks in the segment headers, so the write pass does not
     // look at the adder bitmap again.  MGPU_TWO_STREAMS=1 then moves the write pass and the publish to their own
     // stream, beside the next chunk's convert (measured: the kernels only slow each other down, no gain end to end).
-    q.keep_masks = c->sweep_version == 3;
+    q.keep_masks = true;            // one scoring pass = one segment of at most 64 records
     hipStream_t sw = (q.keep_masks && c->two_streams) ? c->stream_w : s;
     if (launch_prescreen(q, s, sw, sl.ev_scan) != 0) { c->err = "event ordering of the pre-screen passes failed"; return MGPU_E_HIP; }
     HIPCHK(c, hipEventRecord(sl.ev[3], sw));
@@ -782,8 +790,8 @@ static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job) {
     const double t_gpu_done = wall_ms();
     if (c->dbg_print) {
         const unsigned long long *h = sl.h_counters;
-        fprintf(stderr, "dbg: v3 wave cycles: load %llu sweep %llu stageA %llu slice %llu score %llu total %llu | rounds B %llu passes %llu\n",
-                h[16], h[17], h[18], h[19], h[20], h[21], h[22], h[23]);
+        fprintf(stderr, "dbg: k_slice wave cycles: stage %llu expand %llu df %llu slice %llu score %llu total %llu | df batches %llu rounds %llu sumI %llu frames %llu lanes %llu passes %llu scored %llu\n",
+                h[16], h[17], h[18], h[19], h[20], h[21], h[24], h[25], h[26], h[27], h[28], h[29], h[30]);
     }
     if (sl.h_counters[CNT_POOL_OVERFLOW]) {
         c->err = "record pool overflow: recreate the context with a larger record_pool_records";
@@ -792,7 +800,7 @@ static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job) {
     float ms;
     if (hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]) == hipSuccess) c->acc.convert_ms += ms;
     if (hipEventElapsedTime(&ms, sl.ev[1], sl.ev[4]) == hipSuccess) c->acc.sweep_ms += ms;
-    if (c->sweep_version == 4 && hipEventElapsedTime(&ms, sl.ev[4], sl.ev[2]) == hipSuccess) c->acc.slice_ms += ms;
+    if (hipEventElapsedTime(&ms, sl.ev[4], sl.ev[2]) == hipSuccess) c->acc.slice_ms += ms;
     if (hipEventElapsedTime(&ms, sl.ev[2], sl.ev[3]) == hipSuccess) c->acc.prescreen_ms += ms;
     const uint64_t nlive = sl.h_counters[CNT_LIVE_TOTAL];
 
@@ -917,7 +925,7 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
         HIPCHK(c, hipMemcpyAsync(sl.d_msg_pos, sl.h_msg_pos, nmsg * sizeof(uint32_t), hipMemcpyHostToDevice, s2));
         HIPCHK(c, hipMemcpyAsync(sl.d_msg_limit, sl.h_msg_limit, nmsg * sizeof(uint32_t), hipMemcpyHostToDevice, s2));
         HIPCHK(c, hipMemcpyAsync(sl.d_msg_skip, sl.h_msg_skip, nmsg * sizeof(uint16_t), hipMemcpyHostToDevice, s2));
-        launch_window_stats(sl.d_mag, n, sl.thr, c->sweep_version >= 3 ? sl.d_class_final : sl.d_class_bitmap, sl.d_msg_pos, sl.d_msg_skip,
+        launch_window_stats(sl.d_mag, n, sl.thr, sl.d_class_final, sl.d_msg_pos, sl.d_msg_skip,
                             sl.d_msg_limit, nmsg, sl.d_win_part, c->d_win, s2);
         HIPCHK(c, hipEventRecord(sl.ev_window, s2));
         sl.window_pending = true;

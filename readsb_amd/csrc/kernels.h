@@ -11,6 +11,9 @@
 //   pool   : PhaseRec[], per-unit chains of segments written by k_sweep_slice
 //   live   : PhaseRec[], records surviving the pre-screen, globally ordered by (pos, phase)
 #pragma once
+#ifndef MGPU_EXPERIMENTS
+#define MGPU_EXPERIMENTS 0
+#endif
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
@@ -27,7 +30,9 @@ constexpr int kUnit = kTile * kTilesPerUnit;   // positions per unit (one record
 constexpr int kWaveTile = 2048;         // k_sweep_slice: positions per wave-private LDS tile
 constexpr int kTile2 = 4096;            // k_sweep_slice: positions per LDS tile
 constexpr int kBlock = 256;
-constexpr int kSweepMaxBlocks = 256 * 4;  // resident workgroups of k_sweep_slice (at most 4 per CU)
+constexpr int kSweepTile = 2048;          // k_sweep / k_slice: positions per wave tile = per candidate list
+constexpr int kSweepMaxBlocks = 256 * 4;  // resident workgroups of k_slice (at most 4 per CU)
+constexpr int kSweepGridMax = 256 * 8;    // resident workgroups of k_sweep (at most 8 per CU) = rows of sweep_part
 constexpr int kPoolChunkRecords = 256;    // pool records a wave reserves per returning atomic
 constexpr int kSweepMaxWaves = kSweepMaxBlocks * (kBlock / 64);
 constexpr int kBatch = 64;              // candidates sliced per batch (4 waves x 16)
@@ -93,13 +98,17 @@ struct SweepParams {
     uint32_t *unit_first;     // [nunits] index of the unit's first segment header, kNone if empty
     uint32_t *unit_count;     // [nunits] records of the unit (without headers)
     uint32_t nunits;
-    uint16_t *cand;           // generation 4: per-unit candidate codes (pos_in_unit<<3 | phase mask), kUnit slots per unit
-    uint32_t *cand_count;     // [nunits]
+    uint16_t *cand;           // candidate codes (position in the unit << 3 | phase mask), one list per tile of kSweepTile positions, kSweepTile slots each
+    uint32_t *cand_count;     // [tiles]
+    uint32_t *sweep_part;     // [k_sweep workgroups][4] partial counters (candidates, phases 4/5, 6/7, 8), summed by k_slice
+    uint32_t sweep_blocks;    // rows of sweep_part
     uint32_t *adder_bitmap;   // 2^24 bits: addresses some clean DF17 / DF11 IID 0 frame carries
     uint32_t *class_bitmap;   // 1 bit per scan position: candidate whose records are all conditional
-    uint32_t *class_uncond;   // generation 4 scratch plane: candidate with >= 1 unconditional record (both planes zeroed per chunk)
+    uint32_t *class_uncond;   // scratch plane: candidate with >= 1 unconditional record (both planes zeroed per chunk)
     unsigned long long *counters;   // [CNT_NUM]
-    int32_t debug_stage;      // 0 = full; 1 = sweep only; 2 = sweep + DF stage (timing experiments, MGPU_DEBUG_STAGE)
+#if MGPU_EXPERIMENTS
+    int32_t debug_stage;      // generation 3 only: disables kernel stages (timing experiments, MGPU_DEBUG_STAGE)
+#endif
 };
 
 struct ConvertParams {
@@ -116,11 +125,11 @@ struct ConvertParams {
 };
 
 void launch_convert(int format, const ConvertParams &p, hipStream_t s);
-void launch_sweep(const SweepParams &p, hipStream_t s);            // generation 4: k_sweep (streaming preamble sweep -> candidate lists)
-void launch_slice(const SweepParams &p, hipStream_t s);            //               k_slice (frames sliced straight from HBM/L2, no LDS tile)
-void launch_sweep_slice(const SweepParams &p, hipStream_t s);      // generation 3: fused, wave-autonomous LDS tiles (default)
-void launch_sweep_slice_v2(const SweepParams &p, hipStream_t s);   // second version: workgroup tiles, block barriers
-void launch_sweep_slice_v1(const SweepParams &p, hipStream_t s);   // first version: wave per candidate
+unsigned launch_sweep(const SweepParams &p, hipStream_t s);        // k_sweep: preamble sweep -> per-tile candidate lists; returns its grid size (rows of sweep_part)
+void launch_slice(const SweepParams &p, hipStream_t s);            // k_slice: slicer + CRC + scoring over the candidate lists -> record pool
+#if MGPU_EXPERIMENTS
+void launch_sweep_slice(const SweepParams &p, hipStream_t s);      // generation 3: both in one kernel (cross-check build only)
+#endif
 // pre-screen: count / write the records whose address may matter to the ordered walk
 // (the write pass also stores each live record's would-be signal power: sum of mag^2 over its frame)
 // everything between the sweep and the host: class planes -> class bitmap (+ counters, planes zeroed again),

@@ -1,22 +1,21 @@
 // kernels.hip — hand-written HIP kernels (gfx950 / CDNA4, wave64) for readsb's Mode-S hot path.
 //
 //   k_convert_*      IQ -> u16 magnitude                   (convert.c:64-108, 212-250, 329-367)
-//   k_sweep_slice    preamble sweep over every sample position, wave-ballot/prefix compaction of
-//                    the candidates, PPM bit slicing of each tried phase straight from the
-//                    LDS-staged sample window, wave-parallel CRC-24, syndrome lookup and the
-//                    filter-independent half of scoreModesMessage
-//                                                          (demod_2400.c:74-93,133-258,290-378;
-//                                                           mode_s.c:276-419; crc.c:67-82,383-406)
+//   k_sweep          preamble sweep over every sample position: packed pre-check, wave prefix-sum compaction of
+//                    the survivors, threshold tests -> ordered candidate lists     (demod_2400.c:290-378)
+//   k_slice          PPM bit slicing of each tried phase straight from an LDS-staged sample window,
+//                    wave-parallel CRC-24, syndrome lookup and the filter-independent half of
+//                    scoreModesMessage                     (demod_2400.c:74-93,133-258; mode_s.c:276-419;
+//                                                           crc.c:67-82,383-406)
 //   k_prescreen_*    drops records that can only ever score "unknown ICAO"
-//   k_signal_power   sum of mag^2 over an accepted frame  (demod_2400.c:436-457)
 //   k_window_stats   what the skip-ahead hid from the counters (demod_2400.c:468)
+//   k_modeac*, k_beast_*, k_decode_fields: Mode A/C demodulator, beast wire encoder, per-message field decode
 //
 // No MFMA anywhere: this is HBM-bound integer/byte streaming work.  All arithmetic on the
 // message path is integer and bit-exact with the reference; the SC16 converters use IEEE float
 // ops with contraction disabled and a correctly rounded sqrt.
-// One translation unit, in parts (kernels/*.inc, included below in dependency order):
-//   convert | sweep_gen1, slicer, sweep_gen2 (earlier generations, MGPU_SWEEP_VERSION=1|2) | sweep_slice (generation 3,
-//   the default) | sweep_gen4 (split experiment) | class_finalize, prescreen (post-sweep stage) | modeac | window_stats | beast (wire encoder) | fields (per-message field decode)
+// One translation unit, in parts (kernels/*.inc, included below in dependency order).  -DMGPU_EXPERIMENTS adds the
+// superseded fused kernel k_sweep_slice (generation 3) as a cross-check (make exp -> libmodes_gpu_exp.so).
 #include "kernels.h"
 #include "tables.h"
 
@@ -26,9 +25,7 @@ namespace mgpu {
 
 #define WAVE 64
 
-// Per-stage cycle counters of k_sweep_slice (thread 0 of every workgroup, summed into
-// counters[10..22], printed by api.cpp when MGPU_DEBUG_PRINT is set).  Off in production builds:
-// every s_memtime is a scalar-memory round trip.
+// Per-stage cycle counters of the experiments build's k_sweep_slice (make exp TIMERS=1).
 #ifndef MGPU_KERNEL_TIMERS
 #define MGPU_KERNEL_TIMERS 0
 #endif
@@ -87,13 +84,13 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 }
 
 #include "kernels/convert.inc"
-#include "kernels/sweep_gen1.inc"
 #include "kernels/slicer.inc"
-#include "kernels/sweep_gen2.inc"
+#include "kernels/sweep.inc"
+#include "kernels/slice.inc"
+#if MGPU_EXPERIMENTS
 #include "kernels/sweep_slice.inc"
-#include "kernels/sweep_gen4.inc"
+#endif
 #include "kernels/class_finalize.inc"
-#include "kernels/sweep_gen4_launch.inc"
 #include "kernels/prescreen.inc"
 #include "kernels/modeac.inc"
 #include "kernels/window_stats.inc"

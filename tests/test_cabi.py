@@ -119,6 +119,8 @@ def test_parallel_walk_equals_serial_walk(built):
 def test_bench_roofline_helpers():
     """bench.py's informative VALU-issue figure parses the committed SQ counter summary (and degrades to None, never raises)."""
     import bench
-    v = bench.valu_issue(0.19)
-    assert v and v["wave_insts_per_launch"] > 10_000_000 and 0.3 < v["frac"] < 1.0 and v["peak_Tlaneops_s"] == 39.3
-    assert bench.valu_issue(0.19, "/nonexistent/file") is None and bench.valu_issue(0.0) is None
+    v = bench.valu_issue("k_sweep", 0.040, 67108864)
+    assert v and v["wave_insts_per_launch"] > 10_000_000 and 0.2 < v["frac"] < 1.0
+    v2 = bench.valu_issue("k_slice", 0.123, 67108864)
+    assert v2 and v2["wave_insts_per_launch"] > v["wave_insts_per_launch"]
+    assert bench.valu_issue("k_sweep", 0.040, 67108864, "/nonexistent/file") is None and bench.valu_issue("k_sweep", 0.0, 1) is None

@@ -50,7 +50,10 @@ struct mgpu_config {
     int32_t  preamble_threshold;  /* Modes.preambleThreshold, default 58 (readsb.c:2268) */
     uint32_t buf_samples;         /* Modes.sdr_buf_samples, default 131072 (readsb.c:2212); multiple of 4096 */
     uint32_t trailing_samples;    /* Modes.trailing_samples = 326 (readsb.c:288); must be 326 */
-    uint32_t mode_ac;             /* Modes.mode_ac (--modeac): also run demodulate2400AC on every buffer, readsb.c:871-874 */
+    uint32_t mode_ac;             /* Modes.mode_ac (--modeac): also run demodulate2400AC on every buffer, readsb.c:871-874.
+                                   * IQ entries (mgpu_feed_iq*): UC8 only — with SC16 / SC16Q11 they return MGPU_E_INVAL, because the
+                                   * reference's noise floor there is an order-dependent float running sum (convert.c:225-249);
+                                   * mgpu_demod_mag_buf_ac (caller's mean_level / mean_power) works for every format. */
     uint64_t max_samples;         /* largest number of new samples one mgpu_feed_* call may carry */
     int64_t  startup_time_ms;     /* Modes.startup_time: wall clock (ms) the 12 MHz sample clock is anchored to */
     uint64_t record_pool_records; /* device pool for per-phase candidate records; 0 = max_samples/16 + 65536 */
@@ -161,8 +164,19 @@ int  mgpu_device_count(void);
  * 131072-sample buffer (readsb.c:871) and the per-buffer filter clock (readsb.c:1227-1231),
  * for `nsamples` new IQ samples continuing the stream.  nsamples need not be a multiple of
  * buf_samples; a short last buffer ends the stream exactly like a short read() does.
- * Synchronous: on return the accepted messages are available to mgpu_collect(). */
+ * Synchronous (unless mgpu_set_deferred): on return the accepted messages are available to mgpu_collect(). */
 int mgpu_feed_iq(mgpu_ctx *ctx, const void *iq_host, uint64_t nsamples);
+
+/* Deferred feeds — a continuous stream handed over block after block without the pipeline running empty in between.
+ * With on != 0, mgpu_feed_iq / mgpu_feed_iq_device return as soon as the block's chunks are enqueued (they still block while
+ * all three pipeline slots are busy), the next block may follow at once, and mgpu_collect() waits for the OLDEST uncollected
+ * feed only and returns exactly that feed's messages — so the caller's loop is  feed(k+1); collect(k).  At most 4 feeds may be
+ * uncollected.  mgpu_set_message_buffer() then names the array of the NEXT feed (alternate two arrays).  The demod counters
+ * settle when nothing is in flight: passing `counters` to mgpu_collect, and mgpu_finish / mgpu_last_timing / mgpu_reset /
+ * mgpu_filter_* / mgpu_set_deferred, wait for everything enqueued so far (they "drain"); mgpu_last_timing then covers everything
+ * since the previous drain.  The result — messages, their order, every counter — is identical to feeding the same blocks
+ * synchronously.  The struct mag_buf entries and the shard calls are refused (MGPU_E_INVAL) while deferred mode is on. */
+int mgpu_set_deferred(mgpu_ctx *ctx, int on);
 
 /* Same, for IQ already resident in device memory (HBM): d_iq is a device pointer to
  * nsamples samples of cfg.format.  This is the entry the benchmark times. */

@@ -126,6 +126,7 @@ def load_library():
     lib.mgpu_last_error.argtypes = [vp]
     lib.mgpu_last_error.restype = C.c_char_p
     lib.mgpu_device_count.restype = i32
+    lib.mgpu_set_deferred.argtypes = [vp, i32]
     lib.mgpu_feed_iq.argtypes = [vp, vp, u64]
     lib.mgpu_feed_iq_device.argtypes = [vp, vp, u64]
     lib.mgpu_host_cpus.argtypes = [vp, vp, i32]
@@ -373,6 +374,22 @@ class Demodulator:
         cnt = Counters()
         self._chk(self.lib.mgpu_collect(self.ctx, out.ctypes.data, n, C.byref(got), C.byref(cnt)), "mgpu_collect")
         return out[: got.value], cnt.as_dict()
+
+    def set_deferred(self, on=True):
+        """mgpu_set_deferred: feeds return once enqueued; the loop is feed(k+1); collect_feed(k)."""
+        self._chk(self.lib.mgpu_set_deferred(self.ctx, 1 if on else 0), "mgpu_set_deferred")
+
+    def collect_feed(self, out, want_counters=False):
+        """Deferred mode: wait for the oldest uncollected feed and take its messages into `out` (a contiguous mgpu_msg array,
+        possibly the one named by set_message_buffer for that feed: then nothing is copied).  want_counters=True also drains
+        everything in flight and returns the settled counters."""
+        if out.dtype != MSG_DTYPE or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("collect_feed(out): need a contiguous mgpu_msg array")
+        got = C.c_uint64(0)
+        cnt = Counters() if want_counters else None
+        self._chk(self.lib.mgpu_collect(self.ctx, out.ctypes.data, out.size, C.byref(got), C.byref(cnt) if cnt is not None else None),
+                  "mgpu_collect")
+        return out[: got.value], (cnt.as_dict() if cnt is not None else None)
 
     def timing(self):
         t = Timing()

@@ -165,6 +165,7 @@ struct Slot {
     hipEvent_t ev_scan = nullptr;         // pre-screen offsets are final (main stream) -> the write pass may start (second stream)
     // the job
     uint64_t n = 0, stream_pos = 0;
+    int feed = -1;                        // deferred feeds: which FeedSlot the chunk's messages go to (-1: mgpu_ctx::pending)
     int32_t thr = 58;                     // preamble threshold of this chunk (raised after drops, demod_2400.c:335-338)
     bool have_mag = false, busy = false;
     bool have_noise = false;              // mag_buf entry with the caller's mean_level: Mode A/C noise level computed on the host
@@ -223,7 +224,16 @@ struct HostJob {
     uint32_t nmsg = 0;                       // accepted frames: acc[0..nmsg), pos[0..nmsg)
     uint64_t stream_pos = 0;                 // stream position of the chunk's first sample
     int slot = -1;                           // the slot the chunk ran in (the walker still needs its device side)
+    int feed = -1;                           // Slot::feed
     bool busy = false;
+};
+
+// Deferred feeds (mgpu_set_deferred): a feed call returns once its chunks are enqueued, the next one may follow at once, and
+// mgpu_collect waits for the oldest uncollected feed only.  Each feed in flight has its own message list.
+struct FeedSlot {
+    MsgBuf msgs;
+    uint64_t jobs_total = 0, jobs_built = 0;  // chunks submitted / chunks whose messages are complete (under mgpu_ctx::mu)
+    bool closed = false;                      // every chunk of the feed has been submitted
 };
 
 struct mgpu_ctx {
@@ -258,6 +268,12 @@ struct mgpu_ctx {
 
     Resolver resolver;
     MsgBuf pending;
+    static constexpr int kFeeds = 4;
+    FeedSlot feed[kFeeds];                                    // deferred mode: ring of feeds in flight / uncollected
+    uint64_t feed_head = 0, feed_tail = 0;                    // oldest uncollected feed, next feed to open
+    bool deferred = false;
+    bool accounting_open = false;                             // feed_begin has run, feed_end has not (deferred: spans several feeds)
+    double acct_t0 = 0;
     mgpu_counters counters{};
     mgpu_timing timing{}, acc{};
     uint64_t stream_pos = 0;
@@ -688,11 +704,16 @@ void mgpu_destroy(mgpu_ctx *c) {
     delete c;
 }
 
+static int drain(mgpu_ctx *c);
+
 int mgpu_reset(mgpu_ctx *c) {
     if (!c) return MGPU_E_INVAL;
+    (void) drain(c);                         // deferred feeds still in flight land first (their results are discarded)
     HIPCHK(c, hipSetDevice(c->cfg.device));
     c->resolver.reset(c->cfg.startup_time_ms, (int) c->cfg.filter_clock);
     c->pending.clear();
+    for (auto &f : c->feed) { f.msgs.clear(); f.jobs_total = f.jobs_built = 0; f.closed = false; }
+    c->feed_head = c->feed_tail = 0;
     std::memset(&c->counters, 0, sizeof(c->counters));
     std::memset(&c->timing, 0, sizeof(c->timing));
     c->stream_pos = 0;
@@ -964,13 +985,14 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
         ac.resize(keep);
     }
     const uint32_t nac = (uint32_t) ac.size();
-    const size_t first_msg = c->pending.size();
-    if (!c->pending.grow_for((size_t) nmsg + nac)) {
-        c->err = c->pending.external ? "the caller's message buffer (mgpu_set_message_buffer) is full" : "out of memory for the decoded messages";
-        return c->pending.external ? MGPU_E_OVERFLOW : MGPU_E_NOMEM;
+    MsgBuf &pending = job.feed >= 0 ? c->feed[job.feed].msgs : c->pending;
+    const size_t first_msg = pending.size();
+    if (!pending.grow_for((size_t) nmsg + nac)) {
+        c->err = pending.external ? "the caller's message buffer (mgpu_set_message_buffer) is full" : "out of memory for the decoded messages";
+        return pending.external ? MGPU_E_OVERFLOW : MGPU_E_NOMEM;
     }
     const double t1 = wall_ms();
-    mgpu_msg *out = c->pending.data() + first_msg;
+    mgpu_msg *out = pending.data() + first_msg;
     std::vector<mgpu_msg> &stage = c->b_stage;               // with Mode A/C the Mode S messages are built here and merged per buffer
     if (nac) { stage.resize(nmsg); }
     {
@@ -1002,7 +1024,7 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
         }
         c->counters.demod_modeac += nac;
     }
-    c->pending.n = first_msg + nmsg + nac;
+    pending.n = first_msg + nmsg + nac;
     const double t2 = wall_ms();
 
     mgpu_counters &k = c->counters;
@@ -1046,8 +1068,11 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
 // Start / end of one API call that runs chunks: reset and then apply the skip-window corrections of
 // the demod counters (see DESIGN.md §1 "Statistics without a candidate log").
 static int feed_begin(mgpu_ctx *c) {
+    if (c->accounting_open) return MGPU_OK;  // deferred feeds: the accounting opened by an earlier feed is still running
     { std::lock_guard<std::mutex> lk(c->mu); c->hot.store(true, std::memory_order_relaxed); }
     c->cv.notify_all();                      // the stage threads switch from sleeping to polling
+    c->accounting_open = true;
+    c->acct_t0 = wall_ms();
     std::memset(&c->acc, 0, sizeof(c->acc));
     std::memset(c->feed_cand, 0, sizeof(c->feed_cand));
     c->feed_rc = ResolveCounts();
@@ -1056,6 +1081,7 @@ static int feed_begin(mgpu_ctx *c) {
 }
 
 static int feed_end(mgpu_ctx *c) {
+    c->accounting_open = false;
     if (c->shard_mode != 0) return MGPU_OK;   // a shard pass produces no messages and no statistics here
     HIPCHK(c, hipMemcpyAsync(c->h_win, c->d_win, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream2));
     HIPCHK(c, hipStreamSynchronize(c->stream2));
@@ -1078,6 +1104,20 @@ static int feed_end(mgpu_ctx *c) {
     return MGPU_OK;
 }
 
+// A C++ exception (std::bad_alloc from a vector growing with the traffic) must not leave a stage thread — that would
+// terminate the process — nor cross the extern "C" boundary: it becomes MGPU_E_NOMEM for the feed that hit it.
+static int guarded(mgpu_ctx *c, const std::function<int()> &f) {
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        c->err = "out of host memory";
+        return MGPU_E_NOMEM;
+    } catch (const std::exception &e) {
+        c->err = std::string("internal error: ") + e.what();
+        return MGPU_E_NOMEM;
+    }
+}
+
 static void fetcher_main(mgpu_ctx *c) {
     (void) hipSetDevice(c->cfg.device);
     for (;;) {
@@ -1094,7 +1134,8 @@ static void fetcher_main(mgpu_ctx *c) {
         Slot &sl = c->slot[idx];
         HostJob &job = c->job[jidx];
         job.slot = idx;
-        int rc = c->worker_rc == MGPU_OK ? fetch_slot(c, sl, job) : c->worker_rc;   // after an error just drain
+        job.feed = sl.feed;
+        int rc = c->worker_rc == MGPU_OK ? guarded(c, [&] { return fetch_slot(c, sl, job); }) : c->worker_rc;   // after an error just drain
         if (rc == MGPU_OK && c->shard_mode == 2) {           // the chunk's records become a packet: header, records, signal powers
             const uint64_t hdr[4] = {job.stream_pos, sl.n, job.nlive, 0};
             const uint8_t *h8 = (const uint8_t *) hdr;
@@ -1128,7 +1169,7 @@ static void worker_main(mgpu_ctx *c) {
         }
         HostJob &job = c->job[jidx];
         Slot &sl = c->slot[job.slot];
-        int rc = c->worker_rc == MGPU_OK ? walk_job(c, sl, job) : c->worker_rc;
+        int rc = c->worker_rc == MGPU_OK ? guarded(c, [&] { return walk_job(c, sl, job); }) : c->worker_rc;
         {
             std::lock_guard<std::mutex> lk(c->mu);
             if (rc != MGPU_OK && c->worker_rc == MGPU_OK) c->worker_rc = rc;
@@ -1149,11 +1190,12 @@ static void builder_main(mgpu_ctx *c) {
             if (c->build_queue.empty()) return;
             jidx = c->build_queue.front();
         }
-        int rc = build_job(c, c->job[jidx]);
+        int rc = guarded(c, [&] { return build_job(c, c->job[jidx]); });
         {
             std::lock_guard<std::mutex> lk(c->mu);
             if (rc != MGPU_OK && c->worker_rc == MGPU_OK) c->worker_rc = rc;
             c->build_queue.pop_front();      // popped only now: wait_all sees the job until it is done
+            if (c->job[jidx].feed >= 0) c->feed[c->job[jidx].feed].jobs_built++;
             c->job[jidx].busy = false;
         }
         c->cv.notify_all();
@@ -1199,11 +1241,33 @@ static int feed_common(mgpu_ctx *c, const void *src, bool src_is_device, uint64_
     if (c->eof) return MGPU_E_EOF;
     if (n > c->cap_samples) return MGPU_E_CAPACITY;
     if (c->worker_rc != MGPU_OK) return c->worker_rc;
+    if (c->cfg.mode_ac && c->cfg.format != MGPU_FMT_UC8) {
+        // demodulate2400AC's noise floor comes from mag_buf.mean_level / mean_power, which convert_sc16*_nodc accumulate as
+        // order-dependent FLOAT running sums (convert.c:225-249, 342-366); this library's SC16 converters keep exact double
+        // sums, so the accepted Mode A/C replies could differ from the reference's.  Refused rather than approximately right:
+        // convert on the host side of the boundary and use mgpu_demod_mag_buf_ac with the reference's own means.
+        c->err = "mode_ac with SC16/SC16Q11 on the IQ entry is not reference-exact: use mgpu_demod_mag_buf_ac";
+        return MGPU_E_INVAL;
+    }
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const size_t bps = c->cfg.format == MGPU_FMT_UC8 ? 2 : 4;
     const double t_start = wall_ms();
-    c->feed_t0 = t_start;
-    { int brc = feed_begin(c); if (brc != MGPU_OK) return brc; }
+    if (!c->accounting_open) c->feed_t0 = t_start;
+    int fidx = -1;
+    if (c->deferred) {
+        std::lock_guard<std::mutex> lk(c->mu);
+        if (c->feed_tail - c->feed_head >= (uint64_t) mgpu_ctx::kFeeds) {
+            c->err = "deferred feeds: collect the oldest feed before starting another (at most 4 uncollected)";
+            return MGPU_E_INVAL;
+        }
+        fidx = (int) (c->feed_tail % mgpu_ctx::kFeeds);
+        FeedSlot &fs = c->feed[fidx];
+        fs.jobs_total = fs.jobs_built = 0;
+        fs.closed = false;
+        fs.msgs.clear();
+        c->feed_tail++;                      // open: mgpu_collect sees it, and waits for `closed`
+    }
+    { int brc = feed_begin(c); if (brc != MGPU_OK) { c->hot.store(false, std::memory_order_relaxed); return brc; } }
     // host samples go up chunk by chunk on the copy stream, each chunk's convert waits for its own piece only:
     // the transfer of chunk i+1 overlaps the kernels of chunk i (fully so from pinned / mgpu_host_register'ed memory)
     const uint8_t *iq = src_is_device ? (const uint8_t *) src : c->d_iq;
@@ -1215,6 +1279,7 @@ static int feed_common(mgpu_ctx *c, const void *src, bool src_is_device, uint64_
         Slot &sl = acquire_slot(c, k);
         sl.n = len;
         sl.stream_pos = c->stream_pos + off;
+        sl.feed = fidx;
         sl.have_mag = false;
         sl.have_noise = false;
         sl.thr = c->cfg.preamble_threshold;
@@ -1229,8 +1294,18 @@ static int feed_common(mgpu_ctx *c, const void *src, bool src_is_device, uint64_
             c->acc.h2d_ms += (float) (wall_ms() - t0);   // host time spent issuing (pageable memory: staging) the copies
         }
         if (rc == MGPU_OK) rc = enqueue_slot(c, sl, iq + off * bps);
+        if (fidx >= 0) { std::lock_guard<std::mutex> lk(c->mu); c->feed[fidx].jobs_total++; }
         submit_slot(c, k);   // even after an enqueue error: the worker releases the slot
         if (rc != MGPU_OK) { std::lock_guard<std::mutex> lk(c->mu); if (c->worker_rc == MGPU_OK) c->worker_rc = rc; }
+    }
+    if (fidx >= 0) {
+        // deferred: the feed is on its way; its messages are collected by mgpu_collect, the counters settle at the next drain
+        { std::lock_guard<std::mutex> lk(c->mu); c->feed[fidx].closed = true; }
+        c->cv.notify_all();
+        if (rc != MGPU_OK) return rc;
+        c->stream_pos += n;
+        if (n % c->cfg.buf_samples) c->eof = true;
+        return MGPU_OK;
     }
     const int wrc = wait_all(c);
     c->hot.store(false, std::memory_order_relaxed);
@@ -1241,6 +1316,30 @@ static int feed_common(mgpu_ctx *c, const void *src, bool src_is_device, uint64_
     if (n % c->cfg.buf_samples) c->eof = true;   // short read = end of file (sdr_ifile.c:223-237)
     c->acc.total_ms = (float) (wall_ms() - t_start);
     c->timing = c->acc;
+    return MGPU_OK;
+}
+
+// Deferred feeds: wait until nothing is in flight, then settle the counters (feed_end) and the timing of everything since
+// the last drain.  Every call that reads or changes stream state other than feeding and collecting starts with this.
+static int drain(mgpu_ctx *c) {
+    if (!c->accounting_open) return c->worker_rc;
+    (void) hipSetDevice(c->cfg.device);
+    int rc = wait_all(c);
+    c->hot.store(false, std::memory_order_relaxed);
+    if (rc == MGPU_OK) rc = feed_end(c); else c->accounting_open = false;
+    c->acc.total_ms = (float) (wall_ms() - c->acct_t0);
+    c->timing = c->acc;
+    return rc;
+}
+
+int mgpu_set_deferred(mgpu_ctx *c, int on) {
+    if (!c) return MGPU_E_INVAL;
+    const int rc = drain(c);
+    if (rc != MGPU_OK) return rc;
+    if (c->feed_head != c->feed_tail || c->pending.size()) { c->err = "mgpu_set_deferred: collect the pending messages first"; return MGPU_E_INVAL; }
+    if (!on)                                         // the caller's arrays go back to the caller
+        for (auto &f : c->feed) f.msgs.use_external(nullptr, 0);
+    c->deferred = on != 0;
     return MGPU_OK;
 }
 
@@ -1282,6 +1381,7 @@ int mgpu_upload_iq(mgpu_ctx *c, const void *iq_host, uint64_t nsamples) {
 
 int mgpu_finish(mgpu_ctx *c) {
     if (!c) return MGPU_E_INVAL;
+    { const int rc = drain(c); if (rc != MGPU_OK) return rc; }
     if (c->eof) return MGPU_OK;
     // file length an exact multiple of the buffer size: one more zero-length buffer, whose
     // converter call divides 0 by 0 (convert.c:101-107) -> noise_power_sum becomes NaN
@@ -1295,28 +1395,68 @@ int mgpu_finish(mgpu_ctx *c) {
     return MGPU_OK;
 }
 
-int mgpu_collect(mgpu_ctx *c, struct mgpu_msg *out, uint64_t cap, uint64_t *n, struct mgpu_counters *counters) {
-    if (!c || (!out && cap)) return MGPU_E_INVAL;
-    uint64_t k = c->pending.size() < cap ? c->pending.size() : cap;
-    if (c->pending.external && out == c->pending.data() && k == c->pending.size()) {
-        c->pending.clear();                  // the messages already are where the caller wants them
+static void take_messages(MsgBuf &mb, struct mgpu_msg *out, uint64_t cap, uint64_t *n) {
+    const uint64_t k = mb.size() < cap ? mb.size() : cap;
+    if (mb.external && out == mb.data() && k == mb.size()) {
+        mb.clear();                          // the messages already are where the caller wants them
     } else {
-        if (k) std::memcpy(out, c->pending.data(), k * sizeof(mgpu_msg));
-        c->pending.drop_front(k);
+        if (k) std::memcpy(out, mb.data(), k * sizeof(mgpu_msg));
+        mb.drop_front(k);
     }
     if (n) *n = k;
+}
+
+int mgpu_collect(mgpu_ctx *c, struct mgpu_msg *out, uint64_t cap, uint64_t *n, struct mgpu_counters *counters) {
+    if (!c || (!out && cap)) return MGPU_E_INVAL;
+    if (n) *n = 0;
+    if (c->deferred) {
+        if (c->feed_head != c->feed_tail) {                  // the oldest uncollected feed: wait for its last chunk's messages only
+            FeedSlot &fs = c->feed[c->feed_head % mgpu_ctx::kFeeds];
+            {
+                std::unique_lock<std::mutex> lk(c->mu);
+                c->cv.wait(lk, [&] { return c->worker_rc != MGPU_OK || (fs.closed && fs.jobs_built == fs.jobs_total); });
+                if (c->worker_rc != MGPU_OK) return c->worker_rc;
+            }
+            take_messages(fs.msgs, out, cap, n);
+            if (fs.msgs.size() == 0) { std::lock_guard<std::mutex> lk(c->mu); c->feed_head++; }
+        }
+        if (counters) {                                      // exact counters need everything in flight to land: this drains
+            const int rc = drain(c);
+            if (rc != MGPU_OK) return rc;
+            *counters = c->counters;
+        }
+        return MGPU_OK;
+    }
+    take_messages(c->pending, out, cap, n);
     if (counters) *counters = c->counters;
     return MGPU_OK;
 }
 
 int mgpu_set_message_buffer(mgpu_ctx *c, struct mgpu_msg *buf, uint64_t capacity) {
     if (!c || (buf && !capacity)) return MGPU_E_INVAL;
+    if (c->deferred) {                                       // the array of the NEXT feed; earlier feeds keep theirs
+        std::lock_guard<std::mutex> lk(c->mu);
+        if (c->feed_tail - c->feed_head >= (uint64_t) mgpu_ctx::kFeeds) { c->err = "mgpu_set_message_buffer: collect the oldest feed first"; return MGPU_E_INVAL; }
+        c->feed[c->feed_tail % mgpu_ctx::kFeeds].msgs.use_external(buf, (size_t) capacity);
+        return MGPU_OK;
+    }
     if (c->pending.size()) { c->err = "mgpu_set_message_buffer: collect the pending messages first"; return MGPU_E_INVAL; }
     c->pending.use_external(buf, (size_t) capacity);
     return MGPU_OK;
 }
 
-uint64_t mgpu_pending_messages(mgpu_ctx *c) { return c ? c->pending.size() : 0; }
+uint64_t mgpu_pending_messages(mgpu_ctx *c) {
+    if (!c) return 0;
+    if (!c->deferred) return c->pending.size();
+    std::lock_guard<std::mutex> lk(c->mu);                   // deferred: messages of the feeds that are complete
+    uint64_t total = 0;
+    for (uint64_t f = c->feed_head; f != c->feed_tail; ++f) {
+        const FeedSlot &fs = c->feed[f % mgpu_ctx::kFeeds];
+        if (!(fs.closed && fs.jobs_built == fs.jobs_total)) break;
+        total += fs.msgs.n;
+    }
+    return total;
+}
 
 int mgpu_filter_expire(mgpu_ctx *c) {
     if (!c) return MGPU_E_INVAL;
@@ -1324,6 +1464,7 @@ int mgpu_filter_expire(mgpu_ctx *c) {
         c->err = "mgpu_filter_expire: the context runs its own filter clock (cfg.filter_clock)";
         return MGPU_E_INVAL;
     }
+    { const int rc = drain(c); if (rc != MGPU_OK) return rc; }
     c->resolver.external_expire();
     c->counters.nflips = c->resolver.nflips();
     return MGPU_OK;
@@ -1331,12 +1472,14 @@ int mgpu_filter_expire(mgpu_ctx *c) {
 
 int mgpu_filter_add(mgpu_ctx *c, uint32_t addr) {
     if (!c) return MGPU_E_INVAL;
+    { const int rc = drain(c); if (rc != MGPU_OK) return rc; }
     c->resolver.filter().add(addr);
     return MGPU_OK;
 }
 
 int mgpu_last_timing(mgpu_ctx *c, struct mgpu_timing *t) {
     if (!c || !t) return MGPU_E_INVAL;
+    (void) drain(c);
     *t = c->timing;
     return MGPU_OK;
 }
@@ -1344,6 +1487,7 @@ int mgpu_last_timing(mgpu_ctx *c, struct mgpu_timing *t) {
 int mgpu_convert(mgpu_ctx *c, const void *iq_host, uint16_t *mag_host, uint32_t n, double *out_mean_level, double *out_mean_power) {
     if (!c || !iq_host || !mag_host) return MGPU_E_INVAL;
     if (n > c->cap_samples || n > 0x7fffffffu) return MGPU_E_CAPACITY;
+    { const int drc = drain(c); if (drc != MGPU_OK) return drc; }
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const size_t bps = c->cfg.format == MGPU_FMT_UC8 ? 2 : 4;
     hipStream_t s = c->stream;
@@ -1410,6 +1554,7 @@ static int demod_mag_buf(mgpu_ctx *c, const uint16_t *data, uint32_t length, int
                          const double *mean_level, double mean_power, uint32_t dropped) {
     if (!c || !data) return MGPU_E_INVAL;
     if (length > c->chunk_samples) return MGPU_E_CAPACITY;
+    if (c->deferred) { c->err = "deferred feeds are for the IQ entries (mgpu_feed_iq*): mgpu_set_deferred(ctx, 0) first"; return MGPU_E_INVAL; }
     if (c->worker_rc != MGPU_OK) return c->worker_rc;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     if (length == 0) {
@@ -1425,6 +1570,7 @@ static int demod_mag_buf(mgpu_ctx *c, const uint16_t *data, uint32_t length, int
     const int slot_idx = (int) (c->chunk_seq++ % mgpu_ctx::kSlots);
     Slot &sl = acquire_slot(c, slot_idx);
     sl.n = length;
+    sl.feed = -1;
     // demod_2400.c:335-338: after dropped samples the reference raises the threshold to at least PREAMBLE_THRESHOLD_PIZERO
     sl.thr = dropped && c->cfg.preamble_threshold < 75 ? 75 : c->cfg.preamble_threshold;
     sl.have_mag = true;
@@ -1465,7 +1611,7 @@ static int demod_mag_buf(mgpu_ctx *c, const uint16_t *data, uint32_t length, int
 // one context: the ordered walk and the message build, exactly as for an unsharded stream.
 
 int mgpu_shard_begin(mgpu_ctx *c, uint64_t first_sample, const void *history_iq, int mode) {
-    if (!c || mode < 1 || mode > 2 || first_sample % c->cfg.buf_samples) return MGPU_E_INVAL;
+    if (!c || mode < 1 || mode > 2 || first_sample % c->cfg.buf_samples || c->deferred) return MGPU_E_INVAL;
     if (first_sample && !history_iq) return MGPU_E_INVAL;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     c->shard_mode = mode;
@@ -1517,19 +1663,20 @@ int mgpu_shard_packets(mgpu_ctx *c, const void **packets, uint64_t *bytes) {
     return MGPU_OK;
 }
 
-int mgpu_walk_packets(mgpu_ctx *c, const void *packets, uint64_t bytes) {
-    if (!c || (!packets && bytes)) return MGPU_E_INVAL;
-    if (c->eof) return MGPU_E_EOF;
+// The packets come from other ranks over a gather: nothing in a header is trusted before it is checked against the bytes
+// that are really there (record count without a 64-bit overflow), the context's capacity, and the order the walk relies on.
+static int walk_packets_checked(mgpu_ctx *c, const void *packets, uint64_t bytes) {
     const uint8_t *p = (const uint8_t *) packets, *end = p + bytes;
     HostJob &job = c->job[0];
+    constexpr uint64_t kRecBytes = sizeof(PhaseRec) + 8;        // record + its signal power
     while (p < end) {
         uint64_t hdr[4];
-        if ((size_t) (end - p) < sizeof(hdr)) return MGPU_E_INVAL;
+        if ((size_t) (end - p) < sizeof(hdr)) { c->err = "mgpu_walk_packets: truncated packet header"; return MGPU_E_INVAL; }
         std::memcpy(hdr, p, sizeof(hdr));
         p += sizeof(hdr);
         const uint64_t pos = hdr[0], n = hdr[1], nrecs = hdr[2];
-        if (pos != c->stream_pos || n == 0 || (uint64_t) (end - p) < nrecs * (sizeof(PhaseRec) + 8)) {
-            c->err = "mgpu_walk_packets: packets must continue the stream in order";
+        if (pos != c->stream_pos || n == 0 || n > c->cap_samples || n > 0xFFFFFFF0ull || nrecs > (uint64_t) (end - p) / kRecBytes) {
+            c->err = "mgpu_walk_packets: packets must continue the stream in order, within max_samples, with all their records present";
             return MGPU_E_INVAL;
         }
         job.recs.resize(nrecs + 1);
@@ -1539,6 +1686,13 @@ int mgpu_walk_packets(mgpu_ctx *c, const void *packets, uint64_t bytes) {
         job.sig.resize(nrecs);
         std::memcpy(job.sig.data(), p, nrecs * 8);
         p += nrecs * 8;
+        for (uint64_t i = 0; i < nrecs; ++i) {                   // sorted by position, inside the packet's samples, a real phase
+            const PhaseRec &r = job.recs[i];
+            if (r.pos >= n || (i && r.pos < job.recs[i - 1].pos) || r.phase < 4 || r.phase > 8) {
+                c->err = "mgpu_walk_packets: malformed record list";
+                return MGPU_E_INVAL;
+            }
+        }
         ifile_grid(c, pos, n, job.buffers);
         const uint64_t cap = nrecs + 1;
         job.pos.resize(cap); c->w_limit.resize(cap); c->w_skip.resize(cap);
@@ -1559,6 +1713,13 @@ int mgpu_walk_packets(mgpu_ctx *c, const void *packets, uint64_t bytes) {
         if (n % c->cfg.buf_samples) c->eof = true;
     }
     return MGPU_OK;
+}
+
+int mgpu_walk_packets(mgpu_ctx *c, const void *packets, uint64_t bytes) {
+    if (!c || (!packets && bytes)) return MGPU_E_INVAL;
+    if (c->eof) return MGPU_E_EOF;
+    if (c->shard_mode != 0 || c->deferred) { c->err = "mgpu_walk_packets: the context is in the middle of a shard pass (or in deferred mode)"; return MGPU_E_INVAL; }
+    return guarded(c, [&] { return walk_packets_checked(c, packets, bytes); });
 }
 
 // ---- beast wire format (net_io.c:1655-1714) for message records that already are in HBM -----------------------

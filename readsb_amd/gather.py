@@ -63,9 +63,12 @@ class MessageGatherer:
         self.copied = [torch.cuda.Event() if cuda else None for _ in range(depth)]   # H2D of the slot has read the staging buffer
         self.seq = 0
 
-    def staging(self) -> np.ndarray:
-        """Record array (capacity entries) of the next slot; safe to overwrite once this returns."""
-        k = self.seq % self.depth
+    def staging(self, ahead: int = 0) -> np.ndarray:
+        """Record array (capacity entries) of the next slot (ahead=1: of the one after it — a demodulator with deferred
+        feeds fills step k+1's array before step k's is submitted; needs depth >= 3); safe to overwrite once this returns."""
+        if not 0 <= ahead < self.depth - 1 and ahead != 0:
+            raise ValueError("staging(ahead): the ring is too short")
+        k = (self.seq + ahead) % self.depth
         self._wait_slot(k)
         return self.host[k].numpy().view(self.dtype)
 

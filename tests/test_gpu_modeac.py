@@ -72,3 +72,15 @@ def test_mag_buf_entry_with_mode_ac(built):
         d.close()
     helpers.assert_same_messages(got, want)
     helpers.assert_same_counters(cnt, wst)
+
+
+def test_mode_ac_sc16_iq_entry_is_refused(built):
+    """The IQ entry with Mode A/C and an SC16 format would use exact sums where the reference uses an order-dependent float
+    running sum (convert.c:225-249): refused loudly (MGPU_E_INVAL), never approximately decoded."""
+    import readsb_amd
+    iq = helpers.synth(seconds=0.2, seed=5, fmt=2)
+    d = readsb_amd.Demodulator(fmt=2, mode_ac=1, startup_time_ms=helpers.STARTUP_MS, max_samples=max(len(iq) // 4, 131072))
+    with pytest.raises(readsb_amd.MgpuError) as ei:
+        d.demodulate_capture(iq)
+    assert "mgpu_demod_mag_buf_ac" in str(ei.value)
+    d.close()

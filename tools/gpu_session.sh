@@ -5,16 +5,9 @@ out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
 R=$(pwd)
-echo "== dev_check (product library)"
-timeout 400 python tools/dev_check.py > $out/dev_check.log 2>&1; echo "rc=$?"
-cat $out/dev_check.log | cut -c1-300
-for blocks in 1024 768 512 256; do
-  echo "== bench MGPU_SLICE_BLOCKS=$blocks"
-  MGPU_SLICE_BLOCKS=$blocks timeout 200 python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_$blocks.log 2>&1
-  tail -1 $out/bench_$blocks.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['stage_ms'])"
-done
-for blocks in 1536 1024 768; do
-  echo "== bench MGPU_SWEEP_BLOCKS=$blocks"
-  MGPU_SWEEP_BLOCKS=$blocks timeout 200 python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_sw$blocks.log 2>&1
-  tail -1 $out/bench_sw$blocks.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['stage_ms'])"
-done
+echo "== new tests"
+timeout 600 python -m pytest tests/test_gpu_deferred.py tests/test_gpu_modeac.py tests/test_gpu_kernel_generations.py -x -q --timeout 300 > $out/pytest_new.log 2>&1; tail -15 $out/pytest_new.log
+echo "== bench"
+timeout 400 python bench.py --steps 10 --warmup 3 > $out/bench.log 2>&1; tail -2 $out/bench.log | cut -c1-2500
+echo "== full gpu suite"
+timeout 1200 python -m pytest tests -m gpu -q -x --timeout 600 > $out/pytest_gpu.log 2>&1; tail -8 $out/pytest_gpu.log

@@ -60,7 +60,7 @@ def valu_issue(kernel, avg_launch_ms, samples_per_launch, path=PMC_SQ_SUMMARY):
         return None
 
 
-def cpu_reference(iq, nsamples):
+def cpu_reference(iq, nsamples, fmt=0, nfix=1, fixdf=1, thr=58):
     """oracle/_ref (the reference's own convert.c + demodulate2400 + ...) on the host, 1 core."""
     import helpers
     so = os.path.join(ROOT, "oracle", "_ref", "libreadsb_ref.so")
@@ -74,7 +74,7 @@ def cpu_reference(iq, nsamples):
         saved = os.dup(2)
         os.dup2(devnull, 2)   # init_converter prints to stderr
         try:
-            rc = lib.ref_demod_run(0, 1, 1, 58, iq.ctypes.data, nsamples, C.byref(out), C.byref(nout), st.ctypes.data,
+            rc = lib.ref_demod_run(fmt, nfix, fixdf, thr, iq.ctypes.data, nsamples, C.byref(out), C.byref(nout), st.ctypes.data,
                                    None, None, None)
         finally:
             os.dup2(saved, 2)
@@ -83,8 +83,71 @@ def cpu_reference(iq, nsamples):
         msgs = np.zeros(nout.value, dtype=helpers.ORACLE_MSG)
         C.memmove(msgs.ctypes.data, out.value, nout.value * helpers.ORACLE_MSG.itemsize)
         return "reference", msgs, st[0]
-    msgs, st = helpers.oracle_run(iq[: nsamples * 2])
+    msgs, st = helpers.oracle_run(iq[: nsamples * helpers.FMT_BYTES[fmt]], fmt, nfix, fixdf, thr)
     return "port", msgs, st
+
+
+# The other BASELINE configurations and input statistics, measured in the same run (a point is not a curve: the sweep's and the
+# slicer's cost depends on how many positions pass the preamble tests): name -> (format, nfix_crc, synth arguments)
+EXTRA_CONFIGS = {
+    "configs[2]: SC16Q11 --aggressive (2-bit repair)": (2, 2, dict(rate=2000.0)),
+    "dense bursts, 8000 frames/s, overlapping DF17, --aggressive": (0, 2, dict(rate=8000.0, dense=1)),
+    "UC8 --fix, Gaussian noise (sigma 3 LSB)": (0, 1, dict(rate=2000.0, dense=4)),
+}
+
+
+def run_extra_config(name, fmt, nfix, kw, nsamples, device, steps=4):
+    """One more configuration on a fresh context: `steps` back-to-back segments of a resident stream with deferred feeds (timed),
+    then one synchronous pass whose messages and counters must equal the reference's own code on the same samples."""
+    import helpers
+    import readsb_amd
+    iq = helpers.synth(nsamples=nsamples, fmt=fmt, seed=424242, threads=min(64, os.cpu_count() or 8), **kw)
+    d = readsb_amd.Demodulator(fmt=fmt, nfix_crc=nfix, max_samples=nsamples, device=device, startup_time_ms=helpers.STARTUP_MS)
+    d.upload_iq(iq)
+    d.keep_other_threads_away(confine_to_own_l3=False)
+    d.feed_resident(nsamples)
+    m0, _ = d.collect(reuse=True)
+    bufs = [np.empty(len(m0) * 5 // 4 + 1024, dtype=readsb_amd.MSG_DTYPE) for _ in range(2)]
+    d.reset()
+    d.set_deferred(True)
+
+    def submit(k):
+        d.set_message_buffer(bufs[k % 2])
+        d.feed_resident(nsamples)
+
+    submit(0)
+    d.collect_feed(bufs[0], want_counters=True)              # warm-up segment, drained
+    t0 = time.perf_counter()
+    submit(1)
+    for k in range(2, steps + 1):
+        submit(k)
+        d.collect_feed(bufs[(k - 1) % 2])
+    d.collect_feed(bufs[steps % 2], want_counters=True)
+    elapsed = time.perf_counter() - t0
+    tm = d.timing()
+    d.set_deferred(False)
+    d.reset()
+    d.feed_resident(nsamples)
+    d.finish()
+    msgs, counters = d.collect(reuse=True)
+    if helpers.have_ref():                                   # the reference's objects hold one configuration per process: own process
+        kind, (ref_msgs, st) = "reference", helpers.ref_run(iq, fmt, nfix, 1, 58)
+    else:
+        kind, (ref_msgs, st) = "port", helpers.oracle_run(iq, fmt, nfix, 1, 58)
+    helpers.assert_same_messages(msgs, ref_msgs)
+    helpers.assert_same_counters(counters, st, float_tol=0.02 if fmt else 0.0)
+    nl = max(1, tm["n_chunks"])
+    out = {"msamples_s": round(nsamples * steps / elapsed / 1e6, 1), "ms_per_segment": round(elapsed / steps * 1e3, 3),
+           "samples_per_segment": nsamples, "segments_timed": steps, "messages_per_segment": int(len(msgs)),
+           "candidates_per_1000_samples": round(tm["n_candidates"] / (nsamples * steps) * 1e3, 2),
+           "records_per_1000_samples": round(tm["n_records"] / (nsamples * steps) * 1e3, 2),
+           "us_per_launch": {"convert": round(tm["convert_ms"] / nl * 1e3, 1), "k_sweep": round(tm["sweep_ms"] / nl * 1e3, 1),
+                             "k_slice": round(tm["slice_ms"] / nl * 1e3, 1), "post_sweep": round(tm["prescreen_ms"] / nl * 1e3, 1)},
+           "samples_per_launch": int(nsamples * steps // nl),
+           "cpu_reference_msamples_s": round(nsamples / float(st["t_convert_s"] + st["t_demod_s"]) / 1e6, 1),
+           "bit_identical_to_reference": True, "checker": kind}
+    d.close()
+    return out
 
 
 def main():
@@ -95,6 +158,8 @@ def main():
     ap.add_argument("--samples", type=int, default=4096 * BUF, help="samples per stream per step (multiple of 131072)")
     ap.add_argument("--msgs-per-sec", type=float, default=2000.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the `configs` dict (other BASELINE configurations / input statistics)")
+    ap.add_argument("--extra-samples", type=int, default=2048 * BUF, help="samples per segment of the extra configurations")
     ap.add_argument("--main-cpu", type=int, default=-1, help="experiment: pin the calling thread to this CPU after the context exists")
     ap.add_argument("--exercise-gather", action="store_true", help="run the N>1 aggregator exchange even with one rank (needs torchrun env)")
     args = ap.parse_args()
@@ -299,6 +364,14 @@ def main():
                                              f"demodulate2400 {st['t_demod_s']:.2f} s on one host core "
                                              f"({os.cpu_count()} cores present)",
                                    "messages": int(len(ref_msgs)), "bit_identical_to_gpu": True}
+        if not args.no_extra_configs and not args.no_cpu_baseline and world == 1:
+            d.close()
+            out["configs"] = {}
+            for name, (fmt, nfix, kw) in EXTRA_CONFIGS.items():
+                try:
+                    out["configs"][name] = run_extra_config(name, fmt, nfix, kw, args.extra_samples - args.extra_samples % BUF, local_rank)
+                except AssertionError as e:                      # a mismatch is a failed run, not a missing number
+                    raise SystemExit(f"extra configuration '{name}': GPU result differs from the reference: {e}")
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

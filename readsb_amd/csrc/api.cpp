@@ -149,9 +149,11 @@ struct Slot {
     double *d_fsum_level = nullptr, *d_fsum_power = nullptr;
     uint32_t *d_msg_pos = nullptr, *d_msg_limit = nullptr;
     uint16_t *d_msg_len = nullptr, *d_msg_skip = nullptr;
+    PhaseRec *d_live = nullptr;          // k_prescreen_write: the surviving records, in stream order ...
+    unsigned long long *d_live_sig = nullptr;   // ... and each one's would-be signal power
     // pinned host
-    PhaseRec *h_live = nullptr;          // k_prescreen<write> stores the surviving records straight into host memory
-    unsigned long long *h_live_sig = nullptr;   // ... and each one's would-be signal power
+    PhaseRec *h_live = nullptr;          // their copies: the fetcher pulls exactly nlive records over the copy engine (a kernel storing
+    unsigned long long *h_live_sig = nullptr;   // into page-locked host memory waited 64 us per chunk on PCIe write latency)
     hipEvent_t ev_window = nullptr;       // k_window_stats of this slot's last use has run (stream2)
     bool window_pending = false;
     unsigned long long *h_counters = nullptr, *h_sums = nullptr, *h_win = nullptr, *h_sig = nullptr;
@@ -238,7 +240,8 @@ struct FeedSlot {
 
 struct mgpu_ctx {
     mgpu_config cfg{};
-    hipStream_t stream = nullptr, stream2 = nullptr, stream_w = nullptr;   // main | window statistics | pre-screen write pass
+    hipStream_t stream = nullptr, stream2 = nullptr, stream_w = nullptr;   // main | window statistics | pre-screen write pass / IQ uploads
+    hipStream_t stream_d2h = nullptr;                                      // the fetcher's record copies
     std::string err;
 
     uint64_t cap_samples = 0;      // per feed call (cfg.max_samples)
@@ -523,6 +526,8 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
     HIPCHK(c, hipMalloc(&sl.d_msg_len, c->cap_msgs * sizeof(uint16_t)));
     HIPCHK(c, hipMalloc(&sl.d_msg_skip, c->cap_msgs * sizeof(uint16_t)));
     HIPCHK(c, hipMalloc(&sl.d_msg_sig, c->cap_msgs * sizeof(unsigned long long)));
+    HIPCHK(c, hipMalloc(&sl.d_live, c->cap_pool * sizeof(PhaseRec)));
+    HIPCHK(c, hipMalloc(&sl.d_live_sig, c->cap_pool * sizeof(unsigned long long)));
     HIPCHK(c, hipHostMalloc(&sl.h_live, c->cap_pool * sizeof(PhaseRec)));
     HIPCHK(c, hipHostMalloc(&sl.h_live_sig, c->cap_pool * sizeof(unsigned long long)));
     HIPCHK(c, hipEventCreateWithFlags(&sl.ev_window, hipEventDisableTiming));
@@ -543,7 +548,7 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
 }
 
 static void free_slot(Slot &sl) {
-    void *dev[] = {sl.d_mag, sl.d_pool, sl.d_scratch, sl.d_unit_first, sl.d_unit_count, sl.d_unit_live, sl.d_class_bitmap,
+    void *dev[] = {sl.d_live, sl.d_live_sig, sl.d_mag, sl.d_pool, sl.d_scratch, sl.d_unit_first, sl.d_unit_count, sl.d_unit_live, sl.d_class_bitmap,
                    sl.d_class_uncond, sl.d_class_final, sl.d_cand, sl.d_cand_count, sl.d_sweep_part,
                    sl.d_win, sl.d_win_part, sl.d_msg_pos,
                    sl.d_msg_limit, sl.d_msg_len, sl.d_msg_skip, sl.d_msg_sig};
@@ -640,7 +645,8 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     if (hipSetDevice(cfg->device) != hipSuccess) { delete c; return MGPU_E_NODEVICE; }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->stream_w, hipStreamNonBlocking) != hipSuccess) { mgpu_destroy(c); return MGPU_E_HIP; }
+        hipStreamCreateWithFlags(&c->stream_w, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream_d2h, hipStreamNonBlocking) != hipSuccess) { mgpu_destroy(c); return MGPU_E_HIP; }
     // valid_df_*_bitset, init_bitsets() demod_2400.c:112-128 (ENABLE_DF24 off, readsb.h:303)
     c->valid_short = (1u << 0) | (1u << 4) | (1u << 5) | (1u << 11);
     c->valid_long = (1u << 16) | (1u << 17) | (1u << 18) | (1u << 20) | (1u << 21);
@@ -701,6 +707,7 @@ void mgpu_destroy(mgpu_ctx *c) {
     if (c->stream) (void) hipStreamDestroy(c->stream);
     if (c->stream2) (void) hipStreamDestroy(c->stream2);
     if (c->stream_w) (void) hipStreamDestroy(c->stream_w);
+    if (c->stream_d2h) (void) hipStreamDestroy(c->stream_d2h);
     delete c;
 }
 
@@ -790,7 +797,7 @@ static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
     // pinned host memory), counters and per-buffer sums to the host
     PostSweepParams q{};
     q.pool = sl.d_pool; q.unit_first = sl.d_unit_first; q.nunits = nunits; q.adder_bitmap = c->d_adder_bitmap;
-    q.unit_live = sl.d_unit_live; q.block_live = sl.d_unit_live + c->cap_units + 2; q.live = sl.h_live; q.mag = sl.d_mag; q.live_sig = sl.h_live_sig; q.counters = sl.d_counters;
+    q.unit_live = sl.d_unit_live; q.block_live = sl.d_unit_live + c->cap_units + 2; q.live = sl.d_live; q.mag = sl.d_mag; q.live_sig = sl.d_live_sig; q.counters = sl.d_counters;
     q.class_cond = sl.d_class_bitmap; q.class_uncond = sl.d_class_uncond;
     q.class_final = sl.d_class_final;
     q.class_words = (n + 31) / 32;
@@ -825,6 +832,16 @@ static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job) {
     if (hipEventElapsedTime(&ms, sl.ev[2], sl.ev[3]) == hipSuccess) c->acc.prescreen_ms += ms;
     const uint64_t nlive = sl.h_counters[CNT_LIVE_TOTAL];
 
+    const double t_f0 = wall_ms();
+    // exactly nlive records + signal powers, HBM -> page-locked host memory over the copy engine (its own stream: the next
+    // chunk's kernels keep running), then into ordinary memory: page-locked memory the device wrote is slow for the walk's
+    // small scattered reads (4x slower walk) but streams at tens of GB/s (0.1 ms for 70 k records)
+    if (nlive > c->cap_pool) { c->err = "live record count beyond the pool"; return MGPU_E_OVERFLOW; }
+    if (nlive) {
+        HIPCHK(c, hipMemcpyAsync(sl.h_live, sl.d_live, nlive * sizeof(PhaseRec), hipMemcpyDeviceToHost, c->stream_d2h));
+        HIPCHK(c, hipMemcpyAsync(sl.h_live_sig, sl.d_live_sig, nlive * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream_d2h));
+        HIPCHK(c, hipStreamSynchronize(c->stream_d2h));
+    }
     if (!c->dump_dir.empty()) {   // replay material for tools/walk_replay.cpp
         const char *dd = c->dump_dir.c_str();
         static int dumped = 0;
@@ -835,10 +852,6 @@ static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job) {
             f = fopen((base + "bufs.bin").c_str(), "wb"); fwrite(sl.buffers.data(), sizeof(BufferClock), sl.buffers.size(), f); fclose(f);
         }
     }
-    const double t_f0 = wall_ms();
-    // The pinned buffers the GPU writes are slow for the CPU's small scattered reads (4x slower walk)
-    // but stream at tens of GB/s: copy the chunk's records into ordinary memory (0.1 ms for 70 k
-    // records) and walk there.
     job.nlive = nlive;
     job.stream_pos = sl.stream_pos;
     job.recs.resize(nlive + 1);

@@ -5,9 +5,16 @@ out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
 R=$(pwd)
-echo "== new tests"
-timeout 600 python -m pytest tests/test_gpu_deferred.py tests/test_gpu_modeac.py tests/test_gpu_kernel_generations.py -x -q --timeout 300 > $out/pytest_new.log 2>&1; tail -15 $out/pytest_new.log
+echo "== dev_check"
+timeout 400 python tools/dev_check.py > $out/dev_check.log 2>&1; echo "rc=$?"; grep -c "^OK" $out/dev_check.log; grep -v "^OK" $out/dev_check.log | head
 echo "== bench"
-timeout 400 python bench.py --steps 10 --warmup 3 > $out/bench.log 2>&1; tail -2 $out/bench.log | cut -c1-2500
-echo "== full gpu suite"
-timeout 1200 python -m pytest tests -m gpu -q -x --timeout 600 > $out/pytest_gpu.log 2>&1; tail -8 $out/pytest_gpu.log
+timeout 400 python bench.py --steps 10 --warmup 3 > $out/bench.log 2>&1; tail -1 $out/bench.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['stage_ms'], d.get('cpu_baseline',{}).get('bit_identical_to_gpu'))"
+for wt in 5 6; do
+echo "== bench MGPU_WALK_THREADS=$wt"
+MGPU_WALK_THREADS=$wt timeout 400 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_wt$wt.log 2>&1; tail -1 $out/bench_wt$wt.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['stage_ms'])"
+done
+echo "== kernel stats"
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/stats -o bench -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $R/$out/bench_under_rocprof.log 2>&1
+cd $R
+cat $out/stats/bench_kernel_stats.csv | cut -c1-150 | head -20

@@ -1,20 +1,26 @@
 #!/bin/bash
 # rocprofv3 evidence for bench.py's roofline numbers: kernel trace + stats, then one --pmc pass per
-# counter (FETCH_SIZE, WRITE_SIZE) as MI355X_MICROARCH.md prescribes.  Run on the GPU box via gpurun;
+# counter (FETCH_SIZE, WRITE_SIZE) as MI355X_MICROARCH.md prescribes, then the SQ counters.  Run on the GPU box via gpurun;
 # copy the summaries from gpurun_out/ into profiles/ afterwards.
 #   usage: tools/profile_round.sh <tag>
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-tag=${1:-r01}
+tag=${1:-r02}
 out=$R/gpurun_out/$tag
 mkdir -p $out
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python $R/bench.py --steps 5 --warmup 1 > $out/bench_under_rocprof.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $out/bench_under_rocprof.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/pmc_write.log 2>&1
 timeout 300 rocprofv3 --kernel-trace -i $R/tools/pmc_sq.txt --output-format csv -d $out/pmc_sq -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $out/pmc_sq.log 2>&1
+for i in 0 1; do
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_extra$i -o extra -- python $R/tools/profile_extra.py $i > $out/extra$i.log 2>&1
+done
 cd $R
 python tools/pmc_kernels.py $out/pmc_sq > $out/pmc_sq_summary.txt 2>&1
-timeout 200 python bench.py --steps 10 --warmup 2 > $out/bench_plain.log 2>&1
-tail -1 $out/bench_plain.log | cut -c1-400
-cat $out/stats/bench_kernel_stats.csv | cut -c1-160
+python tools/pmc_summary.py $(find $out/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $out/pmc_write -name "*counter_collection.csv" | head -1) $out/pmc_hbm.json > /dev/null 2> $out/pmc_hbm.err
+timeout 400 python bench.py --steps 20 --warmup 3 > $out/bench_plain.log 2>&1
+tail -1 $out/bench_plain.log | cut -c1-3000
+cat $out/stats/bench_kernel_stats.csv | cut -c1-120
+cat $out/pmc_hbm.json | head -40
+for i in 0 1; do tail -1 $out/extra$i.log | cut -c1-600; cut -c1-110 $out/stats_extra$i/extra_kernel_stats.csv | head -8; done

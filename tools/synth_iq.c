@@ -42,7 +42,8 @@ struct synth_cfg {
     int format;          /* SYNTH_FMT_* */
     double msgs_per_sec; /* mean frame rate */
     int naircraft;       /* ICAO pool size */
-    int dense;           /* bit 0: DF17-only bursts (config 5: overlapping 112-bit frames); bit 1: add Mode A/C replies */
+    int dense;           /* bit 0: DF17-only bursts (config 5: overlapping 112-bit frames); bit 1: add Mode A/C replies;
+                          * bit 2: Gaussian instead of uniform noise (sigma = noise_lsb) */
     double noise_lsb;    /* uniform noise amplitude, +-noise_lsb LSB of UC8 */
 };
 
@@ -235,8 +236,16 @@ static void gen_range(const struct synth_cfg *cfg, uint64_t first, uint64_t coun
         uint64_t rng = splitmix64(&s) | 1;
         for (uint64_t i = b_lo; i < lo; i++) { xs64(&rng); xs64(&rng); }
         for (uint64_t i = lo; i < hi; i++) {
-            double nI = ((xs64(&rng) >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0) * cfg->noise_lsb;
-            double nQ = ((xs64(&rng) >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0) * cfg->noise_lsb;
+            double u1 = (xs64(&rng) >> 11) * (1.0 / 9007199254740992.0), u2 = (xs64(&rng) >> 11) * (1.0 / 9007199254740992.0);
+            double nI, nQ;
+            if (cfg->dense & 4) {        /* Gaussian I/Q noise, sigma = noise_lsb (Rayleigh magnitudes): Box-Muller on the same two draws */
+                const double rr = sqrt(-2.0 * log(u1 > 1e-300 ? u1 : 1e-300)) * cfg->noise_lsb;
+                nI = rr * cos(6.283185307179586 * u2);
+                nQ = rr * sin(6.283185307179586 * u2);
+            } else {
+                nI = (u1 * 2.0 - 1.0) * cfg->noise_lsb;
+                nQ = (u2 * 2.0 - 1.0) * cfg->noise_lsb;
+            }
             double vI = accI[i - b_lo] + nI, vQ = accQ[i - b_lo] + nQ;  /* centred, UC8 LSB */
             uint8_t *o = out + (i - first) * bps;
             if (cfg->format == SYNTH_FMT_UC8) {

@@ -143,6 +143,8 @@ struct mgpu_timing {
     uint64_t n_chunks;       /* pipeline chunks = launches of each kernel; the *_ms fields above are sums over them */
     float slice_ms;          /* generation 4 only: k_slice (bit slicer + CRC + score); sweep_ms is then k_sweep alone */
     float build_ms;          /* builder thread: struct modesMessage fields + signal / noise statistics (host) */
+    uint64_t n_timed_chunks; /* chunks that carried the stage timing events: convert_ms, sweep_ms, slice_ms and prescreen_ms are sums
+                              * over THESE (every 4th chunk by default, MGPU_TIMING_EVERY=1: all; an event costs ~5 us of idle stream) */
 };
 
 /* ---- lifecycle -------------------------------------------------------------------- */

@@ -84,7 +84,7 @@ class Timing(C.Structure):
         ("h2d_ms", C.c_float), ("convert_ms", C.c_float), ("sweep_ms", C.c_float), ("prescreen_ms", C.c_float),
         ("resolve_ms", C.c_float), ("sigpower_ms", C.c_float), ("d2h_ms", C.c_float), ("total_ms", C.c_float),
         ("n_candidates", C.c_uint64), ("n_records", C.c_uint64), ("n_live_records", C.c_uint64),
-        ("n_messages", C.c_uint64), ("n_chunks", C.c_uint64), ("slice_ms", C.c_float), ("build_ms", C.c_float),
+        ("n_messages", C.c_uint64), ("n_chunks", C.c_uint64), ("slice_ms", C.c_float), ("build_ms", C.c_float), ("n_timed_chunks", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -160,7 +160,8 @@ struct Slot {
     double *h_fsums = nullptr;
     uint32_t *h_msg_pos = nullptr, *h_msg_limit = nullptr;
     uint16_t *h_msg_len = nullptr, *h_msg_skip = nullptr;
-    hipEvent_t ev[5] = {};
+    hipEvent_t ev[7] = {};               // 3: the chunk is complete (always recorded) | stage timing, sampled chunks only (timed): 0 1 convert, 5 4 k_sweep, 4 2 k_slice, 6 3 post-sweep
+    bool timed = false;
     uint32_t *d_ac_noise = nullptr;       // Mode A/C: per-buffer noise level
     AcCand *h_ac = nullptr;               // ... candidates, written by k_modeac straight into pinned host memory
     hipEvent_t ev_h2d = nullptr;          // the chunk's IQ samples have arrived in HBM (copy stream)
@@ -275,6 +276,8 @@ struct mgpu_ctx {
     FeedSlot feed[kFeeds];                                    // deferred mode: ring of feeds in flight / uncollected
     uint64_t feed_head = 0, feed_tail = 0;                    // oldest uncollected feed, next feed to open
     bool deferred = false;
+    int timing_every = 4;                                     // MGPU_TIMING_EVERY: chunks per set of stage timing events (1 = every chunk)
+    uint64_t timing_seq = 0;
     bool accounting_open = false;                             // feed_begin has run, feed_end has not (deferred: spans several feeds)
     double acct_t0 = 0;
     mgpu_counters counters{};
@@ -312,7 +315,7 @@ struct mgpu_ctx {
     uint8_t *d_hist_iq = nullptr;
     unsigned long long *d_hist_sums = nullptr;
     // experiment / debug switches, read once at creation
-    bool dbg_print = false, dbg_no_window = false, two_streams = false;
+    bool dbg_print = false, dbg_no_window = false;
     int dbg_stage = 0;
     std::string dump_dir;
     double feed_t0 = 0;                                       // wall clock at feed start (MGPU_DEBUG_PRINT timeline)
@@ -661,8 +664,8 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     c->resolver.reset(cfg->startup_time_ms, (int) cfg->filter_clock);
     c->dbg_print = getenv("MGPU_DEBUG_PRINT") != nullptr;
     c->dbg_no_window = getenv("MGPU_DEBUG_NO_WINDOW") != nullptr;
-    c->two_streams = getenv("MGPU_TWO_STREAMS") != nullptr;
     if (const char *e = getenv("MGPU_DEBUG_STAGE")) c->dbg_stage = atoi(e);
+    if (const char *e = getenv("MGPU_TIMING_EVERY")) { const int v = atoi(e); if (v >= 1) c->timing_every = v; }
     if (const char *e = getenv("MGPU_DUMP_DIR")) c->dump_dir = e;
     if (const char *e = getenv("MGPU_WALK_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) c->walk_threads = v; }
     if (const char *e = getenv("MGPU_BUILD_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) c->build_threads = v; }
@@ -737,16 +740,21 @@ int mgpu_reset(mgpu_ctx *c) {
 // ---- GPU half of a chunk: enqueue convert -> sweep/slice -> pre-screen on the main stream ----------
 // `iq` = device pointer to the chunk's IQ samples (ignored when sl.have_mag: sl.d_mag already holds
 // the magnitudes of one struct mag_buf).
-static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
+// (Measured and dropped: the NEXT chunk's converter enqueued between a chunk's slicer and its post-sweep kernels, so that the
+// fetcher's record copies — which start when k_publish has run and slow whatever streams memory at that moment by 30-50 us —
+// would meet k_sweep instead of the converter: k_sweep then took 68 us instead of 37 and the step 2.85 ms instead of 2.52.)
+// HIP events with timing cost ~5 us of idle stream each (the next kernel waits for the marker): only every
+// `timing_every`-th chunk carries the stage events (sl.timed); the others record the completion event alone.
+static int enqueue_convert(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
     const mgpu_config &cfg = c->cfg;
     const uint64_t n = sl.n;
-    const uint32_t nunits = (uint32_t) ((n + kUnit - 1) / kUnit);
     hipStream_t s = c->stream;
+    sl.timed = c->timing_every <= 1 || (c->timing_seq++ % (uint64_t) c->timing_every) == 0;
     // the slot's magnitudes / class bitmap / message lists are still read by the window-statistics
     // kernel of its previous use (stream2)
     if (sl.window_pending) { HIPCHK(c, hipStreamWaitEvent(s, sl.ev_window, 0)); sl.window_pending = false; }
     // (scratch block and class planes are zero: k_publish / k_count_finalize of the slot's previous chunk left them so)
-    HIPCHK(c, hipEventRecord(sl.ev[0], s));
+    if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[0], s));
     if (!sl.have_mag) {
         ConvertParams cp{};
         cp.iq = iq; cp.mag = sl.d_mag; cp.n = n; cp.buf_samples = cfg.buf_samples;
@@ -768,7 +776,15 @@ static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
     if (cfg.mode_ac && !sl.have_mag)       // Mode A/C candidates (needs the converter's per-buffer sums); a few us, streaming
         launch_modeac(sl.d_mag, n, cfg.buf_samples, cfg.format, sl.d_sum_level, sl.d_sum_power, sl.d_fsum_level, sl.d_fsum_power,
                       sl.d_ac_noise, sl.h_ac, (uint32_t) c->cap_ac, sl.d_scratch + CNT_NUM + 1 + 4 * c->cap_buffers, sl.d_counters, s);
-    HIPCHK(c, hipEventRecord(sl.ev[1], s));
+    if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[1], s));
+    return MGPU_OK;
+}
+
+static int enqueue_sweep(mgpu_ctx *c, Slot &sl) {
+    const mgpu_config &cfg = c->cfg;
+    const uint64_t n = sl.n;
+    const uint32_t nunits = (uint32_t) ((n + kUnit - 1) / kUnit);
+    hipStream_t s = c->stream;
     SweepParams sp{};
     sp.mag = sl.d_mag; sp.n = n; sp.thr = sl.thr;
     sp.valid_long = c->valid_long; sp.valid_short = c->valid_short;
@@ -779,22 +795,29 @@ static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
     sp.unit_first = sl.d_unit_first; sp.unit_count = sl.d_unit_count; sp.nunits = nunits;
     sp.adder_bitmap = c->d_adder_bitmap; sp.class_bitmap = sl.d_class_bitmap; sp.counters = sl.d_counters;
     sp.cand = sl.d_cand; sp.cand_count = sl.d_cand_count; sp.class_uncond = sl.d_class_uncond; sp.sweep_part = sl.d_sweep_part;
-    // ev[1] .. ev[4] bracket exactly one kernel: k_sweep (bench.py's roofline); ev[4] .. ev[2]: k_slice
+    // ev[5] .. ev[4] bracket exactly one kernel: k_sweep (bench.py's roofline); ev[4] .. ev[2]: k_slice
+    if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[5], s));
 #if MGPU_EXPERIMENTS
     sp.debug_stage = c->dbg_stage;
     if (c->sweep_version == 3) {
         launch_sweep_slice(sp, s);
-        HIPCHK(c, hipEventRecord(sl.ev[4], s));
+        if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[4], s));
     } else
 #endif
     {
         sp.sweep_blocks = launch_sweep(sp, s);
-        HIPCHK(c, hipEventRecord(sl.ev[4], s));
+        if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[4], s));
         launch_slice(sp, s);
     }
-    HIPCHK(c, hipEventRecord(sl.ev[2], s));
-    // class planes -> class bitmap, pre-screen (the surviving records are written by the kernel straight into
-    // pinned host memory), counters and per-buffer sums to the host
+    if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[2], s));
+    return MGPU_OK;
+}
+
+static int enqueue_post(mgpu_ctx *c, Slot &sl) {
+    const uint64_t n = sl.n;
+    const uint32_t nunits = (uint32_t) ((n + kUnit - 1) / kUnit);
+    hipStream_t s = c->stream;
+    // class planes -> class bitmap, pre-screen (the surviving records stay in HBM: d_live), counters and per-buffer sums to the host
     PostSweepParams q{};
     q.pool = sl.d_pool; q.unit_first = sl.d_unit_first; q.nunits = nunits; q.adder_bitmap = c->d_adder_bitmap;
     q.unit_live = sl.d_unit_live; q.block_live = sl.d_unit_live + c->cap_units + 2; q.live = sl.d_live; q.mag = sl.d_mag; q.live_sig = sl.d_live_sig; q.counters = sl.d_counters;
@@ -802,14 +825,21 @@ static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
     q.class_final = sl.d_class_final;
     q.class_words = (n + 31) / 32;
     q.d_scratch = sl.d_scratch; q.h_scratch = sl.h_scratch; q.scratch_words = (uint32_t) (sl.scratch_bytes / sizeof(unsigned long long));
-    // Generation 3: the count pass leaves its decisions as masks in the segment headers, so the write pass does not
-    // look at the adder bitmap again.  MGPU_TWO_STREAMS=1 then moves the write pass and the publish to their own
-    // stream, beside the next chunk's convert (measured: the kernels only slow each other down, no gain end to end).
-    q.keep_masks = true;            // one scoring pass = one segment of at most 64 records
-    hipStream_t sw = (q.keep_masks && c->two_streams) ? c->stream_w : s;
-    if (launch_prescreen(q, s, sw, sl.ev_scan) != 0) { c->err = "event ordering of the pre-screen passes failed"; return MGPU_E_HIP; }
-    HIPCHK(c, hipEventRecord(sl.ev[3], sw));
+    // the count pass leaves its decisions as masks in the segment headers (one scoring pass = one segment of at most 64
+    // records), so the write pass does not look at the adder bitmap again
+    q.keep_masks = true;
+    if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[6], s));
+    if (launch_prescreen(q, s, s, sl.ev_scan) != 0) { c->err = "event ordering of the pre-screen passes failed"; return MGPU_E_HIP; }
+    HIPCHK(c, hipEventRecord(sl.ev[3], s));
     return MGPU_OK;
+}
+
+// one chunk on its own (struct mag_buf entry, shard passes)
+static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
+    int rc = enqueue_convert(c, sl, iq);
+    if (rc == MGPU_OK) rc = enqueue_sweep(c, sl);
+    if (rc == MGPU_OK) rc = enqueue_post(c, sl);
+    return rc;
 }
 
 // ---- host half of a chunk, part 1 (fetcher thread): wait for the GPU, copy the live records out of pinned memory ----
@@ -826,10 +856,13 @@ static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job) {
         return MGPU_E_OVERFLOW;
     }
     float ms;
-    if (hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]) == hipSuccess) c->acc.convert_ms += ms;
-    if (hipEventElapsedTime(&ms, sl.ev[1], sl.ev[4]) == hipSuccess) c->acc.sweep_ms += ms;
-    if (hipEventElapsedTime(&ms, sl.ev[4], sl.ev[2]) == hipSuccess) c->acc.slice_ms += ms;
-    if (hipEventElapsedTime(&ms, sl.ev[2], sl.ev[3]) == hipSuccess) c->acc.prescreen_ms += ms;
+    if (sl.timed) {
+        if (hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]) == hipSuccess) c->acc.convert_ms += ms;
+        if (hipEventElapsedTime(&ms, sl.ev[5], sl.ev[4]) == hipSuccess) c->acc.sweep_ms += ms;
+        if (hipEventElapsedTime(&ms, sl.ev[4], sl.ev[2]) == hipSuccess) c->acc.slice_ms += ms;
+        if (hipEventElapsedTime(&ms, sl.ev[6], sl.ev[3]) == hipSuccess) c->acc.prescreen_ms += ms;
+        c->acc.n_timed_chunks += 1;
+    }
     const uint64_t nlive = sl.h_counters[CNT_LIVE_TOTAL];
 
     const double t_f0 = wall_ms();
@@ -838,6 +871,7 @@ static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job) {
     // small scattered reads (4x slower walk) but streams at tens of GB/s (0.1 ms for 70 k records)
     if (nlive > c->cap_pool) { c->err = "live record count beyond the pool"; return MGPU_E_OVERFLOW; }
     if (nlive) {
+        // (a copy kernel of our own with 8..32 workgroups in place of the runtime's blit kernel: 2.55-2.63 ms per step instead of 2.45)
         HIPCHK(c, hipMemcpyAsync(sl.h_live, sl.d_live, nlive * sizeof(PhaseRec), hipMemcpyDeviceToHost, c->stream_d2h));
         HIPCHK(c, hipMemcpyAsync(sl.h_live_sig, sl.d_live_sig, nlive * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream_d2h));
         HIPCHK(c, hipStreamSynchronize(c->stream_d2h));
@@ -1306,10 +1340,10 @@ static int feed_common(mgpu_ctx *c, const void *src, bool src_is_device, uint64_
             if (e != hipSuccess) { c->err = std::string("H2D of the IQ samples: ") + hipGetErrorString(e); rc = MGPU_E_HIP; }
             c->acc.h2d_ms += (float) (wall_ms() - t0);   // host time spent issuing (pageable memory: staging) the copies
         }
-        if (rc == MGPU_OK) rc = enqueue_slot(c, sl, iq + off * bps);
         if (fidx >= 0) { std::lock_guard<std::mutex> lk(c->mu); c->feed[fidx].jobs_total++; }
-        submit_slot(c, k);   // even after an enqueue error: the worker releases the slot
+        if (rc == MGPU_OK) rc = enqueue_slot(c, sl, iq + off * bps);
         if (rc != MGPU_OK) { std::lock_guard<std::mutex> lk(c->mu); if (c->worker_rc == MGPU_OK) c->worker_rc = rc; }
+        submit_slot(c, k);   // even after an enqueue error: the stages release the slot
     }
     if (fidx >= 0) {
         // deferred: the feed is on its way; its messages are collected by mgpu_collect, the counters settle at the next drain

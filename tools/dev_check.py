@@ -63,7 +63,7 @@ def main():
                 ok = False
                 print(f"  {name}: {e}")
         fails += 0 if ok else 1
-        nch = max(1, tm["n_chunks"])
+        nch = max(1, tm["n_timed_chunks"])
         print(f"{'OK  ' if ok else 'FAIL'} {name}: {len(got)} msgs, {n} samples, cand {tm['n_candidates']} rec {tm['n_records']} live {tm['n_live_records']}; "
               f"per chunk: convert {tm['convert_ms'] / nch:.3f} sweep {tm['sweep_ms'] / nch:.3f} slice {tm['slice_ms'] / nch:.3f} prescreen {tm['prescreen_ms'] / nch:.3f} ms ({nch} chunks)")
     return fails

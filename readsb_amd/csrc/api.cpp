@@ -391,7 +391,13 @@ static void release_device_slot(int device, int slot) {
     g_device_slots[device & 63] &= ~(1u << slot);
 }
 
-static void bind_near_device(std::thread *const *threads, int nthreads, int device, int device_slot, std::vector<int> *pinned) {
+// Two groups of threads, two L3 groups: `walk` (the walker and its helpers: they pass cache lines of the filter state and of
+// the record list among themselves all the time) and `rest` (fetcher, builder and its helpers).  The hand-off between the
+// two — one job per chunk — crosses CCDs once.  An 8-GPU node has two CCDs per GPU on the GPU's own NUMA node (EPYC 9575F:
+// 16 L3 groups, 8 per socket, 4 GPUs per socket), so the first context of every device gets two groups of its own; further
+// contexts of the same device (fan-in) put both groups of threads on one L3 group, half the node's groups away.
+static void bind_near_device(std::thread *const *walk, int nwalk, std::thread *const *rest, int nrest, int device, int device_slot,
+                             std::vector<int> *pinned) {
     if (getenv("MGPU_NO_AFFINITY")) return;
     char bus[64] = {0};
     if (hipDeviceGetPCIBusId(bus, (int) sizeof(bus), device) != hipSuccess) return;
@@ -424,29 +430,52 @@ static void bind_near_device(std::thread *const *threads, int nthreads, int devi
     // ranks that each see one device as ordinal 0 (per-rank HIP_VISIBLE_DEVICES) still spread out by LOCAL_RANK
     int ordinal = device;
     if (const char *lr = getenv("LOCAL_RANK")) { const int v = atoi(lr); if (v >= 0) ordinal = v; }
-    // further contexts of the same device: half the node's groups away, where an 8-GPU node's other devices do not sit
-    const size_t stride = l3_ids.size() >= 2 ? l3_ids.size() / 2 : 1;
-    const int want = l3_ids[((size_t) ordinal + (size_t) device_slot * stride + (size_t) (device_slot / 2)) % l3_ids.size()];
-    // one logical CPU per physical core of that group; more threads than cores share cores round-robin
-    std::vector<int> pick, cores;
-    for (size_t i = 0; i < cpus.size(); ++i) {
-        if (l3_of[i] != want) continue;
-        const int core = sysfs_int("/sys/devices/system/cpu/cpu" + std::to_string(cpus[i]) + "/topology/core_id", (int) i);
-        if (std::find(cores.begin(), cores.end(), core) != cores.end()) continue;
-        cores.push_back(core);
-        pick.push_back(cpus[i]);
+    const size_t ng = l3_ids.size();
+    int want_walk, want_rest;
+    if (device_slot == 0 && ng >= 2 && !getenv("MGPU_ONE_L3")) {
+        want_walk = l3_ids[((size_t) ordinal * 2) % ng];
+        want_rest = l3_ids[((size_t) ordinal * 2 + 1) % ng];
+    } else {   // further contexts of the same device: half the node's groups away, where an 8-GPU node's other devices do not sit
+        const size_t stride = ng >= 2 ? ng / 2 : 1;
+        want_walk = want_rest = l3_ids[((size_t) ordinal * 2 + (size_t) device_slot * stride + (size_t) (device_slot / 2)) % ng];
     }
-    cpu_set_t set;
-    if (want >= 0 && pick.size() >= 2) {
-        for (int t = 0; t < nthreads; ++t) {
-            CPU_ZERO(&set); CPU_SET(pick[(size_t) t % pick.size()], &set);
-            (void) pthread_setaffinity_np(threads[t]->native_handle(), sizeof(set), &set);
+    // one logical CPU per physical core of a group; more threads than cores share cores round-robin
+    auto cores_of = [&](int want) {
+        std::vector<int> pick, cores;
+        for (size_t i = 0; i < cpus.size(); ++i) {
+            if (l3_of[i] != want) continue;
+            const int core = sysfs_int("/sys/devices/system/cpu/cpu" + std::to_string(cpus[i]) + "/topology/core_id", (int) i);
+            if (std::find(cores.begin(), cores.end(), core) != cores.end()) continue;
+            cores.push_back(core);
+            pick.push_back(cpus[i]);
         }
-        if (pinned) pinned->assign(pick.begin(), pick.begin() + (nthreads < (int) pick.size() ? nthreads : (int) pick.size()));
+        return pick;
+    };
+    const std::vector<int> pw = cores_of(want_walk), pr = cores_of(want_rest);
+    cpu_set_t set;
+    if (want_walk >= 0 && pw.size() >= 2 && pr.size() >= 2) {
+        const bool same = want_walk == want_rest;
+        for (int t = 0; t < nwalk; ++t) {
+            CPU_ZERO(&set); CPU_SET(pw[(size_t) t % pw.size()], &set);
+            (void) pthread_setaffinity_np(walk[t]->native_handle(), sizeof(set), &set);
+        }
+        for (int t = 0; t < nrest; ++t) {       // on a shared group the second set of threads continues where the first ended
+            CPU_ZERO(&set); CPU_SET(pr[(size_t) (t + (same ? nwalk : 0)) % pr.size()], &set);
+            (void) pthread_setaffinity_np(rest[t]->native_handle(), sizeof(set), &set);
+        }
+        if (pinned) {
+            pinned->clear();
+            for (int t = 0; t < nwalk && t < (int) pw.size(); ++t) pinned->push_back(pw[(size_t) t]);
+            for (int t = 0; t < nrest && t < (int) pr.size(); ++t) {
+                const int cpu = pr[(size_t) (t + (same ? nwalk : 0)) % pr.size()];
+                if (std::find(pinned->begin(), pinned->end(), cpu) == pinned->end()) pinned->push_back(cpu);
+            }
+        }
     } else {                               // no cache topology in sysfs: the whole node
         CPU_ZERO(&set);
         for (int k : cpus) CPU_SET(k, &set);
-        for (int t = 0; t < nthreads; ++t) (void) pthread_setaffinity_np(threads[t]->native_handle(), sizeof(set), &set);
+        for (int t = 0; t < nwalk; ++t) (void) pthread_setaffinity_np(walk[t]->native_handle(), sizeof(set), &set);
+        for (int t = 0; t < nrest; ++t) (void) pthread_setaffinity_np(rest[t]->native_handle(), sizeof(set), &set);
     }
 }
 
@@ -667,6 +696,10 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     if (const char *e = getenv("MGPU_DEBUG_STAGE")) c->dbg_stage = atoi(e);
     if (const char *e = getenv("MGPU_TIMING_EVERY")) { const int v = atoi(e); if (v >= 1) c->timing_every = v; }
     if (const char *e = getenv("MGPU_DUMP_DIR")) c->dump_dir = e;
+    c->device_slot = take_device_slot(cfg->device);
+    // the first context of a device has two L3 groups to itself (bind_near_device): a walk team of 8 and a builder team of 6;
+    // further contexts of the device share one group: 4 + 3 as before
+    if (c->device_slot == 0 && !getenv("MGPU_ONE_L3") && !getenv("MGPU_NO_AFFINITY")) { c->walk_threads = 8; c->build_threads = 6; }
     if (const char *e = getenv("MGPU_WALK_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) c->walk_threads = v; }
     if (const char *e = getenv("MGPU_BUILD_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) c->build_threads = v; }
     c->fetcher = std::thread(fetcher_main, c);
@@ -675,11 +708,10 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     c->walk_team.start(c->walk_threads - 1, &c->hot);
     c->build_team.start(c->build_threads - 1, &c->hot);
     {
-        std::vector<std::thread *> th = {&c->worker, &c->builder, &c->fetcher};
-        for (auto &t : c->walk_team.threads) th.push_back(&t);
-        for (auto &t : c->build_team.threads) th.push_back(&t);
-        c->device_slot = take_device_slot(cfg->device);
-        bind_near_device(th.data(), (int) th.size(), cfg->device, c->device_slot, &c->host_cpus);
+        std::vector<std::thread *> tw = {&c->worker}, tr = {&c->builder, &c->fetcher};
+        for (auto &t : c->walk_team.threads) tw.push_back(&t);
+        for (auto &t : c->build_team.threads) tr.push_back(&t);
+        bind_near_device(tw.data(), (int) tw.size(), tr.data(), (int) tr.size(), cfg->device, c->device_slot, &c->host_cpus);
     }
     *out = c;
     return MGPU_OK;

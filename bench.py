@@ -47,7 +47,7 @@ def valu_issue(kernel, avg_launch_ms, samples_per_launch, path=PMC_SQ_SUMMARY):
         insts, inside = None, False
         for ln in open(path):
             if not ln.startswith(" "):
-                inside = ln.strip() == kernel
+                inside = ln.strip().split("<")[0] in (kernel, kernel + "_t")      # k_sweep is the template k_sweep_t<fused?>
             elif inside and ln.split()[0] == "SQ_INSTS_VALU":
                 insts = int(ln.split()[1])
         if not insts or avg_launch_ms <= 0:
@@ -295,7 +295,7 @@ def main():
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_hbm.json")))
             if per_launch == 134217728:
-                traffic = round(pm["mgpu::k_sweep"]["hbm_bytes"])
+                traffic = round(next(v for k, v in pm.items() if k.startswith("mgpu::k_sweep"))["hbm_bytes"])
                 traffic_slice = round(pm["mgpu::k_slice"]["hbm_bytes"])
         except Exception:
             pass

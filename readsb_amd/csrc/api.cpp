@@ -168,6 +168,8 @@ struct Slot {
     hipEvent_t ev_scan = nullptr;         // pre-screen offsets are final (main stream) -> the write pass may start (second stream)
     // the job
     uint64_t n = 0, stream_pos = 0;
+    const uint8_t *fused_iq = nullptr;    // this chunk's converter runs inside k_sweep (enqueue_convert): its IQ samples ...
+    const uint16_t *fused_tail = nullptr; // ... and the 326 magnitudes before them
     int feed = -1;                        // deferred feeds: which FeedSlot the chunk's messages go to (-1: mgpu_ctx::pending)
     int32_t thr = 58;                     // preamble threshold of this chunk (raised after drops, demod_2400.c:335-338)
     bool have_mag = false, busy = false;
@@ -276,6 +278,7 @@ struct mgpu_ctx {
     FeedSlot feed[kFeeds];                                    // deferred mode: ring of feeds in flight / uncollected
     uint64_t feed_head = 0, feed_tail = 0;                    // oldest uncollected feed, next feed to open
     bool deferred = false;
+    bool fused_convert = false;                               // MGPU_FUSED_CONVERT=1: UC8 conversion inside k_sweep's tile load (same speed, see kernels/sweep.inc)
     int timing_every = 4;                                     // MGPU_TIMING_EVERY: chunks per set of stage timing events (1 = every chunk)
     uint64_t timing_seq = 0;
     bool accounting_open = false;                             // feed_begin has run, feed_end has not (deferred: spans several feeds)
@@ -694,6 +697,7 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     c->dbg_print = getenv("MGPU_DEBUG_PRINT") != nullptr;
     c->dbg_no_window = getenv("MGPU_DEBUG_NO_WINDOW") != nullptr;
     if (const char *e = getenv("MGPU_DEBUG_STAGE")) c->dbg_stage = atoi(e);
+    if (const char *e = getenv("MGPU_FUSED_CONVERT")) c->fused_convert = atoi(e) != 0;
     if (const char *e = getenv("MGPU_TIMING_EVERY")) { const int v = atoi(e); if (v >= 1) c->timing_every = v; }
     if (const char *e = getenv("MGPU_DUMP_DIR")) c->dump_dir = e;
     c->device_slot = take_device_slot(cfg->device);
@@ -787,7 +791,15 @@ static int enqueue_convert(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
     if (sl.window_pending) { HIPCHK(c, hipStreamWaitEvent(s, sl.ev_window, 0)); sl.window_pending = false; }
     // (scratch block and class planes are zero: k_publish / k_count_finalize of the slot's previous chunk left them so)
     if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[0], s));
-    if (!sl.have_mag) {
+    // MGPU_FUSED_CONVERT=1, UC8 IQ entry: the converter is part of k_sweep's tile load (kernels/sweep.inc, k_sweep_t<true>) unless
+    // Mode A/C needs the per-buffer sums before the sweep, or the buffer size is not a power of two
+    sl.fused_iq = nullptr;
+    if (!sl.have_mag && c->fused_convert && c->sweep_version == 5 && cfg.format == MGPU_FMT_UC8 && !cfg.mode_ac &&
+        (cfg.buf_samples & (cfg.buf_samples - 1)) == 0) {
+        sl.fused_iq = iq;
+        sl.fused_tail = c->tail_src;
+        c->tail_src = n >= (uint64_t) kTrailing ? sl.d_mag + n : nullptr;
+    } else if (!sl.have_mag) {
         ConvertParams cp{};
         cp.iq = iq; cp.mag = sl.d_mag; cp.n = n; cp.buf_samples = cfg.buf_samples;
         cp.tail = c->tail_src;          // the 326 magnitudes before this chunk (sdr_ifile.c:209-213), read in place
@@ -827,6 +839,11 @@ static int enqueue_sweep(mgpu_ctx *c, Slot &sl) {
     sp.unit_first = sl.d_unit_first; sp.unit_count = sl.d_unit_count; sp.nunits = nunits;
     sp.adder_bitmap = c->d_adder_bitmap; sp.class_bitmap = sl.d_class_bitmap; sp.counters = sl.d_counters;
     sp.cand = sl.d_cand; sp.cand_count = sl.d_cand_count; sp.class_uncond = sl.d_class_uncond; sp.sweep_part = sl.d_sweep_part;
+    if (sl.fused_iq) {
+        sp.iq = sl.fused_iq; sp.mag_w = sl.d_mag; sp.tail = sl.fused_tail; sp.uc8_folded = c->d_uc8_folded;
+        sp.sum_level = sl.d_sum_level; sp.sum_power = sl.d_sum_power;
+        sp.buf_shift = (uint32_t) __builtin_ctz(cfg.buf_samples);
+    }
     // ev[5] .. ev[4] bracket exactly one kernel: k_sweep (bench.py's roofline); ev[4] .. ev[2]: k_slice
     if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[5], s));
 #if MGPU_EXPERIMENTS

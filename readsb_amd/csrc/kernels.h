@@ -102,6 +102,13 @@ struct SweepParams {
     uint32_t *cand_count;     // [tiles]
     uint32_t *sweep_part;     // [k_sweep workgroups][4] partial counters (candidates, phases 4/5, 6/7, 8), summed by k_slice
     uint32_t sweep_blocks;    // rows of sweep_part
+    // the fused UC8 form of k_sweep (iq != nullptr): the tile load converts, writes d_mag and adds the per-buffer sums
+    const uint8_t *iq;        // the chunk's IQ samples
+    uint16_t *mag_w;          // == mag
+    const uint16_t *tail;     // 326 magnitudes preceding the chunk (device), nullptr = zeros
+    const uint16_t *uc8_folded;
+    unsigned long long *sum_level, *sum_power;   // [nbuffers] exact integer sums (ConvertParams)
+    uint32_t buf_shift;       // log2(buf_samples)
     uint32_t *adder_bitmap;   // 2^24 bits: addresses some clean DF17 / DF11 IID 0 frame carries
     uint32_t *class_bitmap;   // 1 bit per scan position: candidate whose records are all conditional
     uint32_t *class_uncond;   // scratch plane: candidate with >= 1 unconditional record (both planes zeroed per chunk)

@@ -36,3 +36,14 @@ def test_generation_matches_oracle(built, version):
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.strip().startswith("OK")
+
+
+def test_fused_uc8_convert_matches_oracle(built):
+    """MGPU_FUSED_CONVERT=1: convert_uc8_nodc inside k_sweep's tile load (k_sweep_t<true>: d_mag, the per-buffer sums and the
+    candidates all come from one kernel) — ragged length, several chunks, 2-bit repair; messages and every counter as the oracle's."""
+    script = SCRIPT.replace("seconds=3.0, seed=404", "nsamples=37 * 131072 + 4321, seed=405").replace("max_samples=64 * 131072", "max_samples=16 * 131072")
+    env = dict(os.environ, MGPU_FUSED_CONVERT="1")
+    code = script.format(root=helpers.ROOT, tests=os.path.join(helpers.ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.strip().startswith("OK")

@@ -165,6 +165,9 @@ def main():
     ap.add_argument("--extra-samples", type=int, default=2048 * BUF, help="samples per segment of the extra configurations")
     ap.add_argument("--main-cpu", type=int, default=-1, help="experiment: pin the calling thread to this CPU after the context exists")
     ap.add_argument("--exercise-gather", action="store_true", help="run the N>1 aggregator exchange even with one rank (needs torchrun env)")
+    ap.add_argument("--dryrun-gloo", action="store_true",
+                    help="dry run of the N>1 code path on ONE GPU: gloo backend, collectives on CPU tensors, every rank on device 0 "
+                         "(torchrun --nproc-per-node 2 bench.py --gpus 2 --dryrun-gloo ...); the numbers mean nothing")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -177,10 +180,17 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libmodes_gpu has no CPU path")
-    torch.cuda.set_device(local_rank)
+    if args.dryrun_gloo:
+        local_rank_dev, coll_dev = 0, torch.device("cpu")
+    else:
+        local_rank_dev, coll_dev = local_rank, torch.device("cuda", local_rank)
+    torch.cuda.set_device(local_rank_dev)
     use_dist = world > 1 or args.exercise_gather
     if use_dist:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dryrun_gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import helpers
     import readsb_amd
@@ -192,7 +202,7 @@ def main():
     threads = max(1, (os.cpu_count() or 8) // max(1, world))
     iq = helpers.synth(nsamples=n, seed=88172645463325252 + rank, rate=args.msgs_per_sec, threads=min(threads, 64))
     t_gen = time.time() - t0
-    d = readsb_amd.Demodulator(max_samples=n, device=local_rank, startup_time_ms=helpers.STARTUP_MS)
+    d = readsb_amd.Demodulator(max_samples=n, device=local_rank_dev, startup_time_ms=helpers.STARTUP_MS)
     d.upload_iq(iq)
     # the application's threads (this one, the HIP / RCCL runtime's) stay off the pipeline's cores; with several ranks on the
     # node they stay inside the rank's own CCD, on the SMT siblings the pipeline leaves free
@@ -208,10 +218,10 @@ def main():
     m0, _ = d.collect(reuse=True)
     cap = len(m0) * 5 // 4 + 1024
     if use_dist:
-        t = torch.tensor([cap], dtype=torch.int64, device="cuda")
+        t = torch.tensor([cap], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         cap = int(t.item())
-        gath = MessageGatherer(readsb_amd.MSG_DTYPE, torch.device("cuda", local_rank), cap, depth=3)
+        gath = MessageGatherer(readsb_amd.MSG_DTYPE, coll_dev, cap, depth=3)
         bufs = None
     else:
         bufs = [np.empty(cap, dtype=readsb_amd.MSG_DTYPE) for _ in range(2)]
@@ -272,14 +282,62 @@ def main():
     msgs = msgs.copy()
     d.set_deferred(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        nm = torch.tensor([len(msgs)], dtype=torch.int64, device="cuda")
+        nm = torch.tensor([len(msgs)], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(nm)
         total_msgs = int(nm.item())
     else:
         total_msgs = len(msgs)
+
+    # ---- bit-identity + CPU baseline, same run.  Every rank checks its own stream: the first two segments, fed exactly as in
+    #      the timed region (deferred, into the consumer's arrays), against the reference's own code on the 2-segment stream, on
+    #      one host core per stream — with N streams that is N pinned reference processes side by side ----
+    cpu_result = None
+    if not args.no_cpu_baseline:
+        d.reset()
+        d.set_deferred(True)
+        vb = [np.empty(cap, dtype=readsb_amd.MSG_DTYPE) for _ in range(2)]
+        for k in range(2):
+            d.set_message_buffer(vb[k])
+            d.feed_resident(n)
+        g0, _ = d.collect_feed(vb[0])
+        g1, vcnt = d.collect_feed(vb[1], want_counters=True)
+        d.finish()
+        _, vcnt = d.collect_feed(vb[0], want_counters=True)
+        gpu_msgs = np.concatenate([g0, g1])
+        d.set_deferred(False)
+        iq2 = np.concatenate([iq[: n * 2], iq[: n * 2]])
+        pin = None
+        try:                                                    # a core of its own, off the pipeline's cores and their siblings
+            free = sorted(os.sched_getaffinity(0))
+            pin = free[(7 + 2 * local_rank) % len(free)]
+            os.sched_setaffinity(0, {pin})
+        except (OSError, AttributeError, ZeroDivisionError):
+            pin = None
+        if use_dist:
+            dist.barrier()                                      # the N reference processes run at the same time
+        kind, ref_msgs, st = cpu_reference(iq2, 2 * n)
+        del iq2
+        cpu_s = float(st["t_convert_s"] + st["t_demod_s"])
+        helpers.assert_same_messages(gpu_msgs, ref_msgs)        # bit-identical decoded message set, same run
+        helpers.assert_same_counters(vcnt, st)
+        rate = 2 * n / cpu_s / 1e6
+        if world > 1:
+            t = torch.tensor([rate, cpu_s], dtype=torch.float64, device=coll_dev)
+            parts = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(parts, t)
+            rates = [float(x[0].item()) for x in parts]
+            slowest = max(float(x[1].item()) for x in parts)
+        else:
+            rates, slowest = [rate], cpu_s
+        cpu_result = {"value": round(world * 2 * n / slowest / 1e6, 1), "unit": "Msamples/s", "cores": world, "kind": kind,
+                      "sample": f"the first two steps of every rank's stream ({2 * n} samples each), {world} reference process(es) side by side, "
+                                f"one pinned host core each: rank 0 convert {st['t_convert_s']:.2f} s + demodulate2400 {st['t_demod_s']:.2f} s "
+                                f"({os.cpu_count()} cores present)",
+                      "per_stream_msamples_s": [round(r, 1) for r in rates],
+                      "messages": int(len(ref_msgs)), "bit_identical_to_gpu": True}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -345,38 +403,14 @@ def main():
         except Exception as e:                                   # the measurement is informative only
             out["pcie_inclusive_msamples_s"] = None
             out["pcie_inclusive_error"] = str(e)[:200]
-        if not args.no_cpu_baseline:
-            # bit-identity, same run: the first two segments of the same stream, fed exactly as in the timed region (deferred,
-            # into the consumer's arrays), against the reference's own code on the 2-segment stream (1 host core)
-            d.reset()
-            d.set_deferred(True)
-            vb = [np.empty(cap, dtype=readsb_amd.MSG_DTYPE) for _ in range(2)]
-            for k in range(2):
-                d.set_message_buffer(vb[k])
-                d.feed_resident(n)
-            g0, _ = d.collect_feed(vb[0])
-            g1, vcnt = d.collect_feed(vb[1], want_counters=True)
-            d.finish()
-            _, vcnt = d.collect_feed(vb[0], want_counters=True)
-            gpu_msgs = np.concatenate([g0, g1])
-            d.set_deferred(False)
-            iq2 = np.concatenate([iq[: n * 2], iq[: n * 2]])
-            kind, ref_msgs, st = cpu_reference(iq2, 2 * n)
-            del iq2
-            cpu_s = float(st["t_convert_s"] + st["t_demod_s"])
-            helpers.assert_same_messages(gpu_msgs, ref_msgs)      # bit-identical decoded message set, same run
-            helpers.assert_same_counters(vcnt, st)
-            out["cpu_baseline"] = {"value": round(2 * n / cpu_s / 1e6, 1), "unit": "Msamples/s", "cores": 1, "kind": kind,
-                                   "sample": f"the first two steps of rank 0's stream ({2 * n} samples): convert {st['t_convert_s']:.2f} s + "
-                                             f"demodulate2400 {st['t_demod_s']:.2f} s on one host core "
-                                             f"({os.cpu_count()} cores present)",
-                                   "messages": int(len(ref_msgs)), "bit_identical_to_gpu": True}
+        if cpu_result is not None:
+            out["cpu_baseline"] = cpu_result
         if not args.no_extra_configs and not args.no_cpu_baseline and world == 1:
             d.close()
             out["configs"] = {}
             for name, (fmt, nfix, kw) in EXTRA_CONFIGS.items():
                 try:
-                    out["configs"][name] = run_extra_config(name, fmt, nfix, kw, args.extra_samples - args.extra_samples % BUF, local_rank)
+                    out["configs"][name] = run_extra_config(name, fmt, nfix, kw, args.extra_samples - args.extra_samples % BUF, local_rank_dev)
                 except AssertionError as e:                      # a mismatch is a failed run, not a missing number
                     raise SystemExit(f"extra configuration '{name}': GPU result differs from the reference: {e}")
         print(json.dumps(out))

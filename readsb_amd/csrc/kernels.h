@@ -184,6 +184,8 @@ void launch_signal_power(const uint16_t *mag, const uint32_t *pos, const uint16_
                          unsigned long long *out, hipStream_t s);
 // candidates / tried phases / conditional-class candidates inside the skip-ahead window of
 // each accepted message (positions pos+1 .. pos+skip, clipped to `limit`), for the stats fix-up
+void launch_stage_in(const uint32_t *h_pos, const uint32_t *h_limit, const uint16_t *h_skip, uint32_t *d_pos, uint32_t *d_limit,
+                     uint16_t *d_skip, uint32_t n, hipStream_t s);   // page-locked host arrays -> device, small grid
 void launch_window_stats(const uint16_t *mag, uint64_t n, int thr, const uint32_t *class_bitmap, const uint32_t *pos,
                          const uint16_t *skip, const uint32_t *limit, uint32_t nmsg, unsigned long long *part, unsigned long long *out,
                          hipStream_t s);

@@ -221,29 +221,54 @@ def main():
         t = torch.tensor([cap], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         cap = int(t.item())
-        gath = MessageGatherer(readsb_amd.MSG_DTYPE, coll_dev, cap, depth=3)
+        gath = MessageGatherer(readsb_amd.MSG_DTYPE, coll_dev, cap, depth=3, host_alloc=d.host_alloc)
         bufs = None
     else:
         bufs = [np.empty(cap, dtype=readsb_amd.MSG_DTYPE) for _ in range(2)]
+        if os.environ.get("MGPU_DBG_PINNED_BUFS"):
+            bufs = [(d.host_alloc(cap * 64) if os.environ["MGPU_DBG_PINNED_BUFS"] == "near" else torch.empty(cap * 64, dtype=torch.uint8, pin_memory=True).numpy()).view(readsb_amd.MSG_DTYPE) for _ in range(2)]
 
     # ---- the job: ONE continuous stream, step k = its k-th 223.7 s segment (the same resident IQ block again: an ifile played
     #      in a loop), fed with deferred calls — feed(k+1) is enqueued before the messages of feed(k) are taken, so the pipeline
     #      does not run empty between steps; a step's messages are built straight into the consumer's array (no copy) ----
     d.reset()
     d.set_deferred(True)
+    # N > 1: the messages are built on the GPU and go from HBM into the RCCL gather — no host build, no staging upload
+    dev_msgs = gath is not None and not args.dryrun_gloo and not os.environ.get("MGPU_DBG_HOST_MESSAGES")
+    if dev_msgs:
+        d.set_device_messages(True)
     arrays = {}
 
+    dbg_t = {"staging": 0.0, "feed": 0.0, "collect": 0.0, "gsubmit": 0.0}
+
     def submit(k):
-        buf = gath.staging(ahead=k - gath.seq) if gath is not None else bufs[k % 2]
-        d.set_message_buffer(buf)
+        t_a = time.perf_counter()
+        buf = None
+        if not dev_msgs:
+            buf = gath.staging(ahead=k - gath.seq) if gath is not None else bufs[k % 2]
+            d.set_message_buffer(buf)
+        t_b = time.perf_counter()
         d.feed_resident(n)                      # everything from HBM-resident IQ to ordered messages
         arrays[k] = buf
+        dbg_t["staging"] += t_b - t_a
+        dbg_t["feed"] += time.perf_counter() - t_b
 
     def take(k, want_counters=False):
-        msgs, counters = d.collect_feed(arrays.pop(k), want_counters=want_counters)
-        if gath is not None:
-            gath.submit(len(msgs))              # counts + records to rank 0's HBM over RCCL, overlapped with the next steps
-        return msgs, counters
+        t_a = time.perf_counter()
+        if dev_msgs:
+            dptr, nmsgs, counters = d.collect_feed_device(want_counters=want_counters)
+            arrays.pop(k)
+            t_b = time.perf_counter()
+            gath.submit_device(dptr, nmsgs)     # counts + records from this rank's HBM to rank 0's over RCCL, overlapped with the next steps
+        else:
+            msgs, counters = d.collect_feed(arrays.pop(k), want_counters=want_counters)
+            nmsgs = len(msgs)
+            t_b = time.perf_counter()
+            if gath is not None:
+                gath.submit(nmsgs)              # (dry run / MGPU_DBG_HOST_MESSAGES: through the pinned staging ring)
+        dbg_t["collect"] += t_b - t_a
+        dbg_t["gsubmit"] += time.perf_counter() - t_b
+        return nmsgs, counters
 
     seq = 0
     if args.warmup:
@@ -262,12 +287,14 @@ def main():
     for k in range(1, args.steps):
         submit(seq + k)
         take(seq + k - 1)
-    msgs, counters = take(seq + args.steps - 1, want_counters=True)   # ... and ends with an empty one
+    nmsgs_last, counters = take(seq + args.steps - 1, want_counters=True)   # ... and ends with an empty one
     if use_dist:
         gath.wait()                             # the last steps' exchanges are part of the job
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("MGPU_DBG_BENCH"):
+        sys.stderr.write(f"dbg bench rank {rank}: main thread, warm-up + timed steps: {dbg_t}\n")
     tm = d.timing()                             # sums over the timed region's launches (everything since the last drain)
     # the stage events ride on every 4th chunk only (an event costs ~5 us of idle stream): scale the sampled sums to all chunks
     ev_scale = tm["n_chunks"] / max(1, tm["n_timed_chunks"])
@@ -279,17 +306,16 @@ def main():
     resolve_ms, total_ms = [tm["resolve_ms"] / K], [tm["total_ms"] / K]
     for key in ("prescreen_ms", "d2h_ms", "build_ms", "sigpower_ms"):
         tm[key] = tm[key] / K
-    msgs = msgs.copy()
-    d.set_deferred(False)
+    d.set_deferred(False)                       # (also leaves the device-messages mode)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        nm = torch.tensor([len(msgs)], dtype=torch.int64, device=coll_dev)
+        nm = torch.tensor([nmsgs_last], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(nm)
         total_msgs = int(nm.item())
     else:
-        total_msgs = len(msgs)
+        total_msgs = nmsgs_last
 
     # ---- bit-identity + CPU baseline, same run.  Every rank checks its own stream: the first two segments, fed exactly as in
     #      the timed region (deferred, into the consumer's arrays), against the reference's own code on the 2-segment stream, on

@@ -180,6 +180,16 @@ int mgpu_feed_iq(mgpu_ctx *ctx, const void *iq_host, uint64_t nsamples);
  * synchronously.  The struct mag_buf entries and the shard calls are refused (MGPU_E_INVAL) while deferred mode is on. */
 int mgpu_set_deferred(mgpu_ctx *ctx, int on);
 
+/* Device-resident messages (deferred mode only, no Mode A/C): the accepted frames' records are built on the GPU
+ * (k_build_messages: demod_2400.c:399-445 + the CRC stage's repair, mode_s.c:443-606, lane = message) from the walk's accept
+ * list and the live records that already are in HBM, into a list per feed; the host builds nothing and no message crosses PCIe
+ * unless asked for.  mgpu_collect_device() waits for the oldest uncollected feed like mgpu_collect() and returns the device
+ * pointer of its `*n` records, in stream order — valid until three more feeds have been started — ready for
+ * mgpu_decode_fields_device / mgpu_beast_encode_device or an aggregator's RCCL gather (readsb_amd/gather.py: submit_device).
+ * mgpu_collect() in this mode copies the whole feed to the host (MGPU_E_OVERFLOW if `cap` is smaller than the feed). */
+int mgpu_set_device_messages(mgpu_ctx *ctx, int on);
+int mgpu_collect_device(mgpu_ctx *ctx, const struct mgpu_msg **d_msgs, uint64_t *n, struct mgpu_counters *counters);
+
 /* Same, for IQ already resident in device memory (HBM): d_iq is a device pointer to
  * nsamples samples of cfg.format.  This is the entry the benchmark times. */
 int mgpu_feed_iq_device(mgpu_ctx *ctx, const void *d_iq, uint64_t nsamples);
@@ -194,6 +204,13 @@ void *mgpu_device_iq_buffer(mgpu_ctx *ctx);
  * MGPU_NO_AFFINITY=1).  An application that wants the full speed keeps its own busy threads off these cores and
  * their SMT siblings: a thread of the application sharing a core with a pipeline stage costs up to 30 %. */
 int mgpu_host_cpus(mgpu_ctx *ctx, int32_t *cpus, int32_t cap);
+
+/* Page-locked host memory placed on the device's NUMA node (hipHostMalloc while the calling thread sits on that node), for the
+ * arrays the library writes at full speed: the message arrays of mgpu_set_message_buffer (an aggregator's staging buffers that
+ * go on to the GPU), sample buffers.  Pinned memory allocated from a thread on the other socket costs the builder ~10 % of the
+ * step.  Free with mgpu_host_free. */
+void *mgpu_host_alloc(mgpu_ctx *ctx, uint64_t bytes);
+void  mgpu_host_free(mgpu_ctx *ctx, void *ptr);
 
 /* Optional: page-lock a host buffer the caller keeps feeding from (the SDR plugin's read buffer, the
  * ifile reader's `readbuf`, sdr_ifile.c:140) so that mgpu_feed_iq's chunked uploads run at PCIe speed

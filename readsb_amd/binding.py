@@ -127,9 +127,15 @@ def load_library():
     lib.mgpu_last_error.restype = C.c_char_p
     lib.mgpu_device_count.restype = i32
     lib.mgpu_set_deferred.argtypes = [vp, i32]
+    lib.mgpu_set_device_messages.argtypes = [vp, i32]
+    lib.mgpu_collect_device.argtypes = [vp, C.POINTER(vp), C.POINTER(u64), vp]
     lib.mgpu_feed_iq.argtypes = [vp, vp, u64]
     lib.mgpu_feed_iq_device.argtypes = [vp, vp, u64]
     lib.mgpu_host_cpus.argtypes = [vp, vp, i32]
+    lib.mgpu_host_alloc.argtypes = [vp, u64]
+    lib.mgpu_host_alloc.restype = vp
+    lib.mgpu_host_free.argtypes = [vp, vp]
+    lib.mgpu_host_free.restype = None
     lib.mgpu_host_register.argtypes = [vp, vp, u64]
     lib.mgpu_host_unregister.argtypes = [vp, vp]
     lib.mgpu_upload_iq.argtypes = [vp, vp, u64]
@@ -375,9 +381,37 @@ class Demodulator:
         self._chk(self.lib.mgpu_collect(self.ctx, out.ctypes.data, n, C.byref(got), C.byref(cnt)), "mgpu_collect")
         return out[: got.value], cnt.as_dict()
 
+    def host_alloc(self, nbytes):
+        """Page-locked host memory on the device's NUMA node as a uint8 numpy array (mgpu_host_alloc); host_free(arr) releases it."""
+        p = self.lib.mgpu_host_alloc(self.ctx, int(nbytes))
+        if not p:
+            raise MgpuError("mgpu_host_alloc failed")
+        arr = np.ctypeslib.as_array((C.c_uint8 * int(nbytes)).from_address(p))
+        self._host_allocs = getattr(self, "_host_allocs", {})
+        self._host_allocs[arr.ctypes.data] = p
+        return arr
+
+    def host_free(self, arr):
+        p = getattr(self, "_host_allocs", {}).pop(arr.ctypes.data, None)
+        if p:
+            self.lib.mgpu_host_free(self.ctx, p)
+
     def set_deferred(self, on=True):
         """mgpu_set_deferred: feeds return once enqueued; the loop is feed(k+1); collect_feed(k)."""
         self._chk(self.lib.mgpu_set_deferred(self.ctx, 1 if on else 0), "mgpu_set_deferred")
+
+    def set_device_messages(self, on=True):
+        """mgpu_set_device_messages (deferred mode): the messages of a feed are built on the GPU and stay there."""
+        self._chk(self.lib.mgpu_set_device_messages(self.ctx, 1 if on else 0), "mgpu_set_device_messages")
+
+    def collect_feed_device(self, want_counters=False):
+        """Device-messages mode: wait for the oldest uncollected feed; returns (device pointer of its mgpu_msg records, count,
+        counters or None).  The pointer stays valid until three more feeds have been started."""
+        ptr, n = C.c_void_p(), C.c_uint64(0)
+        cnt = Counters() if want_counters else None
+        self._chk(self.lib.mgpu_collect_device(self.ctx, C.byref(ptr), C.byref(n), C.byref(cnt) if cnt is not None else None),
+                  "mgpu_collect_device")
+        return int(ptr.value or 0), int(n.value), (cnt.as_dict() if cnt is not None else None)
 
     def collect_feed(self, out, want_counters=False):
         """Deferred mode: wait for the oldest uncollected feed and take its messages into `out` (a contiguous mgpu_msg array,

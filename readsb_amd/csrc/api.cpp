@@ -168,6 +168,7 @@ struct Slot {
     hipEvent_t ev_scan = nullptr;         // pre-screen offsets are final (main stream) -> the write pass may start (second stream)
     // the job
     uint64_t n = 0, stream_pos = 0;
+    uint8_t *h_blob = nullptr, *d_blob = nullptr;   // device-messages mode: the walker's accept list + buffer clocks, page-locked host / device
     const uint8_t *fused_iq = nullptr;    // this chunk's converter runs inside k_sweep (enqueue_convert): its IQ samples ...
     const uint16_t *fused_tail = nullptr; // ... and the 326 magnitudes before them
     int feed = -1;                        // deferred feeds: which FeedSlot the chunk's messages go to (-1: mgpu_ctx::pending)
@@ -237,6 +238,10 @@ struct HostJob {
 // mgpu_collect waits for the oldest uncollected feed only.  Each feed in flight has its own message list.
 struct FeedSlot {
     MsgBuf msgs;
+    // device-messages mode (mgpu_set_device_messages): the feed's messages are built by k_build_messages into d_msgs
+    mgpu_msg *d_msgs = nullptr;
+    uint64_t d_cap = 0, d_count = 0;          // d_count: walker thread only, read by the caller after the feed is complete
+    hipEvent_t ev_built = nullptr;            // the last k_build_messages of the feed has run (stream2)
     uint64_t jobs_total = 0, jobs_built = 0;  // chunks submitted / chunks whose messages are complete (under mgpu_ctx::mu)
     bool closed = false;                      // every chunk of the feed has been submitted
 };
@@ -278,6 +283,7 @@ struct mgpu_ctx {
     FeedSlot feed[kFeeds];                                    // deferred mode: ring of feeds in flight / uncollected
     uint64_t feed_head = 0, feed_tail = 0;                    // oldest uncollected feed, next feed to open
     bool deferred = false;
+    bool device_msgs = false;                                 // mgpu_set_device_messages
     bool fused_convert = false;                               // MGPU_FUSED_CONVERT=1: UC8 conversion inside k_sweep's tile load (same speed, see kernels/sweep.inc)
     int timing_every = 4;                                     // MGPU_TIMING_EVERY: chunks per set of stage timing events (1 = every chunk)
     uint64_t timing_seq = 0;
@@ -393,6 +399,49 @@ static void release_device_slot(int device, int slot) {
     std::lock_guard<std::mutex> lk(g_slot_mu);
     g_device_slots[device & 63] &= ~(1u << slot);
 }
+
+// CPUs of the device's NUMA node that the process may use (empty set: unknown)
+static bool device_local_cpus(int device, cpu_set_t *out) {
+    CPU_ZERO(out);
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int) sizeof(bus), device) != hipSuccess) return false;
+    std::string id(bus);
+    for (auto &ch : id) ch = (char) tolower((unsigned char) ch);
+    FILE *f = fopen(("/sys/bus/pci/devices/" + id + "/local_cpulist").c_str(), "r");
+    if (!f) return false;
+    char line[4096] = {0};
+    const bool ok = fgets(line, sizeof(line), f) != nullptr;
+    fclose(f);
+    if (!ok) return false;
+    cpu_set_t allowed;
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return false;
+    int n = 0;
+    for (char *tok = strtok(line, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+        int a = 0, b = 0;
+        const int got = sscanf(tok, "%d-%d", &a, &b);
+        if (got == 1) b = a;
+        if (got >= 1)
+            for (int k = a; k <= b && k < CPU_SETSIZE; ++k)
+                if (CPU_ISSET(k, &allowed)) { CPU_SET(k, out); ++n; }
+    }
+    return n > 0;
+}
+
+// Page-locked host memory is placed where the allocating thread runs: while the context allocates its buffers (the record
+// copies' destinations, the counter blocks) the calling thread sits on the device's NUMA node, whatever CPU it came from —
+// on a two-socket box a process that happened to start on the other socket had every pipeline stage read its records across
+// the socket link (2.3 vs 2.6 ms per step from run to run).
+struct NearDevice {
+    cpu_set_t saved;
+    bool moved = false;
+    explicit NearDevice(int device) {
+        if (getenv("MGPU_NO_AFFINITY")) return;
+        cpu_set_t local;
+        if (sched_getaffinity(0, sizeof(saved), &saved) != 0 || !device_local_cpus(device, &local)) return;
+        moved = pthread_setaffinity_np(pthread_self(), sizeof(local), &local) == 0;
+    }
+    ~NearDevice() { if (moved) (void) pthread_setaffinity_np(pthread_self(), sizeof(saved), &saved); }
+};
 
 // Two groups of threads, two L3 groups: `walk` (the walker and its helpers: they pass cache lines of the filter state and of
 // the record list among themselves all the time) and `rest` (fetcher, builder and its helpers).  The hand-off between the
@@ -561,6 +610,11 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
     HIPCHK(c, hipMalloc(&sl.d_msg_len, c->cap_msgs * sizeof(uint16_t)));
     HIPCHK(c, hipMalloc(&sl.d_msg_skip, c->cap_msgs * sizeof(uint16_t)));
     HIPCHK(c, hipMalloc(&sl.d_msg_sig, c->cap_msgs * sizeof(unsigned long long)));
+    {
+        const size_t blob = c->cap_msgs * sizeof(Accepted) + c->cap_buffers * sizeof(BufferClock) + 64;
+        HIPCHK(c, hipMalloc(&sl.d_blob, blob));
+        HIPCHK(c, hipHostMalloc(&sl.h_blob, blob));
+    }
     HIPCHK(c, hipMalloc(&sl.d_live, c->cap_pool * sizeof(PhaseRec)));
     HIPCHK(c, hipMalloc(&sl.d_live_sig, c->cap_pool * sizeof(unsigned long long)));
     HIPCHK(c, hipHostMalloc(&sl.h_live, c->cap_pool * sizeof(PhaseRec)));
@@ -583,7 +637,8 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
 }
 
 static void free_slot(Slot &sl) {
-    void *dev[] = {sl.d_live, sl.d_live_sig, sl.d_mag, sl.d_pool, sl.d_scratch, sl.d_unit_first, sl.d_unit_count, sl.d_unit_live, sl.d_class_bitmap,
+    if (sl.h_blob) (void) hipHostFree(sl.h_blob);
+    void *dev[] = {sl.d_blob, sl.d_live, sl.d_live_sig, sl.d_mag, sl.d_pool, sl.d_scratch, sl.d_unit_first, sl.d_unit_count, sl.d_unit_live, sl.d_class_bitmap,
                    sl.d_class_uncond, sl.d_class_final, sl.d_cand, sl.d_cand_count, sl.d_sweep_part,
                    sl.d_win, sl.d_win_part, sl.d_msg_pos,
                    sl.d_msg_limit, sl.d_msg_len, sl.d_msg_skip, sl.d_msg_sig};
@@ -687,7 +742,11 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     c->valid_long = (1u << 16) | (1u << 17) | (1u << 18) | (1u << 20) | (1u << 21);
     if (cfg->fixDF && cfg->nfix_crc)
         for (int b = 0; b < 5; ++b) c->valid_long |= 1u << (17 ^ (1 << b));
-    int rc = alloc_all(c);
+    int rc;
+    {
+        NearDevice near(cfg->device);
+        rc = alloc_all(c);
+    }
     if (rc != MGPU_OK) {
         std::fprintf(stderr, "mgpu_create: %s (%s)\n", mgpu_strerror(rc), c->err.c_str());
         mgpu_destroy(c);
@@ -738,6 +797,10 @@ void mgpu_destroy(mgpu_ctx *c) {
     if (c->stream2) (void) hipStreamSynchronize(c->stream2);
     if (c->stream_w) (void) hipStreamSynchronize(c->stream_w);
     for (auto &sl : c->slot) free_slot(sl);
+    for (auto &f : c->feed) {
+        if (f.d_msgs) (void) hipFree(f.d_msgs);
+        if (f.ev_built) (void) hipEventDestroy(f.ev_built);
+    }
     if (c->h_win) (void) hipHostFree(c->h_win);
     void *dev[] = {c->d_roll_tan, c->d_fields, c->d_beast_off, c->d_beast_len, c->d_beast_in, c->d_beast_out, c->d_beast_blocks, c->d_beast_total, c->d_hist, c->d_hist_iq, c->d_hist_sums, c->d_iq, c->d_win, c->d_adder_bitmap, c->d_bit_syndrome, c->d_group_syndrome, c->d_parity,
                    c->d_tab_long, c->d_tab_short, c->d_uc8_folded};
@@ -1042,7 +1105,23 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
         launch_stage_in(sl.h_msg_pos, sl.h_msg_limit, sl.h_msg_skip, sl.d_msg_pos, sl.d_msg_limit, sl.d_msg_skip, nmsg, s2);
         launch_window_stats(sl.d_mag, n, sl.thr, sl.d_class_final, sl.d_msg_pos, sl.d_msg_skip,
                             sl.d_msg_limit, nmsg, sl.d_win_part, c->d_win, s2);
-        HIPCHK(c, hipEventRecord(sl.ev_window, s2));
+    }
+    if (nmsg && c->device_msgs && job.feed >= 0) {
+        // the accepted frames become message records on the device (kernels/build.inc), appended to the feed's device list
+        FeedSlot &fs = c->feed[job.feed];
+        if (fs.d_count + nmsg > fs.d_cap) { c->err = "device message list of the feed is full"; return MGPU_E_OVERFLOW; }
+        hipStream_t s2 = c->stream2;
+        const size_t acc_bytes = ((size_t) nmsg * sizeof(Accepted) + 15) & ~(size_t) 15;
+        const size_t buf_bytes = sl.buffers.size() * sizeof(BufferClock);
+        std::memcpy(sl.h_blob, job.acc.data(), (size_t) nmsg * sizeof(Accepted));
+        std::memcpy(sl.h_blob + acc_bytes, sl.buffers.data(), buf_bytes);
+        launch_stage_blob(sl.h_blob, sl.d_blob, acc_bytes + buf_bytes, s2);
+        launch_build_messages(sl.d_live, sl.d_live_sig, sl.d_blob, sl.d_blob + acc_bytes, nmsg, fs.d_msgs + fs.d_count, s2);
+        HIPCHK(c, hipEventRecord(fs.ev_built, s2));
+        fs.d_count += nmsg;
+    }
+    if (nmsg && (!c->dbg_no_window || c->device_msgs)) {          // the slot's device side is read on stream2 until here
+        HIPCHK(c, hipEventRecord(sl.ev_window, c->stream2));
         sl.window_pending = true;
     }
     c->acc.sigpower_ms += (float) (wall_ms() - t_sig0);
@@ -1079,9 +1158,10 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
         ac.resize(keep);
     }
     const uint32_t nac = (uint32_t) ac.size();
+    const bool on_device = c->device_msgs && job.feed >= 0;   // the walker had k_build_messages make the records: statistics only here
     MsgBuf &pending = job.feed >= 0 ? c->feed[job.feed].msgs : c->pending;
     const size_t first_msg = pending.size();
-    if (!pending.grow_for((size_t) nmsg + nac)) {
+    if (!on_device && !pending.grow_for((size_t) nmsg + nac)) {
         c->err = pending.external ? "the caller's message buffer (mgpu_set_message_buffer) is full" : "out of memory for the decoded messages";
         return pending.external ? MGPU_E_OVERFLOW : MGPU_E_NOMEM;
     }
@@ -1089,7 +1169,7 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
     mgpu_msg *out = pending.data() + first_msg;
     std::vector<mgpu_msg> &stage = c->b_stage;               // with Mode A/C the Mode S messages are built here and merged per buffer
     if (nac) { stage.resize(nmsg); }
-    {
+    if (!on_device) {
         const int parts = nmsg >= 4096 ? c->build_threads : 1;
         mgpu_msg *dst = nac ? stage.data() : out;
         c->build_team.run(parts, [&](int i) {
@@ -1118,7 +1198,7 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
         }
         c->counters.demod_modeac += nac;
     }
-    pending.n = first_msg + nmsg + nac;
+    if (!on_device) pending.n = first_msg + nmsg + nac;
     const double t2 = wall_ms();
 
     mgpu_counters &k = c->counters;
@@ -1359,6 +1439,16 @@ static int feed_common(mgpu_ctx *c, const void *src, bool src_is_device, uint64_
         fs.jobs_total = fs.jobs_built = 0;
         fs.closed = false;
         fs.msgs.clear();
+        fs.d_count = 0;
+        if (c->device_msgs && !fs.d_msgs) {
+            const uint64_t want = c->cap_samples / 64 + 65536;
+            if (hipSetDevice(c->cfg.device) != hipSuccess || hipMalloc(&fs.d_msgs, want * sizeof(mgpu_msg)) != hipSuccess ||
+                hipEventCreateWithFlags(&fs.ev_built, hipEventDisableTiming) != hipSuccess) {
+                c->err = "device message list: allocation failed";
+                return MGPU_E_NOMEM;
+            }
+            fs.d_cap = want;
+        }
         c->feed_tail++;                      // open: mgpu_collect sees it, and waits for `closed`
     }
     { int brc = feed_begin(c); if (brc != MGPU_OK) { c->hot.store(false, std::memory_order_relaxed); return brc; } }
@@ -1431,8 +1521,10 @@ int mgpu_set_deferred(mgpu_ctx *c, int on) {
     const int rc = drain(c);
     if (rc != MGPU_OK) return rc;
     if (c->feed_head != c->feed_tail || c->pending.size()) { c->err = "mgpu_set_deferred: collect the pending messages first"; return MGPU_E_INVAL; }
-    if (!on)                                         // the caller's arrays go back to the caller
+    if (!on) {                                       // the caller's arrays go back to the caller
         for (auto &f : c->feed) f.msgs.use_external(nullptr, 0);
+        c->device_msgs = false;
+    }
     c->deferred = on != 0;
     return MGPU_OK;
 }
@@ -1444,6 +1536,19 @@ int mgpu_host_cpus(mgpu_ctx *c, int32_t *cpus, int32_t cap) {
     const int n = (int) c->host_cpus.size();
     for (int i = 0; i < n && i < cap; ++i) cpus[i] = c->host_cpus[i];
     return n;
+}
+
+void *mgpu_host_alloc(mgpu_ctx *c, uint64_t bytes) {
+    if (!c || !bytes || hipSetDevice(c->cfg.device) != hipSuccess) return nullptr;
+    NearDevice near(c->cfg.device);
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes) != hipSuccess) return nullptr;
+    std::memset(p, 0, bytes);                    // first touch here, on the device's node
+    return p;
+}
+
+void mgpu_host_free(mgpu_ctx *c, void *ptr) {
+    if (c && ptr) { (void) hipSetDevice(c->cfg.device); (void) hipHostFree(ptr); }
 }
 
 int mgpu_host_register(mgpu_ctx *c, void *ptr, uint64_t bytes) {
@@ -1511,8 +1616,20 @@ int mgpu_collect(mgpu_ctx *c, struct mgpu_msg *out, uint64_t cap, uint64_t *n, s
                 c->cv.wait(lk, [&] { return c->worker_rc != MGPU_OK || (fs.closed && fs.jobs_built == fs.jobs_total); });
                 if (c->worker_rc != MGPU_OK) return c->worker_rc;
             }
-            take_messages(fs.msgs, out, cap, n);
-            if (fs.msgs.size() == 0) { std::lock_guard<std::mutex> lk(c->mu); c->feed_head++; }
+            if (c->device_msgs) {                            // the feed's records are in HBM: this entry copies them out
+                if (fs.d_count > cap) { c->err = "mgpu_collect: the feed's messages do not fit (device-messages mode takes whole feeds)"; return MGPU_E_OVERFLOW; }
+                if (fs.d_count) {
+                    HIPCHK(c, hipSetDevice(c->cfg.device));
+                    HIPCHK(c, hipEventSynchronize(fs.ev_built));
+                    HIPCHK(c, hipMemcpy(out, fs.d_msgs, fs.d_count * sizeof(mgpu_msg), hipMemcpyDeviceToHost));
+                }
+                if (n) *n = fs.d_count;
+                std::lock_guard<std::mutex> lk(c->mu);
+                c->feed_head++;
+            } else {
+                take_messages(fs.msgs, out, cap, n);
+                if (fs.msgs.size() == 0) { std::lock_guard<std::mutex> lk(c->mu); c->feed_head++; }
+            }
         }
         if (counters) {                                      // exact counters need everything in flight to land: this drains
             const int rc = drain(c);
@@ -1523,6 +1640,43 @@ int mgpu_collect(mgpu_ctx *c, struct mgpu_msg *out, uint64_t cap, uint64_t *n, s
     }
     take_messages(c->pending, out, cap, n);
     if (counters) *counters = c->counters;
+    return MGPU_OK;
+}
+
+int mgpu_collect_device(mgpu_ctx *c, const struct mgpu_msg **d_msgs, uint64_t *n, struct mgpu_counters *counters) {
+    if (!c || !d_msgs || !n) return MGPU_E_INVAL;
+    *d_msgs = nullptr; *n = 0;
+    if (!c->deferred || !c->device_msgs) { c->err = "mgpu_collect_device: needs mgpu_set_deferred and mgpu_set_device_messages"; return MGPU_E_INVAL; }
+    if (c->feed_head != c->feed_tail) {
+        FeedSlot &fs = c->feed[c->feed_head % mgpu_ctx::kFeeds];
+        {
+            std::unique_lock<std::mutex> lk(c->mu);
+            c->cv.wait(lk, [&] { return c->worker_rc != MGPU_OK || (fs.closed && fs.jobs_built == fs.jobs_total); });
+            if (c->worker_rc != MGPU_OK) return c->worker_rc;
+        }
+        if (fs.d_count) {
+            HIPCHK(c, hipSetDevice(c->cfg.device));
+            HIPCHK(c, hipEventSynchronize(fs.ev_built));
+        }
+        *d_msgs = fs.d_msgs; *n = fs.d_count;
+        std::lock_guard<std::mutex> lk(c->mu);
+        c->feed_head++;
+    }
+    if (counters) {
+        const int rc = drain(c);
+        if (rc != MGPU_OK) return rc;
+        *counters = c->counters;
+    }
+    return MGPU_OK;
+}
+
+int mgpu_set_device_messages(mgpu_ctx *c, int on) {
+    if (!c) return MGPU_E_INVAL;
+    const int rc = drain(c);
+    if (rc != MGPU_OK) return rc;
+    if (c->feed_head != c->feed_tail) { c->err = "mgpu_set_device_messages: collect the pending feeds first"; return MGPU_E_INVAL; }
+    if (on && (!c->deferred || c->cfg.mode_ac)) { c->err = "mgpu_set_device_messages: needs deferred feeds, and no Mode A/C (its replies are merged on the host)"; return MGPU_E_INVAL; }
+    c->device_msgs = on != 0;
     return MGPU_OK;
 }
 
@@ -1547,7 +1701,7 @@ uint64_t mgpu_pending_messages(mgpu_ctx *c) {
     for (uint64_t f = c->feed_head; f != c->feed_tail; ++f) {
         const FeedSlot &fs = c->feed[f % mgpu_ctx::kFeeds];
         if (!(fs.closed && fs.jobs_built == fs.jobs_total)) break;
-        total += fs.msgs.n;
+        total += c->device_msgs ? fs.d_count : fs.msgs.n;
     }
     return total;
 }

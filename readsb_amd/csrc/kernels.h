@@ -184,6 +184,10 @@ void launch_signal_power(const uint16_t *mag, const uint32_t *pos, const uint16_
                          unsigned long long *out, hipStream_t s);
 // candidates / tried phases / conditional-class candidates inside the skip-ahead window of
 // each accepted message (positions pos+1 .. pos+skip, clipped to `limit`), for the stats fix-up
+// struct modesMessage fields of the accepted frames on the device (kernels/build.inc): acc = Accepted[nacc], bufs = BufferClock[]
+void launch_build_messages(const PhaseRec *live, const unsigned long long *live_sig, const void *d_acc, const void *d_bufs, uint32_t nacc,
+                           mgpu_msg *out, hipStream_t s);
+void launch_stage_blob(const void *h_src, void *d_dst, uint64_t bytes, hipStream_t s);   // page-locked host -> device, small grid
 void launch_stage_in(const uint32_t *h_pos, const uint32_t *h_limit, const uint16_t *h_skip, uint32_t *d_pos, uint32_t *d_limit,
                      uint16_t *d_skip, uint32_t n, hipStream_t s);   // page-locked host arrays -> device, small grid
 void launch_window_stats(const uint16_t *mag, uint64_t n, int thr, const uint32_t *class_bitmap, const uint32_t *pos,

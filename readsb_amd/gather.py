@@ -35,6 +35,13 @@ def gather_messages(msgs: np.ndarray, device: torch.device, dst: int = 0):
     return counts, out
 
 
+class _DeviceBytes:
+    """nbytes of device memory at a raw address, as something torch.as_tensor accepts without copying."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
 class MessageGatherer:
     """The same aggregator step without a host round trip and off the critical path.
 
@@ -46,13 +53,18 @@ class MessageGatherer:
     to the host for tests.  Shapes are static (`capacity` records per rank) so nothing in `submit()`
     waits for a count.  Backend-agnostic like gather_messages (`gloo` + CPU tensors in the tests)."""
 
-    def __init__(self, dtype, device: torch.device, capacity: int, dst: int = 0, depth: int = 2):
+    def __init__(self, dtype, device: torch.device, capacity: int, dst: int = 0, depth: int = 2, host_alloc=None):
+        """host_alloc (optional): nbytes -> page-locked uint8 numpy array, e.g. Demodulator.host_alloc, which places the staging
+        buffers on the GPU's NUMA node (torch's own pinned allocator places them where the calling thread happens to run)."""
         self.dtype, self.device, self.capacity, self.dst, self.depth = dtype, device, int(capacity), dst, depth
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         self.rec = dtype.itemsize
         nbytes = self.capacity * self.rec
         cuda = device.type == "cuda"
-        self.host = [torch.empty(nbytes, dtype=torch.uint8, pin_memory=cuda) for _ in range(depth)]
+        if host_alloc is not None and cuda:
+            self.host = [torch.from_numpy(host_alloc(nbytes)) for _ in range(depth)]
+        else:
+            self.host = [torch.empty(nbytes, dtype=torch.uint8, pin_memory=cuda) for _ in range(depth)]
         self.dev = [torch.empty(nbytes, dtype=torch.uint8, device=device) for _ in range(depth)] if cuda else self.host
         self.recv = ([[torch.empty(nbytes, dtype=torch.uint8, device=device) for _ in range(self.world)] for _ in range(depth)]
                      if self.rank == dst else [None] * depth)
@@ -61,6 +73,9 @@ class MessageGatherer:
         self.counts = [[torch.zeros(1, dtype=torch.int64, device=device) for _ in range(self.world)] for _ in range(depth)]
         self.pending = [None] * depth
         self.copied = [torch.cuda.Event() if cuda else None for _ in range(depth)]   # H2D of the slot has read the staging buffer
+        # everything the gatherer enqueues goes on a stream of its own: torch's default stream is the legacy null stream, and
+        # work on it is ordered against the rest of the device's queues by the runtime
+        self.stream = torch.cuda.Stream(device=device) if cuda else None
         self.seq = 0
 
     def staging(self, ahead: int = 0) -> np.ndarray:
@@ -79,9 +94,46 @@ class MessageGatherer:
         k = self.seq % self.depth
         self._wait_slot(k)
         self.cnt_host[k][0] = n
+        with self._on_stream():
+            return self._submit_host(k, n)
+
+    def _on_stream(self):
+        import contextlib
+        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
+    def _submit_host(self, k, n):
         self.cnt[k].copy_(self.cnt_host[k], non_blocking=True)
-        if self.dev is not self.host and n:
+        import os as _os
+        _dbg = _os.environ.get("MGPU_DBG_GATHER", "")
+        if self.dev is not self.host and n and "nocopy" not in _dbg:
             self.dev[k][: n * self.rec].copy_(self.host[k][: n * self.rec], non_blocking=True)
+        if self.copied[k] is not None:
+            self.copied[k].record()
+        if "nocoll" in _dbg:
+            self.pending[k] = ()
+        else:
+            w1 = dist.all_gather(self.counts[k], self.cnt[k], async_op=True)
+            w2 = dist.gather(self.dev[k], self.recv[k], dst=self.dst, async_op=True)
+            self.pending[k] = (w1, w2)
+        self.seq += 1
+        return k
+
+    def submit_device(self, dptr: int, n: int) -> int:
+        """The step's n records already are in this rank's HBM at device address dptr (Demodulator.collect_feed_device): no
+        staging buffer, no upload — one device-to-device copy into the slot's fixed-size gather buffer, then the exchange."""
+        if n > self.capacity:
+            raise ValueError(f"{n} messages exceed the gatherer's capacity of {self.capacity}")
+        k = self.seq % self.depth
+        self._wait_slot(k)
+        self.cnt_host[k][0] = n
+        with self._on_stream():
+            return self._submit_device(k, dptr, n)
+
+    def _submit_device(self, k, dptr, n):
+        self.cnt[k].copy_(self.cnt_host[k], non_blocking=True)
+        if n:
+            src = torch.as_tensor(_DeviceBytes(dptr, n * self.rec), device=self.device)
+            self.dev[k][: n * self.rec].copy_(src, non_blocking=True)
         if self.copied[k] is not None:
             self.copied[k].record()
         w1 = dist.all_gather(self.counts[k], self.cnt[k], async_op=True)
@@ -92,8 +144,9 @@ class MessageGatherer:
 
     def _wait_slot(self, k):
         if self.pending[k] is not None:
-            for w in self.pending[k]:
-                w.wait()                      # (NCCL: orders the current stream after the collective)
+            with self._on_stream():
+                for w in self.pending[k]:
+                    w.wait()                  # (NCCL: orders the current stream — the gatherer's own — after the collective)
             if self.copied[k] is not None:
                 self.copied[k].synchronize()  # the host may overwrite the staging buffer again
             self.pending[k] = None
@@ -104,8 +157,8 @@ class MessageGatherer:
         slots = range(self.depth) if k is None else [k]
         for i in slots:
             self._wait_slot(i)
-        if self.device.type == "cuda":
-            torch.cuda.current_stream(self.device).synchronize()
+        if self.stream is not None:
+            self.stream.synchronize()
         last = (self.seq - 1) % self.depth if k is None else k
         counts = [int(c.item()) for c in self.counts[last]]
         return counts, self.recv[last]

@@ -105,6 +105,10 @@ int mgpu_convert(mgpu_ctx *c, const void *iq_host, uint16_t *mag_host, uint32_t 
     return MGPU_OK;
 }
 int mgpu_host_register(mgpu_ctx *c, void *p, uint64_t bytes) { (void) c; (void) p; (void) bytes; return MGPU_OK; }
+int mgpu_set_device_messages(mgpu_ctx *c, int on) { (void) c; (void) on; return MGPU_E_INVAL; }
+int mgpu_collect_device(mgpu_ctx *c, const struct mgpu_msg **d, uint64_t *n, struct mgpu_counters *k) { (void) c; (void) d; (void) n; (void) k; return MGPU_E_INVAL; }
+void *mgpu_host_alloc(mgpu_ctx *c, uint64_t bytes) { (void) c; return calloc(1, bytes); }
+void mgpu_host_free(mgpu_ctx *c, void *p) { (void) c; free(p); }
 int mgpu_host_unregister(mgpu_ctx *c, void *p) { (void) c; (void) p; return MGPU_OK; }
 int mgpu_demod_mag_buf(mgpu_ctx *c, const uint16_t *data, uint32_t length, int64_t st, int64_t sys, double mp, uint32_t dropped) {
     (void) dropped;

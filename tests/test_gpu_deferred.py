@@ -80,3 +80,51 @@ def test_deferred_mode_refuses_the_other_entries(built):
     with pytest.raises(readsb_amd.MgpuError):                   # a fifth uncollected feed
         d.feed_iq(iq)
     d.close()
+
+
+def test_device_messages_equal_host_messages(built, monkeypatch):
+    """mgpu_set_device_messages: the records k_build_messages leaves in HBM, feed by feed, are byte for byte the records the
+    host builder writes (and therefore the oracle's messages); the field decoder and the beast encoder take them where they are."""
+    import readsb_amd
+    monkeypatch.setenv("MGPU_CHUNK_BUFFERS", "16")
+    sizes = [48 * B, 40 * B, 19 * B + 999]
+    iq = helpers.synth(nsamples=sum(sizes), seed=1234, rate=3500.0)
+    want, wst = helpers.oracle_run(iq, 0, 2, 1, 58)
+    blocks = _blocks(iq, sizes)
+    host = []
+    d = readsb_amd.Demodulator(nfix_crc=2, startup_time_ms=helpers.STARTUP_MS, max_samples=64 * B)
+    d.set_deferred(True)
+    buf = np.empty(300000, dtype=readsb_amd.MSG_DTYPE)
+    for blk in blocks:
+        d.feed_iq(blk)
+        m, _ = d.collect_feed(buf)
+        host.append(m.copy())
+    d.set_deferred(False)
+    d.close()
+
+    d = readsb_amd.Demodulator(nfix_crc=2, startup_time_ms=helpers.STARTUP_MS, max_samples=64 * B)
+    d.set_deferred(True)
+    d.set_device_messages(True)
+    got = []
+    d.feed_iq(blocks[0])
+    for k in range(1, len(blocks)):
+        d.feed_iq(blocks[k])
+        ptr, n, _ = d.collect_feed_device()
+        assert n == len(host[k - 1]) and ptr
+        got.append((ptr, n))
+    # the last feed through the copying entry, with the settled counters
+    m, cnt = d.collect_feed(buf, want_counters=True)
+    assert m.tobytes() == host[-1].tobytes()
+    # the device lists of the earlier feeds are still valid (three more feeds may start before they are reused)
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    for (ptr, n), h in zip(got, host):
+        dev = np.empty(n, dtype=readsb_amd.MSG_DTYPE)
+        assert hip.hipMemcpy(dev.ctypes.data, ptr, n * 64, 2) == 0          # hipMemcpyDeviceToHost
+        assert dev.tobytes() == h.tobytes()
+    d.finish()
+    _, cnt = d.collect_feed(buf, want_counters=True)
+    helpers.assert_same_messages(np.concatenate(host), want)
+    helpers.assert_same_counters(cnt, wst)
+    d.close()

@@ -15,6 +15,12 @@ Prints ONE JSON line (rank 0): metric/value/unit as BASELINE.json, plus
   cpu_baseline — the reference's own C files (oracle/_ref) timed on this host on the same stream,
                  whose message list must be bit-identical to the GPU's (checked in the same run).
 """
+import os
+# The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  With torch's and RCCL's
+# streams in the process too, the library's main stream and its second stream (window statistics, device message build) ended up
+# on ONE queue and ran back to back: 429 us per chunk instead of 343 (profiles/r02_queue_sharing.txt).  Must be set before HIP starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import argparse
 import ctypes as C
 import json

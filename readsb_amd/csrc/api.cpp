@@ -1676,6 +1676,16 @@ int mgpu_set_device_messages(mgpu_ctx *c, int on) {
     if (rc != MGPU_OK) return rc;
     if (c->feed_head != c->feed_tail) { c->err = "mgpu_set_device_messages: collect the pending feeds first"; return MGPU_E_INVAL; }
     if (on && (!c->deferred || c->cfg.mode_ac)) { c->err = "mgpu_set_device_messages: needs deferred feeds, and no Mode A/C (its replies are merged on the host)"; return MGPU_E_INVAL; }
+    if (on) {                                        // the four feeds' device lists now, not inside somebody's timed region
+        HIPCHK(c, hipSetDevice(c->cfg.device));
+        const uint64_t want = c->cap_samples / 64 + 65536;
+        for (auto &fs : c->feed) {
+            if (fs.d_msgs) continue;
+            HIPCHK(c, hipMalloc(&fs.d_msgs, want * sizeof(mgpu_msg)));
+            HIPCHK(c, hipEventCreateWithFlags(&fs.ev_built, hipEventDisableTiming));
+            fs.d_cap = want;
+        }
+    }
     c->device_msgs = on != 0;
     return MGPU_OK;
 }

@@ -586,7 +586,7 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
     HIPCHK(c, hipMemsetAsync(sl.d_class_uncond, 0, sl.class_bytes, c->stream));
     HIPCHK(c, hipMalloc(&sl.d_cand, (c->cap_units * (size_t) kUnit + 64) * sizeof(uint16_t)));
     HIPCHK(c, hipMalloc(&sl.d_cand_count, (c->cap_units * (size_t) (kUnit / kSweepTile) + 1) * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc(&sl.d_sweep_part, (size_t) kSweepGridMax * 4 * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(&sl.d_sweep_part, ((size_t) kSweepGridMax * 4 + (size_t) kFinMaxBlocks * 2) * sizeof(uint32_t)));
     {
         const size_t nb = c->cap_buffers, words = CNT_NUM + 1 + 4 * nb + kAcLists;   // ... + Mode A/C list counters
         sl.scratch_bytes = words * sizeof(unsigned long long);
@@ -940,6 +940,7 @@ static int enqueue_post(mgpu_ctx *c, Slot &sl) {
     // the count pass leaves its decisions as masks in the segment headers (one scoring pass = one segment of at most 64
     // records), so the write pass does not look at the adder bitmap again
     q.keep_masks = true;
+    q.fin_part = sl.d_sweep_part + (size_t) kSweepGridMax * 4;
     if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[6], s));
     if (launch_prescreen(q, s, s, sl.ev_scan) != 0) { c->err = "event ordering of the pre-screen passes failed"; return MGPU_E_HIP; }
     HIPCHK(c, hipEventRecord(sl.ev[3], s));

@@ -33,6 +33,7 @@ constexpr int kBlock = 256;
 constexpr int kSweepTile = 2048;          // k_sweep / k_slice: positions per wave tile = per candidate list
 constexpr int kSweepMaxBlocks = 256 * 4;  // resident workgroups of k_slice (at most 4 per CU)
 constexpr int kSweepGridMax = 256 * 8;    // resident workgroups of k_sweep (at most 8 per CU) = rows of sweep_part
+constexpr int kFinMaxBlocks = 1024;       // class-plane finalize workgroups (k_count_finalize)
 constexpr int kPoolChunkRecords = 256;    // pool records a wave reserves per returning atomic
 constexpr int kSweepMaxWaves = kSweepMaxBlocks * (kBlock / 64);
 constexpr int kBatch = 64;              // candidates sliced per batch (4 waves x 16)
@@ -156,7 +157,8 @@ struct PostSweepParams {
     uint64_t class_words;
     unsigned long long *d_scratch, *h_scratch;
     uint32_t scratch_words;
-    bool keep_masks;                      // generation 3 only (segments of <= 64 records)
+    bool keep_masks;                      // segments of <= 64 records: the count pass leaves its decisions in the headers
+    uint32_t *fin_part;                   // [kFinMaxBlocks][2] class counts per finalize workgroup, summed by the write pass
 };
 int launch_prescreen(const PostSweepParams &q, hipStream_t s, hipStream_t s_write, hipEvent_t ev_scan);
 // ---- Mode A/C (demodulate2400AC, demod_2400.c:575-761), only when mgpu_config.mode_ac is set ----

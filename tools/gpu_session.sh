@@ -3,9 +3,11 @@ tag=${1:-s1}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
-p() { python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['stage_ms']['resolve_host'], d['stage_ms']['build_host'])"; }
-for i in 1 2 3; do
-echo "== gather device msgs $i"; MASTER_ADDR=127.0.0.1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 2954$i bench.py --gpus 1 --steps 20 --warmup 3 --exercise-gather --no-cpu-baseline 2>/dev/null | tail -1 | p
-echo "== gather host msgs $i"; MGPU_DBG_HOST_MESSAGES=1 MASTER_ADDR=127.0.0.1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 2955$i bench.py --gpus 1 --steps 20 --warmup 3 --exercise-gather --no-cpu-baseline 2>/dev/null | tail -1 | p
-done
+p() { python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['stage_ms'])"; }
+timeout 400 python tools/dev_check.py > $out/dev_check.log 2>&1; echo "dev_check rc=$?"; grep -c "^OK" $out/dev_check.log; grep -v "^OK" $out/dev_check.log | head -5
+timeout 900 python -m pytest tests/test_gpu_pipeline_chain.py tests/test_gpu_parity.py tests/test_gpu_formats.py tests/test_gpu_large.py tests/test_gpu_golden.py tests/test_gpu_deferred.py -x -q --timeout 300 > $out/pytest_sel.log 2>&1; tail -4 $out/pytest_sel.log
 echo "== plain"; timeout 400 python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 | p
+echo "== plain"; timeout 400 python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 | p
+R=$(pwd); cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/stats -o bench -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $R/$out/bench_under_rocprof.log 2>&1
+cd $R; cut -c1-100 $out/stats/bench_kernel_stats.csv | head -14

@@ -165,6 +165,7 @@ struct Slot {
     uint32_t *d_ac_noise = nullptr;       // Mode A/C: per-buffer noise level
     AcCand *h_ac = nullptr;               // ... candidates, written by k_modeac straight into pinned host memory
     hipEvent_t ev_h2d = nullptr;          // the chunk's IQ samples have arrived in HBM (copy stream)
+    hipEvent_t ev_swept = nullptr;        // this chunk's k_sweep has run: the fetcher starts the PREVIOUS chunk's record copies then
     hipEvent_t ev_scan = nullptr;         // pre-screen offsets are final (main stream) -> the write pass may start (second stream)
     // the job
     uint64_t n = 0, stream_pos = 0;
@@ -284,6 +285,7 @@ struct mgpu_ctx {
     uint64_t feed_head = 0, feed_tail = 0;                    // oldest uncollected feed, next feed to open
     bool deferred = false;
     bool device_msgs = false;                                 // mgpu_set_device_messages
+    bool copy_after_sweep = false;                            // MGPU_COPY_AFTER_SWEEP=1: the fetcher holds its copies back until the next chunk's k_sweep has run
     bool fused_convert = false;                               // MGPU_FUSED_CONVERT=1: UC8 conversion inside k_sweep's tile load (same speed, see kernels/sweep.inc)
     int timing_every = 4;                                     // MGPU_TIMING_EVERY: chunks per set of stage timing events (1 = every chunk)
     uint64_t timing_seq = 0;
@@ -361,7 +363,7 @@ static void stage_wait(mgpu_ctx *c, std::unique_lock<std::mutex> &lk, Pred pred)
     }
 }
 
-static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job);
+static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next);
 static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job);
 static int build_job(mgpu_ctx *c, HostJob &job);
 static void fetcher_main(mgpu_ctx *c);
@@ -621,6 +623,7 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
     HIPCHK(c, hipHostMalloc(&sl.h_live_sig, c->cap_pool * sizeof(unsigned long long)));
     HIPCHK(c, hipEventCreateWithFlags(&sl.ev_window, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&sl.ev_scan, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&sl.ev_swept, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming));
     HIPCHK(c, hipHostMalloc(&sl.h_win, 8 * sizeof(unsigned long long)));
     HIPCHK(c, hipHostMalloc(&sl.h_sig, c->cap_msgs * sizeof(unsigned long long)));
@@ -646,6 +649,7 @@ static void free_slot(Slot &sl) {
         if (p) (void) hipFree(p);
     if (sl.ev_window) (void) hipEventDestroy(sl.ev_window);
     if (sl.ev_scan) (void) hipEventDestroy(sl.ev_scan);
+    if (sl.ev_swept) (void) hipEventDestroy(sl.ev_swept);
     if (sl.d_ac_noise) (void) hipFree(sl.d_ac_noise);
     if (sl.h_ac) (void) hipHostFree(sl.h_ac);
     if (sl.ev_h2d) (void) hipEventDestroy(sl.ev_h2d);
@@ -756,6 +760,7 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     c->dbg_print = getenv("MGPU_DEBUG_PRINT") != nullptr;
     c->dbg_no_window = getenv("MGPU_DEBUG_NO_WINDOW") != nullptr;
     if (const char *e = getenv("MGPU_DEBUG_STAGE")) c->dbg_stage = atoi(e);
+    if (const char *e = getenv("MGPU_COPY_AFTER_SWEEP")) c->copy_after_sweep = atoi(e) != 0;
     if (const char *e = getenv("MGPU_FUSED_CONVERT")) c->fused_convert = atoi(e) != 0;
     if (const char *e = getenv("MGPU_TIMING_EVERY")) { const int v = atoi(e); if (v >= 1) c->timing_every = v; }
     if (const char *e = getenv("MGPU_DUMP_DIR")) c->dump_dir = e;
@@ -919,6 +924,7 @@ static int enqueue_sweep(mgpu_ctx *c, Slot &sl) {
     {
         sp.sweep_blocks = launch_sweep(sp, s);
         if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[4], s));
+        if (c->copy_after_sweep) HIPCHK(c, hipEventRecord(sl.ev_swept, s));
         launch_slice(sp, s);
     }
     if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[2], s));
@@ -956,7 +962,7 @@ static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
 }
 
 // ---- host half of a chunk, part 1 (fetcher thread): wait for the GPU, copy the live records out of pinned memory ----
-static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job) {
+static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
     HIPCHK(c, hipEventSynchronize(sl.ev[3]));
     const double t_gpu_done = wall_ms();
     if (c->dbg_print) {
@@ -983,6 +989,11 @@ static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job) {
     // chunk's kernels keep running), then into ordinary memory: page-locked memory the device wrote is slow for the walk's
     // small scattered reads (4x slower walk) but streams at tens of GB/s (0.1 ms for 70 k records)
     if (nlive > c->cap_pool) { c->err = "live record count beyond the pool"; return MGPU_E_OVERFLOW; }
+    // The copies run as blit kernels (the runtime's choice on this box, whatever HSA_ENABLE_SDMA / GPU_FORCE_BLIT_COPY_SIZE say)
+    // and cost whatever is on the main stream meanwhile ~25 us: the converter takes 78 us instead of 52, or — with
+    // MGPU_COPY_AFTER_SWEEP=1, held back until the next chunk's converter and k_sweep are through — k_slice 140 instead of 114.
+    // The same either way (2.23 vs 2.27 ms per step), so: at once.
+    if (nlive && next && c->copy_after_sweep) HIPCHK(c, hipEventSynchronize(next->ev_swept));
     if (nlive) {
         // (a copy kernel of our own with 8..32 workgroups in place of the runtime's blit kernel: 2.55-2.63 ms per step instead of 2.45)
         HIPCHK(c, hipMemcpyAsync(sl.h_live, sl.d_live, nlive * sizeof(PhaseRec), hipMemcpyDeviceToHost, c->stream_d2h));
@@ -1296,12 +1307,13 @@ static int guarded(mgpu_ctx *c, const std::function<int()> &f) {
 static void fetcher_main(mgpu_ctx *c) {
     (void) hipSetDevice(c->cfg.device);
     for (;;) {
-        int idx, jidx;
+        int idx, jidx, next_idx = -1;
         {
             std::unique_lock<std::mutex> lk(c->mu);
             stage_wait(c, lk, [&] { return c->stop || !c->queue.empty(); });
             if (c->queue.empty()) return;   // stop requested and nothing left
             idx = c->queue.front();
+            next_idx = c->queue.size() >= 2 ? c->queue[1] : -1;
             jidx = (int) (c->job_seq++ % 4);
             stage_wait(c, lk, [&] { return !c->job[jidx].busy; });
             c->job[jidx].busy = true;
@@ -1310,7 +1322,7 @@ static void fetcher_main(mgpu_ctx *c) {
         HostJob &job = c->job[jidx];
         job.slot = idx;
         job.feed = sl.feed;
-        int rc = c->worker_rc == MGPU_OK ? guarded(c, [&] { return fetch_slot(c, sl, job); }) : c->worker_rc;   // after an error just drain
+        int rc = c->worker_rc == MGPU_OK ? guarded(c, [&] { return fetch_slot(c, sl, job, next_idx >= 0 ? &c->slot[next_idx] : nullptr); }) : c->worker_rc;   // after an error just drain
         if (rc == MGPU_OK && c->shard_mode == 2) {           // the chunk's records become a packet: header, records, signal powers
             const uint64_t hdr[4] = {job.stream_pos, sl.n, job.nlive, 0};
             const uint8_t *h8 = (const uint8_t *) hdr;

@@ -341,17 +341,19 @@ def main():
         gpu_msgs = np.concatenate([g0, g1])
         d.set_deferred(False)
         iq2 = np.concatenate([iq[: n * 2], iq[: n * 2]])
-        pin = None
+        saved_affinity = None
         try:                                                    # a core of its own, off the pipeline's cores and their siblings
-            free = sorted(os.sched_getaffinity(0))
-            pin = free[(7 + 2 * local_rank) % len(free)]
-            os.sched_setaffinity(0, {pin})
+            saved_affinity = os.sched_getaffinity(0)
+            free = sorted(saved_affinity)
+            os.sched_setaffinity(0, {free[(7 + 2 * local_rank) % len(free)]})
         except (OSError, AttributeError, ZeroDivisionError):
-            pin = None
+            saved_affinity = None
         if use_dist:
             dist.barrier()                                      # the N reference processes run at the same time
         kind, ref_msgs, st = cpu_reference(iq2, 2 * n)
         del iq2
+        if saved_affinity:
+            os.sched_setaffinity(0, saved_affinity)            # (threads created from here on inherit it)
         cpu_s = float(st["t_convert_s"] + st["t_demod_s"])
         helpers.assert_same_messages(gpu_msgs, ref_msgs)        # bit-identical decoded message set, same run
         helpers.assert_same_counters(vcnt, st)
@@ -385,8 +387,8 @@ def main():
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_hbm.json")))
             if per_launch == 134217728:
-                traffic = round(next(v for k, v in pm.items() if k.startswith("mgpu::k_sweep"))["hbm_bytes"])
-                traffic_slice = round(pm["mgpu::k_slice"]["hbm_bytes"])
+                traffic = round(next(v for k, v in pm.items() if "mgpu::k_sweep" in k)["hbm_bytes"])
+                traffic_slice = round(next(v for k, v in pm.items() if "mgpu::k_slice" in k)["hbm_bytes"])
         except Exception:
             pass
         out = {

@@ -159,6 +159,73 @@ def run_extra_config(name, fmt, nfix, kw, nsamples, device, steps=4):
     return out
 
 
+def bench_config5(args, rank, local_rank, world):
+    """BASELINE configs[4]: ONE dense-burst capture (overlapping 112-bit DF17 frames, --aggressive) time-chunked by whole buffers
+    over the ranks (readsb_amd/shard.py): every rank sweeps its range for its adder bitmap, the bitmaps are OR-ed over the ranks
+    (2 MiB all_gather), every rank sweeps / slices / pre-screens its range against the global bitmap, the surviving records go to
+    rank 0 (gather), which runs the ordered walk and builds the messages — the unsharded message list, bit for bit.  Strong
+    scaling: the capture is fixed, a step = the whole capture once; every rank's range is resident in its HBM."""
+    import torch
+    import torch.distributed as dist
+    import helpers
+    import readsb_amd
+    from readsb_amd.shard import demodulate_sharded, shard_ranges
+    dev = 0 if args.dryrun_gloo else local_rank
+    torch.cuda.set_device(dev)
+    coll = torch.device("cpu") if args.dryrun_gloo else torch.device("cuda", local_rank)
+    if not dist.is_initialized():
+        if args.dryrun_gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    helpers.ensure_built()
+    n = args.samples - args.samples % BUF
+    iq = helpers.synth(nsamples=n, seed=5150, rate=8000.0, dense=1, threads=min(64, max(1, (os.cpu_count() or 8) // world)))
+    first, last = shard_ranges(n, world)[rank]
+    chunk = min(512 * BUF, max(BUF, last - first))
+    d = readsb_amd.Demodulator(nfix_crc=2, max_samples=max(chunk, last - first + BUF), device=dev, startup_time_ms=helpers.STARTUP_MS)
+    lo = max(0, first - 326)
+    d.upload_iq(iq[lo * 2:last * 2])
+    resident = (lo, d.device_iq_buffer())
+    d.keep_other_threads_away(confine_to_own_l3=world > 1)
+    res = None
+    for _ in range(max(1, args.warmup)):
+        res = demodulate_sharded(d, iq, coll, resident=resident)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = demodulate_sharded(d, iq, coll, resident=resident)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=coll)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    if rank == 0:
+        msgs, counters = res
+        out = {"metric": "IQ Msamples/s demodulated, one dense-burst UC8 capture time-chunked over the GPUs (--aggressive), whole job",
+               "value": round(n * args.steps / elapsed / 1e6, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "u16", "data": "synthetic",
+               "config": {"workload": f"configs[4]: one {n / 2.4e6:.1f} s dense-burst UC8 capture ({n} samples, 8000 overlapping DF17 frames/s, --aggressive) "
+                                      f"time-chunked by whole buffers over {world} GPU(s), each range resident in its GPU's HBM; adder-bitmap all_gather, "
+                                      "record packets gathered on rank 0, ordered walk there",
+                          "samples": n, "shards": world, "parallelism": f"time-chunked x{world}"},
+               "messages_per_step": int(len(msgs))}
+        if not args.no_cpu_baseline:
+            kind, ref_msgs, st = cpu_reference(iq, n, 0, 2, 1, 58)
+            helpers.assert_same_messages(msgs, ref_msgs)      # (the shards' sweep-side demod counters are not merged: messages only)
+            for f in ("demod_accepted", "demod_bestPhase", "samples_processed", "nbuffers", "nflips"):
+                assert (np.asarray(counters[f], dtype=np.uint64) == np.asarray(st[f], dtype=np.uint64)).all(), f
+            cpu_s = float(st["t_convert_s"] + st["t_demod_s"])
+            out["cpu_baseline"] = {"value": round(n / cpu_s / 1e6, 1), "unit": "Msamples/s", "cores": 1, "kind": kind,
+                                   "sample": f"the whole capture ({n} samples) on one host core", "messages": int(len(ref_msgs)),
+                                   "bit_identical_to_gpu": True}
+        print(json.dumps(out))
+    d.close()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -166,6 +233,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--samples", type=int, default=4096 * BUF, help="samples per stream per step (multiple of 131072)")
     ap.add_argument("--msgs-per-sec", type=float, default=2000.0)
+    ap.add_argument("--config", type=int, default=1, help="1 (default): one stream per GPU (BASELINE configs[1] / configs[3]); 5: one dense-burst "
+                                                          "capture time-chunked over the GPUs (configs[4], strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the `configs` dict (other BASELINE configurations / input statistics)")
     ap.add_argument("--extra-samples", type=int, default=2048 * BUF, help="samples per segment of the extra configurations")
@@ -186,6 +255,8 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libmodes_gpu has no CPU path")
+    if args.config == 5:
+        return bench_config5(args, rank, local_rank, world)
     if args.dryrun_gloo:
         local_rank_dev, coll_dev = 0, torch.device("cpu")
     else:

@@ -46,3 +46,17 @@ def test_bench_multi_rank_path_dry_run(built):
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["streams"] == 2
     assert d["cpu_baseline"]["cores"] == 2 and d["cpu_baseline"]["bit_identical_to_gpu"] and len(d["cpu_baseline"]["per_stream_msamples_s"]) == 2
+
+
+def test_bench_config5_two_shards_dry_run(built):
+    """bench.py --config 5 (one dense-burst capture time-chunked over the ranks, strong scaling) with two ranks sharing the one GPU
+    (gloo, CPU tensors): bitmap exchange, record packets to rank 0, ordered walk there — and the in-run check against the reference."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29519", os.path.join(helpers.ROOT, "bench.py"), "--gpus", "2", "--config", "5", "--steps", "2",
+                        "--warmup", "1", "--samples", str(96 * 131072), "--dryrun-gloo"], capture_output=True, text=True, timeout=600, env=env,
+                       cwd=helpers.ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["shards"] == 2
+    assert d["cpu_baseline"]["bit_identical_to_gpu"] and d["messages_per_step"] == d["cpu_baseline"]["messages"] > 1000

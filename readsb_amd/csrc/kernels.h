@@ -30,7 +30,13 @@ constexpr int kUnit = kTile * kTilesPerUnit;   // positions per unit (one record
 constexpr int kWaveTile = 2048;         // k_sweep_slice: positions per wave-private LDS tile
 constexpr int kTile2 = 4096;            // k_sweep_slice: positions per LDS tile
 constexpr int kBlock = 256;
-constexpr int kSweepTile = 2048;          // k_sweep / k_slice: positions per wave tile = per candidate list
+#ifndef MGPU_SWEEP_TILE
+#define MGPU_SWEEP_TILE 2048
+#endif
+// k_sweep: positions per wave tile = per candidate list; k_slice's tiles are 2048 = one or two lists.  -DMGPU_SWEEP_TILE=1024 gives
+// k_sweep 8 waves/SIMD (56 VGPRs, 17 KB of LDS per workgroup) and 8 tiles per wave exactly — measured: 39.6 us against 39.4,
+// nothing; neither occupancy nor the uneven last round of the grid is what holds the sweep at 42 % of the HBM peak.
+constexpr int kSweepTile = MGPU_SWEEP_TILE;
 constexpr int kSweepMaxBlocks = 256 * 4;  // resident workgroups of k_slice (at most 4 per CU)
 constexpr int kSweepGridMax = 256 * 8;    // resident workgroups of k_sweep (at most 8 per CU) = rows of sweep_part
 constexpr int kFinMaxBlocks = 1024;       // class-plane finalize workgroups (k_count_finalize)

@@ -251,7 +251,8 @@ int mgpu_last_timing(mgpu_ctx *ctx, struct mgpu_timing *t);
 
 /* iq_convert_fn (convert.h:34-39) for the non-DC-filter converters convert_uc8_nodc,
  * convert_sc16_nodc, convert_sc16q11_nodc (convert.c:64,212,329): nsamples IQ samples in
- * host memory -> nsamples u16 magnitudes in host memory; out_mean_* may be NULL. */
+ * host memory -> nsamples u16 magnitudes in host memory; out_mean_* may be NULL.  Not in the middle of a stream fed through
+ * mgpu_feed_iq* on the same context (MGPU_E_INVAL: it would overwrite the stream's 326-sample tail): one context per role. */
 int mgpu_convert(mgpu_ctx *ctx, const void *iq_host, uint16_t *mag_host, uint32_t nsamples,
                  double *out_mean_level, double *out_mean_power);
 

@@ -970,6 +970,36 @@ static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
         fprintf(stderr, "dbg: k_slice wave cycles: stage %llu expand %llu df %llu slice %llu score %llu total %llu | df batches %llu rounds %llu sumI %llu frames %llu lanes %llu passes %llu scored %llu\n",
                 h[16], h[17], h[18], h[19], h[20], h[21], h[24], h[25], h[26], h[27], h[28], h[29], h[30]);
     }
+#if MGPU_KERNEL_TIMERS
+    if (c->dbg_print) {                       // k_sweep's per-wave lifetimes (kernels/sweep.inc), first 8192 waves
+        std::vector<uint16_t> h((size_t) 8192 * kSweepTile);
+        if (hipMemcpy(h.data(), sl.d_cand, h.size() * sizeof(uint16_t), hipMemcpyDeviceToHost) == hipSuccess) {
+            std::vector<double> st, en;
+            unsigned long long tmin = ~0ull;
+            for (size_t w = 0; w < 8192; ++w) {
+                unsigned long long d[4];
+                std::memcpy(d, h.data() + w * kSweepTile + kSweepTile / 2, sizeof(d));
+                if (d[3] != 0x54494d45ull) continue;
+                if (d[0] < tmin) tmin = d[0];
+            }
+            size_t nw = 0; double sum_life = 0, max_end = 0, max_start = 0; unsigned long long tiles = 0;
+            std::vector<double> ends;
+            for (size_t w = 0; w < 8192; ++w) {
+                unsigned long long d[4];
+                std::memcpy(d, h.data() + w * kSweepTile + kSweepTile / 2, sizeof(d));
+                if (d[3] != 0x54494d45ull) continue;
+                const double s0 = (double) (d[0] - tmin) / 100.0, e0 = (double) (d[1] - tmin) / 100.0;   // us
+                ++nw; sum_life += e0 - s0; tiles += d[2];
+                if (e0 > max_end) max_end = e0;
+                if (s0 > max_start) max_start = s0;
+                ends.push_back(e0);
+            }
+            std::sort(ends.begin(), ends.end());
+            if (nw) fprintf(stderr, "dbg: k_sweep waves %zu, tiles %llu: mean life %.1f us, last start %.1f us, end p10 %.1f p50 %.1f p90 %.1f max %.1f us\n", nw, tiles,
+                            sum_life / nw, max_start, ends[nw / 10], ends[nw / 2], ends[nw * 9 / 10], max_end);
+        }
+    }
+#endif
     if (sl.h_counters[CNT_POOL_OVERFLOW]) {
         c->err = "record pool overflow: recreate the context with a larger record_pool_records";
         return MGPU_E_OVERFLOW;
@@ -1759,6 +1789,11 @@ int mgpu_convert(mgpu_ctx *c, const void *iq_host, uint16_t *mag_host, uint32_t 
     if (!c || !iq_host || !mag_host) return MGPU_E_INVAL;
     if (n > c->cap_samples || n > 0x7fffffffu) return MGPU_E_CAPACITY;
     { const int drc = drain(c); if (drc != MGPU_OK) return drc; }
+    if (c->stream_pos != 0 && !c->eof) {
+        // the converter borrows slot 0's magnitude buffer, which may hold the 326-sample tail the stream's next feed starts from
+        c->err = "mgpu_convert: the context is in the middle of a stream (one context per role, or mgpu_reset first)";
+        return MGPU_E_INVAL;
+    }
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const size_t bps = c->cfg.format == MGPU_FMT_UC8 ? 2 : 4;
     hipStream_t s = c->stream;

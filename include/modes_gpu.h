@@ -436,6 +436,13 @@ const uint16_t *mgpu_uc8_table(void);
 int mgpu_selftest_walk(uint64_t seed, uint32_t nchunks, uint32_t buffers_per_chunk, uint32_t nsegments,
                        uint32_t naircraft, uint32_t *speculated_permille);
 
+/* The ordered walk on the device (environment MGPU_DEVICE_WALK=1, or =check to run it beside the host walk and compare every
+ * decision): out[0] chunks, [1] chunks whose decisions came from the device (check: were compared), [2] chunks the fixed point
+ * did not settle on in time, [3] chunks whose premises failed afterwards (the filter table grew, the expiry moved), [4] chunks
+ * the walk does not model, [5] walks run in all, [6] differences found (check mode; must be 0), [7] reserved.
+ * [2]-[4] are walked on the host. */
+int mgpu_debug_device_walk(mgpu_ctx *ctx, uint64_t out[8]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -158,6 +158,7 @@ def load_library():
     lib.mgpu_walk_packets.argtypes = [vp, vp, u64]
     lib.mgpu_pending_messages.restype = u64
     lib.mgpu_last_timing.argtypes = [vp, C.POINTER(Timing)]
+    lib.mgpu_debug_device_walk.argtypes = [vp, C.POINTER(u64)]
     lib.mgpu_convert.argtypes = [vp, vp, vp, u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.mgpu_demod_mag_buf.argtypes = [vp, vp, u32, i64, i64, C.c_double, u32]
     lib.mgpu_demod_mag_buf_ac.argtypes = [vp, vp, u32, i64, i64, C.c_double, C.c_double, u32]
@@ -424,6 +425,13 @@ class Demodulator:
         self._chk(self.lib.mgpu_collect(self.ctx, out.ctypes.data, out.size, C.byref(got), C.byref(cnt) if cnt is not None else None),
                   "mgpu_collect")
         return out[: got.value], (cnt.as_dict() if cnt is not None else None)
+
+    def device_walk_stats(self):
+        """mgpu_debug_device_walk: what the walk on the device (MGPU_DEVICE_WALK) did so far."""
+        out = (C.c_uint64 * 8)()
+        self._chk(self.lib.mgpu_debug_device_walk(self.ctx, out), "mgpu_debug_device_walk")
+        keys = ("chunks", "device", "unsettled", "premises_failed", "not_modelled", "walks", "differences")
+        return dict(zip(keys, [int(v) for v in out]))
 
     def timing(self):
         t = Timing()

@@ -316,6 +316,18 @@ struct mgpu_ctx {
     uint8_t *d_beast_in = nullptr, *d_beast_out = nullptr;
     unsigned long long *d_beast_off = nullptr;
     int device_slot = -1;                                     // which of the device's pipeline core groups this context pinned to
+    // the ordered walk on the device (kernels/walk.inc).  MGPU_DEVICE_WALK=1: the walker thread only checks the walk's premises
+    // and catches the filter up (Resolver::apply_device_walk), the chunk's records stay in HBM; =check: beside the host walk,
+    // every decision compared (mgpu_debug_device_walk)
+    int device_walk = 0;                                      // 0 off, 1 on, 2 check
+    WalkBuffers wk{};
+    uint8_t *h_wk_in = nullptr, *d_wk_in = nullptr, *h_wk_sum = nullptr;
+    size_t wk_in_cap = 0;
+    void *d_wk_acc = nullptr;
+    uint32_t wk_acc_cap = 0;                                  // accepted frames per buffer the walk has room for
+    hipEvent_t ev_wk = nullptr;
+    Resolver wk_shadow;                                       // check mode: the state before the host walk, for apply_device_walk
+    uint64_t wk_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};          // chunks, taken from the device, not converged, premises failed (host walk), refused, walks, mismatches, -
     mgpu_fields *d_fields = nullptr;
     uint64_t fields_cap = 0;
     double *d_roll_tan = nullptr;                             // tables.h build_roll_tangent_table(), uploaded on first use
@@ -694,6 +706,38 @@ static int alloc_all(mgpu_ctx *c) {
         if (rc != MGPU_OK) return rc;
     }
 
+    if (c->device_walk) {
+        WalkBuffers &w = c->wk;
+        const size_t nb = c->cap_buffers + 1;
+        c->wk_acc_cap = cfg.buf_samples / 112 + 16;          // an accepted frame hides the next 112 positions at least
+        HIPCHK(c, hipMalloc(&w.bit_active, (1u << 24) / 8));
+        HIPCHK(c, hipMalloc(&w.bit_inactive, (1u << 24) / 8));
+        HIPCHK(c, hipMemsetAsync(w.bit_active, 0, (1u << 24) / 8, c->stream));
+        HIPCHK(c, hipMemsetAsync(w.bit_inactive, 0, (1u << 24) / 8, c->stream));
+        for (int t = 0; t < 2; ++t) {
+            HIPCHK(c, hipMalloc(&w.first[t], sizeof(uint32_t) << 24));
+            HIPCHK(c, hipMemsetAsync(w.first[t], 0xff, sizeof(uint32_t) << 24, c->stream));
+            HIPCHK(c, hipMalloc(&w.touched[t], kWkTouchedCap * sizeof(uint32_t)));
+        }
+        HIPCHK(c, hipMalloc(&w.state, sizeof(WalkState)));
+        HIPCHK(c, hipMemsetAsync(w.state, 0, sizeof(WalkState), c->stream));
+        HIPCHK(c, hipMalloc(&w.rec_lo, nb * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(&w.nacc, nb * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(&w.nadds, nb * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(&w.counts, nb * kWkCounts * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(&w.end_clock, nb * sizeof(long long)));
+        HIPCHK(c, hipMalloc(&w.acc, nb * c->wk_acc_cap * 2 * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(&w.adds, nb * c->wk_acc_cap * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(&w.offs, nb * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(&w.aoffs, nb * sizeof(uint32_t)));
+        c->wk_in_cap = walk_input_bytes((uint32_t) c->cap_buffers, 1u << 17, 1u << 17);
+        HIPCHK(c, hipHostMalloc(&c->h_wk_in, c->wk_in_cap));
+        HIPCHK(c, hipMalloc(&c->d_wk_in, c->wk_in_cap));
+        HIPCHK(c, hipHostMalloc(&c->h_wk_sum, walk_summary_bytes((uint32_t) c->cap_buffers, c->wk_acc_cap)));
+        HIPCHK(c, hipMalloc(&c->d_wk_acc, c->cap_msgs * 12));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_wk, hipEventDisableTiming));
+    }
+
     // constant tables
     const CrcTables &crc = crc_tables();
     HIPCHK(c, hipMalloc(&c->d_bit_syndrome, 112 * sizeof(uint32_t)));
@@ -746,6 +790,7 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     c->valid_long = (1u << 16) | (1u << 17) | (1u << 18) | (1u << 20) | (1u << 21);
     if (cfg->fixDF && cfg->nfix_crc)
         for (int b = 0; b < 5; ++b) c->valid_long |= 1u << (17 ^ (1 << b));
+    if (const char *e = getenv("MGPU_DEVICE_WALK")) c->device_walk = !strcmp(e, "check") ? 2 : atoi(e) != 0;
     int rc;
     {
         NearDevice near(cfg->device);
@@ -807,6 +852,16 @@ void mgpu_destroy(mgpu_ctx *c) {
         if (f.ev_built) (void) hipEventDestroy(f.ev_built);
     }
     if (c->h_win) (void) hipHostFree(c->h_win);
+    if (c->h_wk_in) (void) hipHostFree(c->h_wk_in);
+    if (c->h_wk_sum) (void) hipHostFree(c->h_wk_sum);
+    if (c->ev_wk) (void) hipEventDestroy(c->ev_wk);
+    {
+        const WalkBuffers &w = c->wk;
+        void *wkp[] = {w.bit_active, w.bit_inactive, w.first[0], w.first[1], w.touched[0], w.touched[1], w.state, w.rec_lo, w.nacc, w.nadds, w.counts,
+                       w.end_clock, w.acc, w.adds, w.offs, w.aoffs, c->d_wk_in, c->d_wk_acc};
+        for (void *p : wkp)
+            if (p) (void) hipFree(p);
+    }
     void *dev[] = {c->d_roll_tan, c->d_fields, c->d_beast_off, c->d_beast_len, c->d_beast_in, c->d_beast_out, c->d_beast_blocks, c->d_beast_total, c->d_hist, c->d_hist_iq, c->d_hist_sums, c->d_iq, c->d_win, c->d_adder_bitmap, c->d_bit_syndrome, c->d_group_syndrome, c->d_parity,
                    c->d_tab_long, c->d_tab_short, c->d_uc8_folded};
     for (void *p : dev)
@@ -1075,6 +1130,72 @@ static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
     return MGPU_OK;
 }
 
+// ---- the ordered walk on the device (kernels/walk.inc) ----
+// Enqueues the walk of the slot's chunk on `s` against the filter as it stands now.  false = this chunk is not one the device
+// walk models (a buffer longer than the context's buffer size, generations too large for the input blob): the host walks it.
+static bool device_walk_enqueue(mgpu_ctx *c, Slot &sl, uint64_t nlive, hipStream_t s) {
+    const uint32_t nbuf = (uint32_t) sl.buffers.size();
+    const std::vector<uint32_t> &act = c->resolver.filter().members(true), &ina = c->resolver.filter().members(false);
+    if (nbuf + 1 > c->cap_buffers + 1 || walk_input_bytes(nbuf, (uint32_t) act.size(), (uint32_t) ina.size()) > c->wk_in_cap) return false;
+    for (const BufferClock &b : sl.buffers) if (b.length > c->cfg.buf_samples) return false;
+    WalkIn in{};
+    in.next_flip = c->resolver.next_flip();
+    in.nbuf = nbuf; in.n_active = (uint32_t) act.size(); in.n_inactive = (uint32_t) ina.size(); in.acc_cap = c->wk_acc_cap;
+    in.nlive = (uint32_t) nlive;
+    uint8_t *p = c->h_wk_in;
+    std::memcpy(p, &in, sizeof(in));
+    std::memcpy(p + kWkInHead, sl.buffers.data(), (size_t) nbuf * sizeof(BufferClock));
+    uint32_t *lists = (uint32_t *) (p + kWkInHead + (size_t) nbuf * sizeof(BufferClock));
+    if (!act.empty()) std::memcpy(lists, act.data(), act.size() * sizeof(uint32_t));
+    if (!ina.empty()) std::memcpy(lists + act.size(), ina.data(), ina.size() * sizeof(uint32_t));
+    launch_device_walk(c->h_wk_in, c->d_wk_in, walk_input_bytes(nbuf, in.n_active, in.n_inactive), c->wk, sl.d_live, nbuf,
+                       c->h_wk_sum, c->d_wk_acc, sl.d_msg_pos, sl.d_msg_limit, sl.d_msg_skip, (uint32_t) c->cap_msgs, s);
+    return hipEventRecord(c->ev_wk, s) == hipSuccess;
+}
+
+static void counts_from_device(const WalkSummary &ws, ResolveCounts &rc) {
+    const unsigned long long *k = ws.counts;   // WKC_* (kernels/walk.inc)
+    rc.visited_groups = k[0]; rc.rejected_unknown = k[1]; rc.rejected_bad = k[2];
+    for (int i = 0; i < 3; ++i) rc.accepted[i] = k[3 + i];
+    for (int i = 0; i < 5; ++i) rc.best_phase[i] = k[6 + i];
+    rc.skipped_uncond_groups = k[11]; rc.skipped_cond_groups = k[12]; rc.visited_cond_groups = k[13]; rc.visited_uncond_groups = k[14];
+}
+
+// check mode: the device walk of the chunk (enqueued before the host walk, against the same state) against what the host decided
+static int device_walk_compare(mgpu_ctx *c, Slot &sl, HostJob &job, uint32_t nmsg) {
+    HIPCHK(c, hipEventSynchronize(c->ev_wk));
+    const WalkSummary &ws = *(const WalkSummary *) c->h_wk_sum;
+    const uint32_t nbuf = (uint32_t) sl.buffers.size();
+    const uint32_t *per_buf = (const uint32_t *) (c->h_wk_sum + sizeof(WalkSummary)), *adds = per_buf + 6 * (size_t) nbuf;
+    c->wk_stats[5] += ws.iterations;
+    if (!ws.converged || ws.bad) { c->wk_stats[2] += 1; if (c->dbg_print) fprintf(stderr, "dbg: device walk: converged %u bad %u after %u walks\n", ws.converged, ws.bad, ws.iterations); return MGPU_OK; }
+    const bool applied = c->wk_shadow.apply_device_walk(per_buf, adds, nbuf, ws.flip);
+    if (!applied) { c->wk_stats[3] += 1; if (c->dbg_print) fprintf(stderr, "dbg: device walk: premises failed (table grew or the expiry moved)\n"); return MGPU_OK; }
+    c->wk_stats[1] += 1;
+    uint64_t bad = 0;
+    if (ws.nmsg != nmsg) ++bad;
+    else if (nmsg) {
+        std::vector<Accepted> dev(nmsg);
+        std::vector<uint32_t> pos(nmsg), limit(nmsg);
+        std::vector<uint16_t> skip(nmsg);
+        HIPCHK(c, hipMemcpy(dev.data(), c->d_wk_acc, (size_t) nmsg * sizeof(Accepted), hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(pos.data(), sl.d_msg_pos, (size_t) nmsg * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(limit.data(), sl.d_msg_limit, (size_t) nmsg * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(skip.data(), sl.d_msg_skip, (size_t) nmsg * 2, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < nmsg; ++i) {
+            const Accepted &h = job.acc[i], &d = dev[i];
+            if (h.rec != d.rec || h.buffer != d.buffer || h.score != d.score || pos[i] != job.pos[i] || limit[i] != c->w_limit[i] || skip[i] != c->w_skip[i]) ++bad;
+        }
+    }
+    ResolveCounts rc;
+    counts_from_device(ws, rc);
+    if (std::memcmp(&rc, &job.rc, sizeof(rc)) != 0) ++bad;
+    if (!c->wk_shadow.same_state(c->resolver)) ++bad;
+    c->wk_stats[6] += bad;
+    if (bad || c->dbg_print) fprintf(stderr, "%s: device walk: %u walks, %u messages (host %u), %u adds, %llu differences\n", bad ? "mgpu" : "dbg", ws.iterations, ws.nmsg, nmsg, ws.nadds_total, (unsigned long long) bad);
+    return MGPU_OK;
+}
+
 // ---- part 2 (walker thread): the ordered accept walk, then the window statistics of what it hid ----
 static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
     const uint64_t n = sl.n;
@@ -1084,6 +1205,13 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
     job.pos.resize(aux_cap); c->w_limit.resize(aux_cap); c->w_skip.resize(aux_cap);
     job.rc = ResolveCounts();
     int64_t wn;
+    bool wk_running = false;
+    if (c->device_walk == 2) {
+        c->wk_stats[0] += 1;
+        c->wk_shadow.copy_state(c->resolver);
+        wk_running = device_walk_enqueue(c, sl, nlive, c->stream2);
+        if (!wk_running) c->wk_stats[4] += 1;
+    }
     const uint32_t nbuf_all = (uint32_t) sl.buffers.size();
     const int K = c->walk_threads;
     if (K >= 2 && nbuf_all >= (uint32_t) (4 * K) && nlive >= 4096) {
@@ -1138,6 +1266,7 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
     if (wn < 0) { c->err = "max_messages exceeded"; return MGPU_E_OVERFLOW; }
     const uint32_t nmsg = (uint32_t) wn;
     c->feed_rc.add(job.rc);
+    if (wk_running) { const int rc = device_walk_compare(c, sl, job, nmsg); if (rc != MGPU_OK) return rc; }
 
     // what the skip windows hid from the counters: asynchronous on the second stream, totals are
     // accumulated on the device and read once at the end of the feed
@@ -1775,6 +1904,13 @@ int mgpu_filter_add(mgpu_ctx *c, uint32_t addr) {
     if (!c) return MGPU_E_INVAL;
     { const int rc = drain(c); if (rc != MGPU_OK) return rc; }
     c->resolver.filter().add(addr);
+    return MGPU_OK;
+}
+
+int mgpu_debug_device_walk(mgpu_ctx *c, uint64_t out[8]) {
+    if (!c || !out) return MGPU_E_INVAL;
+    (void) drain(c);
+    for (int i = 0; i < 8; ++i) out[i] = c->wk_stats[i];
     return MGPU_OK;
 }
 

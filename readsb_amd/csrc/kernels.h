@@ -196,6 +196,46 @@ void launch_signal_power(const uint16_t *mag, const uint32_t *pos, const uint16_
 void launch_build_messages(const PhaseRec *live, const unsigned long long *live_sig, const void *d_acc, const void *d_bufs, uint32_t nacc,
                            mgpu_msg *out, hipStream_t s);
 void launch_stage_blob(const void *h_src, void *d_dst, uint64_t bytes, hipStream_t s);   // page-locked host -> device, small grid
+
+// ---- the ordered accept walk on the device (kernels/walk.inc) ----
+constexpr uint32_t kWkNoAdd = 0xffffffffu;
+constexpr uint32_t kWkTouchedCap = 1u << 16;        // distinct adder addresses per chunk and table
+constexpr int kWkCounts = 16;                       // per-buffer counters (WKC_* in kernels/walk.inc, the order of ResolveCounts)
+constexpr int32_t kWkNoFlip = 0x7fffffff;
+struct WalkIn {                  // head of the per-chunk input blob; then (at kWkInHead) BufferClock[nbuf], active[n_active], inactive[n_inactive]
+    int64_t next_flip;           // Resolver::next_flip(): the expiry is due at the first buffer end with clock >= this
+    uint32_t nbuf, n_active, n_inactive, acc_cap;   // acc_cap: accept-list capacity per buffer
+    uint32_t nlive, pad[3];      // live records of the chunk (the device's own counter block is back to zero by now)
+};
+static_assert(sizeof(WalkIn) == 40, "WalkIn");
+constexpr uint32_t kWkInHead = 48;                  // the buffer clocks start here
+struct WalkState {
+    int32_t flip;                // the expiry is assumed after this buffer (kWkNoFlip: not in this chunk)
+    uint32_t converged, iterations, bad;
+    uint32_t n_touched[2];
+    uint32_t cur, pad;
+};
+struct WalkBuffers {             // device memory of the walk (one set per context)
+    uint32_t *bit_active, *bit_inactive;             // 2^24 bits each: the filter's two generations when the chunk starts
+    uint32_t *first[2];                              // 2^24 entries each: first buffer of the chunk that adds the address
+    uint32_t *touched[2];                            // addresses with an entry in first[t]
+    WalkState *state;
+    uint32_t *rec_lo;                                // [nbuf + 1]: first live record at or after the buffer's first position
+    uint32_t *nacc, *nadds, *counts;                 // per buffer
+    long long *end_clock;                            // per buffer: Modes.synthetic_now at its end
+    uint32_t *acc;                                   // per buffer acc_cap x (record index, score)
+    uint32_t *adds;                                  // per buffer acc_cap addresses, in order of their first add in the buffer
+    uint32_t *offs, *aoffs;                          // [nbuf + 1] prefix of nacc / of nadds
+};
+struct WalkSummary {             // what the host reads (page-locked): this, then per buffer 6 words {accepted, adds, end clock lo, hi,
+    uint32_t converged, bad, iterations, nmsg;       // offset into the adds, offset into the accept list}, then the adds
+    int32_t flip; uint32_t nadds_total, nbuf, pad;
+    unsigned long long counts[kWkCounts];
+};
+size_t walk_summary_bytes(uint32_t nbuf, uint32_t acc_cap);
+size_t walk_input_bytes(uint32_t nbuf, uint32_t n_active, uint32_t n_inactive);
+void launch_device_walk(const uint8_t *h_in, uint8_t *d_in, size_t in_bytes, const WalkBuffers &w, const PhaseRec *live, uint32_t nbuf, void *h_summary, void *d_acc, uint32_t *msg_pos,
+                        uint32_t *msg_limit, uint16_t *msg_skip, uint32_t msg_cap, hipStream_t s);
 void launch_stage_in(const uint32_t *h_pos, const uint32_t *h_limit, const uint16_t *h_skip, uint32_t *d_pos, uint32_t *d_limit,
                      uint16_t *d_skip, uint32_t n, hipStream_t s);   // page-locked host arrays -> device, small grid
 void launch_window_stats(const uint16_t *mag, uint64_t n, int thr, const uint32_t *class_bitmap, const uint32_t *pos,

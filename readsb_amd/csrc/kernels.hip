@@ -95,6 +95,7 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 #include "kernels/modeac.inc"
 #include "kernels/window_stats.inc"
 #include "kernels/build.inc"
+#include "kernels/walk.inc"
 #include "kernels/beast.inc"
 #include "kernels/fields.inc"
 

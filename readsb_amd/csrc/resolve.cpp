@@ -100,6 +100,46 @@ void IcaoFilter::union_sorted(std::vector<uint32_t> &out) const {
     out.erase(std::unique(out.begin(), out.end()), out.end());
 }
 
+bool IcaoFilter::same_as(const IcaoFilter &o) const {
+    if (occupied_ != o.occupied_ || filter_bits_ != o.filter_bits_) return false;
+    for (int g = 0; g < 2; ++g) {
+        std::vector<uint32_t> x = members_[g ? active_ ^ 1 : active_], y = o.members_[g ? o.active_ ^ 1 : o.active_];
+        std::vector<uint32_t> bx = big_[g ? active_ ^ 1 : active_], by = o.big_[g ? o.active_ ^ 1 : o.active_];
+        std::sort(x.begin(), x.end()); std::sort(y.begin(), y.end());
+        std::sort(bx.begin(), bx.end()); std::sort(by.begin(), by.end());
+        if (x != y || bx != by) return false;
+    }
+    return true;
+}
+
+bool Resolver::apply_device_walk(const uint32_t *per_buf, const uint32_t *adds, uint32_t nbuf, int32_t flip) {
+    IcaoFilter::Snapshot snap;
+    filter_.snapshot(snap);
+    const int64_t now0 = synthetic_now_, flip0 = next_flip_;
+    const uint64_t nflips0 = nflips_;
+    bool ok = true;
+    int32_t flipped_at = 0x7fffffff;
+    for (uint32_t b = 0; ok && b < nbuf; ++b) {
+        const uint32_t *row = per_buf + 6 * (size_t) b;
+        const uint32_t *a = adds + row[4];
+        for (uint32_t i = 0; ok && i < row[1]; ++i) {
+            const uint32_t bits = filter_.table_bits();
+            filter_.add(a[i]);
+            ok = filter_.table_bits() == bits;
+        }
+        synthetic_now_ = (int64_t) ((uint64_t) row[2] | ((uint64_t) row[3] << 32));
+        const uint64_t f = nflips_;
+        after_buffer();
+        if (nflips_ != f) { if (flipped_at != 0x7fffffff) ok = false; flipped_at = (int32_t) b; }
+    }
+    if (flipped_at != flip) ok = false;
+    if (!ok) {
+        filter_.restore(snap);
+        synthetic_now_ = now0; next_flip_ = flip0; nflips_ = nflips0;
+    }
+    return ok;
+}
+
 void Resolver::reset(int64_t startup_ms, int clock_mode) {
     filter_.init();
     filter_.add(kShowOnlyDefault);

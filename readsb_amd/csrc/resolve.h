@@ -41,6 +41,8 @@ class IcaoFilter {
     void snapshot(Snapshot &s) const;
     void restore(const Snapshot &s);
     void union_sorted(std::vector<uint32_t> &out) const;      // addresses < 2^24 in either generation, ascending
+    const std::vector<uint32_t> &members(bool active) const { return members_[active ? active_ : active_ ^ 1]; }   // addresses < 2^24
+    bool same_as(const IcaoFilter &o) const;                  // membership per generation, occupied, table size
     // addresses that leave the union (expire / resize) and addresses that enter it (first add)
     void track_changes(std::vector<uint32_t> *drops, std::vector<uint32_t> *news) { drops_ = drops; news_ = news; }
 
@@ -179,6 +181,19 @@ class Resolver {
     void tick_empty(int64_t sysTimestamp);
     IcaoFilter &filter() { return filter_; }
     uint64_t nflips() const { return nflips_; }
+
+    // --- the walk on the device (kernels/walk.inc) ---
+    int64_t next_flip() const { return next_flip_; }
+    // Catch the filter up with what the device walk did — per buffer its first adds in order (summary rows of 6 words:
+    // accepted, adds, end clock lo / hi, offset into `adds`, offset into the accept list), then the clock — and tell
+    // whether the walk's premises held: the table did not grow (growing empties the other generation, icao_filter.c:65-93),
+    // the expiry came after the buffer the walk had put it after (flip; 0x7fffffff = not in this chunk), and only once.
+    // On false the state is what it was and the chunk has to be walked here.
+    bool apply_device_walk(const uint32_t *per_buf, const uint32_t *adds, uint32_t nbuf, int32_t flip);
+    void copy_state(const Resolver &o) { copy_state_from(o); }
+    bool same_state(const Resolver &o) const {
+        return synthetic_now_ == o.synthetic_now_ && next_flip_ == o.next_flip_ && nflips_ == o.nflips_ && filter_.same_as(o.filter_);
+    }
 
   private:
     void copy_state_from(const Resolver &o);

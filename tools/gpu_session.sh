@@ -1,6 +1,6 @@
 #!/bin/bash
-tag=${1:-s1}
-out=gpurun_out/$tag
-mkdir -p $out
-export TMPDIR=/tmp
-MGPU_LIBRARY=libmodes_gpu_tm.so MGPU_DEBUG_PRINT=1 timeout 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | grep "dbg: k_sweep" | tail -12
+# scratch: per-session GPU command
+cd /root/repo
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_gpu_device_walk.py -x -q -s 2>&1 | tail -40 > gpurun_out/s40_devwalk.log
+cat gpurun_out/s40_devwalk.log

@@ -169,6 +169,9 @@ struct Slot {
     hipEvent_t ev_scan = nullptr;         // pre-screen offsets are final (main stream) -> the write pass may start (second stream)
     // the job
     uint64_t n = 0, stream_pos = 0;
+    uint8_t *d_wk_in = nullptr;           // the walk on the device: its input blob (read again by k_build_messages: the buffer clocks) ...
+    void *d_wk_acc = nullptr;             // ... the chunk's ordered accept list ...
+    unsigned long long *d_wk_sig = nullptr;   // ... and per accepted frame the signal power | long flag
     uint8_t *h_blob = nullptr, *d_blob = nullptr;   // device-messages mode: the walker's accept list + buffer clocks, page-locked host / device
     const uint8_t *fused_iq = nullptr;    // this chunk's converter runs inside k_sweep (enqueue_convert): its IQ samples ...
     const uint16_t *fused_tail = nullptr; // ... and the 326 magnitudes before them
@@ -233,6 +236,14 @@ struct HostJob {
     int slot = -1;                           // the slot the chunk ran in (the walker still needs its device side)
     int feed = -1;                           // Slot::feed
     bool busy = false;
+    // the walk ran on the device (MGPU_DEVICE_WALK=1): no records here; per message the signal power (bit 63: a 112-bit frame as
+    // sliced) and — unless the messages stay on the device — the records k_build_messages made, both copied into page-locked memory
+    bool from_device = false;
+    bool fetched = false;                    // recs / sig hold the chunk's live records
+    mgpu_msg *h_msgs = nullptr;
+    unsigned long long *h_msig = nullptr;
+    hipEvent_t ev_copied = nullptr;          // ... the copies have landed (stream2)
+    std::vector<uint32_t> buf_nacc;          // accepted frames per buffer
 };
 
 // Deferred feeds (mgpu_set_deferred): a feed call returns once its chunks are enqueued, the next one may follow at once, and
@@ -251,6 +262,8 @@ struct mgpu_ctx {
     mgpu_config cfg{};
     hipStream_t stream = nullptr, stream2 = nullptr, stream_w = nullptr;   // main | window statistics | pre-screen write pass / IQ uploads
     hipStream_t stream_d2h = nullptr;                                      // the fetcher's record copies
+    hipStream_t s_post = nullptr;                                          // what follows the walk (window statistics, messages on the device): stream2, or stream_wk
+    hipStream_t stream_wk = nullptr;                                       // the walk on the device: highest priority, its small kernels must not queue behind the main stream's
     std::string err;
 
     uint64_t cap_samples = 0;      // per feed call (cfg.max_samples)
@@ -321,9 +334,9 @@ struct mgpu_ctx {
     // every decision compared (mgpu_debug_device_walk)
     int device_walk = 0;                                      // 0 off, 1 on, 2 check
     WalkBuffers wk{};
-    uint8_t *h_wk_in = nullptr, *d_wk_in = nullptr, *h_wk_sum = nullptr;
+    uint8_t *h_wk_in = nullptr, *h_wk_sum = nullptr;
     size_t wk_in_cap = 0;
-    void *d_wk_acc = nullptr;
+    mgpu_msg *d_wk_msgs = nullptr;                            // k_build_messages' output when the messages go to the host
     uint32_t wk_acc_cap = 0;                                  // accepted frames per buffer the walk has room for
     hipEvent_t ev_wk = nullptr;
     Resolver wk_shadow;                                       // check mode: the state before the host walk, for apply_device_walk
@@ -656,7 +669,7 @@ static void free_slot(Slot &sl) {
     void *dev[] = {sl.d_blob, sl.d_live, sl.d_live_sig, sl.d_mag, sl.d_pool, sl.d_scratch, sl.d_unit_first, sl.d_unit_count, sl.d_unit_live, sl.d_class_bitmap,
                    sl.d_class_uncond, sl.d_class_final, sl.d_cand, sl.d_cand_count, sl.d_sweep_part,
                    sl.d_win, sl.d_win_part, sl.d_msg_pos,
-                   sl.d_msg_limit, sl.d_msg_len, sl.d_msg_skip, sl.d_msg_sig};
+                   sl.d_msg_limit, sl.d_msg_len, sl.d_msg_skip, sl.d_msg_sig, sl.d_wk_in, sl.d_wk_acc, sl.d_wk_sig};
     for (void *p : dev)
         if (p) (void) hipFree(p);
     if (sl.ev_window) (void) hipEventDestroy(sl.ev_window);
@@ -732,9 +745,23 @@ static int alloc_all(mgpu_ctx *c) {
         HIPCHK(c, hipMalloc(&w.aoffs, nb * sizeof(uint32_t)));
         c->wk_in_cap = walk_input_bytes((uint32_t) c->cap_buffers, 1u << 17, 1u << 17);
         HIPCHK(c, hipHostMalloc(&c->h_wk_in, c->wk_in_cap));
-        HIPCHK(c, hipMalloc(&c->d_wk_in, c->wk_in_cap));
+        for (auto &sl : c->slot) {
+            HIPCHK(c, hipMalloc(&sl.d_wk_in, c->wk_in_cap));
+            HIPCHK(c, hipMalloc(&sl.d_wk_acc, c->cap_msgs * 12));
+            HIPCHK(c, hipMalloc(&sl.d_wk_sig, c->cap_msgs * sizeof(unsigned long long)));
+        }
+        const WalkState st0 = {kWkNoFlip, 0, 0, 0, {0, 0}, 0, 0};
+        HIPCHK(c, hipMemcpyAsync(w.state, &st0, sizeof(st0), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, hipHostMalloc(&c->h_wk_sum, walk_summary_bytes((uint32_t) c->cap_buffers, c->wk_acc_cap)));
-        HIPCHK(c, hipMalloc(&c->d_wk_acc, c->cap_msgs * 12));
+        if (c->device_walk == 1) {
+            HIPCHK(c, hipMalloc(&c->d_wk_msgs, c->cap_msgs * sizeof(mgpu_msg)));
+            for (auto &j : c->job) {
+                HIPCHK(c, hipHostMalloc(&j.h_msgs, c->cap_msgs * sizeof(mgpu_msg)));
+                HIPCHK(c, hipHostMalloc(&j.h_msig, c->cap_msgs * sizeof(unsigned long long)));
+                HIPCHK(c, hipEventCreateWithFlags(&j.ev_copied, hipEventDisableTiming));
+            }
+        }
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_wk, hipEventDisableTiming));
     }
 
@@ -791,6 +818,13 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     if (cfg->fixDF && cfg->nfix_crc)
         for (int b = 0; b < 5; ++b) c->valid_long |= 1u << (17 ^ (1 << b));
     if (const char *e = getenv("MGPU_DEVICE_WALK")) c->device_walk = !strcmp(e, "check") ? 2 : atoi(e) != 0;
+    if (c->device_walk) {
+        int lo = 0, hi = 0;
+        (void) hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (getenv("MGPU_DBG_WK_PLAIN_STREAM")) hi = 0;
+        if (hipStreamCreateWithPriority(&c->stream_wk, hipStreamNonBlocking, hi) != hipSuccess) { mgpu_destroy(c); return MGPU_E_HIP; }
+    }
+    c->s_post = c->stream2;
     int rc;
     {
         NearDevice near(cfg->device);
@@ -846,6 +880,7 @@ void mgpu_destroy(mgpu_ctx *c) {
     if (c->stream) (void) hipStreamSynchronize(c->stream);
     if (c->stream2) (void) hipStreamSynchronize(c->stream2);
     if (c->stream_w) (void) hipStreamSynchronize(c->stream_w);
+    if (c->stream_wk) (void) hipStreamSynchronize(c->stream_wk);
     for (auto &sl : c->slot) free_slot(sl);
     for (auto &f : c->feed) {
         if (f.d_msgs) (void) hipFree(f.d_msgs);
@@ -855,10 +890,15 @@ void mgpu_destroy(mgpu_ctx *c) {
     if (c->h_wk_in) (void) hipHostFree(c->h_wk_in);
     if (c->h_wk_sum) (void) hipHostFree(c->h_wk_sum);
     if (c->ev_wk) (void) hipEventDestroy(c->ev_wk);
+    for (auto &j : c->job) {
+        if (j.h_msgs) (void) hipHostFree(j.h_msgs);
+        if (j.h_msig) (void) hipHostFree(j.h_msig);
+        if (j.ev_copied) (void) hipEventDestroy(j.ev_copied);
+    }
     {
         const WalkBuffers &w = c->wk;
         void *wkp[] = {w.bit_active, w.bit_inactive, w.first[0], w.first[1], w.touched[0], w.touched[1], w.state, w.rec_lo, w.nacc, w.nadds, w.counts,
-                       w.end_clock, w.acc, w.adds, w.offs, w.aoffs, c->d_wk_in, c->d_wk_acc};
+                       w.end_clock, w.acc, w.adds, w.offs, w.aoffs, c->d_wk_msgs};
         for (void *p : wkp)
             if (p) (void) hipFree(p);
     }
@@ -870,6 +910,7 @@ void mgpu_destroy(mgpu_ctx *c) {
     if (c->stream2) (void) hipStreamDestroy(c->stream2);
     if (c->stream_w) (void) hipStreamDestroy(c->stream_w);
     if (c->stream_d2h) (void) hipStreamDestroy(c->stream_d2h);
+    if (c->stream_wk) (void) hipStreamDestroy(c->stream_wk);
     delete c;
 }
 
@@ -1017,6 +1058,42 @@ static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
 }
 
 // ---- host half of a chunk, part 1 (fetcher thread): wait for the GPU, copy the live records out of pinned memory ----
+// The chunk's live records and their would-be signal powers, HBM -> the job's ordinary memory.
+static int fetch_records(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
+    const uint64_t nlive = job.nlive;
+    // exactly nlive records + signal powers, HBM -> page-locked host memory over the copy engine (its own stream: the next
+    // chunk's kernels keep running), then into ordinary memory: page-locked memory the device wrote is slow for the walk's
+    // small scattered reads (4x slower walk) but streams at tens of GB/s (0.1 ms for 70 k records)
+    // The copies run as blit kernels (the runtime's choice on this box, whatever HSA_ENABLE_SDMA / GPU_FORCE_BLIT_COPY_SIZE say)
+    // and cost whatever is on the main stream meanwhile ~25 us: the converter takes 78 us instead of 52, or — with
+    // MGPU_COPY_AFTER_SWEEP=1, held back until the next chunk's converter and k_sweep are through — k_slice 140 instead of 114.
+    // The same either way (2.23 vs 2.27 ms per step), so: at once.
+    if (nlive && next && c->copy_after_sweep) HIPCHK(c, hipEventSynchronize(next->ev_swept));
+    if (nlive) {
+        // (a copy kernel of our own with 8..32 workgroups in place of the runtime's blit kernel: 2.55-2.63 ms per step instead of 2.45)
+        HIPCHK(c, hipMemcpyAsync(sl.h_live, sl.d_live, nlive * sizeof(PhaseRec), hipMemcpyDeviceToHost, c->stream_d2h));
+        HIPCHK(c, hipMemcpyAsync(sl.h_live_sig, sl.d_live_sig, nlive * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream_d2h));
+        HIPCHK(c, hipStreamSynchronize(c->stream_d2h));
+    }
+    if (!c->dump_dir.empty()) {   // replay material for tools/walk_replay.cpp
+        const char *dd = c->dump_dir.c_str();
+        static int dumped = 0;
+        if (!dumped++) {
+            std::string base = std::string(dd) + "/walk_";
+            FILE *f = fopen((base + "recs.bin").c_str(), "wb"); fwrite(sl.h_live, sizeof(PhaseRec), nlive, f); fclose(f);
+            f = fopen((base + "sig.bin").c_str(), "wb"); fwrite(sl.h_live_sig, 8, nlive, f); fclose(f);
+            f = fopen((base + "bufs.bin").c_str(), "wb"); fwrite(sl.buffers.data(), sizeof(BufferClock), sl.buffers.size(), f); fclose(f);
+        }
+    }
+    job.recs.resize(nlive + 1);
+    job.recs[nlive].pos = 0xFFFFFFFFu;          // sentinel for the walk
+    job.sig.resize(nlive);
+    std::memcpy(job.recs.data(), sl.h_live, nlive * sizeof(PhaseRec));
+    std::memcpy(job.sig.data(), sl.h_live_sig, nlive * sizeof(unsigned long long));
+    job.fetched = true;
+    return MGPU_OK;
+}
+
 static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
     HIPCHK(c, hipEventSynchronize(sl.ev[3]));
     const double t_gpu_done = wall_ms();
@@ -1070,38 +1147,12 @@ static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
     const uint64_t nlive = sl.h_counters[CNT_LIVE_TOTAL];
 
     const double t_f0 = wall_ms();
-    // exactly nlive records + signal powers, HBM -> page-locked host memory over the copy engine (its own stream: the next
-    // chunk's kernels keep running), then into ordinary memory: page-locked memory the device wrote is slow for the walk's
-    // small scattered reads (4x slower walk) but streams at tens of GB/s (0.1 ms for 70 k records)
     if (nlive > c->cap_pool) { c->err = "live record count beyond the pool"; return MGPU_E_OVERFLOW; }
-    // The copies run as blit kernels (the runtime's choice on this box, whatever HSA_ENABLE_SDMA / GPU_FORCE_BLIT_COPY_SIZE say)
-    // and cost whatever is on the main stream meanwhile ~25 us: the converter takes 78 us instead of 52, or — with
-    // MGPU_COPY_AFTER_SWEEP=1, held back until the next chunk's converter and k_sweep are through — k_slice 140 instead of 114.
-    // The same either way (2.23 vs 2.27 ms per step), so: at once.
-    if (nlive && next && c->copy_after_sweep) HIPCHK(c, hipEventSynchronize(next->ev_swept));
-    if (nlive) {
-        // (a copy kernel of our own with 8..32 workgroups in place of the runtime's blit kernel: 2.55-2.63 ms per step instead of 2.45)
-        HIPCHK(c, hipMemcpyAsync(sl.h_live, sl.d_live, nlive * sizeof(PhaseRec), hipMemcpyDeviceToHost, c->stream_d2h));
-        HIPCHK(c, hipMemcpyAsync(sl.h_live_sig, sl.d_live_sig, nlive * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream_d2h));
-        HIPCHK(c, hipStreamSynchronize(c->stream_d2h));
-    }
-    if (!c->dump_dir.empty()) {   // replay material for tools/walk_replay.cpp
-        const char *dd = c->dump_dir.c_str();
-        static int dumped = 0;
-        if (!dumped++) {
-            std::string base = std::string(dd) + "/walk_";
-            FILE *f = fopen((base + "recs.bin").c_str(), "wb"); fwrite(sl.h_live, sizeof(PhaseRec), nlive, f); fclose(f);
-            f = fopen((base + "sig.bin").c_str(), "wb"); fwrite(sl.h_live_sig, 8, nlive, f); fclose(f);
-            f = fopen((base + "bufs.bin").c_str(), "wb"); fwrite(sl.buffers.data(), sizeof(BufferClock), sl.buffers.size(), f); fclose(f);
-        }
-    }
     job.nlive = nlive;
     job.stream_pos = sl.stream_pos;
-    job.recs.resize(nlive + 1);
-    job.recs[nlive].pos = 0xFFFFFFFFu;          // sentinel for the walk
-    job.sig.resize(nlive);
-    std::memcpy(job.recs.data(), sl.h_live, nlive * sizeof(PhaseRec));
-    std::memcpy(job.sig.data(), sl.h_live_sig, nlive * sizeof(unsigned long long));
+    job.fetched = job.from_device = false;
+    // with the walk on the device the records stay in HBM (the walker fetches them itself for a chunk it has to walk here)
+    if (c->device_walk != 1 || c->shard_mode != 0) { const int rc = fetch_records(c, sl, job, next); if (rc != MGPU_OK) return rc; }
     job.ac.clear();
     if (c->cfg.mode_ac && (!sl.have_mag || sl.have_noise)) {
         const unsigned long long *counts = sl.h_scratch + CNT_NUM + 1 + 4 * c->cap_buffers;   // k_modeac's kAcLists lists
@@ -1137,19 +1188,23 @@ static bool device_walk_enqueue(mgpu_ctx *c, Slot &sl, uint64_t nlive, hipStream
     const uint32_t nbuf = (uint32_t) sl.buffers.size();
     const std::vector<uint32_t> &act = c->resolver.filter().members(true), &ina = c->resolver.filter().members(false);
     if (nbuf + 1 > c->cap_buffers + 1 || walk_input_bytes(nbuf, (uint32_t) act.size(), (uint32_t) ina.size()) > c->wk_in_cap) return false;
-    for (const BufferClock &b : sl.buffers) if (b.length > c->cfg.buf_samples) return false;
+    if (nbuf == 0 || sl.buffers[0].length == 0 || sl.buffers[0].length > c->cfg.buf_samples) return false;
+    const uint32_t L = sl.buffers[0].length;                  // the grid the kernels assume: buffer b = positions [b * L, b * L + length <= L)
+    for (uint32_t b = 0; b < nbuf; ++b)
+        if (sl.buffers[b].first != (uint64_t) b * L || sl.buffers[b].length > L || (b + 1 < nbuf && sl.buffers[b].length != L)) return false;
     WalkIn in{};
     in.next_flip = c->resolver.next_flip();
     in.nbuf = nbuf; in.n_active = (uint32_t) act.size(); in.n_inactive = (uint32_t) ina.size(); in.acc_cap = c->wk_acc_cap;
     in.nlive = (uint32_t) nlive;
+    in.buf_len = L;
     uint8_t *p = c->h_wk_in;
     std::memcpy(p, &in, sizeof(in));
     std::memcpy(p + kWkInHead, sl.buffers.data(), (size_t) nbuf * sizeof(BufferClock));
     uint32_t *lists = (uint32_t *) (p + kWkInHead + (size_t) nbuf * sizeof(BufferClock));
     if (!act.empty()) std::memcpy(lists, act.data(), act.size() * sizeof(uint32_t));
     if (!ina.empty()) std::memcpy(lists + act.size(), ina.data(), ina.size() * sizeof(uint32_t));
-    launch_device_walk(c->h_wk_in, c->d_wk_in, walk_input_bytes(nbuf, in.n_active, in.n_inactive), c->wk, sl.d_live, nbuf,
-                       c->h_wk_sum, c->d_wk_acc, sl.d_msg_pos, sl.d_msg_limit, sl.d_msg_skip, (uint32_t) c->cap_msgs, s);
+    launch_device_walk(c->h_wk_in, sl.d_wk_in, walk_input_bytes(nbuf, in.n_active, in.n_inactive), c->wk, sl.d_live, sl.d_live_sig, nbuf,
+                       c->h_wk_sum, sl.d_wk_acc, sl.d_wk_sig, sl.d_msg_pos, sl.d_msg_limit, sl.d_msg_skip, (uint32_t) c->cap_msgs, s);
     return hipEventRecord(c->ev_wk, s) == hipSuccess;
 }
 
@@ -1168,6 +1223,7 @@ static int device_walk_compare(mgpu_ctx *c, Slot &sl, HostJob &job, uint32_t nms
     const uint32_t nbuf = (uint32_t) sl.buffers.size();
     const uint32_t *per_buf = (const uint32_t *) (c->h_wk_sum + sizeof(WalkSummary)), *adds = per_buf + 6 * (size_t) nbuf;
     c->wk_stats[5] += ws.iterations;
+    if (ws.bad) for (int t = 0; t < 2; ++t) HIPCHK(c, hipMemsetAsync(c->wk.first[t], 0xff, sizeof(uint32_t) << 24, c->stream2));
     if (!ws.converged || ws.bad) { c->wk_stats[2] += 1; if (c->dbg_print) fprintf(stderr, "dbg: device walk: converged %u bad %u after %u walks\n", ws.converged, ws.bad, ws.iterations); return MGPU_OK; }
     const bool applied = c->wk_shadow.apply_device_walk(per_buf, adds, nbuf, ws.flip);
     if (!applied) { c->wk_stats[3] += 1; if (c->dbg_print) fprintf(stderr, "dbg: device walk: premises failed (table grew or the expiry moved)\n"); return MGPU_OK; }
@@ -1178,7 +1234,7 @@ static int device_walk_compare(mgpu_ctx *c, Slot &sl, HostJob &job, uint32_t nms
         std::vector<Accepted> dev(nmsg);
         std::vector<uint32_t> pos(nmsg), limit(nmsg);
         std::vector<uint16_t> skip(nmsg);
-        HIPCHK(c, hipMemcpy(dev.data(), c->d_wk_acc, (size_t) nmsg * sizeof(Accepted), hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(dev.data(), sl.d_wk_acc, (size_t) nmsg * sizeof(Accepted), hipMemcpyDeviceToHost));
         HIPCHK(c, hipMemcpy(pos.data(), sl.d_msg_pos, (size_t) nmsg * 4, hipMemcpyDeviceToHost));
         HIPCHK(c, hipMemcpy(limit.data(), sl.d_msg_limit, (size_t) nmsg * 4, hipMemcpyDeviceToHost));
         HIPCHK(c, hipMemcpy(skip.data(), sl.d_msg_skip, (size_t) nmsg * 2, hipMemcpyDeviceToHost));
@@ -1196,6 +1252,66 @@ static int device_walk_compare(mgpu_ctx *c, Slot &sl, HostJob &job, uint32_t nms
     return MGPU_OK;
 }
 
+// MGPU_DEVICE_WALK=1: the chunk's walk on the device; the host checks its premises, catches the filter up, and has the messages
+// and the window statistics made from the accept list where it lies.  MGPU_E_AGAIN = the host has to walk this chunk.
+static constexpr int MGPU_E_AGAIN = -1000;
+static int walk_job_device(mgpu_ctx *c, Slot &sl, HostJob &job) {
+    const double t_res0 = wall_ms();
+    hipStream_t s2 = c->stream2;                            // what follows the walk: behind it by ev_wk, but not in the next walk's way
+    c->wk_stats[0] += 1;
+    if (!device_walk_enqueue(c, sl, job.nlive, c->stream_wk)) { c->wk_stats[4] += 1; return MGPU_E_AGAIN; }
+    const double t_enq = wall_ms();
+    HIPCHK(c, hipEventSynchronize(c->ev_wk));
+    const double t_gpu = wall_ms();
+    const WalkSummary &ws = *(const WalkSummary *) c->h_wk_sum;
+    const uint32_t nbuf = (uint32_t) sl.buffers.size();
+    const uint32_t *per_buf = (const uint32_t *) (c->h_wk_sum + sizeof(WalkSummary)), *adds = per_buf + 6 * (size_t) nbuf;
+    c->wk_stats[5] += ws.iterations;
+    if (ws.bad) {     // a list overflowed: the tables may hold entries nothing remembers
+        for (int t = 0; t < 2; ++t) HIPCHK(c, hipMemsetAsync(c->wk.first[t], 0xff, sizeof(uint32_t) << 24, c->stream_wk));
+    }
+    if (!ws.converged || ws.bad) { c->wk_stats[2] += 1; return MGPU_E_AGAIN; }
+    const bool applied = c->resolver.apply_device_walk(per_buf, adds, nbuf, ws.flip);
+    if (c->dbg_print) fprintf(stderr, "dbg: device walk: enqueue %.3f ms, gpu %.3f ms, apply %.3f ms (%d); %u walks, %u msgs, %u adds\n", t_enq - t_res0, t_gpu - t_enq, wall_ms() - t_gpu, (int) applied, ws.iterations, ws.nmsg, ws.nadds_total);
+    if (!applied) { c->wk_stats[3] += 1; return MGPU_E_AGAIN; }
+    c->wk_stats[1] += 1;
+    const uint32_t nmsg = ws.nmsg;
+    if (nmsg > c->cap_msgs) { c->err = "max_messages exceeded"; return MGPU_E_OVERFLOW; }
+    job.rc = ResolveCounts();
+    counts_from_device(ws, job.rc);
+    c->feed_rc.add(job.rc);
+    job.buf_nacc.resize(nbuf);
+    for (uint32_t b = 0; b < nbuf; ++b) job.buf_nacc[b] = per_buf[6 * (size_t) b];
+    c->acc.resolve_ms += (float) (wall_ms() - t_res0);
+
+    const double t_sig0 = wall_ms();
+    if (nmsg && !c->dbg_no_window)
+        launch_window_stats(sl.d_mag, sl.n, sl.thr, sl.d_class_final, sl.d_msg_pos, sl.d_msg_skip, sl.d_msg_limit, nmsg, sl.d_win_part, c->d_win, s2);
+    const bool to_device_list = c->device_msgs && job.feed >= 0;
+    if (nmsg) {
+        const void *d_bufs = sl.d_wk_in + kWkInHead;           // the buffer clocks went over with the walk's input
+        mgpu_msg *dst = c->d_wk_msgs;
+        if (to_device_list) {
+            FeedSlot &fs = c->feed[job.feed];
+            if (fs.d_count + nmsg > fs.d_cap) { c->err = "device message list of the feed is full"; return MGPU_E_OVERFLOW; }
+            dst = fs.d_msgs + fs.d_count;
+            fs.d_count += nmsg;
+        }
+        launch_build_messages(sl.d_live, sl.d_live_sig, sl.d_wk_acc, d_bufs, nmsg, dst, s2);
+        if (to_device_list) HIPCHK(c, hipEventRecord(c->feed[job.feed].ev_built, s2));
+        else HIPCHK(c, hipMemcpyAsync(job.h_msgs, c->d_wk_msgs, (size_t) nmsg * sizeof(mgpu_msg), hipMemcpyDeviceToHost, s2));
+        HIPCHK(c, hipMemcpyAsync(job.h_msig, sl.d_wk_sig, (size_t) nmsg * sizeof(unsigned long long), hipMemcpyDeviceToHost, s2));
+        HIPCHK(c, hipEventRecord(job.ev_copied, s2));
+        HIPCHK(c, hipEventRecord(sl.ev_window, s2));           // the slot's device side is read on stream2 until here
+        sl.window_pending = true;
+    }
+    c->acc.sigpower_ms += (float) (wall_ms() - t_sig0);
+    job.nmsg = nmsg;
+    job.from_device = true;
+    c->acc.n_messages += nmsg;
+    return MGPU_OK;
+}
+
 // ---- part 2 (walker thread): the ordered accept walk, then the window statistics of what it hid ----
 static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
     const uint64_t n = sl.n;
@@ -1206,6 +1322,13 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
     job.rc = ResolveCounts();
     int64_t wn;
     bool wk_running = false;
+    if (c->device_walk == 1) {
+        const int rc = walk_job_device(c, sl, job);
+        if (rc != MGPU_E_AGAIN) return rc;
+        // not this chunk (see mgpu_debug_device_walk): its records come over after all and it is walked here
+        const int frc = fetch_records(c, sl, job, nullptr);
+        if (frc != MGPU_OK) return frc;
+    }
     if (c->device_walk == 2) {
         c->wk_stats[0] += 1;
         c->wk_shadow.copy_state(c->resolver);
@@ -1272,7 +1395,7 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
     // accumulated on the device and read once at the end of the feed
     const double t_sig0 = wall_ms();
     if (nmsg && !c->dbg_no_window) {
-        hipStream_t s2 = c->stream2;
+        hipStream_t s2 = c->s_post;
         launch_stage_in(sl.h_msg_pos, sl.h_msg_limit, sl.h_msg_skip, sl.d_msg_pos, sl.d_msg_limit, sl.d_msg_skip, nmsg, s2);
         launch_window_stats(sl.d_mag, n, sl.thr, sl.d_class_final, sl.d_msg_pos, sl.d_msg_skip,
                             sl.d_msg_limit, nmsg, sl.d_win_part, c->d_win, s2);
@@ -1281,7 +1404,7 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
         // the accepted frames become message records on the device (kernels/build.inc), appended to the feed's device list
         FeedSlot &fs = c->feed[job.feed];
         if (fs.d_count + nmsg > fs.d_cap) { c->err = "device message list of the feed is full"; return MGPU_E_OVERFLOW; }
-        hipStream_t s2 = c->stream2;
+        hipStream_t s2 = c->s_post;
         const size_t acc_bytes = ((size_t) nmsg * sizeof(Accepted) + 15) & ~(size_t) 15;
         const size_t buf_bytes = sl.buffers.size() * sizeof(BufferClock);
         std::memcpy(sl.h_blob, job.acc.data(), (size_t) nmsg * sizeof(Accepted));
@@ -1292,7 +1415,7 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
         fs.d_count += nmsg;
     }
     if (nmsg && (!c->dbg_no_window || c->device_msgs)) {          // the slot's device side is read on stream2 until here
-        HIPCHK(c, hipEventRecord(sl.ev_window, c->stream2));
+        HIPCHK(c, hipEventRecord(sl.ev_window, c->s_post));
         sl.window_pending = true;
     }
     c->acc.sigpower_ms += (float) (wall_ms() - t_sig0);
@@ -1340,7 +1463,21 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
     mgpu_msg *out = pending.data() + first_msg;
     std::vector<mgpu_msg> &stage = c->b_stage;               // with Mode A/C the Mode S messages are built here and merged per buffer
     if (nac) { stage.resize(nmsg); }
-    if (!on_device) {
+    if (job.from_device) {                                   // the walk ran on the device: wait for what it sent over
+        if (nmsg) HIPCHK(c, hipEventSynchronize(job.ev_copied));
+        if (!on_device && nmsg) {
+            mgpu_msg *dst = nac ? stage.data() : out;
+            const int parts = nmsg >= 4096 ? c->build_threads : 1;
+            c->build_team.run(parts, [&](int i) {
+                const uint64_t lo = (uint64_t) nmsg * i / parts, hi = (uint64_t) nmsg * (i + 1) / parts;
+                std::memcpy(dst + lo, job.h_msgs + lo, (hi - lo) * sizeof(mgpu_msg));
+            });
+        }
+    } else {
+        job.buf_nacc.assign(nbuf, 0);
+        for (uint32_t i = 0; i < nmsg; ++i) job.buf_nacc[job.acc[i].buffer]++;
+    }
+    if (!on_device && !job.from_device) {
         const int parts = nmsg >= 4096 ? c->build_threads : 1;
         mgpu_msg *dst = nac ? stage.data() : out;
         c->build_team.run(parts, [&](int i) {
@@ -1352,7 +1489,7 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
         size_t si = 0, ai = 0, o = 0;
         for (uint32_t b = 0; b < nbuf; ++b) {
             const BufferClock &bc = job.buffers[b];
-            while (si < nmsg && job.acc[si].buffer == b) out[o++] = stage[si++];
+            for (uint32_t k = 0; k < job.buf_nacc[b]; ++k) out[o++] = stage[si++];
             for (; ai < nac && ac_buf[ai] == b; ++ai) {
                 mgpu_msg m;
                 std::memset(&m, 0, sizeof(m));
@@ -1380,10 +1517,15 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
     for (uint32_t b = 0; b < nbuf; ++b) {
         const BufferClock &bc = job.buffers[b];
         uint64_t sum_scaled = 0;
-        while (mi < nmsg && job.pos[mi] < (uint64_t) bc.first + bc.length) {
-            const uint32_t ri = job.acc[mi].rec;              // not from the message: those went out with streaming stores
-            const unsigned long long sumsq = job.sig[ri];
-            const unsigned sig_len = (job.recs[ri].msg[0] & 0x80) ? 268u : 134u;   // msglen * 12 / 5, demod_2400.c:439
+        for (const uint32_t mend = mi + job.buf_nacc[b]; mi < mend;) {
+            unsigned long long sumsq;
+            unsigned sig_len;                                 // msglen * 12 / 5, demod_2400.c:439
+            if (job.from_device) { sumsq = job.h_msig[mi] & ~(1ull << 63); sig_len = (job.h_msig[mi] >> 63) ? 268u : 134u; }
+            else {
+                const uint32_t ri = job.acc[mi].rec;          // not from the message: those went out with streaming stores
+                sumsq = job.sig[ri];
+                sig_len = (job.recs[ri].msg[0] & 0x80) ? 268u : 134u;
+            }
             const double signal_power = (double) sumsq / 65535.0 / 65535.0;
             const double level = signal_power / sig_len;
             k.signal_power_sum += signal_power;
@@ -1421,15 +1563,15 @@ static int feed_begin(mgpu_ctx *c) {
     std::memset(&c->acc, 0, sizeof(c->acc));
     std::memset(c->feed_cand, 0, sizeof(c->feed_cand));
     c->feed_rc = ResolveCounts();
-    HIPCHK(c, hipMemsetAsync(c->d_win, 0, 8 * sizeof(unsigned long long), c->stream2));
+    HIPCHK(c, hipMemsetAsync(c->d_win, 0, 8 * sizeof(unsigned long long), c->s_post));
     return MGPU_OK;
 }
 
 static int feed_end(mgpu_ctx *c) {
     c->accounting_open = false;
     if (c->shard_mode != 0) return MGPU_OK;   // a shard pass produces no messages and no statistics here
-    HIPCHK(c, hipMemcpyAsync(c->h_win, c->d_win, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream2));
-    HIPCHK(c, hipStreamSynchronize(c->stream2));
+    HIPCHK(c, hipMemcpyAsync(c->h_win, c->d_win, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->s_post));
+    HIPCHK(c, hipStreamSynchronize(c->s_post));
     mgpu_counters &k = c->counters;
     k.nflips = c->resolver.nflips();
     const unsigned long long *hw = c->h_win;

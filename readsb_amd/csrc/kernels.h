@@ -205,7 +205,7 @@ constexpr int32_t kWkNoFlip = 0x7fffffff;
 struct WalkIn {                  // head of the per-chunk input blob; then (at kWkInHead) BufferClock[nbuf], active[n_active], inactive[n_inactive]
     int64_t next_flip;           // Resolver::next_flip(): the expiry is due at the first buffer end with clock >= this
     uint32_t nbuf, n_active, n_inactive, acc_cap;   // acc_cap: accept-list capacity per buffer
-    uint32_t nlive, pad[3];      // live records of the chunk (the device's own counter block is back to zero by now)
+    uint32_t nlive, buf_len, pad[2];   // live records of the chunk (the device's own counter block is back to zero by now); buffer b = positions [b * buf_len, ..)
 };
 static_assert(sizeof(WalkIn) == 40, "WalkIn");
 constexpr uint32_t kWkInHead = 48;                  // the buffer clocks start here
@@ -213,7 +213,7 @@ struct WalkState {
     int32_t flip;                // the expiry is assumed after this buffer (kWkNoFlip: not in this chunk)
     uint32_t converged, iterations, bad;
     uint32_t n_touched[2];
-    uint32_t cur, pad;
+    uint32_t cur, done;          // done: workgroups of the running kernel that have finished (last one does the serial part)
 };
 struct WalkBuffers {             // device memory of the walk (one set per context)
     uint32_t *bit_active, *bit_inactive;             // 2^24 bits each: the filter's two generations when the chunk starts
@@ -234,7 +234,8 @@ struct WalkSummary {             // what the host reads (page-locked): this, the
 };
 size_t walk_summary_bytes(uint32_t nbuf, uint32_t acc_cap);
 size_t walk_input_bytes(uint32_t nbuf, uint32_t n_active, uint32_t n_inactive);
-void launch_device_walk(const uint8_t *h_in, uint8_t *d_in, size_t in_bytes, const WalkBuffers &w, const PhaseRec *live, uint32_t nbuf, void *h_summary, void *d_acc, uint32_t *msg_pos,
+void launch_device_walk(const uint8_t *h_in, uint8_t *d_in, size_t in_bytes, const WalkBuffers &w, const PhaseRec *live,
+                        const unsigned long long *live_sig, uint32_t nbuf, void *h_summary, void *d_acc, unsigned long long *msg_sig, uint32_t *msg_pos,
                         uint32_t *msg_limit, uint16_t *msg_skip, uint32_t msg_cap, hipStream_t s);
 void launch_stage_in(const uint32_t *h_pos, const uint32_t *h_limit, const uint16_t *h_skip, uint32_t *d_pos, uint32_t *d_limit,
                      uint16_t *d_skip, uint32_t n, hipStream_t s);   // page-locked host arrays -> device, small grid

@@ -42,3 +42,19 @@ def test_device_walk_equals_host_walk(built, monkeypatch, nfix, rate, dense, sec
     print("device walk:", st)
     assert st["differences"] == 0
     assert st["chunks"] >= 2 and st["device"] >= st["chunks"] // 2, st
+
+
+@pytest.mark.parametrize("nfix,rate,dense,seconds,seed,chunk_buffers", [
+    (1, 2000.0, 0, 30.0, 51, 64),
+    (2, 8000.0, 1, 20.0, 52, None),
+    (1, 3000.0, 0, 130.0, 53, None),
+])
+def test_device_walk_results_equal_the_oracle(built, monkeypatch, nfix, rate, dense, seconds, seed, chunk_buffers):
+    """MGPU_DEVICE_WALK=1: the decisions come from the device, the records never reach the host."""
+    iq = helpers.synth(seconds=seconds, seed=seed, rate=rate, dense=dense, threads=16)
+    want, wst = helpers.oracle_run(iq, 0, nfix, 1, 58)
+    got, cnt, st = _run(iq, monkeypatch, "1", chunk_buffers, nfix_crc=nfix)
+    print("device walk:", st)
+    helpers.assert_same_messages(got, want)
+    helpers.assert_same_counters(cnt, wst)
+    assert st["device"] >= st["chunks"] // 2, st

@@ -333,6 +333,7 @@ struct mgpu_ctx {
     // and catches the filter up (Resolver::apply_device_walk), the chunk's records stay in HBM; =check: beside the host walk,
     // every decision compared (mgpu_debug_device_walk)
     int device_walk = 0;                                      // 0 off, 1 on, 2 check
+    bool wk_serial_only = false;                              // MGPU_DBG_WK_SERIAL: every buffer through k_walk's serial decision loop (cross-check of the lane-parallel one)
     WalkBuffers wk{};
     uint8_t *h_wk_in = nullptr, *h_wk_sum = nullptr;
     size_t wk_in_cap = 0;
@@ -818,6 +819,7 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     if (cfg->fixDF && cfg->nfix_crc)
         for (int b = 0; b < 5; ++b) c->valid_long |= 1u << (17 ^ (1 << b));
     if (const char *e = getenv("MGPU_DEVICE_WALK")) c->device_walk = !strcmp(e, "check") ? 2 : atoi(e) != 0;
+    c->wk_serial_only = getenv("MGPU_DBG_WK_SERIAL") != nullptr;
     if (c->device_walk) {
         int lo = 0, hi = 0;
         (void) hipDeviceGetStreamPriorityRange(&lo, &hi);
@@ -1197,6 +1199,7 @@ static bool device_walk_enqueue(mgpu_ctx *c, Slot &sl, uint64_t nlive, hipStream
     in.nbuf = nbuf; in.n_active = (uint32_t) act.size(); in.n_inactive = (uint32_t) ina.size(); in.acc_cap = c->wk_acc_cap;
     in.nlive = (uint32_t) nlive;
     in.buf_len = L;
+    in.pad[0] = c->wk_serial_only;
     uint8_t *p = c->h_wk_in;
     std::memcpy(p, &in, sizeof(in));
     std::memcpy(p + kWkInHead, sl.buffers.data(), (size_t) nbuf * sizeof(BufferClock));

@@ -28,12 +28,15 @@ def _run(iq, monkeypatch, mode, chunk_buffers=None, **kw):
         d.close()
 
 
-@pytest.mark.parametrize("nfix,rate,dense,seconds,seed,chunk_buffers", [
-    (1, 2000.0, 0, 30.0, 41, 64),        # several small chunks: the aircraft population is learnt in the first ones (the table grows)
-    (2, 8000.0, 1, 20.0, 42, None),      # overlapping DF17 bursts
-    (1, 3000.0, 0, 130.0, 43, None),     # two expiries inside the capture
+@pytest.mark.parametrize("nfix,rate,dense,seconds,seed,chunk_buffers,serial", [
+    (1, 2000.0, 0, 30.0, 41, 64, False),     # several small chunks: the aircraft population is learnt in the first ones (the table grows)
+    (2, 8000.0, 1, 20.0, 42, None, False),   # overlapping DF17 bursts
+    (1, 3000.0, 0, 130.0, 43, None, False),  # two expiries inside the capture
+    (1, 3000.0, 0, 70.0, 44, 128, True),     # every buffer through the serial decision loop (the fallback of the lane-parallel one)
 ])
-def test_device_walk_equals_host_walk(built, monkeypatch, nfix, rate, dense, seconds, seed, chunk_buffers):
+def test_device_walk_equals_host_walk(built, monkeypatch, nfix, rate, dense, seconds, seed, chunk_buffers, serial):
+    if serial:
+        monkeypatch.setenv("MGPU_DBG_WK_SERIAL", "1")
     iq = helpers.synth(seconds=seconds, seed=seed, rate=rate, dense=dense, threads=16)
     want, wst = helpers.oracle_run(iq, 0, nfix, 1, 58)
     got, cnt, st = _run(iq, monkeypatch, "check", chunk_buffers, nfix_crc=nfix)

@@ -99,7 +99,10 @@ EXTRA_CONFIGS = {
     "configs[2]: SC16Q11 --aggressive (2-bit repair)": (2, 2, dict(rate=2000.0)),
     "dense bursts, 8000 frames/s, overlapping DF17, --aggressive": (0, 2, dict(rate=8000.0, dense=1)),
     "UC8 --fix, Gaussian noise (sigma 3 LSB)": (0, 1, dict(rate=2000.0, dense=4)),
+    "UC8 --fix, ordered walk on the device (MGPU_DEVICE_WALK=1)": (0, 1, dict(rate=2000.0)),
 }
+# ... and the environment a configuration's context is created under (library switches are read by mgpu_create)
+EXTRA_ENV = {"UC8 --fix, ordered walk on the device (MGPU_DEVICE_WALK=1)": {"MGPU_DEVICE_WALK": "1"}}
 
 
 def run_extra_config(name, fmt, nfix, kw, nsamples, device, steps=4):
@@ -108,7 +111,17 @@ def run_extra_config(name, fmt, nfix, kw, nsamples, device, steps=4):
     import helpers
     import readsb_amd
     iq = helpers.synth(nsamples=nsamples, fmt=fmt, seed=424242, threads=min(64, os.cpu_count() or 8), **kw)
-    d = readsb_amd.Demodulator(fmt=fmt, nfix_crc=nfix, max_samples=nsamples, device=device, startup_time_ms=helpers.STARTUP_MS)
+    env = EXTRA_ENV.get(name, {})
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        d = readsb_amd.Demodulator(fmt=fmt, nfix_crc=nfix, max_samples=nsamples, device=device, startup_time_ms=helpers.STARTUP_MS)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     d.upload_iq(iq)
     d.keep_other_threads_away(confine_to_own_l3=False)
     d.feed_resident(nsamples)
@@ -155,6 +168,8 @@ def run_extra_config(name, fmt, nfix, kw, nsamples, device, steps=4):
            "samples_per_launch": int(nsamples * steps // nl),
            "cpu_reference_msamples_s": round(nsamples / float(st["t_convert_s"] + st["t_demod_s"]) / 1e6, 1),
            "bit_identical_to_reference": True, "checker": kind}
+    if env.get("MGPU_DEVICE_WALK"):
+        out["device_walk"] = d.device_walk_stats()          # chunks decided on the device / walked on the host after all, walks run
     d.close()
     return out
 

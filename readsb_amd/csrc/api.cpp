@@ -849,6 +849,8 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     // the first context of a device has two L3 groups to itself (bind_near_device): a walk team of 8 and a builder team of 6;
     // further contexts of the device share one group: 4 + 3 as before
     if (c->device_slot == 0 && !getenv("MGPU_ONE_L3") && !getenv("MGPU_NO_AFFINITY")) { c->walk_threads = 8; c->build_threads = 6; }
+    // with the walk on the device the walker only waits for the GPU and replays the adds; the builder copies and sums
+    if (c->device_walk == 1) { c->walk_threads = 1; c->build_threads = 2; }
     if (const char *e = getenv("MGPU_WALK_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) c->walk_threads = v; }
     if (const char *e = getenv("MGPU_BUILD_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) c->build_threads = v; }
     c->fetcher = std::thread(fetcher_main, c);

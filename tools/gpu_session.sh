@@ -1,18 +1,13 @@
 #!/bin/bash
 cd /root/repo
 mkdir -p gpurun_out
-cd /tmp && export TMPDIR=/tmp
-timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_wk -o wk -- python /root/repo/tools/wk_probe.py > /root/repo/gpurun_out/s50.out 2>&1
-grep "differences" /root/repo/gpurun_out/s50.out | tail -2 | cut -c1-200
-t=$(find /tmp/prof_wk -name "*kernel_trace.csv" | head -1)
-if [ -n "$t" ]; then python3 - "$t" > /root/repo/gpurun_out/s50_walk_trace.txt <<'PY'
-import csv,sys
-rows=list(csv.DictReader(open(sys.argv[1])))
-rows.sort(key=lambda r:int(r['Start_Timestamp']))
-t0=int(rows[0]['Start_Timestamp'])
-for r in rows:
-    if 'walk' in r['Kernel_Name'] or 'slice' in r['Kernel_Name']:
-        print(f"{(int(r['Start_Timestamp'])-t0)/1000:9.1f} {(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1000:8.1f} us  {r['Kernel_Name'][:40]}")
+timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -6 > gpurun_out/s52_suite.log
+cat gpurun_out/s52_suite.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
+timeout 600 python bench.py 2>gpurun_out/s52_bench.err | tail -1 > gpurun_out/s52_bench.json
+python - <<'PY'
+import json
+d=json.load(open('gpurun_out/s52_bench.json'))
+print(d['value'], d['ms_per_step'], d['roofline'], d.get('stage_ms'))
+for k,v in d.get('configs',{}).items(): print(k, v['msamples_s'], v['ms_per_segment'], v.get('device_walk'))
 PY
-tail -26 /root/repo/gpurun_out/s50_walk_trace.txt
-fi

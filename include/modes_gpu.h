@@ -436,6 +436,15 @@ const uint16_t *mgpu_uc8_table(void);
 int mgpu_selftest_walk(uint64_t seed, uint32_t nchunks, uint32_t buffers_per_chunk, uint32_t nsegments,
                        uint32_t naircraft, uint32_t *speculated_permille);
 
+/* Same idea for the walk on the device (below), needs no GPU either: its algorithm restated on the host — every buffer walked on
+ * its own against the filter at the start of the chunk plus a table of first adds, iterated (at most max_walks times) until the
+ * table reproduces itself, then the premise check — against the serial walk on the same seeded streams.  Chunks that do not
+ * settle or whose premises fail are walked serially, as the library does.  0 = identical, k > 0 = first differing chunk + 1.
+ * stats (may be NULL): [0] chunks decided by the model, [1] chunks walked serially after all, [2] walks in all, [3] most walks
+ * one chunk took. */
+int mgpu_selftest_device_walk(uint64_t seed, uint32_t nchunks, uint32_t buffers_per_chunk, uint32_t naircraft,
+                              uint32_t max_walks, uint64_t stats[4]);
+
 /* The ordered walk on the device (environment MGPU_DEVICE_WALK=1, or =check to run it beside the host walk and compare every
  * decision): out[0] chunks, [1] chunks whose decisions came from the device (check: were compared), [2] chunks the fixed point
  * did not settle on in time, [3] chunks whose premises failed afterwards (the filter table grew, the expiry moved), [4] chunks

@@ -2442,46 +2442,38 @@ int mgpu_crc_table_size(int nfix_crc, int bits) { return (int) host_table(nfix_c
 
 const uint16_t *mgpu_uc8_table(void) { return uc8_table(); }
 
-// Host-logic self-check (no GPU): a seeded synthetic record stream — aircraft that appear, go quiet and
-// return, so that addresses enter the ICAO filter, expire on the 60 s clock and come back — is walked
-// chunk by chunk once with Resolver::decide and once with Resolver::parallel_walk over `nsegments`
-// buffer ranges per chunk (real threads).  Returns 0 when every decision, every counter and the final
-// filter agree; k > 0 = first differing chunk + 1.  *speculated_permille = share of chunks whose ranges
-// all committed in the first batch (a test that never restarted a batch, or always did, would prove little).
-int mgpu_selftest_walk(uint64_t seed, uint32_t nchunks, uint32_t buffers_per_chunk, uint32_t nsegments, uint32_t naircraft,
-                       uint32_t *speculated_permille) {
-    if (nchunks == 0 || buffers_per_chunk == 0 || nsegments == 0 || naircraft == 0) return -1;
-    uint64_t x = seed ? seed : 88172645463325252ull;
-    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
-    const uint32_t B = 131072;
-    Resolver serial, parallel;
-    serial.reset(1000000);
-    parallel.reset(1000000);
-    uint64_t held = 0, ranges = 0;   // chunks that took a single batch / chunks
-    // aircraft a transmits during [on, off) of every `period` seconds: quiet spells longer than two filter
-    // generations make addresses expire, short ones do not
+}  // extern "C"
+
+// Seeded synthetic record streams for the host-logic self-checks: aircraft that transmit during [on, off) of every `period`
+// seconds — quiet spells longer than two filter generations make addresses expire, short ones do not — and the record kinds the
+// kernels emit (clean adders, repaired frames, address-parity replies that only count when the address is known).
+struct SelftestStream {
     struct Plane { uint32_t addr; double on, off, period; };
-    std::vector<Plane> planes(naircraft);
-    for (uint32_t i = 0; i < naircraft; ++i) {
-        planes[i].addr = 0x400000u + (uint32_t) (rnd() % 4096) * 7u + i;
-        planes[i].period = 40.0 + (double) (rnd() % 400);
-        planes[i].on = (double) (rnd() % 1000) / 1000.0 * planes[i].period;
-        planes[i].off = planes[i].on + 5.0 + (double) (rnd() % 1000) / 1000.0 * planes[i].period;
+    uint64_t x;
+    std::vector<Plane> planes;
+    uint64_t rnd() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; }
+    SelftestStream(uint64_t seed, uint32_t naircraft) : x(seed ? seed : 88172645463325252ull), planes(naircraft) {
+        for (uint32_t i = 0; i < naircraft; ++i) {
+            planes[i].addr = 0x400000u + (uint32_t) (rnd() % 4096) * 7u + i;
+            planes[i].period = 40.0 + (double) (rnd() % 400);
+            planes[i].on = (double) (rnd() % 1000) / 1000.0 * planes[i].period;
+            planes[i].off = planes[i].on + 5.0 + (double) (rnd() % 1000) / 1000.0 * planes[i].period;
+        }
     }
-    const uint32_t K = nsegments < buffers_per_chunk ? nsegments : buffers_per_chunk;
-    std::vector<SegmentWalk> segs(K);
-    uint64_t stream_pos = 0;
-    for (uint32_t ch = 0; ch < nchunks; ++ch) {
-        std::vector<BufferClock> bufs;
-        for (uint32_t b = 0; b < buffers_per_chunk; ++b) {
+    // one chunk of `nbuf` 131072-sample buffers starting at stream position `stream_pos`: its buffer grid and its records
+    // (position order, no sentinel); returns the chunk's length in samples
+    uint64_t chunk(uint64_t stream_pos, uint32_t nbuf, std::vector<BufferClock> &bufs, std::vector<PhaseRec> &recs) {
+        const uint32_t B = 131072;
+        const uint32_t naircraft = (uint32_t) planes.size();
+        bufs.clear(); recs.clear();
+        for (uint32_t b = 0; b < nbuf; ++b) {
             BufferClock bc;
             bc.first = b * B; bc.length = B;
             bc.sampleTimestamp = (int64_t) (stream_pos + (uint64_t) b * B) * 5;
             bc.sysTimestamp = bc.sampleTimestamp / 12000 + 1000000;
             bufs.push_back(bc);
         }
-        std::vector<PhaseRec> recs;
-        const uint64_t npos = (uint64_t) buffers_per_chunk * B;
+        const uint64_t npos = (uint64_t) nbuf * B;
         for (uint64_t pos = rnd() % 600; pos < npos; pos += 40 + rnd() % 900) {
             const double t = (double) (stream_pos + pos) / 2.4e6;
             const Plane &pl = planes[rnd() % naircraft];
@@ -2503,6 +2495,72 @@ int mgpu_selftest_walk(uint64_t seed, uint32_t nchunks, uint32_t buffers_per_chu
                 recs.push_back(r);
             }
         }
+        return npos;
+    }
+};
+
+extern "C" {
+
+// The device walk's algorithm (Resolver::device_walk_model = kernels/walk.inc restated on the host) against the serial walk on the
+// same streams: every decision, every counter, the filter afterwards.  Chunks whose premises fail (the table grows inside the
+// chunk) or that do not settle are walked serially, as the library does.  0 = identical, k > 0 = first differing chunk + 1.
+// stats[0] chunks decided by the model, [1] chunks walked serially after all, [2] walks in all, [3] most walks one chunk took.
+int mgpu_selftest_device_walk(uint64_t seed, uint32_t nchunks, uint32_t buffers_per_chunk, uint32_t naircraft, uint32_t max_walks, uint64_t stats[4]) {
+    if (nchunks == 0 || buffers_per_chunk == 0 || naircraft == 0 || max_walks == 0) return -1;
+    SelftestStream gen(seed, naircraft);
+    Resolver serial, model;
+    serial.reset(1000000);
+    model.reset(1000000);
+    uint64_t st[4] = {0, 0, 0, 0};
+    uint64_t stream_pos = 0;
+    for (uint32_t ch = 0; ch < nchunks; ++ch) {
+        std::vector<BufferClock> bufs;
+        std::vector<PhaseRec> recs;
+        const uint64_t npos = gen.chunk(stream_pos, buffers_per_chunk, bufs, recs);
+        const uint64_t n = recs.size();
+        { PhaseRec s{}; s.pos = 0xFFFFFFFFu; recs.push_back(s); }
+        std::vector<uint32_t> pos(n + 1), lim(n + 1);
+        std::vector<uint16_t> skip(n + 1);
+        std::vector<Accepted> acc_s, acc_m;
+        ResolveCounts rc_s, rc_m;
+        const int64_t ns = serial.decide(recs.data(), n, bufs, acc_s, pos.data(), skip.data(), lim.data(), n + 1, rc_s);
+        uint32_t walks = 0;
+        int64_t nm = model.device_walk_model(recs.data(), n, bufs, acc_m, rc_m, max_walks, &walks);
+        st[2] += walks;
+        if (walks > st[3]) st[3] = walks;
+        if (nm < 0) { ++st[1]; nm = model.decide(recs.data(), n, bufs, acc_m, pos.data(), skip.data(), lim.data(), n + 1, rc_m); }
+        else ++st[0];
+        bool same = nm == ns && std::memcmp(&rc_s, &rc_m, sizeof(rc_s)) == 0 && model.same_state(serial);
+        for (int64_t i = 0; same && i < ns; ++i)
+            same = acc_s[(size_t) i].rec == acc_m[(size_t) i].rec && acc_s[(size_t) i].buffer == acc_m[(size_t) i].buffer && acc_s[(size_t) i].score == acc_m[(size_t) i].score;
+        if (!same) { if (stats) std::memcpy(stats, st, sizeof(st)); return (int) ch + 1; }
+        stream_pos += npos;
+    }
+    if (stats) std::memcpy(stats, st, sizeof(st));
+    return 0;
+}
+
+// Host-logic self-check (no GPU): a seeded synthetic record stream — aircraft that appear, go quiet and
+// return, so that addresses enter the ICAO filter, expire on the 60 s clock and come back — is walked
+// chunk by chunk once with Resolver::decide and once with Resolver::parallel_walk over `nsegments`
+// buffer ranges per chunk (real threads).  Returns 0 when every decision, every counter and the final
+// filter agree; k > 0 = first differing chunk + 1.  *speculated_permille = share of chunks whose ranges
+// all committed in the first batch (a test that never restarted a batch, or always did, would prove little).
+int mgpu_selftest_walk(uint64_t seed, uint32_t nchunks, uint32_t buffers_per_chunk, uint32_t nsegments, uint32_t naircraft,
+                       uint32_t *speculated_permille) {
+    if (nchunks == 0 || buffers_per_chunk == 0 || nsegments == 0 || naircraft == 0) return -1;
+    SelftestStream gen(seed, naircraft);
+    Resolver serial, parallel;
+    serial.reset(1000000);
+    parallel.reset(1000000);
+    uint64_t held = 0, ranges = 0;   // chunks that took a single batch / chunks
+    const uint32_t K = nsegments < buffers_per_chunk ? nsegments : buffers_per_chunk;
+    std::vector<SegmentWalk> segs(K);
+    uint64_t stream_pos = 0;
+    for (uint32_t ch = 0; ch < nchunks; ++ch) {
+        std::vector<BufferClock> bufs;
+        std::vector<PhaseRec> recs;
+        const uint64_t npos = gen.chunk(stream_pos, buffers_per_chunk, bufs, recs);
         const uint64_t n = recs.size();
         { PhaseRec s{}; s.pos = 0xFFFFFFFFu; recs.push_back(s); }
         std::vector<uint32_t> pos(n + 1), lim(n + 1);

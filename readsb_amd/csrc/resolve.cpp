@@ -281,6 +281,89 @@ uint64_t first_record_at(const PhaseRec *recs, uint64_t nrecs, uint32_t pos) {
 }
 }  // namespace
 
+namespace {
+// what one wave of k_walk knows: the generations as they were when the chunk started, the table of first adds, its own adds
+struct ModelPolicy {
+    const IcaoFilter &flt;
+    const std::vector<std::pair<uint32_t, uint32_t>> &first_cur;   // (address, first buffer that adds it), sorted by address
+    uint32_t b;
+    int32_t flip;
+    AddrSet &own;
+    int64_t end_clock = 0;
+    bool odd = false;
+    bool test(uint32_t a) {
+        if (a >> 24) { odd = true; return false; }
+        if (flt.in_generation(a, true) || ((int32_t) b <= flip && flt.in_generation(a, false)) || own.test(a)) return true;
+        auto it = std::lower_bound(first_cur.begin(), first_cur.end(), std::make_pair(a, 0u));
+        return it != first_cur.end() && it->first == a && it->second < b;
+    }
+    void add(uint32_t a) { own.set(a); }
+    void buffer_end(int64_t now) { end_clock = now; }
+};
+}  // namespace
+
+int64_t Resolver::device_walk_model(const PhaseRec *recs, uint64_t nrecs, const std::vector<BufferClock> &buffers, std::vector<Accepted> &acc,
+                                    ResolveCounts &counts, uint32_t max_walks, uint32_t *walks) {
+    const uint32_t nbuf = (uint32_t) buffers.size();
+    const int32_t no_flip = 0x7fffffff;
+    std::vector<std::pair<uint32_t, uint32_t>> cur, next;            // the two tables
+    int32_t flip = no_flip;
+    for (uint32_t b = 0; b < nbuf; ++b) if (buffers[b].sysTimestamp >= next_flip_) { flip = (int32_t) b; break; }   // k_walk_begin's guess
+    std::vector<uint32_t> rows((size_t) 6 * nbuf), adds;
+    std::vector<std::vector<uint32_t>> buf_adds(nbuf);
+    std::vector<int64_t> end_clock(nbuf);
+    std::vector<Accepted> out;
+    std::vector<uint32_t> pos(nrecs + 1), lim(nrecs + 1);
+    std::vector<uint16_t> skip(nrecs + 1);
+    AddrSet own;
+    own.ensure();
+    ResolveCounts rc;
+    bool settled = false;
+    uint32_t w = 0;
+    while (w < max_walks && !settled) {
+        ++w;
+        out.assign(nrecs + 1, Accepted{});
+        rc = ResolveCounts();
+        next.clear();
+        uint64_t nout = 0;
+        bool odd = false;
+        for (uint32_t b = 0; b < nbuf; ++b) {                        // (on the device: all at once, a wave each)
+            own.clear();
+            ModelPolicy pol{filter_, cur, b, flip, own};
+            const uint64_t lo = first_record_at(recs, nrecs, buffers[b].first);
+            const int64_t n = walk_range(pol, recs, lo, buffers.data(), b, b + 1, out.data() + nout, pos.data(), skip.data(), lim.data(), nrecs + 1 - nout, rc);
+            if (n < 0 || pol.odd) { odd = true; break; }
+            rows[6 * b + 0] = (uint32_t) n; rows[6 * b + 5] = (uint32_t) nout;
+            nout += (uint64_t) n;
+            end_clock[b] = pol.end_clock;
+            buf_adds[b] = own.list;
+            for (uint32_t a : own.list)                              // only what is not known for the whole chunk anyway
+                if (!(filter_.in_generation(a, true) || (flip == no_flip && filter_.in_generation(a, false)))) next.emplace_back(a, b);
+        }
+        if (odd) { if (walks) *walks = w; return -1; }
+        std::sort(next.begin(), next.end());                         // first add per address = the smallest buffer
+        next.erase(std::unique(next.begin(), next.end(), [](const std::pair<uint32_t, uint32_t> &x, const std::pair<uint32_t, uint32_t> &y) { return x.first == y.first; }), next.end());
+        int32_t f = no_flip;
+        for (uint32_t b = 0; b < nbuf; ++b) if (end_clock[b] >= next_flip_) { f = (int32_t) b; break; }
+        settled = next == cur && f == flip;
+        if (!settled) { cur.swap(next); flip = f; }
+        else acc.assign(out.begin(), out.begin() + (std::ptrdiff_t) nout);
+    }
+    if (walks) *walks = w;
+    if (!settled) return -1;
+    adds.clear();
+    for (uint32_t b = 0; b < nbuf; ++b) {
+        rows[6 * b + 1] = (uint32_t) buf_adds[b].size();
+        rows[6 * b + 2] = (uint32_t) (uint64_t) end_clock[b]; rows[6 * b + 3] = (uint32_t) ((uint64_t) end_clock[b] >> 32);
+        rows[6 * b + 4] = (uint32_t) adds.size();
+        adds.insert(adds.end(), buf_adds[b].begin(), buf_adds[b].end());
+    }
+    adds.push_back(0);                                               // (never empty: data() stays valid)
+    if (!apply_device_walk(rows.data(), adds.data(), nbuf, flip)) return -1;
+    counts.add(rc);
+    return (int64_t) acc.size();
+}
+
 int64_t Resolver::decide(const PhaseRec *recs, uint64_t nrecs, const std::vector<BufferClock> &buffers, std::vector<Accepted> &acc,
                          uint32_t *aux_pos, uint16_t *aux_skip, uint32_t *aux_limit, uint64_t aux_cap, ResolveCounts &counts) {
     (void) nrecs;

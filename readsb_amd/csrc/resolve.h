@@ -43,6 +43,9 @@ class IcaoFilter {
     void union_sorted(std::vector<uint32_t> &out) const;      // addresses < 2^24 in either generation, ascending
     const std::vector<uint32_t> &members(bool active) const { return members_[active ? active_ : active_ ^ 1]; }   // addresses < 2^24
     bool same_as(const IcaoFilter &o) const;                  // membership per generation, occupied, table size
+    bool in_generation(uint32_t addr, bool active) const {    // addr < 2^24
+        return (bits_[active ? active_ : active_ ^ 1][addr >> 6] >> (addr & 63)) & 1;
+    }
     // addresses that leave the union (expire / resize) and addresses that enter it (first add)
     void track_changes(std::vector<uint32_t> *drops, std::vector<uint32_t> *news) { drops_ = drops; news_ = news; }
 
@@ -190,6 +193,13 @@ class Resolver {
     // the expiry came after the buffer the walk had put it after (flip; 0x7fffffff = not in this chunk), and only once.
     // On false the state is what it was and the chunk has to be walked here.
     bool apply_device_walk(const uint32_t *per_buf, const uint32_t *adds, uint32_t nbuf, int32_t flip);
+    // The device walk's algorithm (kernels/walk.inc) restated on the host — every buffer walked on its own against the state at the
+    // start of the chunk plus a table of first adds, iterated until the table reproduces itself, then apply_device_walk — so that
+    // its exactness argument is tested without a GPU against the serial walk on streams with arriving aircraft, expiries and table
+    // growth (mgpu_selftest_device_walk).  Returns the number of accepted frames, or -1 when the fixed point did not settle in
+    // `max_walks` or the premises failed (state untouched: the caller walks the chunk with decide()).
+    int64_t device_walk_model(const PhaseRec *recs, uint64_t nrecs, const std::vector<BufferClock> &buffers, std::vector<Accepted> &acc,
+                              ResolveCounts &counts, uint32_t max_walks, uint32_t *walks);
     void copy_state(const Resolver &o) { copy_state_from(o); }
     bool same_state(const Resolver &o) const {
         return synthetic_now_ == o.synthetic_now_ && next_flip_ == o.next_flip_ && nflips_ == o.nflips_ && filter_.same_as(o.filter_);

@@ -116,6 +116,30 @@ def test_parallel_walk_equals_serial_walk(built):
     assert any(h > 500 for h in held) and any(h < 1000 for h in held), held
 
 
+@pytest.mark.parametrize("seed,nchunks,nbuf,naircraft", [
+    (11, 40, 64, 60),        # 3.5 s chunks: an expiry every 17th chunk, aircraft arriving all the time
+    (12, 12, 512, 300),      # 28 s chunks, enough aircraft for the filter table to grow twice (86, 171 addresses)
+    (13, 6, 1200, 40),       # chunks longer than the filter's 60 s clock: a chunk two expiries fall into is walked serially
+    (14, 60, 16, 500),       # many small chunks, a large population
+])
+def test_device_walk_model_equals_serial_walk(built, seed, nchunks, nbuf, naircraft):
+    """Host logic, no GPU: the device walk's fixed point over per-buffer walks (kernels/walk.inc restated in
+    Resolver::device_walk_model) and its premise check (Resolver::apply_device_walk) make exactly the serial walk's decisions
+    — and most chunks are decided by it, in at most three walks."""
+    import readsb_amd
+    lib = C.CDLL(readsb_amd.lib_path())
+    f = lib.mgpu_selftest_device_walk
+    f.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+    f.restype = C.c_int
+    st = (C.c_uint64 * 4)()
+    assert f(seed, nchunks, nbuf, naircraft, 3, st) == 0, f"device walk model differs from the serial walk: {list(st)}"
+    by_model, serial, walks, most = list(st)
+    print("model:", by_model, "serial:", serial, "walks:", walks, "most:", most)
+    assert by_model + serial == nchunks and most <= 3
+    if nbuf <= 512:
+        assert by_model >= nchunks // 2, list(st)
+
+
 def test_bench_roofline_helpers():
     """bench.py's informative VALU-issue figure parses the committed SQ counter summary (and degrades to None, never raises)."""
     import bench

@@ -175,6 +175,7 @@ struct Slot {
     uint8_t *h_blob = nullptr, *d_blob = nullptr;   // device-messages mode: the walker's accept list + buffer clocks, page-locked host / device
     const uint8_t *fused_iq = nullptr;    // this chunk's converter runs inside k_sweep (enqueue_convert): its IQ samples ...
     const uint16_t *fused_tail = nullptr; // ... and the 326 magnitudes before them
+    bool sig_late = false;                // the signal powers of this chunk are computed after the walk, for the accepted frames (k_msg_sig)
     int feed = -1;                        // deferred feeds: which FeedSlot the chunk's messages go to (-1: mgpu_ctx::pending)
     int32_t thr = 58;                     // preamble threshold of this chunk (raised after drops, demod_2400.c:335-338)
     bool have_mag = false, busy = false;
@@ -239,6 +240,7 @@ struct HostJob {
     // the walk ran on the device (MGPU_DEVICE_WALK=1): no records here; per message the signal power (bit 63: a 112-bit frame as
     // sliced) and — unless the messages stay on the device — the records k_build_messages made, both copied into page-locked memory
     bool from_device = false;
+    bool sig_late = false;                   // Slot::sig_late: sig[] is empty, h_msig holds the accepted frames' signal powers (ev_copied)
     bool fetched = false;                    // recs / sig hold the chunk's live records
     mgpu_msg *h_msgs = nullptr;
     unsigned long long *h_msig = nullptr;
@@ -299,6 +301,7 @@ struct mgpu_ctx {
     bool deferred = false;
     bool device_msgs = false;                                 // mgpu_set_device_messages
     bool copy_after_sweep = false;                            // MGPU_COPY_AFTER_SWEEP=1: the fetcher holds its copies back until the next chunk's k_sweep has run
+    bool sig_late = true;                                     // MGPU_SIG_LATE=0: signal power of every live record in the pre-screen write pass (as in shard passes) instead of the accepted frames' after the walk
     bool fused_convert = false;                               // MGPU_FUSED_CONVERT=1: UC8 conversion inside k_sweep's tile load (same speed, see kernels/sweep.inc)
     int timing_every = 4;                                     // MGPU_TIMING_EVERY: chunks per set of stage timing events (1 = every chunk)
     uint64_t timing_seq = 0;
@@ -720,6 +723,10 @@ static int alloc_all(mgpu_ctx *c) {
         if (rc != MGPU_OK) return rc;
     }
 
+    for (auto &j : c->job) {
+        HIPCHK(c, hipHostMalloc(&j.h_msig, c->cap_msgs * sizeof(unsigned long long)));
+        HIPCHK(c, hipEventCreateWithFlags(&j.ev_copied, hipEventDisableTiming));
+    }
     if (c->device_walk) {
         WalkBuffers &w = c->wk;
         const size_t nb = c->cap_buffers + 1;
@@ -757,11 +764,7 @@ static int alloc_all(mgpu_ctx *c) {
         HIPCHK(c, hipHostMalloc(&c->h_wk_sum, walk_summary_bytes((uint32_t) c->cap_buffers, c->wk_acc_cap)));
         if (c->device_walk == 1) {
             HIPCHK(c, hipMalloc(&c->d_wk_msgs, c->cap_msgs * sizeof(mgpu_msg)));
-            for (auto &j : c->job) {
-                HIPCHK(c, hipHostMalloc(&j.h_msgs, c->cap_msgs * sizeof(mgpu_msg)));
-                HIPCHK(c, hipHostMalloc(&j.h_msig, c->cap_msgs * sizeof(unsigned long long)));
-                HIPCHK(c, hipEventCreateWithFlags(&j.ev_copied, hipEventDisableTiming));
-            }
+            for (auto &j : c->job) HIPCHK(c, hipHostMalloc(&j.h_msgs, c->cap_msgs * sizeof(mgpu_msg)));
         }
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_wk, hipEventDisableTiming));
     }
@@ -843,8 +846,9 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     if (const char *e = getenv("MGPU_DEBUG_STAGE")) c->dbg_stage = atoi(e);
     if (const char *e = getenv("MGPU_COPY_AFTER_SWEEP")) c->copy_after_sweep = atoi(e) != 0;
     if (const char *e = getenv("MGPU_FUSED_CONVERT")) c->fused_convert = atoi(e) != 0;
+    if (const char *e = getenv("MGPU_SIG_LATE")) c->sig_late = atoi(e) != 0;
     if (const char *e = getenv("MGPU_TIMING_EVERY")) { const int v = atoi(e); if (v >= 1) c->timing_every = v; }
-    if (const char *e = getenv("MGPU_DUMP_DIR")) c->dump_dir = e;
+    if (const char *e = getenv("MGPU_DUMP_DIR")) { c->dump_dir = e; c->sig_late = false; }   // (the dump holds per-record signal powers)
     c->device_slot = take_device_slot(cfg->device);
     // the first context of a device has two L3 groups to itself (bind_near_device): a walk team of 8 and a builder team of 6;
     // further contexts of the device share one group: 4 + 3 as before
@@ -1038,7 +1042,11 @@ static int enqueue_post(mgpu_ctx *c, Slot &sl) {
     // class planes -> class bitmap, pre-screen (the surviving records stay in HBM: d_live), counters and per-buffer sums to the host
     PostSweepParams q{};
     q.pool = sl.d_pool; q.unit_first = sl.d_unit_first; q.nunits = nunits; q.adder_bitmap = c->d_adder_bitmap;
-    q.unit_live = sl.d_unit_live; q.block_live = sl.d_unit_live + c->cap_units + 2; q.live = sl.d_live; q.mag = sl.d_mag; q.live_sig = sl.d_live_sig; q.counters = sl.d_counters;
+    q.unit_live = sl.d_unit_live; q.block_live = sl.d_unit_live + c->cap_units + 2; q.live = sl.d_live; q.live_sig = sl.d_live_sig; q.counters = sl.d_counters;
+    // a shard pass hands its records to another rank, which has no samples: their signal powers go with them.  Otherwise they are
+    // computed after the walk, for the accepted frames only (k_msg_sig): 40 % of the work, off the main stream
+    sl.sig_late = c->sig_late && c->shard_mode == 0;
+    q.mag = sl.sig_late ? nullptr : sl.d_mag;
     q.class_cond = sl.d_class_bitmap; q.class_uncond = sl.d_class_uncond;
     q.class_final = sl.d_class_final;
     q.class_words = (n + 31) / 32;
@@ -1076,7 +1084,7 @@ static int fetch_records(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
     if (nlive) {
         // (a copy kernel of our own with 8..32 workgroups in place of the runtime's blit kernel: 2.55-2.63 ms per step instead of 2.45)
         HIPCHK(c, hipMemcpyAsync(sl.h_live, sl.d_live, nlive * sizeof(PhaseRec), hipMemcpyDeviceToHost, c->stream_d2h));
-        HIPCHK(c, hipMemcpyAsync(sl.h_live_sig, sl.d_live_sig, nlive * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream_d2h));
+        if (!sl.sig_late) HIPCHK(c, hipMemcpyAsync(sl.h_live_sig, sl.d_live_sig, nlive * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream_d2h));
         HIPCHK(c, hipStreamSynchronize(c->stream_d2h));
     }
     if (!c->dump_dir.empty()) {   // replay material for tools/walk_replay.cpp
@@ -1091,9 +1099,11 @@ static int fetch_records(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
     }
     job.recs.resize(nlive + 1);
     job.recs[nlive].pos = 0xFFFFFFFFu;          // sentinel for the walk
-    job.sig.resize(nlive);
     std::memcpy(job.recs.data(), sl.h_live, nlive * sizeof(PhaseRec));
-    std::memcpy(job.sig.data(), sl.h_live_sig, nlive * sizeof(unsigned long long));
+    if (!sl.sig_late) {
+        job.sig.resize(nlive);
+        std::memcpy(job.sig.data(), sl.h_live_sig, nlive * sizeof(unsigned long long));
+    }
     job.fetched = true;
     return MGPU_OK;
 }
@@ -1155,6 +1165,7 @@ static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
     job.nlive = nlive;
     job.stream_pos = sl.stream_pos;
     job.fetched = job.from_device = false;
+    job.sig_late = sl.sig_late;
     // with the walk on the device the records stay in HBM (the walker fetches them itself for a chunk it has to walk here)
     if (c->device_walk != 1 || c->shard_mode != 0) { const int rc = fetch_records(c, sl, job, next); if (rc != MGPU_OK) return rc; }
     job.ac.clear();
@@ -1208,8 +1219,8 @@ static bool device_walk_enqueue(mgpu_ctx *c, Slot &sl, uint64_t nlive, hipStream
     uint32_t *lists = (uint32_t *) (p + kWkInHead + (size_t) nbuf * sizeof(BufferClock));
     if (!act.empty()) std::memcpy(lists, act.data(), act.size() * sizeof(uint32_t));
     if (!ina.empty()) std::memcpy(lists + act.size(), ina.data(), ina.size() * sizeof(uint32_t));
-    launch_device_walk(c->h_wk_in, sl.d_wk_in, walk_input_bytes(nbuf, in.n_active, in.n_inactive), c->wk, sl.d_live, sl.d_live_sig, nbuf,
-                       c->h_wk_sum, sl.d_wk_acc, sl.d_wk_sig, sl.d_msg_pos, sl.d_msg_limit, sl.d_msg_skip, (uint32_t) c->cap_msgs, s);
+    launch_device_walk(c->h_wk_in, sl.d_wk_in, walk_input_bytes(nbuf, in.n_active, in.n_inactive), c->wk, sl.d_live, nbuf,
+                       c->h_wk_sum, sl.d_wk_acc, sl.d_msg_pos, sl.d_msg_limit, sl.d_msg_skip, (uint32_t) c->cap_msgs, s);
     return hipEventRecord(c->ev_wk, s) == hipSuccess;
 }
 
@@ -1302,7 +1313,8 @@ static int walk_job_device(mgpu_ctx *c, Slot &sl, HostJob &job) {
             dst = fs.d_msgs + fs.d_count;
             fs.d_count += nmsg;
         }
-        launch_build_messages(sl.d_live, sl.d_live_sig, sl.d_wk_acc, d_bufs, nmsg, dst, s2);
+        launch_msg_sig(sl.d_mag, sl.d_msg_pos, sl.d_msg_skip, nmsg, sl.d_wk_sig, s2);
+        launch_build_messages(sl.d_live, nullptr, sl.d_wk_sig, sl.d_wk_acc, d_bufs, nmsg, dst, s2);
         if (to_device_list) HIPCHK(c, hipEventRecord(c->feed[job.feed].ev_built, s2));
         else HIPCHK(c, hipMemcpyAsync(job.h_msgs, c->d_wk_msgs, (size_t) nmsg * sizeof(mgpu_msg), hipMemcpyDeviceToHost, s2));
         HIPCHK(c, hipMemcpyAsync(job.h_msig, sl.d_wk_sig, (size_t) nmsg * sizeof(unsigned long long), hipMemcpyDeviceToHost, s2));
@@ -1399,28 +1411,34 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
     // what the skip windows hid from the counters: asynchronous on the second stream, totals are
     // accumulated on the device and read once at the end of the feed
     const double t_sig0 = wall_ms();
-    if (nmsg && !c->dbg_no_window) {
-        hipStream_t s2 = c->s_post;
+    hipStream_t s2 = c->s_post;
+    if (nmsg && (!c->dbg_no_window || job.sig_late))
         launch_stage_in(sl.h_msg_pos, sl.h_msg_limit, sl.h_msg_skip, sl.d_msg_pos, sl.d_msg_limit, sl.d_msg_skip, nmsg, s2);
+    if (nmsg && !c->dbg_no_window)
         launch_window_stats(sl.d_mag, n, sl.thr, sl.d_class_final, sl.d_msg_pos, sl.d_msg_skip,
                             sl.d_msg_limit, nmsg, sl.d_win_part, c->d_win, s2);
-    }
+    if (nmsg && job.sig_late)      // the accepted frames' signal powers, now that it is known which frames they are
+        launch_msg_sig(sl.d_mag, sl.d_msg_pos, sl.d_msg_skip, nmsg, sl.d_msg_sig, s2);
     if (nmsg && c->device_msgs && job.feed >= 0) {
         // the accepted frames become message records on the device (kernels/build.inc), appended to the feed's device list
         FeedSlot &fs = c->feed[job.feed];
         if (fs.d_count + nmsg > fs.d_cap) { c->err = "device message list of the feed is full"; return MGPU_E_OVERFLOW; }
-        hipStream_t s2 = c->s_post;
         const size_t acc_bytes = ((size_t) nmsg * sizeof(Accepted) + 15) & ~(size_t) 15;
         const size_t buf_bytes = sl.buffers.size() * sizeof(BufferClock);
         std::memcpy(sl.h_blob, job.acc.data(), (size_t) nmsg * sizeof(Accepted));
         std::memcpy(sl.h_blob + acc_bytes, sl.buffers.data(), buf_bytes);
         launch_stage_blob(sl.h_blob, sl.d_blob, acc_bytes + buf_bytes, s2);
-        launch_build_messages(sl.d_live, sl.d_live_sig, sl.d_blob, sl.d_blob + acc_bytes, nmsg, fs.d_msgs + fs.d_count, s2);
+        launch_build_messages(sl.d_live, sl.d_live_sig, job.sig_late ? sl.d_msg_sig : nullptr, sl.d_blob, sl.d_blob + acc_bytes, nmsg,
+                              fs.d_msgs + fs.d_count, s2);
         HIPCHK(c, hipEventRecord(fs.ev_built, s2));
         fs.d_count += nmsg;
     }
-    if (nmsg && (!c->dbg_no_window || c->device_msgs)) {          // the slot's device side is read on stream2 until here
-        HIPCHK(c, hipEventRecord(sl.ev_window, c->s_post));
+    if (nmsg && job.sig_late) {    // ... to the builder (statistics, and the sig_sumsq field of messages built on the host)
+        HIPCHK(c, hipMemcpyAsync(job.h_msig, sl.d_msg_sig, (size_t) nmsg * sizeof(unsigned long long), hipMemcpyDeviceToHost, s2));
+        HIPCHK(c, hipEventRecord(job.ev_copied, s2));
+    }
+    if (nmsg && (!c->dbg_no_window || c->device_msgs || job.sig_late)) {          // the slot's device side is read on stream2 until here
+        HIPCHK(c, hipEventRecord(sl.ev_window, s2));
         sl.window_pending = true;
     }
     c->acc.sigpower_ms += (float) (wall_ms() - t_sig0);
@@ -1468,8 +1486,8 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
     mgpu_msg *out = pending.data() + first_msg;
     std::vector<mgpu_msg> &stage = c->b_stage;               // with Mode A/C the Mode S messages are built here and merged per buffer
     if (nac) { stage.resize(nmsg); }
-    if (job.from_device) {                                   // the walk ran on the device: wait for what it sent over
-        if (nmsg) HIPCHK(c, hipEventSynchronize(job.ev_copied));
+    if ((job.from_device || job.sig_late) && nmsg) HIPCHK(c, hipEventSynchronize(job.ev_copied));   // what the walk's stream sent over
+    if (job.from_device) {                                   // the walk ran on the device
         if (!on_device && nmsg) {
             mgpu_msg *dst = nac ? stage.data() : out;
             const int parts = nmsg >= 4096 ? c->build_threads : 1;
@@ -1487,7 +1505,7 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
         mgpu_msg *dst = nac ? stage.data() : out;
         c->build_team.run(parts, [&](int i) {
             const uint64_t lo = (uint64_t) nmsg * i / parts, hi = (uint64_t) nmsg * (i + 1) / parts;
-            Resolver::build_messages(job.recs.data(), job.sig.data(), job.buffers, job.acc.data() + lo, hi - lo, dst + lo);
+            Resolver::build_messages(job.recs.data(), job.sig.data(), job.sig_late ? job.h_msig + lo : nullptr, job.buffers, job.acc.data() + lo, hi - lo, dst + lo);
         });
     }
     if (nac) {   // netUseMessage order: per buffer the Mode S messages of demodulate2400, then the replies of demodulate2400AC
@@ -1525,7 +1543,7 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
         for (const uint32_t mend = mi + job.buf_nacc[b]; mi < mend;) {
             unsigned long long sumsq;
             unsigned sig_len;                                 // msglen * 12 / 5, demod_2400.c:439
-            if (job.from_device) { sumsq = job.h_msig[mi] & ~(1ull << 63); sig_len = (job.h_msig[mi] >> 63) ? 268u : 134u; }
+            if (job.from_device || job.sig_late) { sumsq = job.h_msig[mi] & ~(1ull << 63); sig_len = (job.h_msig[mi] >> 63) ? 268u : 134u; }
             else {
                 const uint32_t ri = job.acc[mi].rec;          // not from the message: those went out with streaming stores
                 sumsq = job.sig[ri];
@@ -2291,7 +2309,7 @@ static int walk_packets_checked(mgpu_ctx *c, const void *packets, uint64_t bytes
         if (wn < 0) return MGPU_E_OVERFLOW;
         const size_t first = c->pending.size();
         if (!c->pending.grow_for((size_t) wn)) return c->pending.external ? MGPU_E_OVERFLOW : MGPU_E_NOMEM;
-        Resolver::build_messages(job.recs.data(), job.sig.data(), job.buffers, job.acc.data(), (uint64_t) wn, c->pending.data() + first);
+        Resolver::build_messages(job.recs.data(), job.sig.data(), nullptr, job.buffers, job.acc.data(), (uint64_t) wn, c->pending.data() + first);
         c->pending.n = first + (size_t) wn;
         for (int i = 0; i < 3; ++i) c->counters.demod_accepted[i] += job.rc.accepted[i];
         for (int i = 0; i < 5; ++i) c->counters.demod_bestPhase[i] += job.rc.best_phase[i];

@@ -193,8 +193,8 @@ void launch_signal_power(const uint16_t *mag, const uint32_t *pos, const uint16_
 // candidates / tried phases / conditional-class candidates inside the skip-ahead window of
 // each accepted message (positions pos+1 .. pos+skip, clipped to `limit`), for the stats fix-up
 // struct modesMessage fields of the accepted frames on the device (kernels/build.inc): acc = Accepted[nacc], bufs = BufferClock[]
-void launch_build_messages(const PhaseRec *live, const unsigned long long *live_sig, const void *d_acc, const void *d_bufs, uint32_t nacc,
-                           mgpu_msg *out, hipStream_t s);
+void launch_build_messages(const PhaseRec *live, const unsigned long long *live_sig, const unsigned long long *msg_sig, const void *d_acc,
+                           const void *d_bufs, uint32_t nacc, mgpu_msg *out, hipStream_t s);   // msg_sig (per accepted frame) or, when null, live_sig (per live record)
 void launch_stage_blob(const void *h_src, void *d_dst, uint64_t bytes, hipStream_t s);   // page-locked host -> device, small grid
 
 // ---- the ordered accept walk on the device (kernels/walk.inc) ----
@@ -234,9 +234,10 @@ struct WalkSummary {             // what the host reads (page-locked): this, the
 };
 size_t walk_summary_bytes(uint32_t nbuf, uint32_t acc_cap);
 size_t walk_input_bytes(uint32_t nbuf, uint32_t n_active, uint32_t n_inactive);
-void launch_device_walk(const uint8_t *h_in, uint8_t *d_in, size_t in_bytes, const WalkBuffers &w, const PhaseRec *live,
-                        const unsigned long long *live_sig, uint32_t nbuf, void *h_summary, void *d_acc, unsigned long long *msg_sig, uint32_t *msg_pos,
-                        uint32_t *msg_limit, uint16_t *msg_skip, uint32_t msg_cap, hipStream_t s);
+void launch_device_walk(const uint8_t *h_in, uint8_t *d_in, size_t in_bytes, const WalkBuffers &w, const PhaseRec *live, uint32_t nbuf,
+                        void *h_summary, void *d_acc, uint32_t *msg_pos, uint32_t *msg_limit, uint16_t *msg_skip, uint32_t msg_cap, hipStream_t s);
+// signal power of the accepted frames after the walk: out[i] = sum of mag^2 over frame i | 1 << 63 for a 112-bit frame
+void launch_msg_sig(const uint16_t *mag, const uint32_t *d_pos, const uint16_t *d_skip, uint32_t n, unsigned long long *d_out, hipStream_t s);
 void launch_stage_in(const uint32_t *h_pos, const uint32_t *h_limit, const uint16_t *h_skip, uint32_t *d_pos, uint32_t *d_limit,
                      uint16_t *d_skip, uint32_t n, hipStream_t s);   // page-locked host arrays -> device, small grid
 void launch_window_stats(const uint16_t *mag, uint64_t n, int thr, const uint32_t *class_bitmap, const uint32_t *pos,

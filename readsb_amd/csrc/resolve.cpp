@@ -524,7 +524,7 @@ void Resolver::parallel_walk(const PhaseRec *recs, uint64_t nrecs, const std::ve
 
 uint64_t segment_first_record(const PhaseRec *recs, uint64_t nrecs, uint32_t pos) { return first_record_at(recs, nrecs, pos); }
 
-void Resolver::build_messages(const PhaseRec *recs, const unsigned long long *sig, const std::vector<BufferClock> &buffers,
+void Resolver::build_messages(const PhaseRec *recs, const unsigned long long *sig, const unsigned long long *msig, const std::vector<BufferClock> &buffers,
                               const Accepted *acc, uint64_t nacc, mgpu_msg *out) {
     static_assert(sizeof(PhaseRec) == 32 && offsetof(PhaseRec, msg) == 16, "frame bytes are the record's second half");
     for (uint64_t n = 0; n < nacc; ++n) {
@@ -547,7 +547,7 @@ void Resolver::build_messages(const PhaseRec *recs, const unsigned long long *si
         mgpu_msg m;
         m.timestamp = b.sampleTimestamp + (int64_t) (r.pos - b.first) * 5 + (8 + 56) * 12 + r.phase;   // demod_2400.c:406
         m.sysTimestamp = b.sysTimestamp + (m.timestamp - b.sampleTimestamp) / 12000;                    // :409
-        m.sig_sumsq = sig[acc[n].rec];                         // :442-445, precomputed per record on the GPU
+        m.sig_sumsq = msig ? msig[n] & ~(1ull << 63) : sig[acc[n].rec];   // :442-445, from the GPU: per accepted frame (k_msg_sig) or per live record
         m.sig_len = (uint16_t) (frame_bits(r) * 12 / 5);       // :439
         m.score = (int16_t) acc[n].score;
         m.phase = r.phase;
@@ -581,7 +581,7 @@ int64_t Resolver::walk(const PhaseRec *recs, const unsigned long long *sig, uint
     if (n <= 0) return n;
     const size_t first = out.size();
     out.resize(first + (size_t) n);
-    build_messages(recs, sig, buffers, acc.data(), (uint64_t) n, out.data() + first);
+    build_messages(recs, sig, nullptr, buffers, acc.data(), (uint64_t) n, out.data() + first);
     return n;
 }
 

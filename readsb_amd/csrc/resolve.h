@@ -173,8 +173,8 @@ class Resolver {
     void union_snapshot(std::vector<uint32_t> &sorted_union) const { filter_.union_sorted(sorted_union); }
 
     // The stateless part: struct modesMessage fields of the accepted frames (demod_2400.c:399-445,
-    // mode_s.c:443-606).  sig[i] = sum of mag^2 over the frame record i would occupy.
-    static void build_messages(const PhaseRec *recs, const unsigned long long *sig, const std::vector<BufferClock> &buffers,
+    // mode_s.c:443-606).  sig[i] = sum of mag^2 over the frame record i would occupy; or msig[n] (when not null) = that of accepted frame n, bit 63 aside.
+    static void build_messages(const PhaseRec *recs, const unsigned long long *sig, const unsigned long long *msig, const std::vector<BufferClock> &buffers,
                                const Accepted *acc, uint64_t nacc, mgpu_msg *out);
     // decide + build_messages in one call
     int64_t walk(const PhaseRec *recs, const unsigned long long *sig, uint64_t nrecs,

@@ -33,7 +33,7 @@ int main(int argc, char **argv) {
         auto t0 = std::chrono::steady_clock::now();
         int64_t n = r.decide(recs.data(), nrecs, bufs, acc, pos.data(), skip.data(), lim.data(), nrecs, rc);
         auto t1 = std::chrono::steady_clock::now();
-        Resolver::build_messages(recs.data(), sig.data(), bufs, acc.data(), (uint64_t) n, out.data());
+        Resolver::build_messages(recs.data(), sig.data(), nullptr, bufs, acc.data(), (uint64_t) n, out.data());
         auto t2 = std::chrono::steady_clock::now();
         best_d = std::min(best_d, std::chrono::duration<double, std::milli>(t1 - t0).count());
         best_b = std::min(best_b, std::chrono::duration<double, std::milli>(t2 - t1).count());

@@ -547,7 +547,7 @@ void Resolver::build_messages(const PhaseRec *recs, const unsigned long long *si
         mgpu_msg m;
         m.timestamp = b.sampleTimestamp + (int64_t) (r.pos - b.first) * 5 + (8 + 56) * 12 + r.phase;   // demod_2400.c:406
         m.sysTimestamp = b.sysTimestamp + (m.timestamp - b.sampleTimestamp) / 12000;                    // :409
-        m.sig_sumsq = msig ? msig[n] & ~(1ull << 63) : sig[acc[n].rec];   // :442-445, from the GPU: per accepted frame (k_msg_sig) or per live record
+        m.sig_sumsq = msig ? msig[n] & ~(1ull << 63) : sig ? sig[acc[n].rec] : 0;   // :442-445, from the GPU: per accepted frame (k_msg_sig), per live record, or filled in by the caller
         m.sig_len = (uint16_t) (frame_bits(r) * 12 / 5);       // :439
         m.score = (int16_t) acc[n].score;
         m.phase = r.phase;

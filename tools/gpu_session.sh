@@ -1,7 +1,5 @@
 #!/bin/bash
 cd /root/repo
 mkdir -p gpurun_out
-timeout 300 python -m pytest tests/test_gpu_device_walk.py -x -q -s 2>&1 | grep -v "^$" | tail -10
-MGPU_DEBUG_PRINT=1 MGPU_DEVICE_WALK=1 timeout 200 python bench.py --no-extra-configs --no-cpu-baseline --steps 3 --warmup 1 2>gpurun_out/s45.err | tail -1 | cut -c1-200
-grep "device walk" gpurun_out/s45.err | sed -n 30,36p
-for i in 1 2; do MGPU_DEVICE_WALK=1 timeout 200 python bench.py --no-extra-configs --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('walk=1', d['value'], d['ms_per_step'], d.get('stage_ms'))"; done
+timeout 600 python -m pytest tests/test_gpu_golden.py tests/test_gpu_deferred.py tests/test_gpu_pipeline_chain.py -x -q 2>&1 | tail -3
+for v in "X=1" "MGPU_SIG_LATE=0" "X=1" "MGPU_SIG_LATE=0"; do env $v timeout 200 python bench.py --no-extra-configs --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', d['value'], d['ms_per_step'], d.get('stage_ms'))"; done

@@ -1414,11 +1414,14 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
     hipStream_t s2 = c->s_post;
     if (nmsg && (!c->dbg_no_window || job.sig_late))
         launch_stage_in(sl.h_msg_pos, sl.h_msg_limit, sl.h_msg_skip, sl.d_msg_pos, sl.d_msg_limit, sl.d_msg_skip, nmsg, s2);
+    if (nmsg && job.sig_late) {    // the accepted frames' signal powers, now that it is known which frames they are: first, the builder waits for them
+        launch_msg_sig(sl.d_mag, sl.d_msg_pos, sl.d_msg_skip, nmsg, sl.d_msg_sig, s2);
+        HIPCHK(c, hipMemcpyAsync(job.h_msig, sl.d_msg_sig, (size_t) nmsg * sizeof(unsigned long long), hipMemcpyDeviceToHost, s2));
+        HIPCHK(c, hipEventRecord(job.ev_copied, s2));
+    }
     if (nmsg && !c->dbg_no_window)
         launch_window_stats(sl.d_mag, n, sl.thr, sl.d_class_final, sl.d_msg_pos, sl.d_msg_skip,
                             sl.d_msg_limit, nmsg, sl.d_win_part, c->d_win, s2);
-    if (nmsg && job.sig_late)      // the accepted frames' signal powers, now that it is known which frames they are
-        launch_msg_sig(sl.d_mag, sl.d_msg_pos, sl.d_msg_skip, nmsg, sl.d_msg_sig, s2);
     if (nmsg && c->device_msgs && job.feed >= 0) {
         // the accepted frames become message records on the device (kernels/build.inc), appended to the feed's device list
         FeedSlot &fs = c->feed[job.feed];
@@ -1432,10 +1435,6 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
                               fs.d_msgs + fs.d_count, s2);
         HIPCHK(c, hipEventRecord(fs.ev_built, s2));
         fs.d_count += nmsg;
-    }
-    if (nmsg && job.sig_late) {    // ... to the builder (statistics, and the sig_sumsq field of messages built on the host)
-        HIPCHK(c, hipMemcpyAsync(job.h_msig, sl.d_msg_sig, (size_t) nmsg * sizeof(unsigned long long), hipMemcpyDeviceToHost, s2));
-        HIPCHK(c, hipEventRecord(job.ev_copied, s2));
     }
     if (nmsg && (!c->dbg_no_window || c->device_msgs || job.sig_late)) {          // the slot's device side is read on stream2 until here
         HIPCHK(c, hipEventRecord(sl.ev_window, s2));
@@ -1486,8 +1485,8 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
     mgpu_msg *out = pending.data() + first_msg;
     std::vector<mgpu_msg> &stage = c->b_stage;               // with Mode A/C the Mode S messages are built here and merged per buffer
     if (nac) { stage.resize(nmsg); }
-    if ((job.from_device || job.sig_late) && nmsg) HIPCHK(c, hipEventSynchronize(job.ev_copied));   // what the walk's stream sent over
-    if (job.from_device) {                                   // the walk ran on the device
+    if (job.from_device) {                                   // the walk ran on the device: the messages come from there
+        if (nmsg) HIPCHK(c, hipEventSynchronize(job.ev_copied));
         if (!on_device && nmsg) {
             mgpu_msg *dst = nac ? stage.data() : out;
             const int parts = nmsg >= 4096 ? c->build_threads : 1;
@@ -1503,11 +1502,17 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
     if (!on_device && !job.from_device) {
         const int parts = nmsg >= 4096 ? c->build_threads : 1;
         mgpu_msg *dst = nac ? stage.data() : out;
+        // (sig_late: the accepted frames' signal powers are still on their way — k_msg_sig and a copy on the second stream — so the
+        // messages are built without them and the one field is filled in below: the builder does not wait idle)
         c->build_team.run(parts, [&](int i) {
             const uint64_t lo = (uint64_t) nmsg * i / parts, hi = (uint64_t) nmsg * (i + 1) / parts;
-            Resolver::build_messages(job.recs.data(), job.sig.data(), job.sig_late ? job.h_msig + lo : nullptr, job.buffers, job.acc.data() + lo, hi - lo, dst + lo);
+            Resolver::build_messages(job.recs.data(), job.sig_late ? nullptr : job.sig.data(), nullptr, job.buffers, job.acc.data() + lo, hi - lo, dst + lo);
         });
-    }
+        if (job.sig_late && nmsg) {
+            HIPCHK(c, hipEventSynchronize(job.ev_copied));
+            for (uint32_t i = 0; i < nmsg; ++i) dst[i].sig_sumsq = job.h_msig[i] & ~(1ull << 63);
+        }
+    } else if (!job.from_device && job.sig_late && nmsg) HIPCHK(c, hipEventSynchronize(job.ev_copied));   // (messages on the device: statistics only)
     if (nac) {   // netUseMessage order: per buffer the Mode S messages of demodulate2400, then the replies of demodulate2400AC
         size_t si = 0, ai = 0, o = 0;
         for (uint32_t b = 0; b < nbuf; ++b) {

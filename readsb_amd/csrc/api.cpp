@@ -1502,16 +1502,15 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
     if (!on_device && !job.from_device) {
         const int parts = nmsg >= 4096 ? c->build_threads : 1;
         mgpu_msg *dst = nac ? stage.data() : out;
-        // (sig_late: the accepted frames' signal powers are still on their way — k_msg_sig and a copy on the second stream — so the
-        // messages are built without them and the one field is filled in below: the builder does not wait idle)
+        // (sig_late: the accepted frames' signal powers come over the second stream — k_msg_sig and a copy, ahead of the window
+        // statistics.  Building first and filling the field in afterwards was slower: the messages leave with streaming stores,
+        // and touching 27 000 of their lines again costs more than the wait.)
+        if (job.sig_late && nmsg) HIPCHK(c, hipEventSynchronize(job.ev_copied));
         c->build_team.run(parts, [&](int i) {
             const uint64_t lo = (uint64_t) nmsg * i / parts, hi = (uint64_t) nmsg * (i + 1) / parts;
-            Resolver::build_messages(job.recs.data(), job.sig_late ? nullptr : job.sig.data(), nullptr, job.buffers, job.acc.data() + lo, hi - lo, dst + lo);
+            Resolver::build_messages(job.recs.data(), job.sig_late ? nullptr : job.sig.data(), job.sig_late ? job.h_msig + lo : nullptr, job.buffers,
+                                     job.acc.data() + lo, hi - lo, dst + lo);
         });
-        if (job.sig_late && nmsg) {
-            HIPCHK(c, hipEventSynchronize(job.ev_copied));
-            for (uint32_t i = 0; i < nmsg; ++i) dst[i].sig_sumsq = job.h_msig[i] & ~(1ull << 63);
-        }
     } else if (!job.from_device && job.sig_late && nmsg) HIPCHK(c, hipEventSynchronize(job.ev_copied));   // (messages on the device: statistics only)
     if (nac) {   // netUseMessage order: per buffer the Mode S messages of demodulate2400, then the replies of demodulate2400AC
         size_t si = 0, ai = 0, o = 0;

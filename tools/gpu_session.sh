@@ -1,14 +1,20 @@
 #!/bin/bash
 cd /root/repo
-mkdir -p gpurun_out
-timeout 300 python -m pytest tests/test_gpu_golden.py tests/test_gpu_deferred.py -x -q 2>&1 | tail -2
-for v in "X=1" "MGPU_SIG_LATE=0" "X=1"; do env $v timeout 200 python bench.py --no-extra-configs --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', d['value'], d['ms_per_step'], d.get('stage_ms'))"; done
+R=/root/repo
+mkdir -p gpurun_out/r02f
+timeout 300 python -m pytest tests/test_gpu_modeac.py tests/test_gpu_pipeline_chain.py tests/test_gpu_device_walk.py tests/test_gpu_large.py -x -q 2>&1 | tail -2
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1 | cut -c1-120
+cd /tmp && export TMPDIR=/tmp
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r02f/stats2 -o bench -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extra-configs > $R/gpurun_out/r02f/bench_under_rocprof.log 2>&1
+cd $R
+f=$(find gpurun_out/r02f/stats2 -name "*kernel_stats.csv" | head -1)
+if [ -n "$f" ]; then cp "$f" gpurun_out/r02f/kernel_stats.csv; cut -c1-100 "$f" | head -14; fi
+timeout 600 python bench.py > gpurun_out/r02f/bench_plain.log 2> gpurun_out/r02f/bench_plain.err
+tail -1 gpurun_out/r02f/bench_plain.log > gpurun_out/r02f/bench_line.json
 python - <<'PY'
-import bench, json, os
-for name in ["dense bursts, 8000 frames/s, overlapping DF17, --aggressive"]:
-    fmt, nfix, kw = bench.EXTRA_CONFIGS[name]
-    for env in ({}, {"MGPU_SIG_LATE": "0"}):
-        os.environ.pop("MGPU_SIG_LATE", None); os.environ.update(env)
-        r = bench.run_extra_config(name, fmt, nfix, kw, 2048*131072, 0)
-        print(env, r["msamples_s"], r["ms_per_segment"], r["us_per_launch"])
+import json
+d=json.load(open('gpurun_out/r02f/bench_line.json'))
+print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['avg_launch_ms'], d.get('stage_ms'))
+print(d.get('cpu_baseline',{}).get('value'), d.get('pcie_inclusive_msamples_s'))
+for k,v in d.get('configs',{}).items(): print(k, v['msamples_s'], v['ms_per_segment'], v.get('device_walk'))
 PY

@@ -1,20 +1,31 @@
 #!/bin/bash
 cd /root/repo
-R=/root/repo
-mkdir -p gpurun_out/r02f
-timeout 300 python -m pytest tests/test_gpu_modeac.py tests/test_gpu_pipeline_chain.py tests/test_gpu_device_walk.py tests/test_gpu_large.py -x -q 2>&1 | tail -2
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1 | cut -c1-120
-cd /tmp && export TMPDIR=/tmp
-timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r02f/stats2 -o bench -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extra-configs > $R/gpurun_out/r02f/bench_under_rocprof.log 2>&1
-cd $R
-f=$(find gpurun_out/r02f/stats2 -name "*kernel_stats.csv" | head -1)
-if [ -n "$f" ]; then cp "$f" gpurun_out/r02f/kernel_stats.csv; cut -c1-100 "$f" | head -14; fi
-timeout 600 python bench.py > gpurun_out/r02f/bench_plain.log 2> gpurun_out/r02f/bench_plain.err
-tail -1 gpurun_out/r02f/bench_plain.log > gpurun_out/r02f/bench_line.json
 python - <<'PY'
-import json
-d=json.load(open('gpurun_out/r02f/bench_line.json'))
-print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['avg_launch_ms'], d.get('stage_ms'))
-print(d.get('cpu_baseline',{}).get('value'), d.get('pcie_inclusive_msamples_s'))
-for k,v in d.get('configs',{}).items(): print(k, v['msamples_s'], v['ms_per_segment'], v.get('device_walk'))
+import bench, json, os, time
+import numpy as np
+import helpers, readsb_amd
+name="dense bursts, 8000 frames/s, overlapping DF17, --aggressive"
+fmt, nfix, kw = bench.EXTRA_CONFIGS[name]
+nsamples=2048*131072
+iq = helpers.synth(nsamples=nsamples, fmt=fmt, seed=424242, threads=64, **kw)
+d = readsb_amd.Demodulator(fmt=fmt, nfix_crc=nfix, max_samples=nsamples, device=0, startup_time_ms=helpers.STARTUP_MS)
+d.upload_iq(iq)
+d.keep_other_threads_away(confine_to_own_l3=False)
+d.feed_resident(nsamples); m0,_=d.collect(reuse=True)
+bufs=[np.empty(len(m0)*5//4+1024, dtype=readsb_amd.MSG_DTYPE) for _ in range(2)]
+for rep in range(4):
+    d.reset(); d.set_deferred(True)
+    def submit(k):
+        d.set_message_buffer(bufs[k%2]); d.feed_resident(nsamples)
+    submit(0); d.collect_feed(bufs[0], want_counters=True)
+    steps=4
+    t0=time.perf_counter(); submit(1)
+    ts=[]
+    for k in range(2, steps+1):
+        submit(k); d.collect_feed(bufs[(k-1)%2]); ts.append(time.perf_counter())
+    d.collect_feed(bufs[steps%2], want_counters=True)
+    el=time.perf_counter()-t0
+    tm=d.timing()
+    print(rep, round(el/steps*1e3,3), "ms/segment", {k: round(tm[k],3) for k in ("resolve_ms","build_ms","sigpower_ms","d2h_ms","total_ms")}, [round((b-a)*1e3,2) for a,b in zip([t0]+ts, ts)])
+    d.set_deferred(False)
 PY

@@ -39,3 +39,19 @@ def test_parallel_walk_equals_serial_walk_on_a_real_chunk(replay, ranges):
         m = re.search(r"serial (\d+) msgs, parallel\(\d+\) (\d+) msgs", ln)
         assert m and m.group(1) == m.group(2)
     assert "serial 26915 msgs" in rounds[0] and "serial 27010 msgs" in rounds[1]      # cold filter, then warm
+
+
+def test_device_walk_model_equals_serial_walk_on_a_real_chunk(replay):
+    """The device walk's algorithm (kernels/walk.inc restated in Resolver::device_walk_model) on the same real chunk: the cold
+    round is the one the library hands to the host (the filter table grows while the aircraft are learnt), the warm ones are
+    decided by the model, in at most three walks — always with the serial walk's decisions and final filter."""
+    exe, d = replay
+    r = subprocess.run([exe, d, "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    rounds = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("model round")]
+    assert len(rounds) == 4, r.stdout
+    for ln in rounds:
+        assert "identical 1" in ln, ln
+    assert "decided by the model 0" in rounds[0]
+    assert all("decided by the model 1" in ln for ln in rounds[1:]), rounds
+    assert all(int(re.search(r"walks (\d+)", ln).group(1)) <= 3 for ln in rounds)

@@ -77,5 +77,25 @@ int main(int argc, char **argv) {
                    std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count());
         }
     }
+    // ---- the device walk's algorithm restated on the host (Resolver::device_walk_model: per-buffer walks, fixed point over the
+    //      table of first adds, premise check) against the serial walk: same chunk four times, cold filter first ----
+    {
+        Resolver rs, rm; rs.reset(1000000); rm.reset(1000000);
+        for (int round = 0; round < 4; ++round) {
+            std::vector<Accepted> acc_s, acc_m; ResolveCounts rc_s, rc_m;
+            const int64_t ns = rs.decide(recs.data(), nrecs, bufs, acc_s, pos.data(), skip.data(), lim.data(), nrecs, rc_s);
+            uint32_t walks = 0;
+            auto t0 = std::chrono::steady_clock::now();
+            int64_t nm2 = rm.device_walk_model(recs.data(), nrecs, bufs, acc_m, rc_m, 3, &walks);
+            auto t1 = std::chrono::steady_clock::now();
+            const bool by_model = nm2 >= 0;
+            if (!by_model) nm2 = rm.decide(recs.data(), nrecs, bufs, acc_m, pos.data(), skip.data(), lim.data(), nrecs, rc_m);
+            bool same = nm2 == ns && rm.same_state(rs);
+            for (int64_t i = 0; same && i < ns; ++i)
+                same = acc_s[(size_t) i].rec == acc_m[(size_t) i].rec && acc_s[(size_t) i].buffer == acc_m[(size_t) i].buffer && acc_s[(size_t) i].score == acc_m[(size_t) i].score;
+            printf("model round %d: serial %lld msgs, model %lld msgs, identical %d, decided by the model %d, walks %u, %.3f ms\n", round, (long long) ns,
+                   (long long) nm2, (int) same, (int) by_model, walks, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        }
+    }
     return 0;
 }

@@ -1313,7 +1313,7 @@ static int walk_job_device(mgpu_ctx *c, Slot &sl, HostJob &job) {
             dst = fs.d_msgs + fs.d_count;
             fs.d_count += nmsg;
         }
-        launch_msg_sig(sl.d_mag, sl.d_msg_pos, sl.d_msg_skip, nmsg, sl.d_wk_sig, s2);
+        launch_msg_sig(sl.d_mag, sl.d_msg_pos, sl.d_msg_skip, nmsg, sl.d_wk_sig, nullptr, s2);
         launch_build_messages(sl.d_live, nullptr, sl.d_wk_sig, sl.d_wk_acc, d_bufs, nmsg, dst, s2);
         if (to_device_list) HIPCHK(c, hipEventRecord(c->feed[job.feed].ev_built, s2));
         else HIPCHK(c, hipMemcpyAsync(job.h_msgs, c->d_wk_msgs, (size_t) nmsg * sizeof(mgpu_msg), hipMemcpyDeviceToHost, s2));
@@ -1415,8 +1415,8 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
     if (nmsg && (!c->dbg_no_window || job.sig_late))
         launch_stage_in(sl.h_msg_pos, sl.h_msg_limit, sl.h_msg_skip, sl.d_msg_pos, sl.d_msg_limit, sl.d_msg_skip, nmsg, s2);
     if (nmsg && job.sig_late) {    // the accepted frames' signal powers, now that it is known which frames they are: first, the builder waits for them
-        launch_msg_sig(sl.d_mag, sl.d_msg_pos, sl.d_msg_skip, nmsg, sl.d_msg_sig, s2);
-        HIPCHK(c, hipMemcpyAsync(job.h_msig, sl.d_msg_sig, (size_t) nmsg * sizeof(unsigned long long), hipMemcpyDeviceToHost, s2));
+        // (the kernel stores the builder's copy itself: a hipMemcpyAsync from this thread contends with the fetcher's inside the runtime)
+        launch_msg_sig(sl.d_mag, sl.d_msg_pos, sl.d_msg_skip, nmsg, sl.d_msg_sig, job.h_msig, s2);
         HIPCHK(c, hipEventRecord(job.ev_copied, s2));
     }
     if (nmsg && !c->dbg_no_window)

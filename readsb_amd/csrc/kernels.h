@@ -237,7 +237,8 @@ size_t walk_input_bytes(uint32_t nbuf, uint32_t n_active, uint32_t n_inactive);
 void launch_device_walk(const uint8_t *h_in, uint8_t *d_in, size_t in_bytes, const WalkBuffers &w, const PhaseRec *live, uint32_t nbuf,
                         void *h_summary, void *d_acc, uint32_t *msg_pos, uint32_t *msg_limit, uint16_t *msg_skip, uint32_t msg_cap, hipStream_t s);
 // signal power of the accepted frames after the walk: out[i] = sum of mag^2 over frame i | 1 << 63 for a 112-bit frame
-void launch_msg_sig(const uint16_t *mag, const uint32_t *d_pos, const uint16_t *d_skip, uint32_t n, unsigned long long *d_out, hipStream_t s);
+void launch_msg_sig(const uint16_t *mag, const uint32_t *d_pos, const uint16_t *d_skip, uint32_t n, unsigned long long *d_out, unsigned long long *h_out,
+                    hipStream_t s);   // h_out (page-locked host memory, may be null): a second copy for the builder
 void launch_stage_in(const uint32_t *h_pos, const uint32_t *h_limit, const uint16_t *h_skip, uint32_t *d_pos, uint32_t *d_limit,
                      uint16_t *d_skip, uint32_t n, hipStream_t s);   // page-locked host arrays -> device, small grid
 void launch_window_stats(const uint16_t *mag, uint64_t n, int thr, const uint32_t *class_bitmap, const uint32_t *pos,

@@ -533,6 +533,8 @@ def main():
                     out["configs"][name] = run_extra_config(name, fmt, nfix, kw, args.extra_samples - args.extra_samples % BUF, local_rank_dev)
                 except AssertionError as e:                      # a mismatch is a failed run, not a missing number
                     raise SystemExit(f"extra configuration '{name}': GPU result differs from the reference: {e}")
+                except Exception as e:                           # anything else (an allocation, the checker's binary): this entry is missing, the line is not
+                    out["configs"][name] = {"error": f"{type(e).__name__}: {e}"[:300]}
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

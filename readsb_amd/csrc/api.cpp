@@ -173,8 +173,6 @@ struct Slot {
     void *d_wk_acc = nullptr;             // ... the chunk's ordered accept list ...
     unsigned long long *d_wk_sig = nullptr;   // ... and per accepted frame the signal power | long flag
     uint8_t *h_blob = nullptr, *d_blob = nullptr;   // device-messages mode: the walker's accept list + buffer clocks, page-locked host / device
-    const uint8_t *fused_iq = nullptr;    // this chunk's converter runs inside k_sweep (enqueue_convert): its IQ samples ...
-    const uint16_t *fused_tail = nullptr; // ... and the 326 magnitudes before them
     bool sig_late = false;                // the signal powers of this chunk are computed after the walk, for the accepted frames (k_msg_sig)
     int feed = -1;                        // deferred feeds: which FeedSlot the chunk's messages go to (-1: mgpu_ctx::pending)
     int32_t thr = 58;                     // preamble threshold of this chunk (raised after drops, demod_2400.c:335-338)
@@ -302,7 +300,6 @@ struct mgpu_ctx {
     bool device_msgs = false;                                 // mgpu_set_device_messages
     bool copy_after_sweep = false;                            // MGPU_COPY_AFTER_SWEEP=1: the fetcher holds its copies back until the next chunk's k_sweep has run
     bool sig_late = true;                                     // MGPU_SIG_LATE=0: signal power of every live record in the pre-screen write pass (as in shard passes) instead of the accepted frames' after the walk
-    bool fused_convert = false;                               // MGPU_FUSED_CONVERT=1: UC8 conversion inside k_sweep's tile load (same speed, see kernels/sweep.inc)
     int timing_every = 4;                                     // MGPU_TIMING_EVERY: chunks per set of stage timing events (1 = every chunk)
     uint64_t timing_seq = 0;
     bool accounting_open = false;                             // feed_begin has run, feed_end has not (deferred: spans several feeds)
@@ -845,7 +842,6 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     c->dbg_no_window = getenv("MGPU_DEBUG_NO_WINDOW") != nullptr;
     if (const char *e = getenv("MGPU_DEBUG_STAGE")) c->dbg_stage = atoi(e);
     if (const char *e = getenv("MGPU_COPY_AFTER_SWEEP")) c->copy_after_sweep = atoi(e) != 0;
-    if (const char *e = getenv("MGPU_FUSED_CONVERT")) c->fused_convert = atoi(e) != 0;
     if (const char *e = getenv("MGPU_SIG_LATE")) c->sig_late = atoi(e) != 0;
     if (const char *e = getenv("MGPU_TIMING_EVERY")) { const int v = atoi(e); if (v >= 1) c->timing_every = v; }
     if (const char *e = getenv("MGPU_DUMP_DIR")) { c->dump_dir = e; c->sig_late = false; }   // (the dump holds per-record signal powers)
@@ -963,15 +959,7 @@ static int enqueue_convert(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
     if (sl.window_pending) { HIPCHK(c, hipStreamWaitEvent(s, sl.ev_window, 0)); sl.window_pending = false; }
     // (scratch block and class planes are zero: k_publish / k_count_finalize of the slot's previous chunk left them so)
     if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[0], s));
-    // MGPU_FUSED_CONVERT=1, UC8 IQ entry: the converter is part of k_sweep's tile load (kernels/sweep.inc, k_sweep_t<true>) unless
-    // Mode A/C needs the per-buffer sums before the sweep, or the buffer size is not a power of two
-    sl.fused_iq = nullptr;
-    if (!sl.have_mag && c->fused_convert && c->sweep_version == 5 && cfg.format == MGPU_FMT_UC8 && !cfg.mode_ac &&
-        (cfg.buf_samples & (cfg.buf_samples - 1)) == 0) {
-        sl.fused_iq = iq;
-        sl.fused_tail = c->tail_src;
-        c->tail_src = n >= (uint64_t) kTrailing ? sl.d_mag + n : nullptr;
-    } else if (!sl.have_mag) {
+    if (!sl.have_mag) {
         ConvertParams cp{};
         cp.iq = iq; cp.mag = sl.d_mag; cp.n = n; cp.buf_samples = cfg.buf_samples;
         cp.tail = c->tail_src;          // the 326 magnitudes before this chunk (sdr_ifile.c:209-213), read in place
@@ -1011,11 +999,6 @@ static int enqueue_sweep(mgpu_ctx *c, Slot &sl) {
     sp.unit_first = sl.d_unit_first; sp.unit_count = sl.d_unit_count; sp.nunits = nunits;
     sp.adder_bitmap = c->d_adder_bitmap; sp.class_bitmap = sl.d_class_bitmap; sp.counters = sl.d_counters;
     sp.cand = sl.d_cand; sp.cand_count = sl.d_cand_count; sp.class_uncond = sl.d_class_uncond; sp.sweep_part = sl.d_sweep_part;
-    if (sl.fused_iq) {
-        sp.iq = sl.fused_iq; sp.mag_w = sl.d_mag; sp.tail = sl.fused_tail; sp.uc8_folded = c->d_uc8_folded;
-        sp.sum_level = sl.d_sum_level; sp.sum_power = sl.d_sum_power;
-        sp.buf_shift = (uint32_t) __builtin_ctz(cfg.buf_samples);
-    }
     // ev[5] .. ev[4] bracket exactly one kernel: k_sweep (bench.py's roofline); ev[4] .. ev[2]: k_slice
     if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[5], s));
 #if MGPU_EXPERIMENTS
@@ -1116,36 +1099,6 @@ static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
         fprintf(stderr, "dbg: k_slice wave cycles: stage %llu expand %llu df %llu slice %llu score %llu total %llu | df batches %llu rounds %llu sumI %llu frames %llu lanes %llu passes %llu scored %llu\n",
                 h[16], h[17], h[18], h[19], h[20], h[21], h[24], h[25], h[26], h[27], h[28], h[29], h[30]);
     }
-#if MGPU_KERNEL_TIMERS
-    if (c->dbg_print) {                       // k_sweep's per-wave lifetimes (kernels/sweep.inc), first 8192 waves
-        std::vector<uint16_t> h((size_t) 8192 * kSweepTile);
-        if (hipMemcpy(h.data(), sl.d_cand, h.size() * sizeof(uint16_t), hipMemcpyDeviceToHost) == hipSuccess) {
-            std::vector<double> st, en;
-            unsigned long long tmin = ~0ull;
-            for (size_t w = 0; w < 8192; ++w) {
-                unsigned long long d[4];
-                std::memcpy(d, h.data() + w * kSweepTile + kSweepTile / 2, sizeof(d));
-                if (d[3] != 0x54494d45ull) continue;
-                if (d[0] < tmin) tmin = d[0];
-            }
-            size_t nw = 0; double sum_life = 0, max_end = 0, max_start = 0; unsigned long long tiles = 0;
-            std::vector<double> ends;
-            for (size_t w = 0; w < 8192; ++w) {
-                unsigned long long d[4];
-                std::memcpy(d, h.data() + w * kSweepTile + kSweepTile / 2, sizeof(d));
-                if (d[3] != 0x54494d45ull) continue;
-                const double s0 = (double) (d[0] - tmin) / 100.0, e0 = (double) (d[1] - tmin) / 100.0;   // us
-                ++nw; sum_life += e0 - s0; tiles += d[2];
-                if (e0 > max_end) max_end = e0;
-                if (s0 > max_start) max_start = s0;
-                ends.push_back(e0);
-            }
-            std::sort(ends.begin(), ends.end());
-            if (nw) fprintf(stderr, "dbg: k_sweep waves %zu, tiles %llu: mean life %.1f us, last start %.1f us, end p10 %.1f p50 %.1f p90 %.1f max %.1f us\n", nw, tiles,
-                            sum_life / nw, max_start, ends[nw / 10], ends[nw / 2], ends[nw * 9 / 10], max_end);
-        }
-    }
-#endif
     if (sl.h_counters[CNT_POOL_OVERFLOW]) {
         c->err = "record pool overflow: recreate the context with a larger record_pool_records";
         return MGPU_E_OVERFLOW;

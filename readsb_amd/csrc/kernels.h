@@ -30,13 +30,8 @@ constexpr int kUnit = kTile * kTilesPerUnit;   // positions per unit (one record
 constexpr int kWaveTile = 2048;         // k_sweep_slice: positions per wave-private LDS tile
 constexpr int kTile2 = 4096;            // k_sweep_slice: positions per LDS tile
 constexpr int kBlock = 256;
-#ifndef MGPU_SWEEP_TILE
-#define MGPU_SWEEP_TILE 2048
-#endif
-// k_sweep: positions per wave tile = per candidate list; k_slice's tiles are 2048 = one or two lists.  -DMGPU_SWEEP_TILE=1024 gives
-// k_sweep 8 waves/SIMD (56 VGPRs, 17 KB of LDS per workgroup) and 8 tiles per wave exactly — measured: 39.6 us against 39.4,
-// nothing; neither occupancy nor the uneven last round of the grid is what holds the sweep at 42 % of the HBM peak.
-constexpr int kSweepTile = MGPU_SWEEP_TILE;
+// k_sweep: positions per candidate list = one of its pre-check steps (16 positions per lane); k_slice's tiles are 2048 = two lists
+constexpr int kSweepTile = 1024;
 constexpr int kSweepMaxBlocks = 256 * 4;  // resident workgroups of k_slice (at most 4 per CU)
 constexpr int kSweepGridMax = 256 * 8;    // resident workgroups of k_sweep (at most 8 per CU) = rows of sweep_part
 constexpr int kFinMaxBlocks = 1024;       // class-plane finalize workgroups (k_count_finalize)
@@ -105,23 +100,17 @@ struct SweepParams {
     uint32_t *unit_first;     // [nunits] index of the unit's first segment header, kNone if empty
     uint32_t *unit_count;     // [nunits] records of the unit (without headers)
     uint32_t nunits;
-    uint16_t *cand;           // candidate codes (position in the unit << 3 | phase mask), one list per tile of kSweepTile positions, kSweepTile slots each
-    uint32_t *cand_count;     // [tiles]
+    uint16_t *cand;           // candidate codes (position in the unit << 3 | phase mask), one list per step of kSweepTile positions, kSweepTile slots each
+    uint32_t *cand_count;     // [steps], + one empty list behind an odd number of steps
     uint32_t *sweep_part;     // [k_sweep workgroups][4] partial counters (candidates, phases 4/5, 6/7, 8), summed by k_slice
     uint32_t sweep_blocks;    // rows of sweep_part
-    // the fused UC8 form of k_sweep (iq != nullptr): the tile load converts, writes d_mag and adds the per-buffer sums
-    const uint8_t *iq;        // the chunk's IQ samples
-    uint16_t *mag_w;          // == mag
-    const uint16_t *tail;     // 326 magnitudes preceding the chunk (device), nullptr = zeros
-    const uint16_t *uc8_folded;
-    unsigned long long *sum_level, *sum_power;   // [nbuffers] exact integer sums (ConvertParams)
-    uint32_t buf_shift;       // log2(buf_samples)
     uint32_t *adder_bitmap;   // 2^24 bits: addresses some clean DF17 / DF11 IID 0 frame carries
     uint32_t *class_bitmap;   // 1 bit per scan position: candidate whose records are all conditional
     uint32_t *class_uncond;   // scratch plane: candidate with >= 1 unconditional record (both planes zeroed per chunk)
     unsigned long long *counters;   // [CNT_NUM]
 #if MGPU_EXPERIMENTS
     int32_t debug_stage;      // generation 3 only: disables kernel stages (timing experiments, MGPU_DEBUG_STAGE)
+    unsigned long long *dbg_waves;   // k_sweep: [waves][2] start / end of every wave, 100 MHz (tools/micro/sweep_cold.hip), or null
 #endif
 };
 

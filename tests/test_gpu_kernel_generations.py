@@ -1,5 +1,5 @@
 """-m gpu: the cross-check build of the library (`make -C readsb_amd/csrc exp` -> libmodes_gpu_exp.so) carries the superseded
-fused kernel k_sweep_slice (generation 3) next to the shipped pair k_sweep + k_slice (5); both must be bit-identical to the
+fused kernel k_sweep_slice (generation 3) next to the shipped pair k_sweep + k_slice; both must be bit-identical to the
 oracle — run in a subprocess because library and generation are read from the environment when the context is created."""
 import os
 import subprocess
@@ -38,12 +38,17 @@ def test_generation_matches_oracle(built, version):
     assert r.stdout.strip().startswith("OK")
 
 
-def test_fused_uc8_convert_matches_oracle(built):
-    """MGPU_FUSED_CONVERT=1: convert_uc8_nodc inside k_sweep's tile load (k_sweep_t<true>: d_mag, the per-buffer sums and the
-    candidates all come from one kernel) — ragged length, several chunks, 2-bit repair; messages and every counter as the oracle's."""
-    script = SCRIPT.replace("seconds=3.0, seed=404", "nsamples=37 * 131072 + 4321, seed=405").replace("max_samples=64 * 131072", "max_samples=16 * 131072")
-    env = dict(os.environ, MGPU_FUSED_CONVERT="1")
-    code = script.format(root=helpers.ROOT, tests=os.path.join(helpers.ROOT, "tests"))
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+@pytest.mark.parametrize("buffers,ragged,dense", [(16, 0, 0), (5, 1025, 1), (3, 7 * 1024 + 1, 0), (1, 0, 1)])
+def test_sweep_kernel_alone_matches_cpu_scan(built, buffers, ragged, dense):
+    """k_sweep on its own (tools/micro/sweep_cold.hip includes the product's kernels.hip): the candidate lists of a chunk — an
+    even and an odd number of 1024-position steps, fewer steps than resident waves, a ragged end — against a plain CPU scan of
+    the same magnitudes (pre-check + threshold tests, demod_2400.c:311-378)."""
+    import json
+    exe = os.path.join(helpers.ROOT, "tools", "micro", "sweep_cold")
+    if not os.path.exists(exe):
+        r = subprocess.run(["make", "-s", "-C", os.path.join(helpers.ROOT, "tools"), "micro"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run([exe, str(buffers), "2", "2", str(dense), "2000", "0", str(ragged)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.strip().startswith("OK")
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["mismatches_vs_cpu_scan"] == 0 and out["candidates"] == out["candidates_cpu"] > 0

@@ -75,7 +75,9 @@ struct mgpu_config {
  *                 mgpu_filter_expire() (and foreign icaoFilterAdd()s, e.g. from network input, with mgpu_filter_add())
  *                 between two feed calls.  This is what a readsb process linked against the library uses
  *                 (readsb_amd/host/readsb_tree/demod_gpu_wrap.c wraps icaoFilterExpire): its own filter and the
- *                 library's then flip at the same buffer boundaries whatever clock the host runs (synthetic or wall). */
+ *                 library's then flip at the same buffer boundaries whatever clock the host runs (synthetic or wall).
+ *                 In this mode the filter starts EMPTY: the host's own first add — modesInit's icaoFilterAdd(Modes.show_only),
+ *                 readsb.c:310, whatever --show-only is — must be mirrored with mgpu_filter_add() like every other one. */
 #define MGPU_FILTER_CLOCK_AFTER_FIRST  0
 #define MGPU_FILTER_CLOCK_BEFORE_FIRST 1
 #define MGPU_FILTER_CLOCK_EXTERNAL     2
@@ -153,7 +155,7 @@ struct mgpu_timing {
  * icaoFilterAdd(show_only), init_converter() (readsb.c:306-310, sdr_ifile.c:156). */
 int  mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out);
 void mgpu_destroy(mgpu_ctx *ctx);
-/* Back to the state right after mgpu_create (sample clock 0, filter = {show_only}). */
+/* Back to the state right after mgpu_create (sample clock 0, filter = {show_only's default}; empty with the EXTERNAL clock). */
 int  mgpu_reset(mgpu_ctx *ctx);
 const char *mgpu_strerror(int code);
 const char *mgpu_last_error(mgpu_ctx *ctx);
@@ -177,7 +179,10 @@ int mgpu_feed_iq(mgpu_ctx *ctx, const void *iq_host, uint64_t nsamples);
  * settle when nothing is in flight: passing `counters` to mgpu_collect, and mgpu_finish / mgpu_last_timing / mgpu_reset /
  * mgpu_filter_* / mgpu_set_deferred, wait for everything enqueued so far (they "drain"); mgpu_last_timing then covers everything
  * since the previous drain.  The result — messages, their order, every counter — is identical to feeding the same blocks
- * synchronously.  The struct mag_buf entries and the shard calls are refused (MGPU_E_INVAL) while deferred mode is on. */
+ * synchronously.  The struct mag_buf entries and the shard calls are refused (MGPU_E_INVAL) while deferred mode is on.
+ * Lifetime of the caller's block: a deferred mgpu_feed_iq returns when the last byte of `iq_host` has been copied to the device
+ * (the kernels are still to run), so the block may be reused at once, exactly as after a synchronous feed; a device block
+ * (mgpu_feed_iq_device) is read by kernels that are still to run and must stay untouched until that feed has been collected. */
 int mgpu_set_deferred(mgpu_ctx *ctx, int on);
 
 /* Device-resident messages (deferred mode only, no Mode A/C): the accepted frames' records are built on the GPU
@@ -186,7 +191,8 @@ int mgpu_set_deferred(mgpu_ctx *ctx, int on);
  * unless asked for.  mgpu_collect_device() waits for the oldest uncollected feed like mgpu_collect() and returns the device
  * pointer of its `*n` records, in stream order — valid until three more feeds have been started — ready for
  * mgpu_decode_fields_device / mgpu_beast_encode_device or an aggregator's RCCL gather (readsb_amd/gather.py: submit_device).
- * mgpu_collect() in this mode copies the whole feed to the host (MGPU_E_OVERFLOW if `cap` is smaller than the feed). */
+ * mgpu_collect() in this mode copies the whole feed to the host (MGPU_E_OVERFLOW if `cap` is smaller than the feed).
+ * The list of a feed holds (chunks per feed) x cfg.max_messages records (default per chunk: samples / 64 + 65536). */
 int mgpu_set_device_messages(mgpu_ctx *ctx, int on);
 int mgpu_collect_device(mgpu_ctx *ctx, const struct mgpu_msg **d_msgs, uint64_t *n, struct mgpu_counters *counters);
 

@@ -162,6 +162,8 @@ struct Slot {
     uint16_t *h_msg_len = nullptr, *h_msg_skip = nullptr;
     hipEvent_t ev[7] = {};               // 3: the chunk is complete (always recorded) | stage timing, sampled chunks only (timed): 0 1 convert, 5 4 k_sweep, 4 2 k_slice, 6 3 post-sweep
     bool timed = false;
+    uint32_t slice_blocks = 0;            // rows of d_sweep_part the chunk's k_slice wrote
+    uint32_t sweep_blocks = 0;            // grid of the chunk's k_sweep
     uint32_t *d_ac_noise = nullptr;       // Mode A/C: per-buffer noise level
     AcCand *h_ac = nullptr;               // ... candidates, written by k_modeac straight into pinned host memory
     hipEvent_t ev_h2d = nullptr;          // the chunk's IQ samples have arrived in HBM (copy stream)
@@ -271,6 +273,10 @@ struct mgpu_ctx {
     uint64_t cap_units = 0, cap_buffers = 0, cap_pool = 0, cap_msgs = 0, cap_ac = 0;   // per slot
 
     uint8_t *d_iq = nullptr;
+    // host feeds upload chunk i of a feed into region i of d_iq (copy stream); the converter that read region i last (main stream)
+    // must have run before the next upload into it may start — with deferred feeds of one or two chunks nothing else orders them
+    std::vector<hipEvent_t> ev_iq_read;   // per region: recorded behind the converter of the last chunk uploaded there
+    std::vector<char> iq_region_used;
     const uint16_t *tail_src = nullptr;   // device: the 326 magnitudes before the next chunk (end of the previous chunk's d_mag)
     uint64_t chunk_seq = 0;               // chunks alternate between the two slots across feeds
     uint32_t *d_adder_bitmap = nullptr;
@@ -711,6 +717,9 @@ static int alloc_all(mgpu_ctx *c) {
     const size_t bps = cfg.format == MGPU_FMT_UC8 ? 2 : 4;
 
     HIPCHK(c, hipMalloc(&c->d_iq, n * bps + 64));
+    c->ev_iq_read.assign((size_t) ((n + cs - 1) / cs) + 1, nullptr);
+    c->iq_region_used.assign(c->ev_iq_read.size(), 0);
+    for (auto &e : c->ev_iq_read) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(c, hipMalloc(&c->d_win, 8 * sizeof(unsigned long long)));
     HIPCHK(c, hipHostMalloc(&c->h_win, 8 * sizeof(unsigned long long)));
     HIPCHK(c, hipMalloc(&c->d_adder_bitmap, (1u << 24) / 8));
@@ -906,6 +915,8 @@ void mgpu_destroy(mgpu_ctx *c) {
         for (void *p : wkp)
             if (p) (void) hipFree(p);
     }
+    for (hipEvent_t e : c->ev_iq_read)
+        if (e) (void) hipEventDestroy(e);
     void *dev[] = {c->d_roll_tan, c->d_fields, c->d_beast_off, c->d_beast_len, c->d_beast_in, c->d_beast_out, c->d_beast_blocks, c->d_beast_total, c->d_hist, c->d_hist_iq, c->d_hist_sums, c->d_iq, c->d_win, c->d_adder_bitmap, c->d_bit_syndrome, c->d_group_syndrome, c->d_parity,
                    c->d_tab_long, c->d_tab_short, c->d_uc8_folded};
     for (void *p : dev)
@@ -1005,14 +1016,15 @@ static int enqueue_sweep(mgpu_ctx *c, Slot &sl) {
     sp.debug_stage = c->dbg_stage;
     if (c->sweep_version == 3) {
         launch_sweep_slice(sp, s);
+        sl.slice_blocks = 0;
         if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[4], s));
     } else
 #endif
     {
-        sp.sweep_blocks = launch_sweep(sp, s);
+        sl.sweep_blocks = launch_sweep(sp, s);
         if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[4], s));
         if (c->copy_after_sweep) HIPCHK(c, hipEventRecord(sl.ev_swept, s));
-        launch_slice(sp, s);
+        sl.slice_blocks = launch_slice(sp, s);
     }
     if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[2], s));
     return MGPU_OK;
@@ -1038,6 +1050,7 @@ static int enqueue_post(mgpu_ctx *c, Slot &sl) {
     // records), so the write pass does not look at the adder bitmap again
     q.keep_masks = true;
     q.fin_part = sl.d_sweep_part + (size_t) kSweepGridMax * 4;
+    q.slice_part = sl.d_sweep_part; q.slice_blocks = sl.slice_blocks;       // k_slice's rows of counts (0 rows: the experiments build's fused kernel counts for itself)
     if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[6], s));
     if (launch_prescreen(q, s, s, sl.ev_scan) != 0) { c->err = "event ordering of the pre-screen passes failed"; return MGPU_E_HIP; }
     HIPCHK(c, hipEventRecord(sl.ev[3], s));
@@ -1045,8 +1058,9 @@ static int enqueue_post(mgpu_ctx *c, Slot &sl) {
 }
 
 // one chunk on its own (struct mag_buf entry, shard passes)
-static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
+static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq, hipEvent_t after_convert = nullptr) {
     int rc = enqueue_convert(c, sl, iq);
+    if (rc == MGPU_OK && after_convert) HIPCHK(c, hipEventRecord(after_convert, c->stream));   // the chunk's IQ samples have been read
     if (rc == MGPU_OK) rc = enqueue_sweep(c, sl);
     if (rc == MGPU_OK) rc = enqueue_post(c, sl);
     return rc;
@@ -1106,7 +1120,7 @@ static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
     float ms;
     if (sl.timed) {
         if (hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]) == hipSuccess) c->acc.convert_ms += ms;
-        if (hipEventElapsedTime(&ms, sl.ev[5], sl.ev[4]) == hipSuccess) c->acc.sweep_ms += ms;
+        if (hipEventElapsedTime(&ms, sl.ev[5], sl.ev[4]) == hipSuccess) { c->acc.sweep_ms += ms; if (c->sweep_version == 5) sweep_pace_feedback(ms * 1e3f, sl.n, sl.sweep_blocks); }
         if (hipEventElapsedTime(&ms, sl.ev[4], sl.ev[2]) == hipSuccess) c->acc.slice_ms += ms;
         if (hipEventElapsedTime(&ms, sl.ev[6], sl.ev[3]) == hipSuccess) c->acc.prescreen_ms += ms;
         c->acc.n_timed_chunks += 1;
@@ -1735,7 +1749,7 @@ static int feed_common(mgpu_ctx *c, const void *src, bool src_is_device, uint64_
         fs.msgs.clear();
         fs.d_count = 0;
         if (c->device_msgs && !fs.d_msgs) {
-            const uint64_t want = c->cap_samples / 64 + 65536;
+            const uint64_t want = ((c->cap_samples + c->chunk_samples - 1) / c->chunk_samples) * c->cap_msgs;   // every chunk of a feed may fill its slot's list
             if (hipSetDevice(c->cfg.device) != hipSuccess || hipMalloc(&fs.d_msgs, want * sizeof(mgpu_msg)) != hipSuccess ||
                 hipEventCreateWithFlags(&fs.ev_built, hipEventDisableTiming) != hipSuccess) {
                 c->err = "device message list: allocation failed";
@@ -1751,6 +1765,7 @@ static int feed_common(mgpu_ctx *c, const void *src, bool src_is_device, uint64_
     const uint8_t *iq = src_is_device ? (const uint8_t *) src : c->d_iq;
     // software pipeline over chunks: GPU works on chunk i+1 while the worker walks chunk i
     int rc = MGPU_OK;
+    hipEvent_t last_h2d = nullptr;
     for (uint64_t off = 0; off < n && rc == MGPU_OK; off += c->chunk_samples) {
         const uint64_t len = n - off < c->chunk_samples ? n - off : c->chunk_samples;
         const int k = (int) (c->chunk_seq++ % mgpu_ctx::kSlots);
@@ -1763,23 +1778,35 @@ static int feed_common(mgpu_ctx *c, const void *src, bool src_is_device, uint64_
         sl.thr = c->cfg.preamble_threshold;
         sl.given_mean_power.clear();
         ifile_grid(c, c->stream_pos + off, len, sl.buffers);
+        hipEvent_t ev_read = nullptr;
         if (!src_is_device) {
             const double t0 = wall_ms();
-            hipError_t e = hipMemcpyAsync(c->d_iq + off * bps, (const uint8_t *) src + off * bps, len * bps, hipMemcpyHostToDevice, c->stream_w);
+            const size_t region = (size_t) (off / c->chunk_samples);
+            hipError_t e = hipSuccess;
+            // the previous chunk uploaded into this region of the staging buffer (an earlier feed) must have been converted
+            if (c->iq_region_used[region]) e = hipStreamWaitEvent(c->stream_w, c->ev_iq_read[region], 0);
+            ev_read = c->ev_iq_read[region];
+            c->iq_region_used[region] = 1;
+            if (e == hipSuccess) e = hipMemcpyAsync(c->d_iq + off * bps, (const uint8_t *) src + off * bps, len * bps, hipMemcpyHostToDevice, c->stream_w);
             if (e == hipSuccess) e = hipEventRecord(sl.ev_h2d, c->stream_w);
             if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, sl.ev_h2d, 0);
             if (e != hipSuccess) { c->err = std::string("H2D of the IQ samples: ") + hipGetErrorString(e); rc = MGPU_E_HIP; }
             c->acc.h2d_ms += (float) (wall_ms() - t0);   // host time spent issuing (pageable memory: staging) the copies
         }
         if (fidx >= 0) { std::lock_guard<std::mutex> lk(c->mu); c->feed[fidx].jobs_total++; }
-        if (rc == MGPU_OK) rc = enqueue_slot(c, sl, iq + off * bps);
+        if (rc == MGPU_OK) rc = enqueue_slot(c, sl, iq + off * bps, ev_read);
         if (rc != MGPU_OK) { std::lock_guard<std::mutex> lk(c->mu); if (c->worker_rc == MGPU_OK) c->worker_rc = rc; }
+        last_h2d = src_is_device ? nullptr : sl.ev_h2d;
         submit_slot(c, k);   // even after an enqueue error: the stages release the slot
     }
     if (fidx >= 0) {
         // deferred: the feed is on its way; its messages are collected by mgpu_collect, the counters settle at the next drain
         { std::lock_guard<std::mutex> lk(c->mu); c->feed[fidx].closed = true; }
         c->cv.notify_all();
+        // a deferred feed returns with its kernels still to run, but not with the caller's samples still to be read: the last
+        // upload has landed when this returns (from page-locked memory the copies are truly asynchronous), so the caller may
+        // reuse its block at once, as after a synchronous feed
+        if (rc == MGPU_OK && last_h2d && hipEventSynchronize(last_h2d) != hipSuccess) { c->err = "H2D of the IQ samples failed"; rc = MGPU_E_HIP; }
         if (rc != MGPU_OK) return rc;
         c->stream_pos += n;
         if (n % c->cfg.buf_samples) c->eof = true;
@@ -1972,7 +1999,7 @@ int mgpu_set_device_messages(mgpu_ctx *c, int on) {
     if (on && (!c->deferred || c->cfg.mode_ac)) { c->err = "mgpu_set_device_messages: needs deferred feeds, and no Mode A/C (its replies are merged on the host)"; return MGPU_E_INVAL; }
     if (on) {                                        // the four feeds' device lists now, not inside somebody's timed region
         HIPCHK(c, hipSetDevice(c->cfg.device));
-        const uint64_t want = c->cap_samples / 64 + 65536;
+        const uint64_t want = ((c->cap_samples + c->chunk_samples - 1) / c->chunk_samples) * c->cap_msgs;   // every chunk of a feed may fill its slot's list
         for (auto &fs : c->feed) {
             if (fs.d_msgs) continue;
             HIPCHK(c, hipMalloc(&fs.d_msgs, want * sizeof(mgpu_msg)));

@@ -102,8 +102,8 @@ struct SweepParams {
     uint32_t nunits;
     uint16_t *cand;           // candidate codes (position in the unit << 3 | phase mask), one list per step of kSweepTile positions, kSweepTile slots each
     uint32_t *cand_count;     // [steps], + one empty list behind an odd number of steps
-    uint32_t *sweep_part;     // [k_sweep workgroups][4] partial counters (candidates, phases 4/5, 6/7, 8), summed by k_slice
-    uint32_t sweep_blocks;    // rows of sweep_part
+    uint32_t pace_recip;      // k_sweep: 2^32 / reference step time in 10 ns ticks (set by launch_sweep; 0 = no pacing)
+    uint32_t *sweep_part;     // [k_slice workgroups][8] partial counters (records, candidates, phases 4/5, 6/7, 8), summed by the pre-screen write pass
     uint32_t *adder_bitmap;   // 2^24 bits: addresses some clean DF17 / DF11 IID 0 frame carries
     uint32_t *class_bitmap;   // 1 bit per scan position: candidate whose records are all conditional
     uint32_t *class_uncond;   // scratch plane: candidate with >= 1 unconditional record (both planes zeroed per chunk)
@@ -128,8 +128,9 @@ struct ConvertParams {
 };
 
 void launch_convert(int format, const ConvertParams &p, hipStream_t s);
-unsigned launch_sweep(const SweepParams &p, hipStream_t s);        // k_sweep: preamble sweep -> per-tile candidate lists; returns its grid size (rows of sweep_part)
-void launch_slice(const SweepParams &p, hipStream_t s);            // k_slice: slicer + CRC + scoring over the candidate lists -> record pool
+unsigned launch_sweep(const SweepParams &p, hipStream_t s);        // k_sweep: preamble sweep -> per-step candidate lists; returns its grid size
+void sweep_pace_feedback(float kernel_us, uint64_t n, unsigned blocks);   // a timed k_sweep launch: feeds the pacing's step-time estimate
+unsigned launch_slice(const SweepParams &p, hipStream_t s);        // k_slice: slicer + CRC + scoring over the candidate lists -> record pool; returns its grid size (rows of sweep_part)
 #if MGPU_EXPERIMENTS
 void launch_sweep_slice(const SweepParams &p, hipStream_t s);      // generation 3: both in one kernel (cross-check build only)
 #endif
@@ -154,6 +155,8 @@ struct PostSweepParams {
     uint32_t scratch_words;
     bool keep_masks;                      // segments of <= 64 records: the count pass leaves its decisions in the headers
     uint32_t *fin_part;                   // [kFinMaxBlocks][2] class counts per finalize workgroup, summed by the write pass
+    const uint32_t *slice_part;           // k_slice's rows of counts (SweepParams::sweep_part), summed by the write pass; slice_blocks = 0: none
+    uint32_t slice_blocks;
 };
 int launch_prescreen(const PostSweepParams &q, hipStream_t s, hipStream_t s_write, hipEvent_t ev_scan);
 // ---- Mode A/C (demodulate2400AC, demod_2400.c:575-761), only when mgpu_config.mode_ac is set ----

@@ -142,7 +142,10 @@ bool Resolver::apply_device_walk(const uint32_t *per_buf, const uint32_t *adds, 
 
 void Resolver::reset(int64_t startup_ms, int clock_mode) {
     filter_.init();
-    filter_.add(kShowOnlyDefault);
+    // external clock: the host mirrors every icaoFilterAdd() it performs, modesInit's icaoFilterAdd(Modes.show_only) included — with
+    // a user --show-only a default entry added here as well would leave `occupied` one ahead of the host's and the resize
+    // thresholds (icao_filter.c:65-93) firing on different adds
+    if (clock_mode != 2) filter_.add(kShowOnlyDefault);
     synthetic_now_ = startup_ms;   // Modes.synthetic_now armed by ifileOpen (sdr_ifile.c:131-133)
     next_flip_ = 0;                // static next_flip = 0 (readsb.c:1227)
     nflips_ = 0;

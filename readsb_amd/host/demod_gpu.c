@@ -93,10 +93,15 @@ static void deliver(struct gpu_demod *g) {
 
 void demodulate2400_gpu(struct gpu_demod *g, struct mag_buf *mag) {
     /* with --modeac the decode thread runs demodulate2400AC(buf) right after demodulate2400(buf) (readsb.c:871-874) */
+    /* `dropped` of the library entry = "Modes.stats_15min.samples_dropped != 0" (demod_2400.c:335-338), not this buffer's
+     * own count: the host adds mag->dropped to its statistics (readsb.c:884-887) and the 15-minute window holds it for 15
+     * minutes.  Stand-alone there is no struct stats: the window is kept here, on the buffers' own clock. */
+    if (mag->dropped) { g->dropped_seen = 1; g->dropped_until_ms = mag->sysTimestamp + 15 * 60 * 1000; }
+    const uint32_t dropped15 = g->dropped_seen && mag->sysTimestamp < g->dropped_until_ms;
     int rc = g->mode_ac ? mgpu_demod_mag_buf_ac(g->ctx, mag->data, mag->length, mag->sampleTimestamp, mag->sysTimestamp,
-                                                mag->mean_level, mag->mean_power, mag->dropped)
+                                                mag->mean_level, mag->mean_power, dropped15)
                         : mgpu_demod_mag_buf(g->ctx, mag->data, mag->length, mag->sampleTimestamp, mag->sysTimestamp,
-                                             mag->mean_power, mag->dropped);
+                                             mag->mean_power, dropped15);
     if (rc != MGPU_OK) {
         fprintf(stderr, "demodulate2400_gpu: %s (%s)\n", mgpu_strerror(rc), mgpu_last_error(g->ctx));
         abort();   /* the reference's demodulate2400 cannot fail; silently dropping a buffer would be worse */

@@ -57,6 +57,8 @@ struct gpu_demod {
     struct mgpu_msg *scratch;
     uint64_t scratch_cap;
     struct mgpu_counters counters;   /* mirrors Modes.stats_current's demod counters */
+    int dropped_seen;                /* a buffer with dropped samples has passed ... */
+    int64_t dropped_until_ms;        /* ... and counts, as in Modes.stats_15min, until this sysTimestamp */
     uint8_t *readbuf[2];             /* the file reader's two page-locked chunk buffers (gpu_demod_reserve_input) */
     size_t readbuf_bytes;
     int readbuf_pinned[2];

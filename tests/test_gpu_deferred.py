@@ -128,3 +128,55 @@ def test_device_messages_equal_host_messages(built, monkeypatch):
     helpers.assert_same_messages(np.concatenate(host), want)
     helpers.assert_same_counters(cnt, wst)
     d.close()
+
+
+def test_one_chunk_host_feeds_on_a_busy_gpu(built, monkeypatch):
+    """Deferred HOST feeds of one pipeline chunk each, all different, from one page-locked block that is overwritten as soon as
+    the feed call returns, while a second context keeps the GPU's main queue full: every feed uploads into the same region of
+    the library's staging buffer, so feed k+1's upload must wait for feed k's converter (round-2 advisor finding: it did not),
+    and the caller's block must have been read when mgpu_feed_iq returns."""
+    import threading
+    import readsb_amd
+    monkeypatch.setenv("MGPU_CHUNK_BUFFERS", "64")
+    nfeeds, per = 12, 48 * B                                   # one chunk per feed
+    iq = helpers.synth(nsamples=nfeeds * per, seed=31337, rate=4000.0)
+    want, wst = helpers.oracle_run(iq, 0, 1, 1, 58)
+
+    stop = threading.Event()
+
+    def hog():                                                  # a stream of its own, resident, looping: the GPU stays saturated
+        h = readsb_amd.Demodulator(startup_time_ms=helpers.STARTUP_MS, max_samples=256 * B)
+        h.upload_iq(helpers.synth(nsamples=256 * B, seed=5, rate=6000.0))
+        while not stop.is_set():
+            h.reset()
+            h.feed_resident(256 * B)
+            h.collect(reuse=True)
+        h.close()
+
+    t = threading.Thread(target=hog)
+    t.start()
+    try:
+        d = readsb_amd.Demodulator(startup_time_ms=helpers.STARTUP_MS, max_samples=64 * B)
+        d.set_deferred(True)
+        block = d.host_alloc(per * 2)                           # page-locked: the uploads are truly asynchronous
+        out = np.empty(400000, dtype=readsb_amd.MSG_DTYPE)
+        got = []
+        for k in range(nfeeds):
+            block[:] = iq[k * per * 2:(k + 1) * per * 2]
+            d.feed_iq(block)
+            block[:] = 0x55                                     # the block is the caller's again
+            if k >= 2:
+                m, _ = d.collect_feed(out)
+                got.append(m.copy())
+        for _ in range(2):
+            m, _ = d.collect_feed(out)
+            got.append(m.copy())
+        d.finish()
+        _, cnt = d.collect_feed(out, want_counters=True)
+    finally:
+        stop.set()
+        t.join()
+    helpers.assert_same_messages(np.concatenate(got), want)
+    helpers.assert_same_counters(cnt, wst)
+    d.host_free(block)
+    d.close()

@@ -7,7 +7,7 @@
 // compared with a plain CPU scan of the same magnitudes (demod_2400.c:311-378 restated in check_cpu below).
 //
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DMGPU_EXPERIMENTS=1 [-DMGPU_SW_STAGE=k] -o sweep_cold sweep_cold.hip -ldl
-//   sweep_cold [buffers=512] [replicas=9] [rounds=4] [dense=0] [rate=2000] [blocks=0 (resident grid)] [ragged=0 (samples added to the chunk)]
+//   sweep_cold [buffers=512] [replicas=9] [rounds=4] [dense=0] [rate=2000] [blocks=0 (resident grid)] [ragged=0 (samples added to the chunk)] [pace=-1 (feedback as the library's; 0 off; else 10 ns ticks per step)]
 // Output: one JSON line (per-launch time cold / warm, GB/s of algorithmic bytes, fraction of the 8 TB/s peak, wave lifetimes).
 #include "../../readsb_amd/csrc/kernels.hip"
 #include "../../readsb_amd/csrc/tables.cpp"
@@ -51,6 +51,8 @@ int main(int argc, char **argv) {
     const double rate = argc > 5 ? atof(argv[5]) : 2000.0;
     unsigned blocks = argc > 6 ? (unsigned) atoi(argv[6]) : 0u;
     const int ragged = argc > 7 ? atoi(argv[7]) : 0;
+    const int pace_arg = argc > 8 ? atoi(argv[8]) : -1;      // -1: paced with the library's feedback rule, 0: no pacing, else fixed ticks
+    float pace_ticks = pace_arg < 0 ? 260.0f : (float) pace_arg;
     const int thr = 58;
     const uint64_t n = (uint64_t) buffers * 131072 + (uint64_t) ragged;
     const uint64_t stride = ((n + kTrailing + 4096 + 4095) / 4096) * 4096;      // magnitudes per replica (16-byte aligned, with the tile slack)
@@ -73,7 +75,7 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&d_mag, (size_t) replicas * stride * 2));
     CK(hipMalloc(&d_cand, (size_t) (nsteps + 2) * kSwStep * 2));
     CK(hipMalloc(&d_count, (size_t) (nsteps + 2) * 4));
-    CK(hipMalloc(&d_part, 65536 * kSwPartWords * 4));
+    CK(hipMalloc(&d_part, 65536 * 8 * 4));
     CK(hipMalloc(&d_sums, (size_t) (buffers + 3) * 2 * 8));
     CK(hipMalloc(&d_waves, 65536 * 4 * 2 * 8));
     const std::vector<uint16_t> lut = uc8_folded_table();
@@ -106,12 +108,18 @@ int main(int argc, char **argv) {
     auto run = [&](int r, float &us) -> int {
         p.mag = d_mag + (size_t) r * stride;
         CK(hipEventRecord(e0, nullptr));
+        p.pace_recip = pace_ticks > 0.0f ? (uint32_t) (4294967296.0 / pace_ticks) : 0u;
         hipLaunchKernelGGL(k_sweep, dim3(blocks), dim3(kBlock), 0, nullptr, p);
         CK(hipEventRecord(e1, nullptr));
         CK(hipEventSynchronize(e1));
         float ms = 0;
         CK(hipEventElapsedTime(&ms, e0, e1));
         us = ms * 1e3f;
+        if (pace_arg < 0 && (double) nsteps / (blocks * 4.0) >= 4.0 && us > 8.0f) {   // the library's feedback (sweep_pace_feedback)
+            float t = (float) ((us - 4.5) * 100.0 / ((double) nsteps / (blocks * 4.0)));
+            t = t < 120.0f ? 120.0f : t > 800.0f ? 800.0f : t;
+            pace_ticks = 0.5f * pace_ticks + 0.5f * t;
+        }
         return 0;
     };
     // ---- correctness of every replica's lists against the CPU scan (first round) ----
@@ -124,7 +132,7 @@ int main(int argc, char **argv) {
             float us;
             if (run(r, us)) return 2;
             if (rd > 0) cold.push_back(us);                // (the first round also pays the first-touch of the code and the TLBs)
-            if (rd == 0 && MGPU_SW_STAGE == 0 && (r == 0 || r == replicas - 1)) {
+            if (rd == 0 && MGPU_SW_STAGE == 0 && MGPU_SW_EXP != 1 && MGPU_SW_EXP != 2 && (r == 0 || r == replicas - 1)) {
                 CK(hipMemcpy(hc.data(), d_cand, hc.size() * 2, hipMemcpyDeviceToHost));
                 CK(hipMemcpy(hn.data(), d_count, (size_t) (nsteps + 1) * 4, hipMemcpyDeviceToHost));
                 std::vector<uint32_t> got;
@@ -169,14 +177,14 @@ int main(int argc, char **argv) {
     stat(cold, cmin, cmed, cmax, cavg);
     stat(warm, wmin, wmed, wmax, wavg);
     const double bytes = (double) n * 2.0;
-    printf("{\"kernel\": \"k_sweep\", \"stage\": %d, \"samples_per_launch\": %llu, \"algorithmic_bytes_per_launch\": %.0f, \"replicas\": %d, "
-           "\"cold_array_bytes\": %.0f, \"blocks\": %u, \"waves\": %u, \"dense\": %d, \"rate\": %.0f, \"candidates\": %llu, \"candidates_cpu\": %zu, "
+    printf("{\"kernel\": \"k_sweep\", \"variant\": \"exp %d nbuf %d\", \"stage\": %d, \"samples_per_launch\": %llu, \"algorithmic_bytes_per_launch\": %.0f, \"replicas\": %d, "
+           "\"cold_array_bytes\": %.0f, \"pace_ticks\": %.0f, \"blocks\": %u, \"waves\": %u, \"dense\": %d, \"rate\": %.0f, \"candidates\": %llu, \"candidates_cpu\": %zu, "
            "\"mismatches_vs_cpu_scan\": %llu, "
            "\"cold_us\": {\"min\": %.2f, \"median\": %.2f, \"mean\": %.2f, \"max\": %.2f, \"launches\": %zu}, "
            "\"cold_GBs\": %.1f, \"cold_frac_of_8TBs\": %.4f, "
            "\"warm_us\": {\"min\": %.2f, \"median\": %.2f, \"mean\": %.2f, \"max\": %.2f, \"launches\": %zu}, \"warm_GBs\": %.1f, \"warm_frac_of_8TBs\": %.4f, "
            "\"waves_alive_frac\": %.3f, \"wave_life_mean_us\": %.2f, \"last_start_us\": %.2f, \"end_us\": {\"p10\": %.2f, \"p50\": %.2f, \"p90\": %.2f, \"max\": %.2f}}\n",
-           (int) MGPU_SW_STAGE, (unsigned long long) n, bytes, replicas, (double) replicas * stride * 2, blocks, nwaves, dense, rate,
+           (int) MGPU_SW_EXP, (int) MGPU_SW_NBUF, (int) MGPU_SW_STAGE, (unsigned long long) n, bytes, replicas, (double) replicas * stride * 2, (double) pace_ticks, blocks, nwaves, dense, rate,
            (unsigned long long) ncand, want.size(), (unsigned long long) mismatches,
            cmin, cmed, cavg, cmax, cold.size(), bytes / (cavg * 1e-6) / 1e9, bytes / (cavg * 1e-6) / 1e9 / 8000.0,
            wmin, wmed, wavg, wmax, warm.size(), bytes / (wavg * 1e-6) / 1e9, bytes / (wavg * 1e-6) / 1e9 / 8000.0,

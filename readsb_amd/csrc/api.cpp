@@ -137,6 +137,7 @@ struct Slot {
     // device
     uint16_t *d_mag = nullptr;
     PhaseRec *d_pool = nullptr;
+    uint32_t *d_dealer = nullptr;         // k_slice's tile dealer: 64 counters, one per 256 bytes (handed back zeroed by k_publish)
     uint32_t *d_pool_used = nullptr, *d_unit_first = nullptr, *d_unit_count = nullptr, *d_unit_live = nullptr, *d_class_bitmap = nullptr;
     uint32_t *d_class_uncond = nullptr, *d_class_final = nullptr, *d_cand_count = nullptr, *d_sweep_part = nullptr;
     uint16_t *d_cand = nullptr;
@@ -608,7 +609,7 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
     HIPCHK(c, hipMalloc(&sl.d_mag, mag_len * sizeof(uint16_t)));
     HIPCHK(c, hipMemsetAsync(sl.d_mag, 0, mag_len * sizeof(uint16_t), c->stream));
     HIPCHK(c, hipMalloc(&sl.d_pool, c->cap_pool * sizeof(PhaseRec)));
-    HIPCHK(c, hipMalloc(&sl.d_unit_first, (c->cap_units + 1) * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(&sl.d_unit_first, (c->cap_units * (size_t) (kUnit / 2048) + 1) * sizeof(uint32_t)));   // one record chain per k_slice tile
     HIPCHK(c, hipMalloc(&sl.d_unit_count, (c->cap_units + 1) * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc(&sl.d_unit_live, (c->cap_units + 2 + c->cap_units / 4 + 2) * sizeof(uint32_t)));   // per unit, then per count-pass workgroup
     sl.class_bytes = (mag_len / 32 + 64) * sizeof(uint32_t);
@@ -620,6 +621,8 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
     HIPCHK(c, hipMemsetAsync(sl.d_class_uncond, 0, sl.class_bytes, c->stream));
     HIPCHK(c, hipMalloc(&sl.d_cand, (c->cap_units * (size_t) kUnit + 64) * sizeof(uint16_t)));
     HIPCHK(c, hipMalloc(&sl.d_cand_count, (c->cap_units * (size_t) (kUnit / kSweepTile) + 1) * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(&sl.d_dealer, (size_t) kDealerCounters * kDealerStride * sizeof(uint32_t)));   // (k_publish hands it back zeroed)
+    HIPCHK(c, hipMemsetAsync(sl.d_dealer, 0, (size_t) kDealerCounters * kDealerStride * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMalloc(&sl.d_sweep_part, ((size_t) kSweepGridMax * 4 + (size_t) kFinMaxBlocks * 2) * sizeof(uint32_t)));
     {
         const size_t nb = c->cap_buffers, words = CNT_NUM + 1 + 4 * nb + kAcLists;   // ... + Mode A/C list counters
@@ -673,7 +676,7 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
 
 static void free_slot(Slot &sl) {
     if (sl.h_blob) (void) hipHostFree(sl.h_blob);
-    void *dev[] = {sl.d_blob, sl.d_live, sl.d_live_sig, sl.d_mag, sl.d_pool, sl.d_scratch, sl.d_unit_first, sl.d_unit_count, sl.d_unit_live, sl.d_class_bitmap,
+    void *dev[] = {sl.d_dealer, sl.d_blob, sl.d_live, sl.d_live_sig, sl.d_mag, sl.d_pool, sl.d_scratch, sl.d_unit_first, sl.d_unit_count, sl.d_unit_live, sl.d_class_bitmap,
                    sl.d_class_uncond, sl.d_class_final, sl.d_cand, sl.d_cand_count, sl.d_sweep_part,
                    sl.d_win, sl.d_win_part, sl.d_msg_pos,
                    sl.d_msg_limit, sl.d_msg_len, sl.d_msg_skip, sl.d_msg_sig, sl.d_wk_in, sl.d_wk_acc, sl.d_wk_sig};
@@ -1007,7 +1010,7 @@ static int enqueue_sweep(mgpu_ctx *c, Slot &sl) {
     sp.bit_syndrome = c->d_bit_syndrome; sp.parity = c->d_parity; sp.group_syndrome = c->d_group_syndrome;
     sp.tab_long = c->d_tab_long; sp.tab_short = c->d_tab_short; sp.n_long = c->n_long; sp.n_short = c->n_short;
     sp.pool = sl.d_pool; sp.pool_cap = (uint32_t) c->cap_pool; sp.pool_used = sl.d_pool_used;
-    sp.unit_first = sl.d_unit_first; sp.unit_count = sl.d_unit_count; sp.nunits = nunits;
+    sp.unit_first = sl.d_unit_first; sp.unit_count = sl.d_unit_count; sp.nunits = nunits; sp.dealer = sl.d_dealer;
     sp.adder_bitmap = c->d_adder_bitmap; sp.class_bitmap = sl.d_class_bitmap; sp.counters = sl.d_counters;
     sp.cand = sl.d_cand; sp.cand_count = sl.d_cand_count; sp.class_uncond = sl.d_class_uncond; sp.sweep_part = sl.d_sweep_part;
     // ev[5] .. ev[4] bracket exactly one kernel: k_sweep (bench.py's roofline); ev[4] .. ev[2]: k_slice
@@ -1036,7 +1039,7 @@ static int enqueue_post(mgpu_ctx *c, Slot &sl) {
     hipStream_t s = c->stream;
     // class planes -> class bitmap, pre-screen (the surviving records stay in HBM: d_live), counters and per-buffer sums to the host
     PostSweepParams q{};
-    q.pool = sl.d_pool; q.unit_first = sl.d_unit_first; q.nunits = nunits; q.adder_bitmap = c->d_adder_bitmap;
+    q.pool = sl.d_pool; q.unit_first = sl.d_unit_first; q.nunits = nunits; q.chains_per_unit = c->sweep_version == 3 ? 1u : (uint32_t) (kUnit / 2048); q.adder_bitmap = c->d_adder_bitmap;
     q.unit_live = sl.d_unit_live; q.block_live = sl.d_unit_live + c->cap_units + 2; q.live = sl.d_live; q.live_sig = sl.d_live_sig; q.counters = sl.d_counters;
     // a shard pass hands its records to another rank, which has no samples: their signal powers go with them.  Otherwise they are
     // computed after the walk, for the accepted frames only (k_msg_sig): 40 % of the work, off the main stream
@@ -1045,6 +1048,7 @@ static int enqueue_post(mgpu_ctx *c, Slot &sl) {
     q.class_cond = sl.d_class_bitmap; q.class_uncond = sl.d_class_uncond;
     q.class_final = sl.d_class_final;
     q.class_words = (n + 31) / 32;
+    q.dealer = sl.d_dealer;
     q.d_scratch = sl.d_scratch; q.h_scratch = sl.h_scratch; q.scratch_words = (uint32_t) (sl.scratch_bytes / sizeof(unsigned long long));
     // the count pass leaves its decisions as masks in the segment headers (one scoring pass = one segment of at most 64
     // records), so the write pass does not look at the adder bitmap again

@@ -34,6 +34,8 @@ constexpr int kBlock = 256;
 constexpr int kSweepTile = 1024;
 constexpr int kSweepMaxBlocks = 256 * 4;  // resident workgroups of k_slice (at most 4 per CU)
 constexpr int kSweepGridMax = 256 * 8;    // resident workgroups of k_sweep (at most 8 per CU) = rows of sweep_part
+constexpr int kDealerCounters = 64;       // k_slice's tile dealer: pools of workgroups, one counter each ...
+constexpr int kDealerStride = 64;         // ... 256 bytes apart: device atomics on words of one 64-byte line serialise with each other (tools/micro/atomic_cost.hip)
 constexpr int kFinMaxBlocks = 1024;       // class-plane finalize workgroups (k_count_finalize)
 constexpr int kPoolChunkRecords = 256;    // pool records a wave reserves per returning atomic
 constexpr int kSweepMaxWaves = kSweepMaxBlocks * (kBlock / 64);
@@ -97,8 +99,9 @@ struct SweepParams {
     PhaseRec *pool;
     uint32_t pool_cap;
     uint32_t *pool_used;      // device counter (records incl. headers)
-    uint32_t *unit_first;     // [nunits] index of the unit's first segment header, kNone if empty
-    uint32_t *unit_count;     // [nunits] records of the unit (without headers)
+    uint32_t *unit_first;     // k_slice: [tiles of 2048 positions] index of the tile's first segment header, kNone if empty (generation 3: per unit)
+    uint32_t *unit_count;     // generation 3 only: [nunits] records of the unit (without headers)
+    uint32_t *dealer;         // k_slice: [kDealerCounters] tiles dealt from each pool so far, kDealerStride words apart (zero at launch)
     uint32_t nunits;
     uint16_t *cand;           // candidate codes (position in the unit << 3 | phase mask), one list per step of kSweepTile positions, kSweepTile slots each
     uint32_t *cand_count;     // [steps], + one empty list behind an odd number of steps
@@ -140,7 +143,8 @@ void launch_sweep_slice(const SweepParams &p, hipStream_t s);      // generation
 // pre-screen count / scan / write, scratch block to the host (and zeroed again)
 struct PostSweepParams {
     PhaseRec *pool;                       // (the count pass may leave live masks in the segment headers)
-    const uint32_t *unit_first;
+    const uint32_t *unit_first;           // first segment header of every chain, chains_per_unit consecutive chains per unit
+    uint32_t chains_per_unit;             // 4: one chain per k_slice tile of 2048 positions; 1: generation 3
     uint32_t nunits;
     const uint32_t *adder_bitmap;
     uint32_t *unit_live;                  // live records per unit (count pass)
@@ -151,6 +155,7 @@ struct PostSweepParams {
     unsigned long long *counters;
     uint32_t *class_cond, *class_uncond, *class_final;   // class_final == nullptr: generations 1/2 (bitmap written by the sweep)
     uint64_t class_words;
+    uint32_t *dealer;                     // k_slice's dealer counters: zeroed again by k_publish
     unsigned long long *d_scratch, *h_scratch;
     uint32_t scratch_words;
     bool keep_masks;                      // segments of <= 64 records: the count pass leaves its decisions in the headers

@@ -41,8 +41,23 @@ SWEEP_BYTES_PER_SAMPLE = 2.0   # k_preamble_sweep reads one u16 m
 
 # VALU issue rate measured on this chip (tools/micro/valu_issue.hip, profiles/r02_valu_issue.txt): three-operand / packed /
 # dot2 instructions — what these kernels are made of — sustain 36 T lane-ops/s chip-wide (v_add/v_xor: ~60)
-VALU_PEAK_TLANEOPS = 36.4
-PMC_SQ_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_sq_summary.txt")
+VALU_PEAK_TLANEOPS = 37.3
+PMC_SQ_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_sq_summary.txt")
+PMC_HBM = os.path.join(ROOT, "profiles", "r03_pmc_hbm.json")
+
+
+def kernel_source_sha():
+    """Hash of the device code the library was built from (kernels.hip + kernels/*.inc + kernels.h).  The committed PMC
+    summaries under profiles/ carry the hash they were collected with (tools/profile_round.sh): numbers of other code are
+    not reported as this run's (`traffic` / `valu_issue` stay null)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "readsb_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(base, "kernels", "*.inc")) + [os.path.join(base, "kernels.hip"), os.path.join(base, "kernels.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def valu_issue(kernel, avg_launch_ms, samples_per_launch, path=PMC_SQ_SUMMARY):
@@ -50,13 +65,16 @@ def valu_issue(kernel, avg_launch_ms, samples_per_launch, path=PMC_SQ_SUMMARY):
     from the committed SQ counter pass of this same command (SQ_INSTS_VALU) over the launch time measured live.
     Informative; None if the summary is missing or does not parse."""
     try:
-        insts, inside = None, False
+        insts, inside, sha_ok = None, False, False
         for ln in open(path):
+            if ln.startswith("# kernel_source_sha:"):
+                sha_ok = ln.split(":")[1].strip() == kernel_source_sha()
+                continue
             if not ln.startswith(" "):
                 inside = ln.strip().split("<")[0] in (kernel, kernel + "_t")      # k_sweep is the template k_sweep_t<fused?>
             elif inside and ln.split()[0] == "SQ_INSTS_VALU":
                 insts = int(ln.split()[1])
-        if not insts or avg_launch_ms <= 0:
+        if not insts or avg_launch_ms <= 0 or not sha_ok:
             return None
         tl = insts * 64 / (avg_launch_ms * 1e-3) / 1e12
         return {"wave_insts_per_launch": insts, "lane_ops_per_sample": round(insts * 64 / samples_per_launch, 1),
@@ -64,6 +82,16 @@ def valu_issue(kernel, avg_launch_ms, samples_per_launch, path=PMC_SQ_SUMMARY):
                 "frac": round(tl / VALU_PEAK_TLANEOPS, 3), "source": "SQ_INSTS_VALU, " + os.path.relpath(path, ROOT)}
     except Exception:
         return None
+
+
+def emit(out):
+    """The ONE JSON line, as the last line of stdout: RCCL writes its banner ("Librccl path : ...") through C stdio, which is
+    flushed at exit — behind Python's line unless it is flushed first."""
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(out), flush=True)
 
 
 def cpu_reference(iq, nsamples, fmt=0, nfix=1, fixdf=1, thr=58):
@@ -107,7 +135,8 @@ EXTRA_ENV = {"UC8 --fix, ordered walk on the device (MGPU_DEVICE_WALK=1)": {"MGP
 
 def run_extra_config(name, fmt, nfix, kw, nsamples, device, steps=4):
     """One more configuration on a fresh context: `steps` back-to-back segments of a resident stream with deferred feeds (timed),
-    then one synchronous pass whose messages and counters must equal the reference's own code on the same samples."""
+    then two more deferred segments of a fresh stream, fed the same way, whose messages and counters must equal the reference's
+    own code on the same two-segment stream."""
     import helpers
     import readsb_amd
     iq = helpers.synth(nsamples=nsamples, fmt=fmt, seed=424242, threads=min(64, os.cpu_count() or 8), **kw)
@@ -136,6 +165,7 @@ def run_extra_config(name, fmt, nfix, kw, nsamples, device, steps=4):
 
     submit(0)
     d.collect_feed(bufs[0], want_counters=True)              # warm-up segment, drained
+    d.timing()
     t0 = time.perf_counter()
     submit(1)
     for k in range(2, steps + 1):
@@ -147,15 +177,26 @@ def run_extra_config(name, fmt, nfix, kw, nsamples, device, steps=4):
     ev_scale = tm["n_chunks"] / max(1, tm["n_timed_chunks"])
     for key in ("convert_ms", "sweep_ms", "slice_ms", "prescreen_ms"):
         tm[key] *= ev_scale
-    d.set_deferred(False)
+    # the check: the same deferred feeds from a fresh stream — two segments, the consumer's arrays, feed k+1 enqueued before feed k
+    # is collected, exactly what was timed — against the reference's own code on the two-segment stream
     d.reset()
-    d.feed_resident(nsamples)
+    got = []
+    submit(0)
+    submit(1)
+    m, _ = d.collect_feed(bufs[0])
+    got.append(m.copy())
+    m, counters = d.collect_feed(bufs[1], want_counters=True)
+    got.append(m.copy())
     d.finish()
-    msgs, counters = d.collect(reuse=True)
+    _, counters = d.collect_feed(bufs[0], want_counters=True)
+    d.set_deferred(False)
+    msgs = np.concatenate(got)
+    iq2 = np.concatenate([iq, iq])
     if helpers.have_ref():                                   # the reference's objects hold one configuration per process: own process
-        kind, (ref_msgs, st) = "reference", helpers.ref_run(iq, fmt, nfix, 1, 58)
+        kind, (ref_msgs, st) = "reference", helpers.ref_run(iq2, fmt, nfix, 1, 58)
     else:
-        kind, (ref_msgs, st) = "port", helpers.oracle_run(iq, fmt, nfix, 1, 58)
+        kind, (ref_msgs, st) = "port", helpers.oracle_run(iq2, fmt, nfix, 1, 58)
+    del iq2
     helpers.assert_same_messages(msgs, ref_msgs)
     helpers.assert_same_counters(counters, st, float_tol=0.02 if fmt else 0.0)
     nl = max(1, tm["n_chunks"])
@@ -166,8 +207,13 @@ def run_extra_config(name, fmt, nfix, kw, nsamples, device, steps=4):
            "us_per_launch": {"convert": round(tm["convert_ms"] / nl * 1e3, 1), "k_sweep": round(tm["sweep_ms"] / nl * 1e3, 1),
                              "k_slice": round(tm["slice_ms"] / nl * 1e3, 1), "post_sweep": round(tm["prescreen_ms"] / nl * 1e3, 1)},
            "samples_per_launch": int(nsamples * steps // nl),
-           "cpu_reference_msamples_s": round(nsamples / float(st["t_convert_s"] + st["t_demod_s"]) / 1e6, 1),
-           "bit_identical_to_reference": True, "checker": kind}
+           # per segment: the GPU stages (HIP events, summed over the segment's launches) and the host stages behind them (wall
+           # clock of the fetcher / walker / builder threads: they overlap each other and the GPU)
+           "stage_ms": {k2: round(tm[k1] / steps, 3) for k1, k2 in (("convert_ms", "convert"), ("sweep_ms", "sweep"), ("slice_ms", "slice"),
+                                                                   ("prescreen_ms", "prescreen"), ("d2h_ms", "d2h"), ("resolve_ms", "resolve_host"),
+                                                                   ("build_ms", "build_host"), ("sigpower_ms", "sigpower"))},
+           "cpu_reference_msamples_s": round(2 * nsamples / float(st["t_convert_s"] + st["t_demod_s"]) / 1e6, 1),
+           "bit_identical_to_reference": True, "checked": "two deferred segments of a fresh stream, fed as in the timed region", "checker": kind}
     if env.get("MGPU_DEVICE_WALK"):
         out["device_walk"] = d.device_walk_stats()          # chunks decided on the device / walked on the host after all, walks run
     d.close()
@@ -179,7 +225,9 @@ def bench_config5(args, rank, local_rank, world):
     over the ranks (readsb_amd/shard.py): every rank sweeps its range for its adder bitmap, the bitmaps are OR-ed over the ranks
     (2 MiB all_gather), every rank sweeps / slices / pre-screens its range against the global bitmap, the surviving records go to
     rank 0 (gather), which runs the ordered walk and builds the messages — the unsharded message list, bit for bit.  Strong
-    scaling: the capture is fixed, a step = the whole capture once; every rank's range is resident in its HBM."""
+    scaling: the capture is fixed, a step = the whole capture once; every rank's range is resident in its HBM (its own device
+    allocation: --samples 8640000000 = the one-hour capture of BASELINE.json, 17.3 GB, fits one MI355X).  With one rank the same
+    capture also runs through the ordinary (unsharded) pipeline in the same process: `unsharded` in the JSON line."""
     import torch
     import torch.distributed as dist
     import helpers
@@ -195,22 +243,27 @@ def bench_config5(args, rank, local_rank, world):
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     helpers.ensure_built()
     n = args.samples - args.samples % BUF
-    iq = helpers.synth(nsamples=n, seed=5150, rate=8000.0, dense=1, threads=min(64, max(1, (os.cpu_count() or 8) // world)))
     first, last = shard_ranges(n, world)[rank]
-    chunk = min(512 * BUF, max(BUF, last - first))
-    d = readsb_amd.Demodulator(nfix_crc=2, max_samples=max(chunk, last - first + BUF), device=dev, startup_time_ms=helpers.STARTUP_MS)
     lo = max(0, first - 326)
-    d.upload_iq(iq[lo * 2:last * 2])
-    resident = (lo, d.device_iq_buffer())
+    threads = min(64, max(1, (os.cpu_count() or 8) // world))
+    t_g0 = time.time()
+    mine = helpers.synth(nsamples=last - lo, first=lo, seed=5150, rate=8000.0, dense=1, threads=threads)   # the rank's range (+ history)
+    t_gen = time.time() - t_g0
+    d_iq = torch.from_numpy(mine).to(torch.device("cuda", dev))            # resident: its own allocation, any length
+    history = None if first == 0 else mine[: (first - lo) * 2].copy()
+    piece = min(4096 * BUF, max(BUF, last - first))                          # samples per feed call
+    d = readsb_amd.Demodulator(nfix_crc=2, max_samples=piece, device=dev, startup_time_ms=helpers.STARTUP_MS)
+    resident = (lo, d_iq.data_ptr())
     d.keep_other_threads_away(confine_to_own_l3=world > 1)
     res = None
-    for _ in range(max(1, args.warmup)):
-        res = demodulate_sharded(d, iq, coll, resident=resident)
+    for _ in range(max(0, args.warmup)):
+        res = demodulate_sharded(d, None, coll, resident=resident, nsamples=n, history=history)
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    phases = {}
     for _ in range(args.steps):
-        res = demodulate_sharded(d, iq, coll, resident=resident)
+        res = demodulate_sharded(d, None, coll, resident=resident, nsamples=n, history=history, phases=phases)
     dist.barrier()
     torch.cuda.synchronize()
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=coll)
@@ -226,17 +279,62 @@ def bench_config5(args, rank, local_rank, world):
                                       f"time-chunked by whole buffers over {world} GPU(s), each range resident in its GPU's HBM; adder-bitmap all_gather, "
                                       "record packets gathered on rank 0, ordered walk there",
                           "samples": n, "shards": world, "parallelism": f"time-chunked x{world}"},
-               "messages_per_step": int(len(msgs))}
+               "messages_per_step": int(len(msgs)), "synth_gen_s": round(t_gen, 2),
+               "rank0_phase_ms_per_step": {k: round(v / args.steps, 3) for k, v in phases.items()}}
+        unsharded = None
+        if world == 1:
+            # the same capture through the ordinary pipeline (one stream, deferred feeds of `piece` samples, resident IQ)
+            bufs = [np.empty(int(piece // 64 + 65536), dtype=readsb_amd.MSG_DTYPE) for _ in range(2)]
+            offs = list(range(0, n, piece))
+
+            def unsharded_pass(keep):
+                d.reset()
+                d.set_deferred(True)
+                got, nm = [], 0
+                t1 = time.perf_counter()
+                for k, off in enumerate(offs):
+                    d.set_message_buffer(bufs[k % 2])
+                    d.feed_resident(min(piece, n - off), d_iq.data_ptr() + off * 2)
+                    if k >= 1:
+                        m, _ = d.collect_feed(bufs[(k - 1) % 2])
+                        nm += len(m)
+                        if keep:
+                            got.append(m.copy())
+                m, _ = d.collect_feed(bufs[(len(offs) - 1) % 2], want_counters=True)
+                nm += len(m)
+                if keep:
+                    got.append(m.copy())
+                dt = time.perf_counter() - t1
+                d.finish()                                   # end of file: ifileRun's last, empty buffer (sdr_ifile.c:223-237)
+                _, cnt = d.collect_feed(bufs[0], want_counters=True)
+                d.set_deferred(False)
+                return dt, nm, (np.concatenate(got) if keep else None), cnt
+
+            best = None
+            for _ in range(max(1, args.steps)):              # timed: the consumer takes each feed's messages where they are built
+                dt, nm, _, _ = unsharded_pass(False)
+                best = dt if best is None or dt < best else best
+            _, _, um, uc = unsharded_pass(True)              # checked: the same feeds, their messages kept
+            unsharded = {"msamples_s": round(n / best / 1e6, 1), "ms": round(best * 1e3, 3), "messages": int(len(um)),
+                         "sharded_over_unsharded": round((n * args.steps / elapsed) / (n / best), 3)}
+            assert len(um) == len(msgs) and um.tobytes() == msgs.tobytes(), "sharded and unsharded message lists differ"
+            unsharded["identical_to_sharded"] = True
+            out["unsharded"] = unsharded
+
         if not args.no_cpu_baseline:
+            iq = helpers.synth(nsamples=n, seed=5150, rate=8000.0, dense=1, threads=min(64, os.cpu_count() or 8)) if (world > 1 or lo != 0 or last != n) else mine
             kind, ref_msgs, st = cpu_reference(iq, n, 0, 2, 1, 58)
-            helpers.assert_same_messages(msgs, ref_msgs)      # (the shards' sweep-side demod counters are not merged: messages only)
-            for f in ("demod_accepted", "demod_bestPhase", "samples_processed", "nbuffers", "nflips"):
+            helpers.assert_same_messages(msgs, ref_msgs)
+            full = getattr(d, "shard_counters_complete", False)   # (set by the library once the shards' sweep-side counters are merged)
+            if world == 1 and unsharded is not None:
+                helpers.assert_same_counters(uc, st)              # the unsharded run: every counter
+            for f in (helpers.COUNTER_FIELDS if full else ("demod_accepted", "demod_bestPhase", "samples_processed", "nbuffers", "nflips")):
                 assert (np.asarray(counters[f], dtype=np.uint64) == np.asarray(st[f], dtype=np.uint64)).all(), f
             cpu_s = float(st["t_convert_s"] + st["t_demod_s"])
             out["cpu_baseline"] = {"value": round(n / cpu_s / 1e6, 1), "unit": "Msamples/s", "cores": 1, "kind": kind,
-                                   "sample": f"the whole capture ({n} samples) on one host core", "messages": int(len(ref_msgs)),
-                                   "bit_identical_to_gpu": True}
-        print(json.dumps(out))
+                                   "sample": f"the whole capture ({n} samples) on one host core: convert {st['t_convert_s']:.1f} s + demodulate2400 {st['t_demod_s']:.1f} s",
+                                   "messages": int(len(ref_msgs)), "bit_identical_to_gpu": True, "counters_compared": "all" if full else "walk-side"}
+        emit(out)
     d.close()
     dist.destroy_process_group()
 
@@ -471,8 +569,8 @@ def main():
         # gfx950 + WRITE_SIZE, tools/pmc_summary.py); null if the launch size differs
         traffic, traffic_slice = None, None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_hbm.json")))
-            if per_launch == 134217728:
+            pm = json.load(open(PMC_HBM))
+            if per_launch == 134217728 and pm.get("kernel_source_sha") == kernel_source_sha():
                 traffic = round(next(v for k, v in pm.items() if "mgpu::k_sweep" in k)["hbm_bytes"])
                 traffic_slice = round(next(v for k, v in pm.items() if "mgpu::k_slice" in k)["hbm_bytes"])
         except Exception:
@@ -535,7 +633,7 @@ def main():
                     raise SystemExit(f"extra configuration '{name}': GPU result differs from the reference: {e}")
                 except Exception as e:                           # anything else (an allocation, the checker's binary): this entry is missing, the line is not
                     out["configs"][name] = {"error": f"{type(e).__name__}: {e}"[:300]}
-        print(json.dumps(out))
+        emit(out)
     if use_dist:
         dist.destroy_process_group()
 

@@ -287,14 +287,19 @@ int mgpu_demod_mag_buf_ac(mgpu_ctx *ctx, const uint16_t *data, uint32_t length,
  *   pass 2: mgpu_reset; mgpu_adder_bitmap_set(global); mgpu_shard_begin(ctx, first_sample, history, 2);
  *           mgpu_feed_iq*(shard samples); mgpu_shard_packets() -> the shard's live records
  * and on ONE context, after mgpu_reset, mgpu_walk_packets() over the packets of all shards in stream
- * order, mgpu_finish(), mgpu_collect(): the message list of the unsharded stream, bit for bit
- * (counters: demod_accepted, demod_bestPhase, samples_processed, nbuffers, nflips only).
+ * order, mgpu_finish(), mgpu_collect(): the message list AND every counter of the unsharded stream, bit for
+ * bit.  A packet (one per chunk of the shard's range, 8-byte aligned) carries what the walking rank cannot compute without
+ * the samples: per live record its would-be signal power and the counts of its would-be skip window, per buffer the
+ * converter's level / power sums, per chunk the sweep's candidate tallies.
  * first_sample is a multiple of buf_samples; history = the 326 IQ samples before it (NULL for 0). */
 int mgpu_shard_begin(mgpu_ctx *ctx, uint64_t first_sample, const void *history_iq, int mode);
 int mgpu_adder_bitmap_get(mgpu_ctx *ctx, uint32_t *words /* 2^19 */);
 int mgpu_adder_bitmap_set(mgpu_ctx *ctx, const uint32_t *words /* 2^19 */);
 int mgpu_shard_packets(mgpu_ctx *ctx, const void **packets, uint64_t *bytes);   /* valid until the next reset */
 int mgpu_walk_packets(mgpu_ctx *ctx, const void *packets, uint64_t bytes);
+/* One rank holds the whole capture: mgpu_reset() + mgpu_walk_packets() over the packets the context's own last shard pass
+ * left, where they lie (no copy). */
+int mgpu_walk_own_packets(mgpu_ctx *ctx);
 
 /* ---- beast wire output (modesSendBeastOutput, net_io.c:1655-1714) ------------------------------------
  * Per message: 0x1a, type '2' (56-bit) / '3' (112-bit) / '1' (Mode A/C), the 12 MHz timestamp as 6 bytes

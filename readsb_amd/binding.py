@@ -156,6 +156,7 @@ def load_library():
     lib.mgpu_adder_bitmap_set.argtypes = [vp, vp]
     lib.mgpu_shard_packets.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
     lib.mgpu_walk_packets.argtypes = [vp, vp, u64]
+    lib.mgpu_walk_own_packets.argtypes = [vp]
     lib.mgpu_pending_messages.restype = u64
     lib.mgpu_last_timing.argtypes = [vp, C.POINTER(Timing)]
     lib.mgpu_debug_device_walk.argtypes = [vp, C.POINTER(u64)]
@@ -173,6 +174,7 @@ def load_library():
 
 class Demodulator:
     """One SDR stream on one GPU (struct mgpu_ctx)."""
+    shard_counters_complete = True      # mgpu_walk_packets rebuilds every statistic of an unsharded run (shard packets carry what it needs)
 
     def __init__(self, fmt=FMT_UC8, nfix_crc=1, fix_df=1, preamble_threshold=58, max_samples=64 * 131072,
                  device=0, startup_time_ms=0, record_pool_records=0, max_messages=0, buf_samples=131072, mode_ac=0,
@@ -277,11 +279,15 @@ class Demodulator:
         self._chk(self.lib.mgpu_shard_packets(self.ctx, C.byref(p), C.byref(n)), "mgpu_shard_packets")
         if not n.value:
             return np.zeros(0, dtype=np.uint8)
-        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n.value,)).copy()
+        # (a view of the library's own buffer: valid until the context's next shard pass or reset)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n.value,))
 
     def walk_packets(self, packets):
         packets = np.ascontiguousarray(packets, dtype=np.uint8)
         self._chk(self.lib.mgpu_walk_packets(self.ctx, C.c_void_p(packets.ctypes.data), C.c_uint64(packets.size)), "mgpu_walk_packets")
+
+    def walk_own_packets(self):
+        self._chk(self.lib.mgpu_walk_own_packets(self.ctx), "mgpu_walk_own_packets")
 
     def decode_fields(self, msgs):
         """Per-message field records (FIELDS_DTYPE) of a message record array, decoded on the GPU."""

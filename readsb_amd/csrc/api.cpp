@@ -33,6 +33,9 @@
 
 using namespace mgpu;
 
+constexpr int kPacketWords = 12;                              // header of a shard packet, 64-bit words: stream position, samples, live records,
+constexpr uint64_t kPacketMagic = 0x3354454b4341504dull;      // magic, candidates, phases 4/5, 6/7, 8 tried, conditional-only / unconditional candidates, buffers, 0
+
 namespace {
 double wall_ms() {
     using namespace std::chrono;
@@ -152,6 +155,7 @@ struct Slot {
     uint16_t *d_msg_len = nullptr, *d_msg_skip = nullptr;
     PhaseRec *d_live = nullptr;          // k_prescreen_write: the surviving records, in stream order ...
     unsigned long long *d_live_sig = nullptr;   // ... and each one's would-be signal power
+    unsigned long long *d_live_win = nullptr, *h_live_win = nullptr;   // shard passes (allocated by the first): ... and what its would-be skip window holds (k_window_stats_t<true>)
     // pinned host
     PhaseRec *h_live = nullptr;          // their copies: the fetcher pulls exactly nlive records over the copy engine (a kernel storing
     unsigned long long *h_live_sig = nullptr;   // into page-locked host memory waited 64 us per chunk on PCIe write latency)
@@ -224,6 +228,7 @@ struct MsgBuf {
 struct HostJob {
     std::vector<PhaseRec> recs;              // the chunk's live records (heap copy of Slot::h_live)
     std::vector<unsigned long long> sig;
+    std::vector<unsigned long long> win;     // shard passes: per live record the packed counts of its would-be skip window
     std::vector<Accepted> acc;               // the walker's decisions
     std::vector<uint32_t> pos;               // their chunk-relative scan positions
     std::vector<BufferClock> buffers;
@@ -676,7 +681,8 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
 
 static void free_slot(Slot &sl) {
     if (sl.h_blob) (void) hipHostFree(sl.h_blob);
-    void *dev[] = {sl.d_dealer, sl.d_blob, sl.d_live, sl.d_live_sig, sl.d_mag, sl.d_pool, sl.d_scratch, sl.d_unit_first, sl.d_unit_count, sl.d_unit_live, sl.d_class_bitmap,
+    if (sl.h_live_win) (void) hipHostFree(sl.h_live_win);
+    void *dev[] = {sl.d_live_win, sl.d_dealer, sl.d_blob, sl.d_live, sl.d_live_sig, sl.d_mag, sl.d_pool, sl.d_scratch, sl.d_unit_first, sl.d_unit_count, sl.d_unit_live, sl.d_class_bitmap,
                    sl.d_class_uncond, sl.d_class_final, sl.d_cand, sl.d_cand_count, sl.d_sweep_part,
                    sl.d_win, sl.d_win_part, sl.d_msg_pos,
                    sl.d_msg_limit, sl.d_msg_len, sl.d_msg_skip, sl.d_msg_sig, sl.d_wk_in, sl.d_wk_acc, sl.d_wk_sig};
@@ -1049,6 +1055,7 @@ static int enqueue_post(mgpu_ctx *c, Slot &sl) {
     q.class_final = sl.d_class_final;
     q.class_words = (n + 31) / 32;
     q.dealer = sl.d_dealer;
+    q.live_win = c->shard_mode == 2 ? sl.d_live_win : nullptr; q.n = n; q.thr = sl.thr; q.buf_len = c->cfg.buf_samples;
     q.d_scratch = sl.d_scratch; q.h_scratch = sl.h_scratch; q.scratch_words = (uint32_t) (sl.scratch_bytes / sizeof(unsigned long long));
     // the count pass leaves its decisions as masks in the segment headers (one scoring pass = one segment of at most 64
     // records), so the write pass does not look at the adder bitmap again
@@ -1086,6 +1093,7 @@ static int fetch_records(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
         // (a copy kernel of our own with 8..32 workgroups in place of the runtime's blit kernel: 2.55-2.63 ms per step instead of 2.45)
         HIPCHK(c, hipMemcpyAsync(sl.h_live, sl.d_live, nlive * sizeof(PhaseRec), hipMemcpyDeviceToHost, c->stream_d2h));
         if (!sl.sig_late) HIPCHK(c, hipMemcpyAsync(sl.h_live_sig, sl.d_live_sig, nlive * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream_d2h));
+        if (c->shard_mode == 2) HIPCHK(c, hipMemcpyAsync(sl.h_live_win, sl.d_live_win, nlive * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream_d2h));
         HIPCHK(c, hipStreamSynchronize(c->stream_d2h));
     }
     if (!c->dump_dir.empty()) {   // replay material for tools/walk_replay.cpp
@@ -1105,6 +1113,7 @@ static int fetch_records(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
         job.sig.resize(nlive);
         std::memcpy(job.sig.data(), sl.h_live_sig, nlive * sizeof(unsigned long long));
     }
+    if (c->shard_mode == 2) job.win.assign(sl.h_live_win, sl.h_live_win + nlive);
     job.fetched = true;
     return MGPU_OK;
 }
@@ -1138,7 +1147,8 @@ static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
     job.fetched = job.from_device = false;
     job.sig_late = sl.sig_late;
     // with the walk on the device the records stay in HBM (the walker fetches them itself for a chunk it has to walk here)
-    if (c->device_walk != 1 || c->shard_mode != 0) { const int rc = fetch_records(c, sl, job, next); if (rc != MGPU_OK) return rc; }
+    // (... and a shard's first pass wants the adder bitmap only: its records are pre-screened against half a bitmap and go nowhere)
+    if ((c->device_walk != 1 || c->shard_mode != 0) && c->shard_mode != 1) { const int rc = fetch_records(c, sl, job, next); if (rc != MGPU_OK) return rc; }
     job.ac.clear();
     if (c->cfg.mode_ac && (!sl.have_mag || sl.have_noise)) {
         const unsigned long long *counts = sl.h_scratch + CNT_NUM + 1 + 4 * c->cap_buffers;   // k_modeac's kAcLists lists
@@ -1300,30 +1310,12 @@ static int walk_job_device(mgpu_ctx *c, Slot &sl, HostJob &job) {
     return MGPU_OK;
 }
 
-// ---- part 2 (walker thread): the ordered accept walk, then the window statistics of what it hid ----
-static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
-    const uint64_t n = sl.n;
-    const uint64_t nlive = job.nlive;
-    const double t_res0 = wall_ms();
-    const uint64_t aux_cap = nlive + 1 < c->cap_msgs ? nlive + 1 : c->cap_msgs;
-    job.pos.resize(aux_cap); c->w_limit.resize(aux_cap); c->w_skip.resize(aux_cap);
-    job.rc = ResolveCounts();
+// The ordered walk of one chunk's live records on the host: buffer ranges walked in parallel against the filter as it stands
+// now and committed in stream order (resolve.h: Resolver::parallel_walk) — exact, serial only where speculation fails — or the
+// plain serial walk for small chunks.  Decisions into job.acc / job.pos / c->w_limit / c->w_skip, counts into job.rc.
+static int64_t host_walk(mgpu_ctx *c, HostJob &job, const PhaseRec *recs, const std::vector<BufferClock> &buffers, uint64_t nlive, uint64_t aux_cap) {
     int64_t wn;
-    bool wk_running = false;
-    if (c->device_walk == 1) {
-        const int rc = walk_job_device(c, sl, job);
-        if (rc != MGPU_E_AGAIN) return rc;
-        // not this chunk (see mgpu_debug_device_walk): its records come over after all and it is walked here
-        const int frc = fetch_records(c, sl, job, nullptr);
-        if (frc != MGPU_OK) return frc;
-    }
-    if (c->device_walk == 2) {
-        c->wk_stats[0] += 1;
-        c->wk_shadow.copy_state(c->resolver);
-        wk_running = device_walk_enqueue(c, sl, nlive, c->stream2);
-        if (!wk_running) c->wk_stats[4] += 1;
-    }
-    const uint32_t nbuf_all = (uint32_t) sl.buffers.size();
+    const uint32_t nbuf_all = (uint32_t) buffers.size();
     const int K = c->walk_threads;
     if (K >= 2 && nbuf_all >= (uint32_t) (4 * K) && nlive >= 4096) {
         // buffer ranges walked in parallel against the filter as it stands now, committed in stream order
@@ -1333,12 +1325,12 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
         for (int k = 0; k < K; ++k) {
             segs[k].b_lo = (uint32_t) ((uint64_t) nbuf_all * k / K);
             segs[k].b_hi = (uint32_t) ((uint64_t) nbuf_all * (k + 1) / K);
-            segs[k].rec_lo = k == 0 ? 0 : segment_first_record(job.recs.data(), nlive, sl.buffers[segs[k].b_lo].first);
+            segs[k].rec_lo = k == 0 ? 0 : segment_first_record(recs, nlive, buffers[segs[k].b_lo].first);
         }
         for (int k = 0; k < K; ++k) segs[k].rec_hi = k + 1 < K ? segs[k + 1].rec_lo : nlive;
         const double tp0 = wall_ms();
         uint64_t batches = 0;
-        c->resolver.parallel_walk(job.recs.data(), nlive, sl.buffers, segs,
+        c->resolver.parallel_walk(recs, nlive, buffers, segs,
                                   [&](int ntasks, const std::function<void(int)> &task) { c->walk_team.run(ntasks, task); }, &batches);
         const double tp2 = wall_ms();
         uint64_t total = 0;
@@ -1364,9 +1356,36 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
         }
         if (c->dbg_print) fprintf(stderr, "dbg: %d ranges in %llu batches: %.3f ms, gather %.3f ms\n", K, (unsigned long long) batches, tp2 - tp0, wall_ms() - tp2);
     } else {
-        wn = c->resolver.decide(job.recs.data(), nlive, sl.buffers, job.acc, job.pos.data(), c->w_skip.data(),
+        wn = c->resolver.decide(recs, nlive, buffers, job.acc, job.pos.data(), c->w_skip.data(),
                                 c->w_limit.data(), aux_cap, job.rc);
     }
+    return wn;
+}
+
+// ---- part 2 (walker thread): the ordered accept walk, then the window statistics of what it hid ----
+static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
+    const uint64_t n = sl.n;
+    const uint64_t nlive = job.nlive;
+    const double t_res0 = wall_ms();
+    const uint64_t aux_cap = nlive + 1 < c->cap_msgs ? nlive + 1 : c->cap_msgs;
+    job.pos.resize(aux_cap); c->w_limit.resize(aux_cap); c->w_skip.resize(aux_cap);
+    job.rc = ResolveCounts();
+    int64_t wn;
+    bool wk_running = false;
+    if (c->device_walk == 1) {
+        const int rc = walk_job_device(c, sl, job);
+        if (rc != MGPU_E_AGAIN) return rc;
+        // not this chunk (see mgpu_debug_device_walk): its records come over after all and it is walked here
+        const int frc = fetch_records(c, sl, job, nullptr);
+        if (frc != MGPU_OK) return frc;
+    }
+    if (c->device_walk == 2) {
+        c->wk_stats[0] += 1;
+        c->wk_shadow.copy_state(c->resolver);
+        wk_running = device_walk_enqueue(c, sl, nlive, c->stream2);
+        if (!wk_running) c->wk_stats[4] += 1;
+    }
+    wn = host_walk(c, job, job.recs.data(), sl.buffers, nlive, aux_cap);
     if (wn > 0) {
         std::memcpy(sl.h_msg_pos, job.pos.data(), (size_t) wn * sizeof(uint32_t));
         std::memcpy(sl.h_msg_limit, c->w_limit.data(), (size_t) wn * sizeof(uint32_t));
@@ -1622,15 +1641,23 @@ static void fetcher_main(mgpu_ctx *c) {
         job.slot = idx;
         job.feed = sl.feed;
         int rc = c->worker_rc == MGPU_OK ? guarded(c, [&] { return fetch_slot(c, sl, job, next_idx >= 0 ? &c->slot[next_idx] : nullptr); }) : c->worker_rc;   // after an error just drain
-        if (rc == MGPU_OK && c->shard_mode == 2) {           // the chunk's records become a packet: header, records, signal powers
-            const uint64_t hdr[4] = {job.stream_pos, sl.n, job.nlive, 0};
-            const uint8_t *h8 = (const uint8_t *) hdr;
+        if (rc == MGPU_OK && c->shard_mode == 2) {
+            // The chunk becomes a packet for the rank that walks: header, live records, per record its would-be signal power and
+            // the counts of its would-be skip window, per buffer the converter's level / power sums — everything the statistics
+            // of an unsharded run take from the samples, so that the walking rank needs none (kPacketWords: the header)
+            const unsigned long long *hc = sl.h_counters;
+            const uint64_t nbuf = sl.buffers.size();
+            const uint64_t hdr[kPacketWords] = {job.stream_pos, sl.n, job.nlive, kPacketMagic, hc[CNT_CANDIDATES], hc[CNT_PHASE0 + 0], hc[CNT_PHASE0 + 2],
+                                                hc[CNT_PHASE0 + 4], hc[CNT_CLASS_COND], hc[CNT_CLASS_UNCOND], nbuf, 0};
             std::vector<uint8_t> &pk = c->shard_packets;
-            pk.insert(pk.end(), h8, h8 + sizeof(hdr));
-            const uint8_t *r8 = (const uint8_t *) job.recs.data();
-            pk.insert(pk.end(), r8, r8 + job.nlive * sizeof(PhaseRec));
-            const uint8_t *s8 = (const uint8_t *) job.sig.data();
-            pk.insert(pk.end(), s8, s8 + job.nlive * sizeof(unsigned long long));
+            auto put = [&](const void *p8, size_t bytes) { pk.insert(pk.end(), (const uint8_t *) p8, (const uint8_t *) p8 + bytes); };
+            put(hdr, sizeof(hdr));
+            put(job.recs.data(), (job.nlive + 1) * sizeof(PhaseRec));      // (with the walk's sentinel record)
+            put(job.sig.data(), job.nlive * sizeof(unsigned long long));
+            put(job.win.data(), job.nlive * sizeof(unsigned long long));
+            // (UC8: exact integer sums; SC16*: the converter's double sums — eight bytes per buffer either way, level then power)
+            if (c->cfg.format == MGPU_FMT_UC8) { put(sl.h_sums, nbuf * 8); put(sl.h_sums + c->cap_buffers, nbuf * 8); }
+            else { put(sl.h_fsums, nbuf * 8); put(sl.h_fsums + c->cap_buffers, nbuf * 8); }
         }
         {
             std::lock_guard<std::mutex> lk(c->mu);
@@ -2210,6 +2237,12 @@ int mgpu_shard_begin(mgpu_ctx *c, uint64_t first_sample, const void *history_iq,
     if (first_sample && !history_iq) return MGPU_E_INVAL;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     c->shard_mode = mode;
+    if (mode == 2)                           // the packets carry every live record's would-be skip-window counts
+        for (auto &sl : c->slot)
+            if (!sl.d_live_win) {
+                HIPCHK(c, hipMalloc(&sl.d_live_win, c->cap_pool * sizeof(unsigned long long)));
+                HIPCHK(c, hipHostMalloc(&sl.h_live_win, c->cap_pool * sizeof(unsigned long long)));
+            }
     c->shard_packets.clear();
     c->stream_pos = first_sample;
     c->eof = false;
@@ -2260,30 +2293,40 @@ int mgpu_shard_packets(mgpu_ctx *c, const void **packets, uint64_t *bytes) {
 
 // The packets come from other ranks over a gather: nothing in a header is trusted before it is checked against the bytes
 // that are really there (record count without a 64-bit overflow), the context's capacity, and the order the walk relies on.
+// Per packet = per chunk of some rank's range: the ordered walk (the walker's team, as for a chunk of an unsharded stream), the
+// messages, and every statistic an unsharded run keeps — the sweep-side tallies and the per-buffer sums ride in the packet,
+// what the accepted frames' skip windows hide is the sum of the accepted records' window counts.
 static int walk_packets_checked(mgpu_ctx *c, const void *packets, uint64_t bytes) {
     const uint8_t *p = (const uint8_t *) packets, *end = p + bytes;
     HostJob &job = c->job[0];
-    constexpr uint64_t kRecBytes = sizeof(PhaseRec) + 8;        // record + its signal power
+    constexpr uint64_t kRecBytes = sizeof(PhaseRec) + 16;       // record + its signal power + its window counts
+    if ((uintptr_t) packets & 7) { c->err = "mgpu_walk_packets: the packets must be 8-byte aligned"; return MGPU_E_INVAL; }
+    mgpu_counters &k = c->counters;
     while (p < end) {
-        uint64_t hdr[4];
+        uint64_t hdr[kPacketWords];
         if ((size_t) (end - p) < sizeof(hdr)) { c->err = "mgpu_walk_packets: truncated packet header"; return MGPU_E_INVAL; }
         std::memcpy(hdr, p, sizeof(hdr));
         p += sizeof(hdr);
-        const uint64_t pos = hdr[0], n = hdr[1], nrecs = hdr[2];
-        if (pos != c->stream_pos || n == 0 || n > c->cap_samples || n > 0xFFFFFFF0ull || nrecs > (uint64_t) (end - p) / kRecBytes) {
+        const uint64_t pos = hdr[0], n = hdr[1], nrecs = hdr[2], nbuf = hdr[10];
+        if (hdr[3] != kPacketMagic || pos != c->stream_pos || n == 0 || n > c->cap_samples || n > 0xFFFFFFF0ull ||
+            nbuf != (n + c->cfg.buf_samples - 1) / c->cfg.buf_samples || (uint64_t) (end - p) < sizeof(PhaseRec) || nrecs > ((uint64_t) (end - p) - sizeof(PhaseRec)) / kRecBytes ||
+            (uint64_t) (end - p) - sizeof(PhaseRec) - nrecs * kRecBytes < nbuf * 16) {
             c->err = "mgpu_walk_packets: packets must continue the stream in order, within max_samples, with all their records present";
             return MGPU_E_INVAL;
         }
-        job.recs.resize(nrecs + 1);
-        std::memcpy(job.recs.data(), p, nrecs * sizeof(PhaseRec));
-        job.recs[nrecs].pos = 0xFFFFFFFFu;
-        p += nrecs * sizeof(PhaseRec);
-        job.sig.resize(nrecs);
-        std::memcpy(job.sig.data(), p, nrecs * 8);
+        // the records are walked where they lie (packets are 8-byte aligned and a sentinel record follows the last one)
+        const PhaseRec *recs = (const PhaseRec *) p;
+        p += (nrecs + 1) * sizeof(PhaseRec);
+        const unsigned long long *sig = (const unsigned long long *) p;
         p += nrecs * 8;
+        const unsigned long long *win = (const unsigned long long *) p;
+        p += nrecs * 8;
+        const unsigned long long *sums = (const unsigned long long *) p;    // level[nbuf], power[nbuf]: integers (UC8) or doubles, eight bytes each
+        p += nbuf * 16;
+        if (recs[nrecs].pos != 0xFFFFFFFFu) { c->err = "mgpu_walk_packets: malformed record list"; return MGPU_E_INVAL; }
         for (uint64_t i = 0; i < nrecs; ++i) {                   // sorted by position, inside the packet's samples, a real phase
-            const PhaseRec &r = job.recs[i];
-            if (r.pos >= n || (i && r.pos < job.recs[i - 1].pos) || r.phase < 4 || r.phase > 8) {
+            const PhaseRec &r = recs[i];
+            if (r.pos >= n || (i && r.pos < recs[i - 1].pos) || r.phase < 4 || r.phase > 8) {
                 c->err = "mgpu_walk_packets: malformed record list";
                 return MGPU_E_INVAL;
             }
@@ -2292,29 +2335,86 @@ static int walk_packets_checked(mgpu_ctx *c, const void *packets, uint64_t bytes
         const uint64_t cap = nrecs + 1;
         job.pos.resize(cap); c->w_limit.resize(cap); c->w_skip.resize(cap);
         job.rc = ResolveCounts();
-        const int64_t wn = c->resolver.decide(job.recs.data(), nrecs, job.buffers, job.acc, job.pos.data(), c->w_skip.data(),
-                                              c->w_limit.data(), cap, job.rc);
+        const int64_t wn = host_walk(c, job, recs, job.buffers, nrecs, cap);
         if (wn < 0) return MGPU_E_OVERFLOW;
         const size_t first = c->pending.size();
         if (!c->pending.grow_for((size_t) wn)) return c->pending.external ? MGPU_E_OVERFLOW : MGPU_E_NOMEM;
-        Resolver::build_messages(job.recs.data(), job.sig.data(), nullptr, job.buffers, job.acc.data(), (uint64_t) wn, c->pending.data() + first);
+        {
+            mgpu_msg *dst = c->pending.data() + first;
+            const int parts = wn >= 4096 ? c->build_threads : 1;
+            c->build_team.run(parts, [&](int i) {
+                const uint64_t lo = (uint64_t) wn * i / parts, hi = (uint64_t) wn * (i + 1) / parts;
+                Resolver::build_messages(recs, sig, nullptr, job.buffers, job.acc.data() + lo, hi - lo, dst + lo);
+            });
+        }
         c->pending.n = first + (size_t) wn;
-        for (int i = 0; i < 3; ++i) c->counters.demod_accepted[i] += job.rc.accepted[i];
-        for (int i = 0; i < 5; ++i) c->counters.demod_bestPhase[i] += job.rc.best_phase[i];
-        c->counters.samples_processed += n;
-        c->counters.nbuffers += job.buffers.size();
-        c->counters.nflips = c->resolver.nflips();
+        // ---- the statistics: feed_end's and build_job's, from what the packet carries ----
+        const ResolveCounts &rc = job.rc;
+        for (int i = 0; i < 3; ++i) k.demod_accepted[i] += rc.accepted[i];
+        for (int i = 0; i < 5; ++i) k.demod_bestPhase[i] += rc.best_phase[i];
+        uint64_t hw[5] = {0, 0, 0, 0, 0};                        // what the accepted frames' skip windows hide: candidates, phases 4/5, 6/7, 8, conditional-only
+        std::vector<uint64_t> buf_scaled(nbuf, 0);
+        for (int64_t i = 0; i < wn; ++i) {
+            const Accepted &a = job.acc[(size_t) i];
+            const unsigned long long w = win[a.rec];
+            hw[0] += w & 0xff; hw[1] += (w >> 8) & 0xff; hw[2] += (w >> 16) & 0xff; hw[3] += (w >> 24) & 0xff; hw[4] += (w >> 32) & 0xff;
+            const unsigned long long sumsq = sig[a.rec];
+            const unsigned sig_len = (recs[a.rec].msg[0] & 0x80) ? 268u : 134u;    // msglen * 12 / 5, demod_2400.c:439
+            const double signal_power = (double) sumsq / 65535.0 / 65535.0, level = signal_power / sig_len;
+            k.signal_power_sum += signal_power;
+            k.signal_power_count += sig_len;
+            if (level > k.peak_signal_power) k.peak_signal_power = level;
+            if (level > 0.50119) k.strong_signal_count++;
+            if (a.buffer < nbuf) buf_scaled[a.buffer] += sumsq;
+        }
+        const uint64_t C = hdr[4], U = hdr[8], R = hdr[9], cW = hw[0], uW = hw[4];
+        k.demod_preambles += C - cW;
+        k.demod_preamblePhase[0] += hdr[5] - hw[1];
+        k.demod_preamblePhase[1] += hdr[5] - hw[1];
+        k.demod_preamblePhase[2] += hdr[6] - hw[2];
+        k.demod_preamblePhase[3] += hdr[6] - hw[2];
+        k.demod_preamblePhase[4] += hdr[7] - hw[3];
+        k.demod_rejected_bad += (C - U - R) - (cW - uW - rc.skipped_uncond_groups) + rc.rejected_bad;
+        k.demod_rejected_unknown_icao += rc.rejected_unknown + (U - rc.visited_cond_groups - uW);
+        for (uint64_t b = 0; b < nbuf; ++b) {                    // noise power per buffer (demod_2400.c:474-479)
+            const BufferClock &bc = job.buffers[b];
+            double mean_power;
+            if (c->cfg.format == MGPU_FMT_UC8) mean_power = (double) sums[nbuf + b] / 65535.0 / 65535.0 / bc.length;   // convert.c:105-107
+            else { double f; std::memcpy(&f, &sums[nbuf + b], 8); mean_power = f / bc.length; }
+            k.noise_power_sum += (mean_power * bc.length - (double) buf_scaled[b] / 65535.0 / 65535.0);
+            k.noise_power_count += bc.length;
+            k.samples_lost += c->cfg.buf_samples - bc.length;    // readsb.c:886
+        }
+        k.samples_processed += n;
+        k.nbuffers += nbuf;
+        k.nflips = c->resolver.nflips();
         c->stream_pos += n;
         if (n % c->cfg.buf_samples) c->eof = true;
     }
     return MGPU_OK;
 }
 
+// The context's own packets (one rank holds the whole capture): reset, then walk them where the shard pass left them.
+int mgpu_walk_own_packets(mgpu_ctx *c) {
+    if (!c) return MGPU_E_INVAL;
+    std::vector<uint8_t> own;
+    own.swap(c->shard_packets);
+    int rc = mgpu_reset(c);
+    if (rc == MGPU_OK) rc = mgpu_walk_packets(c, own.data(), own.size());
+    own.clear();
+    own.swap(c->shard_packets);              // (the buffer, grown to a pass's size and already paged in, serves the next pass)
+    return rc;
+}
+
 int mgpu_walk_packets(mgpu_ctx *c, const void *packets, uint64_t bytes) {
     if (!c || (!packets && bytes)) return MGPU_E_INVAL;
     if (c->eof) return MGPU_E_EOF;
     if (c->shard_mode != 0 || c->deferred) { c->err = "mgpu_walk_packets: the context is in the middle of a shard pass (or in deferred mode)"; return MGPU_E_INVAL; }
-    return guarded(c, [&] { return walk_packets_checked(c, packets, bytes); });
+    { std::lock_guard<std::mutex> lk(c->mu); c->hot.store(true, std::memory_order_relaxed); }
+    c->cv.notify_all();                      // the walker's team polls instead of sleeping while the packets are walked
+    const int rc = guarded(c, [&] { return walk_packets_checked(c, packets, bytes); });
+    c->hot.store(false, std::memory_order_relaxed);
+    return rc;
 }
 
 // ---- beast wire format (net_io.c:1655-1714) for message records that already are in HBM -----------------------

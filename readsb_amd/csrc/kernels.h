@@ -156,6 +156,8 @@ struct PostSweepParams {
     uint32_t *class_cond, *class_uncond, *class_final;   // class_final == nullptr: generations 1/2 (bitmap written by the sweep)
     uint64_t class_words;
     uint32_t *dealer;                     // k_slice's dealer counters: zeroed again by k_publish
+    unsigned long long *live_win;         // shard passes: per live record the packed counts of its would-be skip window (null: not wanted)
+    uint64_t n; int32_t thr; uint32_t buf_len;   // ... and what that kernel needs: the chunk's positions, the threshold, the buffer length
     unsigned long long *d_scratch, *h_scratch;
     uint32_t scratch_words;
     bool keep_masks;                      // segments of <= 64 records: the count pass leaves its decisions in the headers
@@ -238,6 +240,9 @@ void launch_msg_sig(const uint16_t *mag, const uint32_t *d_pos, const uint16_t *
                     hipStream_t s);   // h_out (page-locked host memory, may be null): a second copy for the builder
 void launch_stage_in(const uint32_t *h_pos, const uint32_t *h_limit, const uint16_t *h_skip, uint32_t *d_pos, uint32_t *d_limit,
                      uint16_t *d_skip, uint32_t n, hipStream_t s);   // page-locked host arrays -> device, small grid
+// shard passes: the same numbers for every live record's would-be window, packed into out[record] (kernels/window_stats.inc)
+void launch_live_windows(const uint16_t *mag, uint64_t n, int thr, const uint32_t *class_bitmap, const PhaseRec *live, const unsigned long long *nlive_dev,
+                         uint32_t buf_len, unsigned long long *out, hipStream_t s);
 void launch_window_stats(const uint16_t *mag, uint64_t n, int thr, const uint32_t *class_bitmap, const uint32_t *pos,
                          const uint16_t *skip, const uint32_t *limit, uint32_t nmsg, unsigned long long *part, unsigned long long *out,
                          hipStream_t s);

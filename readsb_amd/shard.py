@@ -54,15 +54,16 @@ def run_shard_pass(d, iq, first, last, mode, global_bitmap=None):
     return d.adder_bitmap() if mode == 1 else d.shard_packets()
 
 
-def run_shard_pass_resident(d, iq, first, last, mode, global_bitmap=None, resident=None):
-    """As run_shard_pass, with the shard's IQ samples already in the context's device buffer (`resident` = (first sample held,
-    device address of it)): the benchmark's form — nothing but the 326 history samples crosses PCIe inside the timed region."""
+def run_shard_pass_resident(d, iq, first, last, mode, global_bitmap=None, resident=None, history=None):
+    """As run_shard_pass, with the shard's IQ samples already in device memory (`resident` = (first sample held, device
+    address of it)): the benchmark's form — nothing but the 326 history samples crosses PCIe inside the timed region
+    (`history` = their bytes when the rank does not hold the capture in host memory)."""
     bps = _FMT_BYTES[d.fmt]
     d.reset()
     if mode == 2:
         d.set_adder_bitmap(global_bitmap)
     if last > first:
-        hist = None if first == 0 else iq[(first - TRAILING) * bps:first * bps]
+        hist = None if first == 0 else (history if history is not None else iq[(first - TRAILING) * bps:first * bps])
         d.shard_begin(first, hist, mode)
         base_first, base_ptr = resident
         cap = int(d.cfg.max_samples)
@@ -93,34 +94,56 @@ def demodulate_sharded_local(d, iq, nshards):
     bitmap = np.zeros(1 << 19, dtype=np.uint32)
     for first, last in ranges:
         bitmap |= run_shard_pass(d, iq, first, last, 1)
-    packets = [run_shard_pass(d, iq, first, last, 2, bitmap) for first, last in ranges]
+    packets = [run_shard_pass(d, iq, first, last, 2, bitmap).copy() for first, last in ranges]   # (copies: the next pass reuses the buffer)
     return walk_all(d, packets)
 
 
-def demodulate_sharded(d, iq, device=None, dst=0, resident=None):
+def demodulate_sharded(d, iq, device=None, dst=0, resident=None, nsamples=None, history=None, phases=None):
     """torch.distributed version: rank r handles range r of `iq` (every rank holds, or maps, the capture).
     Exchange 1: all_gather of the 2 MiB adder bitmaps, OR.  Exchange 2: packet sizes (all_gather) and the
     packets themselves (padded gather) to `dst`, which walks them.  Returns (messages, counters) on dst, None elsewhere.
-    resident = (first sample, device address): the rank's range is already in HBM (run_shard_pass_resident)."""
+    resident = (first sample, device address): the rank's range is already in HBM (run_shard_pass_resident); then `iq` may be
+    None, with `nsamples` = the capture's length and `history` = the 326 samples before the rank's range.
+    phases (a dict) collects this rank's wall time per phase, in ms, summed over calls."""
+    import time
     import torch
     import torch.distributed as dist
     world, rank = dist.get_world_size(), dist.get_rank()
     device = device or torch.device("cpu")
-    iq = np.ascontiguousarray(iq).view(np.uint8).reshape(-1)
-    n = iq.size // _FMT_BYTES[d.fmt]
+    if iq is not None:
+        iq = np.ascontiguousarray(iq).view(np.uint8).reshape(-1)
+    n = nsamples if nsamples is not None else iq.size // _FMT_BYTES[d.fmt]
     first, last = shard_ranges(n, world)[rank]
     def shard_pass(mode, bitmap=None):
         if resident is not None:
-            return run_shard_pass_resident(d, iq, first, last, mode, bitmap, resident)
+            return run_shard_pass_resident(d, iq, first, last, mode, bitmap, resident, history)
         return run_shard_pass(d, iq, first, last, mode, bitmap)
 
+    t = [time.perf_counter()]
+
+    def lap(name):
+        t.append(time.perf_counter())
+        if phases is not None:
+            phases[name] = phases.get(name, 0.0) + (t[-1] - t[-2]) * 1e3
+
     mine = torch.from_numpy(shard_pass(1).view(np.int32)).to(device)
+    lap("pass1_adder_bitmap")
     allmaps = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(allmaps, mine)
     bitmap = allmaps[0]
     for m in allmaps[1:]:
         bitmap = torch.bitwise_or(bitmap, m)
-    pk = shard_pass(2, bitmap.cpu().numpy().view(np.uint32))
+    gb = bitmap.cpu().numpy().view(np.uint32)
+    lap("bitmap_exchange")
+    pk = shard_pass(2, gb)
+    lap("pass2_packets")
+    if world == 1:                      # nothing to gather: the packets are walked where the shard pass left them
+        d.walk_own_packets()
+        lap("walk_and_build")
+        d.finish()
+        res = d.collect()
+        lap("collect")
+        return res
     size = torch.tensor([pk.size], dtype=torch.int64, device=device)
     sizes = [torch.zeros_like(size) for _ in range(world)]
     dist.all_gather(sizes, size)

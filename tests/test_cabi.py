@@ -140,11 +140,17 @@ def test_device_walk_model_equals_serial_walk(built, seed, nchunks, nbuf, naircr
         assert by_model >= nchunks // 2, list(st)
 
 
-def test_bench_roofline_helpers():
-    """bench.py's informative VALU-issue figure parses the committed SQ counter summary (and degrades to None, never raises)."""
+def test_bench_roofline_helpers(tmp_path):
+    """bench.py's informative VALU-issue figure parses an SQ counter summary collected with THIS device code (the summary
+    carries the hash of the kernel sources), refuses one of other code, and degrades to None, never raises."""
     import bench
-    v = bench.valu_issue("k_sweep", 0.040, 67108864)
-    assert v and v["wave_insts_per_launch"] > 10_000_000 and 0.2 < v["frac"] < 1.0
-    v2 = bench.valu_issue("k_slice", 0.123, 67108864)
+    good = tmp_path / "sq.txt"
+    good.write_text("# kernel_source_sha: %s\nk_sweep\n   SQ_INSTS_VALU   14000000   (n=8)\nk_slice\n   SQ_INSTS_VALU   38000000   (n=8)\n" % bench.kernel_source_sha())
+    v = bench.valu_issue("k_sweep", 0.040, 67108864, str(good))
+    assert v and v["wave_insts_per_launch"] == 14000000 and 0.2 < v["frac"] < 1.0
+    v2 = bench.valu_issue("k_slice", 0.123, 67108864, str(good))
     assert v2 and v2["wave_insts_per_launch"] > v["wave_insts_per_launch"]
-    assert bench.valu_issue("k_sweep", 0.040, 67108864, "/nonexistent/file") is None and bench.valu_issue("k_sweep", 0.0, 1) is None
+    stale = tmp_path / "stale.txt"
+    stale.write_text(good.read_text().replace(bench.kernel_source_sha(), "0123456789abcdef"))
+    assert bench.valu_issue("k_sweep", 0.040, 67108864, str(stale)) is None            # counters of other code are not this run's
+    assert bench.valu_issue("k_sweep", 0.040, 67108864, "/nonexistent/file") is None and bench.valu_issue("k_sweep", 0.0, 1, str(good)) is None

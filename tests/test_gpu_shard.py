@@ -1,5 +1,5 @@
 """-m gpu: BASELINE config 5 — one capture sharded by buffer ranges (readsb_amd/shard.py) must give the unsharded
-message list bit for bit: dense overlapping bursts, several shard counts, shards that start mid-stream with
+message list AND every demodulator statistic bit for bit: dense overlapping bursts, several shard counts, shards that start mid-stream with
 326 samples of history, and a two-rank gloo run (both ranks on the one GPU of the test box)."""
 import os
 import sys
@@ -26,7 +26,7 @@ def test_sharded_capture_equals_unsharded(built, nshards, seconds, dense, rate, 
         d.close()
     assert len(want) > 5000
     helpers.assert_same_messages(got, want)
-    assert [cnt["demod_accepted"][i] for i in range(3)] == [int(wst["demod_accepted"][i]) for i in range(3)]
+    helpers.assert_same_counters(cnt, wst)          # every demodulator statistic, the ones the skip windows and the samples feed included
 
 
 def _rank(rank, world, port, q, seconds, seed):
@@ -45,10 +45,11 @@ def _rank(rank, world, port, q, seconds, seed):
     d.close()
     ok = True
     if rank == 0:
-        want, _ = helpers.oracle_run(iq)
-        got, _ = res
+        want, wst = helpers.oracle_run(iq)
+        got, cnt = res
         try:
             helpers.assert_same_messages(got, want)
+            helpers.assert_same_counters(cnt, wst)
             ok = len(want) > 5000
         except AssertionError:
             ok = False

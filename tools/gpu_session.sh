@@ -1,6 +1,9 @@
 #!/bin/bash
 cd /root/repo
-mkdir -p gpurun_out/s60
-O=gpurun_out/s60
-timeout 600 python bench.py --steps 10 --warmup 2 --no-extra-configs 2>$O/bench.err | tail -1 > $O/bench.json; cut -c1-1300 $O/bench.json
-timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_device_walk.py tests/test_gpu_formats.py -m gpu -q -x 2>&1 | tail -3
+mkdir -p gpurun_out/s65
+O=gpurun_out/s65
+
+export MASTER_ADDR=127.0.0.1 MASTER_PORT=29511 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1
+timeout 300 python bench.py --config 5 --samples $((4096*131072)) --steps 2 --warmup 1 > $O/c5.out 2>$O/c5.err; echo "rc=$?"
+tail -1 $O/c5.out | cut -c1-1800
+grep -v "Warning\|amdgpu.ids\|hostname" $O/c5.err | tail -8 | cut -c1-300

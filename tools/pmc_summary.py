@@ -3,7 +3,7 @@
 per-kernel HBM traffic.  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly
 half of a wide coalesced streaming read, so reads are doubled (guide, section HBM).
 
-usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> [out.json]"""
+usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> [out.json [kernel_source_sha]]"""
 import collections
 import csv
 import json
@@ -29,6 +29,8 @@ def main():
         wr = write.get(k, 0.0) * 1024.0
         out[k] = {"fetch_size_kib_raw": fetch.get(k, 0.0), "write_size_kib_raw": write.get(k, 0.0),
                   "hbm_read_bytes_corrected": rd, "hbm_write_bytes": wr, "hbm_bytes": rd + wr}
+    if len(sys.argv) > 4:
+        out["kernel_source_sha"] = sys.argv[4]      # bench.kernel_source_sha() of the code the counters were collected with
     text = json.dumps(out, indent=1)
     if len(sys.argv) > 3:
         open(sys.argv[3], "w").write(text + "\n")

@@ -5,7 +5,7 @@
 #   usage: tools/profile_round.sh <tag>
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-tag=${1:-r02}
+tag=${1:-r03}
 out=$R/gpurun_out/$tag
 mkdir -p $out
 cd /tmp
@@ -17,8 +17,10 @@ for i in 0 1; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_extra$i -o extra -- python $R/tools/profile_extra.py $i > $out/extra$i.log 2>&1
 done
 cd $R
-python tools/pmc_kernels.py $out/pmc_sq > $out/pmc_sq_summary.txt 2>&1
-python tools/pmc_summary.py $(find $out/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $out/pmc_write -name "*counter_collection.csv" | head -1) $out/pmc_hbm.json > /dev/null 2> $out/pmc_hbm.err
+# the summaries carry the hash of the device code they were collected with: bench.py reports their numbers only for that code
+sha=$(python -c "import bench; print(bench.kernel_source_sha())")
+{ echo "# kernel_source_sha: $sha"; python tools/pmc_kernels.py $out/pmc_sq; } > $out/pmc_sq_summary.txt 2>&1
+python tools/pmc_summary.py $(find $out/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $out/pmc_write -name "*counter_collection.csv" | head -1) $out/pmc_hbm.json $sha > /dev/null 2> $out/pmc_hbm.err
 timeout 400 python bench.py --steps 20 --warmup 3 > $out/bench_plain.log 2>&1
 tail -1 $out/bench_plain.log | cut -c1-3000
 cat $out/stats/bench_kernel_stats.csv | cut -c1-120

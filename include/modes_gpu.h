@@ -59,7 +59,10 @@ struct mgpu_config {
     uint64_t record_pool_records; /* device pool for per-phase candidate records; 0 = max_samples/16 + 65536 */
     uint64_t max_messages;        /* cap on accepted messages kept per feed; 0 = max_samples/64 + 65536 */
     uint32_t filter_clock;        /* MGPU_FILTER_CLOCK_*: who runs icaoFilterExpire (readsb.c:1227-1231), see below */
-    uint32_t reserved0;
+    uint32_t streams_on_device;   /* how many contexts this process runs on the device (0 / 1: this one alone).  With several, every one of them
+                                   * keeps its host stages small (4 walkers, 3 builders): the stage threads poll while a feed runs, and eight
+                                   * contexts with a lone stream's teams (8 + 6) oversubscribe the device's two L3 groups — measured, 8 streams:
+                                   * 9.4 Gsamples/s, with small teams 18.7 (profiles/r03_fanin.txt) */
 };
 
 /* The ICAO filter's 60 s expiry (backgroundTasks, readsb.c:1227-1231: `static next_flip = 0`, so the first

@@ -56,7 +56,7 @@ class Config(C.Structure):
         ("preamble_threshold", C.c_int32), ("buf_samples", C.c_uint32), ("trailing_samples", C.c_uint32),
         ("mode_ac", C.c_uint32), ("max_samples", C.c_uint64), ("startup_time_ms", C.c_int64),
         ("record_pool_records", C.c_uint64), ("max_messages", C.c_uint64),
-        ("filter_clock", C.c_uint32), ("reserved0", C.c_uint32),
+        ("filter_clock", C.c_uint32), ("streams_on_device", C.c_uint32),
     ]
 
 

@@ -172,7 +172,6 @@ struct Slot {
     uint32_t *d_ac_noise = nullptr;       // Mode A/C: per-buffer noise level
     AcCand *h_ac = nullptr;               // ... candidates, written by k_modeac straight into pinned host memory
     hipEvent_t ev_h2d = nullptr;          // the chunk's IQ samples have arrived in HBM (copy stream)
-    hipEvent_t ev_swept = nullptr;        // this chunk's k_sweep has run: the fetcher starts the PREVIOUS chunk's record copies then
     hipEvent_t ev_scan = nullptr;         // pre-screen offsets are final (main stream) -> the write pass may start (second stream)
     // the job
     uint64_t n = 0, stream_pos = 0;
@@ -310,7 +309,6 @@ struct mgpu_ctx {
     uint64_t feed_head = 0, feed_tail = 0;                    // oldest uncollected feed, next feed to open
     bool deferred = false;
     bool device_msgs = false;                                 // mgpu_set_device_messages
-    bool copy_after_sweep = false;                            // MGPU_COPY_AFTER_SWEEP=1: the fetcher holds its copies back until the next chunk's k_sweep has run
     bool sig_late = true;                                     // MGPU_SIG_LATE=0: signal power of every live record in the pre-screen write pass (as in shard passes) instead of the accepted frames' after the walk
     int timing_every = 4;                                     // MGPU_TIMING_EVERY: chunks per set of stage timing events (1 = every chunk)
     uint64_t timing_seq = 0;
@@ -364,7 +362,7 @@ struct mgpu_ctx {
     uint8_t *d_hist_iq = nullptr;
     unsigned long long *d_hist_sums = nullptr;
     // experiment / debug switches, read once at creation
-    bool dbg_print = false, dbg_no_window = false;
+    bool dbg_print = false;
     int dbg_stage = 0;
     std::string dump_dir;
     double feed_t0 = 0;                                       // wall clock at feed start (MGPU_DEBUG_PRINT timeline)
@@ -524,7 +522,7 @@ static void bind_near_device(std::thread *const *walk, int nwalk, std::thread *c
     if (const char *lr = getenv("LOCAL_RANK")) { const int v = atoi(lr); if (v >= 0) ordinal = v; }
     const size_t ng = l3_ids.size();
     int want_walk, want_rest;
-    if (device_slot == 0 && ng >= 2 && !getenv("MGPU_ONE_L3")) {
+    if (device_slot == 0 && ng >= 2) {
         want_walk = l3_ids[((size_t) ordinal * 2) % ng];
         want_rest = l3_ids[((size_t) ordinal * 2 + 1) % ng];
     } else {   // further contexts of the same device: half the node's groups away, where an 8-GPU node's other devices do not sit
@@ -663,7 +661,6 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
     HIPCHK(c, hipHostMalloc(&sl.h_live_sig, c->cap_pool * sizeof(unsigned long long)));
     HIPCHK(c, hipEventCreateWithFlags(&sl.ev_window, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&sl.ev_scan, hipEventDisableTiming));
-    HIPCHK(c, hipEventCreateWithFlags(&sl.ev_swept, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming));
     HIPCHK(c, hipHostMalloc(&sl.h_win, 8 * sizeof(unsigned long long)));
     HIPCHK(c, hipHostMalloc(&sl.h_sig, c->cap_msgs * sizeof(unsigned long long)));
@@ -690,7 +687,6 @@ static void free_slot(Slot &sl) {
         if (p) (void) hipFree(p);
     if (sl.ev_window) (void) hipEventDestroy(sl.ev_window);
     if (sl.ev_scan) (void) hipEventDestroy(sl.ev_scan);
-    if (sl.ev_swept) (void) hipEventDestroy(sl.ev_swept);
     if (sl.d_ac_noise) (void) hipFree(sl.d_ac_noise);
     if (sl.h_ac) (void) hipHostFree(sl.h_ac);
     if (sl.ev_h2d) (void) hipEventDestroy(sl.ev_h2d);
@@ -841,7 +837,6 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     if (c->device_walk) {
         int lo = 0, hi = 0;
         (void) hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (getenv("MGPU_DBG_WK_PLAIN_STREAM")) hi = 0;
         if (hipStreamCreateWithPriority(&c->stream_wk, hipStreamNonBlocking, hi) != hipSuccess) { mgpu_destroy(c); return MGPU_E_HIP; }
     }
     c->s_post = c->stream2;
@@ -857,16 +852,15 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     }
     c->resolver.reset(cfg->startup_time_ms, (int) cfg->filter_clock);
     c->dbg_print = getenv("MGPU_DEBUG_PRINT") != nullptr;
-    c->dbg_no_window = getenv("MGPU_DEBUG_NO_WINDOW") != nullptr;
-    if (const char *e = getenv("MGPU_DEBUG_STAGE")) c->dbg_stage = atoi(e);
-    if (const char *e = getenv("MGPU_COPY_AFTER_SWEEP")) c->copy_after_sweep = atoi(e) != 0;
-    if (const char *e = getenv("MGPU_SIG_LATE")) c->sig_late = atoi(e) != 0;
+#if MGPU_EXPERIMENTS
+    if (const char *e = getenv("MGPU_DEBUG_STAGE")) c->dbg_stage = atoi(e);   // (generation 3 only)
+#endif
     if (const char *e = getenv("MGPU_TIMING_EVERY")) { const int v = atoi(e); if (v >= 1) c->timing_every = v; }
     if (const char *e = getenv("MGPU_DUMP_DIR")) { c->dump_dir = e; c->sig_late = false; }   // (the dump holds per-record signal powers)
     c->device_slot = take_device_slot(cfg->device);
     // the first context of a device has two L3 groups to itself (bind_near_device): a walk team of 8 and a builder team of 6;
     // further contexts of the device share one group: 4 + 3 as before
-    if (c->device_slot == 0 && !getenv("MGPU_ONE_L3") && !getenv("MGPU_NO_AFFINITY")) { c->walk_threads = 8; c->build_threads = 6; }
+    if (c->device_slot == 0 && cfg->streams_on_device <= 1 && !getenv("MGPU_NO_AFFINITY")) { c->walk_threads = 8; c->build_threads = 6; }
     // with the walk on the device the walker only waits for the GPU and replays the adds; the builder copies and sums
     if (c->device_walk == 1) { c->walk_threads = 1; c->build_threads = 2; }
     if (const char *e = getenv("MGPU_WALK_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) c->walk_threads = v; }
@@ -1032,7 +1026,6 @@ static int enqueue_sweep(mgpu_ctx *c, Slot &sl) {
     {
         sl.sweep_blocks = launch_sweep(sp, s);
         if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[4], s));
-        if (c->copy_after_sweep) HIPCHK(c, hipEventRecord(sl.ev_swept, s));
         sl.slice_blocks = launch_slice(sp, s);
     }
     if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[2], s));
@@ -1085,10 +1078,9 @@ static int fetch_records(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
     // chunk's kernels keep running), then into ordinary memory: page-locked memory the device wrote is slow for the walk's
     // small scattered reads (4x slower walk) but streams at tens of GB/s (0.1 ms for 70 k records)
     // The copies run as blit kernels (the runtime's choice on this box, whatever HSA_ENABLE_SDMA / GPU_FORCE_BLIT_COPY_SIZE say)
-    // and cost whatever is on the main stream meanwhile ~25 us: the converter takes 78 us instead of 52, or — with
-    // MGPU_COPY_AFTER_SWEEP=1, held back until the next chunk's converter and k_sweep are through — k_slice 140 instead of 114.
-    // The same either way (2.23 vs 2.27 ms per step), so: at once.
-    if (nlive && next && c->copy_after_sweep) HIPCHK(c, hipEventSynchronize(next->ev_swept));
+    // and cost whatever is on the main stream meanwhile ~25 us: the converter takes 78 us instead of 52, or — held back until the
+    // next chunk's converter and k_sweep are through (measured in round 2) — k_slice 140 instead of 114.  The same either way
+    // (2.23 vs 2.27 ms per step), so: at once.
     if (nlive) {
         // (a copy kernel of our own with 8..32 workgroups in place of the runtime's blit kernel: 2.55-2.63 ms per step instead of 2.45)
         HIPCHK(c, hipMemcpyAsync(sl.h_live, sl.d_live, nlive * sizeof(PhaseRec), hipMemcpyDeviceToHost, c->stream_d2h));
@@ -1282,7 +1274,7 @@ static int walk_job_device(mgpu_ctx *c, Slot &sl, HostJob &job) {
     c->acc.resolve_ms += (float) (wall_ms() - t_res0);
 
     const double t_sig0 = wall_ms();
-    if (nmsg && !c->dbg_no_window)
+    if (nmsg)
         launch_window_stats(sl.d_mag, sl.n, sl.thr, sl.d_class_final, sl.d_msg_pos, sl.d_msg_skip, sl.d_msg_limit, nmsg, sl.d_win_part, c->d_win, s2);
     const bool to_device_list = c->device_msgs && job.feed >= 0;
     if (nmsg) {
@@ -1402,14 +1394,14 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
     // accumulated on the device and read once at the end of the feed
     const double t_sig0 = wall_ms();
     hipStream_t s2 = c->s_post;
-    if (nmsg && (!c->dbg_no_window || job.sig_late))
+    if (nmsg)
         launch_stage_in(sl.h_msg_pos, sl.h_msg_limit, sl.h_msg_skip, sl.d_msg_pos, sl.d_msg_limit, sl.d_msg_skip, nmsg, s2);
     if (nmsg && job.sig_late) {    // the accepted frames' signal powers, now that it is known which frames they are: first, the builder waits for them
         // (the kernel stores the builder's copy itself: a hipMemcpyAsync from this thread contends with the fetcher's inside the runtime)
         launch_msg_sig(sl.d_mag, sl.d_msg_pos, sl.d_msg_skip, nmsg, sl.d_msg_sig, job.h_msig, s2);
         HIPCHK(c, hipEventRecord(job.ev_copied, s2));
     }
-    if (nmsg && !c->dbg_no_window)
+    if (nmsg)
         launch_window_stats(sl.d_mag, n, sl.thr, sl.d_class_final, sl.d_msg_pos, sl.d_msg_skip,
                             sl.d_msg_limit, nmsg, sl.d_win_part, c->d_win, s2);
     if (nmsg && c->device_msgs && job.feed >= 0) {
@@ -1426,7 +1418,7 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
         HIPCHK(c, hipEventRecord(fs.ev_built, s2));
         fs.d_count += nmsg;
     }
-    if (nmsg && (!c->dbg_no_window || c->device_msgs || job.sig_late)) {          // the slot's device side is read on stream2 until here
+    if (nmsg) {          // the slot's device side is read on stream2 until here
         HIPCHK(c, hipEventRecord(sl.ev_window, s2));
         sl.window_pending = true;
     }

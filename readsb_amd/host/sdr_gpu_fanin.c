@@ -95,6 +95,8 @@ int gpuFaninOpen(struct gpu_fanin *f, gpu_stream_sink sink, void *user) {
         }
         struct mgpu_config cfg = f->cfg;
         cfg.device = (int) (i % (unsigned) ndev);
+        /* how many of the streams land on this device: with more than one, every context keeps its host stages small */
+        cfg.streams_on_device = (f->nstreams - (unsigned) cfg.device + (unsigned) ndev - 1) / (unsigned) ndev;
         cfg.format = (int) s->format;
         cfg.max_samples = (uint64_t) f->chunk_buffers * 131072;
         s->device = cfg.device;

@@ -1,9 +1,8 @@
 #!/bin/bash
 cd /root/repo
-mkdir -p gpurun_out/s65
-O=gpurun_out/s65
-
-export MASTER_ADDR=127.0.0.1 MASTER_PORT=29511 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1
-timeout 300 python bench.py --config 5 --samples $((4096*131072)) --steps 2 --warmup 1 > $O/c5.out 2>$O/c5.err; echo "rc=$?"
-tail -1 $O/c5.out | cut -c1-1800
-grep -v "Warning\|amdgpu.ids\|hostname" $O/c5.err | tail -8 | cut -c1-300
+mkdir -p gpurun_out/s66
+O=gpurun_out/s66
+timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -4 | tee $O/pytest.log
+timeout 600 python tools/bench_fanin.py --seconds 60 --streams 1,2,4,8 2>&1 | tail -6 | tee $O/fanin.txt
+MGPU_WALK_THREADS=4 MGPU_BUILD_THREADS=3 timeout 300 python tools/bench_fanin.py --seconds 60 --streams 8 2>&1 | tail -2 | tee -a $O/fanin.txt
+timeout 300 python tools/bench_formats.py 2>&1 | tail -8 | tee $O/formats.txt

@@ -1,8 +1,9 @@
 #!/bin/bash
 cd /root/repo
-mkdir -p gpurun_out/s66
-O=gpurun_out/s66
-timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -4 | tee $O/pytest.log
-timeout 600 python tools/bench_fanin.py --seconds 60 --streams 1,2,4,8 2>&1 | tail -6 | tee $O/fanin.txt
-MGPU_WALK_THREADS=4 MGPU_BUILD_THREADS=3 timeout 300 python tools/bench_fanin.py --seconds 60 --streams 8 2>&1 | tail -2 | tee -a $O/fanin.txt
-timeout 300 python tools/bench_formats.py 2>&1 | tail -8 | tee $O/formats.txt
+mkdir -p gpurun_out/s24
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15
+timeout 600 python bench.py --no-extra-configs > gpurun_out/s24/bench.log 2>&1
+tail -1 gpurun_out/s24/bench.log | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.readline())
+print(d['value'], d['ms_per_step'], d['stage_ms'], d['roofline']['avg_launch_ms'], d['roofline']['frac'], d['kernels'])"

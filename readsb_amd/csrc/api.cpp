@@ -1016,7 +1016,7 @@ static int enqueue_sweep(mgpu_ctx *c, Slot &sl) {
     // ev[5] .. ev[4] bracket exactly one kernel: k_sweep (bench.py's roofline); ev[4] .. ev[2]: k_slice
     if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[5], s));
 #if MGPU_EXPERIMENTS
-    sp.debug_stage = c->dbg_stage;
+    sp.debug_stage = c->dbg_stage;     // (generation 3's stages, or k_slice's leave-out experiments)
     if (c->sweep_version == 3) {
         launch_sweep_slice(sp, s);
         sl.slice_blocks = 0;
@@ -1113,11 +1113,13 @@ static int fetch_records(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
 static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
     HIPCHK(c, hipEventSynchronize(sl.ev[3]));
     const double t_gpu_done = wall_ms();
-    if (c->dbg_print) {
-        const unsigned long long *h = sl.h_counters;
-        fprintf(stderr, "dbg: k_slice wave cycles: stage %llu expand %llu df %llu slice %llu score %llu total %llu | df batches %llu rounds %llu sumI %llu frames %llu lanes %llu passes %llu scored %llu\n",
-                h[16], h[17], h[18], h[19], h[20], h[21], h[24], h[25], h[26], h[27], h[28], h[29], h[30]);
+#if MGPU_KERNEL_TIMERS
+    if (c->dbg_print) {      // make exp TIMERS=1: k_slice's wave cycles per stage and event counts (kernels/slice.inc)
+        const unsigned long long *h = sl.h_counters + CNT_DEBUG0;
+        fprintf(stderr, "dbg: k_slice wave cycles: stage-in %llu expand %llu df %llu slice %llu score %llu other %llu alive %llu | df batches %llu rounds %llu sumI %llu frames %llu lanes %llu passes %llu scored %llu tiles %llu\n",
+                h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11], h[12], h[13], h[14]);
     }
+#endif
     if (sl.h_counters[CNT_POOL_OVERFLOW]) {
         c->err = "record pool overflow: recreate the context with a larger record_pool_records";
         return MGPU_E_OVERFLOW;

@@ -1,10 +1,7 @@
 #!/bin/bash
 cd /root/repo
-for ms in 1 2 1 2; do
-MGPU_MAIN_STREAMS=$ms timeout 300 python bench.py --no-extra-configs 2>/dev/null | tail -1 | python3 -c "
-import json,sys
-d=json.loads(sys.stdin.readline())
-s=d['stage_ms']
-print('main_streams=$ms', d['value'], d['ms_per_step'], s, 'sweep', d['roofline']['avg_launch_ms'], 'slice', d['kernels']['k_slice']['avg_launch_ms'], 'identical', d.get('cpu_baseline',{}).get('bit_identical_to_gpu'))"
-done
-MGPU_MAIN_STREAMS=2 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+mkdir -p gpurun_out/s40
+TR="python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511"
+timeout 1500 $TR bench.py --gpus 1 --config 5 --samples 8640000000 --steps 2 --warmup 1 > gpurun_out/s40/config5_hour.log 2>&1
+tail -1 gpurun_out/s40/config5_hour.log | cut -c1-2500
+timeout 300 $TR bench.py --gpus 1 --config 5 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | cut -c1-1500

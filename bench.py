@@ -222,17 +222,17 @@ def run_extra_config(name, fmt, nfix, kw, nsamples, device, steps=4):
 
 def bench_config5(args, rank, local_rank, world):
     """BASELINE configs[4]: ONE dense-burst capture (overlapping 112-bit DF17 frames, --aggressive) time-chunked by whole buffers
-    over the ranks (readsb_amd/shard.py): every rank sweeps its range for its adder bitmap, the bitmaps are OR-ed over the ranks
-    (2 MiB all_gather), every rank sweeps / slices / pre-screens its range against the global bitmap, the surviving records go to
-    rank 0 (gather), which runs the ordered walk and builds the messages — the unsharded message list, bit for bit.  Strong
-    scaling: the capture is fixed, a step = the whole capture once; every rank's range is resident in its HBM (its own device
+    over the ranks (readsb_amd/shard.py): rank 0 puts the first range through the ordinary pipeline; every other rank sweeps the
+    120 s before its range for their adder addresses, then its range against them, and ships the surviving records to rank 0
+    (gather), which continues its stream with them — the unsharded message list and counters, bit for bit.  Strong scaling: the
+    capture is fixed, a step = the whole capture once; every rank's samples are resident in its HBM (its own device
     allocation: --samples 8640000000 = the one-hour capture of BASELINE.json, 17.3 GB, fits one MI355X).  With one rank the same
-    capture also runs through the ordinary (unsharded) pipeline in the same process: `unsharded` in the JSON line."""
+    capture also runs through the deferred-feed loop of the headline benchmark in the same process: `unsharded` in the JSON line."""
     import torch
     import torch.distributed as dist
     import helpers
     import readsb_amd
-    from readsb_amd.shard import demodulate_sharded, shard_ranges
+    from readsb_amd.shard import demodulate_sharded, shard_ranges, needed_from, warmup_start
     dev = 0 if args.dryrun_gloo else local_rank
     torch.cuda.set_device(dev)
     coll = torch.device("cpu") if args.dryrun_gloo else torch.device("cuda", local_rank)
@@ -244,26 +244,28 @@ def bench_config5(args, rank, local_rank, world):
     helpers.ensure_built()
     n = args.samples - args.samples % BUF
     first, last = shard_ranges(n, world)[rank]
-    lo = max(0, first - 326)
+    lo = needed_from(first)
     threads = min(64, max(1, (os.cpu_count() or 8) // world))
     t_g0 = time.time()
-    mine = helpers.synth(nsamples=last - lo, first=lo, seed=5150, rate=8000.0, dense=1, threads=threads)   # the rank's range (+ history)
+    mine = helpers.synth(nsamples=last - lo, first=lo, seed=5150, rate=8000.0, dense=1, threads=threads)   # the rank's range, its warm-up and histories
     t_gen = time.time() - t_g0
     d_iq = torch.from_numpy(mine).to(torch.device("cuda", dev))            # resident: its own allocation, any length
-    history = None if first == 0 else mine[: (first - lo) * 2].copy()
+    wf = warmup_start(first)
+    histories = (None if wf == 0 else mine[(wf - 326 - lo) * 2:(wf - lo) * 2].copy(), None if first == 0 else mine[(first - 326 - lo) * 2:(first - lo) * 2].copy())
     piece = min(4096 * BUF, max(BUF, last - first))                          # samples per feed call
     d = readsb_amd.Demodulator(nfix_crc=2, max_samples=piece, device=dev, startup_time_ms=helpers.STARTUP_MS)
     resident = (lo, d_iq.data_ptr())
     d.keep_other_threads_away(confine_to_own_l3=world > 1)
+    out_buf = np.empty(int(n // 512 + 65536), dtype=readsb_amd.MSG_DTYPE) if rank == 0 else None   # rank 0 builds every message in place
     res = None
     for _ in range(max(0, args.warmup)):
-        res = demodulate_sharded(d, None, coll, resident=resident, nsamples=n, history=history)
+        res = demodulate_sharded(d, None, coll, resident=resident, nsamples=n, histories=histories, out=out_buf)
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     phases = {}
     for _ in range(args.steps):
-        res = demodulate_sharded(d, None, coll, resident=resident, nsamples=n, history=history, phases=phases)
+        res = demodulate_sharded(d, None, coll, resident=resident, nsamples=n, histories=histories, phases=phases, out=out_buf)
     dist.barrier()
     torch.cuda.synchronize()
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=coll)
@@ -276,14 +278,15 @@ def bench_config5(args, rank, local_rank, world):
                "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "u16", "data": "synthetic",
                "config": {"workload": f"configs[4]: one {n / 2.4e6:.1f} s dense-burst UC8 capture ({n} samples, 8000 overlapping DF17 frames/s, --aggressive) "
-                                      f"time-chunked by whole buffers over {world} GPU(s), each range resident in its GPU's HBM; adder-bitmap all_gather, "
-                                      "record packets gathered on rank 0, ordered walk there",
+                                      f"time-chunked by whole buffers over {world} GPU(s), each range (+ 120 s of warm-up before it) resident in its GPU's HBM; "
+                                      "rank 0: first range through the ordinary pipeline, then the other ranks' record packets (gathered) through the ordered walk",
                           "samples": n, "shards": world, "parallelism": f"time-chunked x{world}"},
                "messages_per_step": int(len(msgs)), "synth_gen_s": round(t_gen, 2),
                "rank0_phase_ms_per_step": {k: round(v / args.steps, 3) for k, v in phases.items()}}
         unsharded = None
         if world == 1:
-            # the same capture through the ordinary pipeline (one stream, deferred feeds of `piece` samples, resident IQ)
+            # the same capture through the headline benchmark's loop (one stream, deferred feeds of `piece` samples, resident IQ)
+            d.set_message_buffer(None)
             bufs = [np.empty(int(piece // 64 + 65536), dtype=readsb_amd.MSG_DTYPE) for _ in range(2)]
             offs = list(range(0, n, piece))
 

@@ -283,15 +283,18 @@ int mgpu_demod_mag_buf_ac(mgpu_ctx *ctx, const uint16_t *data, uint32_t length,
                           double mean_level, double mean_power, uint32_t dropped);
 
 /* ---- one capture sharded by buffer ranges over several contexts / GPUs (BASELINE config 5) ----
- * Buffers are independent except for the ICAO filter, and the pre-screen needs the adder addresses
- * of the whole capture.  Per shard (a context, after mgpu_reset):
- *   pass 1: mgpu_shard_begin(ctx, first_sample, history, 1); mgpu_feed_iq*(shard samples);
- *           mgpu_adder_bitmap_get() -> OR over all shards (the exchange step, 2 MiB per rank)
- *   pass 2: mgpu_reset; mgpu_adder_bitmap_set(global); mgpu_shard_begin(ctx, first_sample, history, 2);
- *           mgpu_feed_iq*(shard samples); mgpu_shard_packets() -> the shard's live records
- * and on ONE context, after mgpu_reset, mgpu_walk_packets() over the packets of all shards in stream
- * order, mgpu_finish(), mgpu_collect(): the message list AND every counter of the unsharded stream, bit for
- * bit.  A packet (one per chunk of the shard's range, 8-byte aligned) carries what the walking rank cannot compute without
+ * Buffers are independent except for the ICAO filter; the pre-screen needs (a superset of) the addresses the filter may
+ * hold: those some clean DF17 / DF11-IID0 frame carried within the last two filter generations (120 s of samples).
+ *   the context that owns the capture's FIRST range: mgpu_reset; mgpu_feed_iq*(its samples) as for any stream;
+ *   every other range (a context, after mgpu_reset):
+ *     pass 1: mgpu_shard_begin(ctx, range_first - 120 s (whole buffers, >= 0), history, 1); mgpu_feed_iq*(those samples up to
+ *             range_first); mgpu_adder_bitmap_get()                       -> the addresses that may still be known at range_first
+ *     pass 2: mgpu_reset; mgpu_adder_bitmap_set(that); mgpu_shard_begin(ctx, range_first, history, 2);
+ *             mgpu_feed_iq*(the range's samples); mgpu_shard_packets()    -> the range's live records
+ *   the first context again: mgpu_walk_packets() over the other ranges' packets in stream order, mgpu_finish(),
+ *   mgpu_collect(): the message list AND every counter of the unsharded stream, bit for bit.
+ * (Any superset of the needed addresses is exact too, e.g. the OR of pass-1 bitmaps over all ranges.)
+ * A packet (one per chunk of the shard's range, 8-byte aligned) carries what the walking rank cannot compute without
  * the samples: per live record its would-be signal power and the counts of its would-be skip window, per buffer the
  * converter's level / power sums, per chunk the sweep's candidate tallies.
  * first_sample is a multiple of buf_samples; history = the 326 IQ samples before it (NULL for 0). */
@@ -299,10 +302,7 @@ int mgpu_shard_begin(mgpu_ctx *ctx, uint64_t first_sample, const void *history_i
 int mgpu_adder_bitmap_get(mgpu_ctx *ctx, uint32_t *words /* 2^19 */);
 int mgpu_adder_bitmap_set(mgpu_ctx *ctx, const uint32_t *words /* 2^19 */);
 int mgpu_shard_packets(mgpu_ctx *ctx, const void **packets, uint64_t *bytes);   /* valid until the next reset */
-int mgpu_walk_packets(mgpu_ctx *ctx, const void *packets, uint64_t bytes);
-/* One rank holds the whole capture: mgpu_reset() + mgpu_walk_packets() over the packets the context's own last shard pass
- * left, where they lie (no copy). */
-int mgpu_walk_own_packets(mgpu_ctx *ctx);
+int mgpu_walk_packets(mgpu_ctx *ctx, const void *packets, uint64_t bytes);   /* continues the context's stream: the packets' first sample = where it stands */
 
 /* ---- beast wire output (modesSendBeastOutput, net_io.c:1655-1714) ------------------------------------
  * Per message: 0x1a, type '2' (56-bit) / '3' (112-bit) / '1' (Mode A/C), the 12 MHz timestamp as 6 bytes

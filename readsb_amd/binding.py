@@ -156,7 +156,6 @@ def load_library():
     lib.mgpu_adder_bitmap_set.argtypes = [vp, vp]
     lib.mgpu_shard_packets.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
     lib.mgpu_walk_packets.argtypes = [vp, vp, u64]
-    lib.mgpu_walk_own_packets.argtypes = [vp]
     lib.mgpu_pending_messages.restype = u64
     lib.mgpu_last_timing.argtypes = [vp, C.POINTER(Timing)]
     lib.mgpu_debug_device_walk.argtypes = [vp, C.POINTER(u64)]
@@ -285,9 +284,6 @@ class Demodulator:
     def walk_packets(self, packets):
         packets = np.ascontiguousarray(packets, dtype=np.uint8)
         self._chk(self.lib.mgpu_walk_packets(self.ctx, C.c_void_p(packets.ctypes.data), C.c_uint64(packets.size)), "mgpu_walk_packets")
-
-    def walk_own_packets(self):
-        self._chk(self.lib.mgpu_walk_own_packets(self.ctx), "mgpu_walk_own_packets")
 
     def decode_fields(self, msgs):
         """Per-message field records (FIELDS_DTYPE) of a message record array, decoded on the GPU."""

@@ -2389,17 +2389,6 @@ static int walk_packets_checked(mgpu_ctx *c, const void *packets, uint64_t bytes
 }
 
 // The context's own packets (one rank holds the whole capture): reset, then walk them where the shard pass left them.
-int mgpu_walk_own_packets(mgpu_ctx *c) {
-    if (!c) return MGPU_E_INVAL;
-    std::vector<uint8_t> own;
-    own.swap(c->shard_packets);
-    int rc = mgpu_reset(c);
-    if (rc == MGPU_OK) rc = mgpu_walk_packets(c, own.data(), own.size());
-    own.clear();
-    own.swap(c->shard_packets);              // (the buffer, grown to a pass's size and already paged in, serves the next pass)
-    return rc;
-}
-
 int mgpu_walk_packets(mgpu_ctx *c, const void *packets, uint64_t bytes) {
     if (!c || (!packets && bytes)) return MGPU_E_INVAL;
     if (c->eof) return MGPU_E_EOF;

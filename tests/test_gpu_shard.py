@@ -1,6 +1,7 @@
 """-m gpu: BASELINE config 5 — one capture sharded by buffer ranges (readsb_amd/shard.py) must give the unsharded
 message list AND every demodulator statistic bit for bit: dense overlapping bursts, several shard counts, shards that start mid-stream with
-326 samples of history, and a two-rank gloo run (both ranks on the one GPU of the test box)."""
+326 samples of history, a capture long enough for a shard's 120 s warm-up NOT to reach back to the start (aircraft that fell
+silent and expired before it), and a two-rank gloo run (both ranks on the one GPU of the test box)."""
 import os
 import sys
 
@@ -13,11 +14,15 @@ import helpers
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("nshards,seconds,dense,rate,nfix", [(2, 8.0, 1, 8000.0, 2), (3, 8.0, 0, 2000.0, 1), (8, 70.0, 1, 6000.0, 1)])
+@pytest.mark.parametrize("nshards,seconds,dense,rate,nfix", [(2, 8.0, 1, 8000.0, 2), (3, 8.0, 0, 2000.0, 1), (8, 70.0, 1, 6000.0, 1),
+                                                             (2, 290.0, 0, 1500.0, 1)])     # second range from 145 s: warm-up [25 s, 145 s)
 def test_sharded_capture_equals_unsharded(built, nshards, seconds, dense, rate, nfix):
     import readsb_amd
     from readsb_amd.shard import demodulate_sharded_local
-    iq = helpers.synth(seconds=seconds, seed=900 + nshards, rate=rate, dense=dense, threads=16)
+    from readsb_amd import shard
+    iq = helpers.synth(seconds=seconds, seed=900 + nshards + int(seconds), rate=rate, dense=dense, threads=16)
+    if seconds > 200:
+        assert shard.warmup_start(shard.shard_ranges(iq.size // 2, nshards)[-1][0]) > 0     # the cutoff is exercised
     want, wst = helpers.oracle_run(iq, 0, nfix, 1, 58)
     d = readsb_amd.Demodulator(nfix_crc=nfix, startup_time_ms=helpers.STARTUP_MS, max_samples=256 * 131072)
     try:

@@ -252,7 +252,7 @@ def bench_config5(args, rank, local_rank, world):
     d_iq = torch.from_numpy(mine).to(torch.device("cuda", dev))            # resident: its own allocation, any length
     wf = warmup_start(first)
     histories = (None if wf == 0 else mine[(wf - 326 - lo) * 2:(wf - lo) * 2].copy(), None if first == 0 else mine[(first - 326 - lo) * 2:(first - lo) * 2].copy())
-    piece = min(4096 * BUF, max(BUF, last - first))                          # samples per feed call
+    piece = min(8192 * BUF, max(BUF, last - first))                          # samples per feed call (rank 0 feeds synchronously: a drain per call)
     d = readsb_amd.Demodulator(nfix_crc=2, max_samples=piece, device=dev, startup_time_ms=helpers.STARTUP_MS)
     resident = (lo, d_iq.data_ptr())
     d.keep_other_threads_away(confine_to_own_l3=world > 1)

@@ -1113,13 +1113,6 @@ static int fetch_records(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
 static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
     HIPCHK(c, hipEventSynchronize(sl.ev[3]));
     const double t_gpu_done = wall_ms();
-#if MGPU_KERNEL_TIMERS
-    if (c->dbg_print) {      // make exp TIMERS=1: k_slice's wave cycles per stage and event counts (kernels/slice.inc)
-        const unsigned long long *h = sl.h_counters + CNT_DEBUG0;
-        fprintf(stderr, "dbg: k_slice wave cycles: stage-in %llu expand %llu df %llu slice %llu score %llu other %llu alive %llu | df batches %llu rounds %llu sumI %llu frames %llu lanes %llu passes %llu scored %llu tiles %llu\n",
-                h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11], h[12], h[13], h[14]);
-    }
-#endif
     if (sl.h_counters[CNT_POOL_OVERFLOW]) {
         c->err = "record pool overflow: recreate the context with a larger record_pool_records";
         return MGPU_E_OVERFLOW;

@@ -198,7 +198,7 @@ def run_extra_config(name, fmt, nfix, kw, nsamples, device, steps=4):
         kind, (ref_msgs, st) = "port", helpers.oracle_run(iq2, fmt, nfix, 1, 58)
     del iq2
     helpers.assert_same_messages(msgs, ref_msgs)
-    helpers.assert_same_counters(counters, st, float_tol=0.02 if fmt else 0.0)
+    helpers.assert_same_counters(counters, st)
     nl = max(1, tm["n_chunks"])
     out = {"msamples_s": round(nsamples * steps / elapsed / 1e6, 1), "ms_per_segment": round(elapsed / steps * 1e3, 3),
            "samples_per_segment": nsamples, "segments_timed": steps, "messages_per_segment": int(len(msgs)),

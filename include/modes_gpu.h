@@ -50,10 +50,9 @@ struct mgpu_config {
     int32_t  preamble_threshold;  /* Modes.preambleThreshold, default 58 (readsb.c:2268) */
     uint32_t buf_samples;         /* Modes.sdr_buf_samples, default 131072 (readsb.c:2212); multiple of 4096 */
     uint32_t trailing_samples;    /* Modes.trailing_samples = 326 (readsb.c:288); must be 326 */
-    uint32_t mode_ac;             /* Modes.mode_ac (--modeac): also run demodulate2400AC on every buffer, readsb.c:871-874.
-                                   * IQ entries (mgpu_feed_iq*): UC8 only — with SC16 / SC16Q11 they return MGPU_E_INVAL, because the
-                                   * reference's noise floor there is an order-dependent float running sum (convert.c:225-249);
-                                   * mgpu_demod_mag_buf_ac (caller's mean_level / mean_power) works for every format. */
+    uint32_t mode_ac;             /* Modes.mode_ac (--modeac): also run demodulate2400AC on every buffer, readsb.c:871-874.  Every
+                                   * format: its noise floor comes from the buffer's mean level / power, which for SC16 / SC16Q11 are
+                                   * the reference's sequential float sums (convert.c:225-249), reproduced bit for bit. */
     uint64_t max_samples;         /* largest number of new samples one mgpu_feed_* call may carry */
     int64_t  startup_time_ms;     /* Modes.startup_time: wall clock (ms) the 12 MHz sample clock is anchored to */
     uint64_t record_pool_records; /* device pool for per-phase candidate records; 0 = max_samples/16 + 65536 */

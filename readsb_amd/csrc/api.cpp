@@ -172,6 +172,10 @@ struct Slot {
     uint32_t *d_ac_noise = nullptr;       // Mode A/C: per-buffer noise level
     AcCand *h_ac = nullptr;               // ... candidates, written by k_modeac straight into pinned host memory
     hipEvent_t ev_h2d = nullptr;          // the chunk's IQ samples have arrived in HBM (copy stream)
+    // SC16 formats: the per-buffer float sums run beside the chunk's kernels on stream2 (k_fsum_sc16): what the converter waited
+    // for | the sums are there | the converter has read the samples too
+    hipEvent_t ev_pre = nullptr, ev_fsum = nullptr, ev_convdone = nullptr;
+    bool fsum_pending = false;
     hipEvent_t ev_scan = nullptr;         // pre-screen offsets are final (main stream) -> the write pass may start (second stream)
     // the job
     uint64_t n = 0, stream_pos = 0;
@@ -662,6 +666,9 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
     HIPCHK(c, hipEventCreateWithFlags(&sl.ev_window, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&sl.ev_scan, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&sl.ev_pre, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&sl.ev_fsum, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&sl.ev_convdone, hipEventDisableTiming));
     HIPCHK(c, hipHostMalloc(&sl.h_win, 8 * sizeof(unsigned long long)));
     HIPCHK(c, hipHostMalloc(&sl.h_sig, c->cap_msgs * sizeof(unsigned long long)));
     HIPCHK(c, hipHostMalloc(&sl.h_msg_pos, c->cap_msgs * sizeof(uint32_t)));
@@ -690,6 +697,9 @@ static void free_slot(Slot &sl) {
     if (sl.d_ac_noise) (void) hipFree(sl.d_ac_noise);
     if (sl.h_ac) (void) hipHostFree(sl.h_ac);
     if (sl.ev_h2d) (void) hipEventDestroy(sl.ev_h2d);
+    if (sl.ev_pre) (void) hipEventDestroy(sl.ev_pre);
+    if (sl.ev_fsum) (void) hipEventDestroy(sl.ev_fsum);
+    if (sl.ev_convdone) (void) hipEventDestroy(sl.ev_convdone);
     void *host[] = {sl.h_live, sl.h_live_sig, sl.h_scratch, sl.h_win, sl.h_sig, sl.h_msg_pos,
                     sl.h_msg_limit, sl.h_msg_len, sl.h_msg_skip};
     for (void *p : host)
@@ -968,6 +978,7 @@ static int enqueue_convert(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
     const uint64_t n = sl.n;
     hipStream_t s = c->stream;
     sl.timed = c->timing_every <= 1 || (c->timing_seq++ % (uint64_t) c->timing_every) == 0;
+    sl.fsum_pending = false;
     // the slot's magnitudes / class bitmap / message lists are still read by the window-statistics
     // kernel of its previous use (stream2)
     if (sl.window_pending) { HIPCHK(c, hipStreamWaitEvent(s, sl.ev_window, 0)); sl.window_pending = false; }
@@ -980,7 +991,16 @@ static int enqueue_convert(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
         cp.uc8_folded = c->d_uc8_folded;
         cp.sum_level = sl.d_sum_level; cp.sum_power = sl.d_sum_power;
         cp.fsum_level = sl.d_fsum_level; cp.fsum_power = sl.d_fsum_power;
+        if (cfg.format != MGPU_FMT_UC8) HIPCHK(c, hipEventRecord(sl.ev_pre, s));
         launch_convert(cfg.format, cp, s);
+        if (cfg.format != MGPU_FMT_UC8) {
+            // mean level / power of the SC16 formats = the reference's sequential float sums: a chain per buffer, ~0.2 ms, on the second
+            // stream beside this chunk's sweep and slicer; whoever needs them (Mode A/C below, k_publish) waits for ev_fsum
+            HIPCHK(c, hipStreamWaitEvent(c->stream2, sl.ev_pre, 0));
+            launch_fsum_sc16(cfg.format, iq, n, cfg.buf_samples, sl.d_fsum_level, sl.d_fsum_power, c->stream2);
+            HIPCHK(c, hipEventRecord(sl.ev_fsum, c->stream2));
+            sl.fsum_pending = true;
+        }
         // lastbuf->length < trailing_samples -> zeros (only possible for a stream shorter than 326 samples)
         c->tail_src = n >= (uint64_t) kTrailing ? sl.d_mag + n : nullptr;
     } else {
@@ -991,6 +1011,7 @@ static int enqueue_convert(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
         launch_modeac_scan(sl.d_mag, n, cfg.buf_samples, sl.d_ac_noise, sl.h_ac, (uint32_t) c->cap_ac,
                            sl.d_scratch + CNT_NUM + 1 + 4 * c->cap_buffers, sl.d_counters, s);
     }
+    if (cfg.mode_ac && !sl.have_mag && sl.fsum_pending) HIPCHK(c, hipStreamWaitEvent(s, sl.ev_fsum, 0));
     if (cfg.mode_ac && !sl.have_mag)       // Mode A/C candidates (needs the converter's per-buffer sums); a few us, streaming
         launch_modeac(sl.d_mag, n, cfg.buf_samples, cfg.format, sl.d_sum_level, sl.d_sum_power, sl.d_fsum_level, sl.d_fsum_power,
                       sl.d_ac_noise, sl.h_ac, (uint32_t) c->cap_ac, sl.d_scratch + CNT_NUM + 1 + 4 * c->cap_buffers, sl.d_counters, s);
@@ -1055,6 +1076,7 @@ static int enqueue_post(mgpu_ctx *c, Slot &sl) {
     q.keep_masks = true;
     q.fin_part = sl.d_sweep_part + (size_t) kSweepGridMax * 4;
     q.slice_part = sl.d_sweep_part; q.slice_blocks = sl.slice_blocks;       // k_slice's rows of counts (0 rows: the experiments build's fused kernel counts for itself)
+    if (sl.fsum_pending) { HIPCHK(c, hipStreamWaitEvent(s, sl.ev_fsum, 0)); sl.fsum_pending = false; }   // k_publish copies the sums out
     if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[6], s));
     if (launch_prescreen(q, s, s, sl.ev_scan) != 0) { c->err = "event ordering of the pre-screen passes failed"; return MGPU_E_HIP; }
     HIPCHK(c, hipEventRecord(sl.ev[3], s));
@@ -1064,7 +1086,13 @@ static int enqueue_post(mgpu_ctx *c, Slot &sl) {
 // one chunk on its own (struct mag_buf entry, shard passes)
 static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq, hipEvent_t after_convert = nullptr) {
     int rc = enqueue_convert(c, sl, iq);
-    if (rc == MGPU_OK && after_convert) HIPCHK(c, hipEventRecord(after_convert, c->stream));   // the chunk's IQ samples have been read
+    if (rc == MGPU_OK && after_convert) {                                                        // the chunk's IQ samples have been read
+        if (sl.fsum_pending) {               // ... by the converter AND by the float sums on the second stream
+            HIPCHK(c, hipEventRecord(sl.ev_convdone, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->stream2, sl.ev_convdone, 0));
+            HIPCHK(c, hipEventRecord(after_convert, c->stream2));
+        } else HIPCHK(c, hipEventRecord(after_convert, c->stream));
+    }
     if (rc == MGPU_OK) rc = enqueue_sweep(c, sl);
     if (rc == MGPU_OK) rc = enqueue_post(c, sl);
     return rc;
@@ -1542,7 +1570,7 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
         double mean_power;
         if (!job.given_mean_power.empty()) mean_power = job.given_mean_power[b];
         else if (cfg.format == MGPU_FMT_UC8) mean_power = (double) job.sums[c->cap_buffers + b] / 65535.0 / 65535.0 / bc.length;   // convert.c:105-107
-        else mean_power = job.fsums[c->cap_buffers + b] / bc.length;
+        else mean_power = (double) ((float) job.fsums[c->cap_buffers + b] / (float) bc.length);   // convert.c:246-248: a float sum, a float division
         const double sum_signal_power = (double) sum_scaled / 65535.0 / 65535.0;
         k.noise_power_sum += (mean_power * bc.length - sum_signal_power);
         k.noise_power_count += bc.length;
@@ -1741,14 +1769,6 @@ static int feed_common(mgpu_ctx *c, const void *src, bool src_is_device, uint64_
     if (c->eof) return MGPU_E_EOF;
     if (n > c->cap_samples) return MGPU_E_CAPACITY;
     if (c->worker_rc != MGPU_OK) return c->worker_rc;
-    if (c->cfg.mode_ac && c->cfg.format != MGPU_FMT_UC8) {
-        // demodulate2400AC's noise floor comes from mag_buf.mean_level / mean_power, which convert_sc16*_nodc accumulate as
-        // order-dependent FLOAT running sums (convert.c:225-249, 342-366); this library's SC16 converters keep exact double
-        // sums, so the accepted Mode A/C replies could differ from the reference's.  Refused rather than approximately right:
-        // convert on the host side of the boundary and use mgpu_demod_mag_buf_ac with the reference's own means.
-        c->err = "mode_ac with SC16/SC16Q11 on the IQ entry is not reference-exact: use mgpu_demod_mag_buf_ac";
-        return MGPU_E_INVAL;
-    }
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const size_t bps = c->cfg.format == MGPU_FMT_UC8 ? 2 : 4;
     const double t_start = wall_ms();
@@ -2117,6 +2137,7 @@ int mgpu_convert(mgpu_ctx *c, const void *iq_host, uint16_t *mag_host, uint32_t 
         cp.sum_level = sl.d_sum_level; cp.sum_power = sl.d_sum_power;
         cp.fsum_level = sl.d_fsum_level; cp.fsum_power = sl.d_fsum_power;
         launch_convert(c->cfg.format, cp, s);
+        launch_fsum_sc16(c->cfg.format, c->d_iq, len, 0x80000000u, sl.d_fsum_level, sl.d_fsum_power, s);   // (the call's one bucket: the state carries over)
         HIPCHK(c, hipMemcpyAsync(mag_host + off, sl.d_mag + kTrailing, len * sizeof(uint16_t), hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
     }
@@ -2130,8 +2151,8 @@ int mgpu_convert(mgpu_ctx *c, const void *iq_host, uint16_t *mag_host, uint32_t 
             ml = (double) sl.h_sums[0] / 65536.0 / n;              // convert.c:101-103 (sic, 65536)
             mp = (double) sl.h_sums[1] / 65535.0 / 65535.0 / n;    // convert.c:105-107
         } else {
-            ml = sl.h_fsums[0] / n;
-            mp = sl.h_fsums[1] / n;
+            ml = (double) ((float) sl.h_fsums[0] / (float) n);      // convert.c:242-248: float sums, float divisions
+            mp = (double) ((float) sl.h_fsums[1] / (float) n);
         }
     }
     // leave the slot's accumulation buckets zero again (the chunk pipeline relies on it)
@@ -2367,7 +2388,7 @@ static int walk_packets_checked(mgpu_ctx *c, const void *packets, uint64_t bytes
             const BufferClock &bc = job.buffers[b];
             double mean_power;
             if (c->cfg.format == MGPU_FMT_UC8) mean_power = (double) sums[nbuf + b] / 65535.0 / 65535.0 / bc.length;   // convert.c:105-107
-            else { double f; std::memcpy(&f, &sums[nbuf + b], 8); mean_power = f / bc.length; }
+            else { double f; std::memcpy(&f, &sums[nbuf + b], 8); mean_power = (double) ((float) f / (float) bc.length); }
             k.noise_power_sum += (mean_power * bc.length - (double) buf_scaled[b] / 65535.0 / 65535.0);
             k.noise_power_count += bc.length;
             k.samples_lost += c->cfg.buf_samples - bc.length;    // readsb.c:886

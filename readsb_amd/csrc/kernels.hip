@@ -45,6 +45,21 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// inclusive prefix sum over the wave, DPP only: row_shr 1/2/4/8 inside the rows of 16, then row_bcast 15 / 31
+// across them (the sequence LLVM's atomic optimizer emits for gfx9).  total = lane 63's value.
+__device__ __forceinline__ int wave_incl_scan_dpp(int v, int &total) {
+    int x = v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);    // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);    // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);    // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);    // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);    // row_bcast:15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);    // row_bcast:31 -> rows 2, 3
+    total = __builtin_amdgcn_readlane(x, WAVE - 1);
+    return x;
+}
+
+
 __device__ __forceinline__ uint64_t readlane64(uint64_t v, int src) {
     uint32_t lo = __builtin_amdgcn_readlane((uint32_t) v, src);
     uint32_t hi = __builtin_amdgcn_readlane((uint32_t) (v >> 32), src);

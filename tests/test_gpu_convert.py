@@ -47,12 +47,10 @@ def test_sc16q11_all_12bit_pairs(built):
     d.close()
     want, wml, wmp = helpers.oracle_convert(iq, 2)
     assert np.array_equal(mag, want)
-    # The reference accumulates mean level/power in a FLOAT running sum (convert.c:342-366): over
-    # 16.7 M samples that sum stops absorbing small addends (it reads 0.779 where the true mean is
-    # 0.738), so the device's double-precision sum is checked against the exact mean instead; the
-    # per-131072-sample-buffer comparison against the reference lives in test_gpu_formats.py.
+    # The reference accumulates mean level / power in a FLOAT running sum (convert.c:342-366): over 16.7 M samples that sum stops
+    # absorbing small addends (it reads 0.779 where the true mean is 0.738).  The device reproduces that sum, rounding for rounding.
     exact_ml = float(np.minimum(np.sqrt((i.ravel().astype(np.float64) ** 2 + q.ravel().astype(np.float64) ** 2)) / 2048.0, 1.0).mean())
-    assert abs(ml - exact_ml) < 1e-6
+    assert ml == wml and mp == wmp
     assert abs(wml - exact_ml) < 0.1
 
 
@@ -65,7 +63,19 @@ def test_sc16_random_and_extremes(built, fmt):
     small = rng.integers(-3000, 3000, size=2 * (n // 2), dtype=np.int32).astype("<i2")
     iq[2 * (n - n // 2):] = small
     d = _dem(fmt, n)
-    mag, _, _ = d.convert(iq)
-    d.close()
-    want, _, _ = helpers.oracle_convert(iq, fmt)
+    mag, ml, mp = d.convert(iq)
+    want, wml, wmp = helpers.oracle_convert(iq, fmt)
     assert np.array_equal(mag, want)
+    assert ml == wml and mp == wmp                      # the reference's sequential float sums (convert.c:225-249), rounding for rounding
+    # ... and for buffer-sized calls with quiet starts, all-zero stretches, a clipped burst and an odd length
+    for k, length in enumerate((131072, 131072, 100001, 7, 1)):
+        blk = iq[2 * 262144 * k: 2 * 262144 * k + 2 * length].copy()
+        if k == 1:
+            blk[: 2 * 5000] = 0
+            blk[2 * 60000: 2 * 60100] = 32767
+        if k == 2:
+            blk[:] = (blk.astype(np.int32) // 700).astype("<i2")     # a weak signal: the sum crawls through many binades
+        m2, ml2, mp2 = d.convert(blk)
+        w2, wml2, wmp2 = helpers.oracle_convert(blk, fmt)
+        assert np.array_equal(m2, w2) and ml2 == wml2 and mp2 == wmp2, (k, ml2, wml2, mp2, wmp2)
+    d.close()

@@ -29,4 +29,4 @@ def test_multi_chunk_capture(built, fmt, nfix, fixdf, thr, rate, dense, seconds,
     got, cnt = _run(iq, fmt=fmt, nfix_crc=nfix, fix_df=fixdf, preamble_threshold=thr)
     assert len(want) > 50000
     helpers.assert_same_messages(got, want)
-    helpers.assert_same_counters(cnt, wst, float_tol=0.02 if fmt else 0.0)
+    helpers.assert_same_counters(cnt, wst)          # (SC16 formats included: their mean power is the reference's float sum, bit for bit)

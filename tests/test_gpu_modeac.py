@@ -1,6 +1,6 @@
 """-m gpu: Mode A/C replies (demodulate2400AC, demod_2400.c:575-761) beside Mode S, in netUseMessage order
-(per buffer: the Mode S messages, then the replies), against the CPU oracle; UC8 input (the reply threshold
-depends on the converter's exact per-buffer sums)."""
+(per buffer: the Mode S messages, then the replies), against the CPU oracle; every input format (the reply threshold
+depends on the converter's exact per-buffer sums: integer for UC8, the reference's sequential float sums for SC16 / SC16Q11)."""
 import numpy as np
 import pytest
 
@@ -74,13 +74,16 @@ def test_mag_buf_entry_with_mode_ac(built):
     helpers.assert_same_counters(cnt, wst)
 
 
-def test_mode_ac_sc16_iq_entry_is_refused(built):
-    """The IQ entry with Mode A/C and an SC16 format would use exact sums where the reference uses an order-dependent float
-    running sum (convert.c:225-249): refused loudly (MGPU_E_INVAL), never approximately decoded."""
-    import readsb_amd
-    iq = helpers.synth(seconds=0.2, seed=5, fmt=2)
-    d = readsb_amd.Demodulator(fmt=2, mode_ac=1, startup_time_ms=helpers.STARTUP_MS, max_samples=max(len(iq) // 4, 131072))
-    with pytest.raises(readsb_amd.MgpuError) as ei:
-        d.demodulate_capture(iq)
-    assert "mgpu_demod_mag_buf_ac" in str(ei.value)
-    d.close()
+@pytest.mark.parametrize("fmt,seconds,rate,seed", [(2, 3.0, 800.0, 414), (1, 2.0, 500.0, 415)])
+def test_mode_ac_on_the_sc16_formats(built, fmt, seconds, rate, seed):
+    """Mode A/C on the IQ entry with SC16Q11 / SC16 input: the reply threshold comes from the buffer's mean level and power, which
+    the reference's converters accumulate as sequential FLOAT sums (convert.c:225-249, 342-366) — reproduced bit for bit
+    (k_fsum_sc16), so the replies and every counter, the noise power sums included, equal the reference's."""
+    iq = helpers.synth(seconds=seconds, seed=seed, rate=rate, dense=2, fmt=fmt, threads=16)
+    want, wst = helpers.oracle_run(iq, fmt, 1, 1, 58, mode_ac=1)
+    got, cnt = _run(iq, fmt=fmt)
+    nac = int((want["msgtype"] == 77).sum())
+    assert nac > 100 and (want["msgtype"] != 77).sum() > 100
+    helpers.assert_same_messages(got, want)
+    helpers.assert_same_counters(cnt, wst)
+    assert int(cnt["demod_modeac"]) == nac == int(wst["demod_modeac"])

@@ -163,6 +163,7 @@ struct Slot {
     bool window_pending = false;
     unsigned long long *h_counters = nullptr, *h_sums = nullptr, *h_win = nullptr, *h_sig = nullptr;
     double *h_fsums = nullptr;
+    double *d_fsx = nullptr, *h_fsx = nullptr;   // SC16 formats: the float sums' own device / page-locked buffers (k_fsum_sc16 runs beside the chunk and ends on its own)
     uint32_t *h_msg_pos = nullptr, *h_msg_limit = nullptr;
     uint16_t *h_msg_len = nullptr, *h_msg_skip = nullptr;
     hipEvent_t ev[7] = {};               // 3: the chunk is complete (always recorded) | stage timing, sampled chunks only (timed): 0 1 convert, 5 4 k_sweep, 4 2 k_slice, 6 3 post-sweep
@@ -646,6 +647,12 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
         sl.h_counters = sl.h_scratch;
         sl.h_sums = sl.h_scratch + CNT_NUM + 1;                 // level[nb] then power[nb]
         sl.h_fsums = (double *) (sl.h_scratch + CNT_NUM + 1 + 2 * nb);   // level[nb] then power[nb]
+        if (c->cfg.format != MGPU_FMT_UC8) {
+            HIPCHK(c, hipMalloc(&sl.d_fsx, 2 * nb * sizeof(double)));
+            HIPCHK(c, hipHostMalloc(&sl.h_fsx, 2 * nb * sizeof(double)));
+            HIPCHK(c, hipMemsetAsync(sl.d_fsx, 0, 2 * nb * sizeof(double), c->stream));
+            sl.d_fsum_level = sl.d_fsx; sl.d_fsum_power = sl.d_fsx + nb; sl.h_fsums = sl.h_fsx;
+        }
     }
     HIPCHK(c, hipMalloc(&sl.d_win, 8 * sizeof(unsigned long long)));
     HIPCHK(c, hipMalloc(&sl.d_win_part, kWinPartWords * sizeof(unsigned long long)));
@@ -686,6 +693,8 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
 static void free_slot(Slot &sl) {
     if (sl.h_blob) (void) hipHostFree(sl.h_blob);
     if (sl.h_live_win) (void) hipHostFree(sl.h_live_win);
+    if (sl.h_fsx) (void) hipHostFree(sl.h_fsx);
+    if (sl.d_fsx) (void) hipFree(sl.d_fsx);
     void *dev[] = {sl.d_live_win, sl.d_dealer, sl.d_blob, sl.d_live, sl.d_live_sig, sl.d_mag, sl.d_pool, sl.d_scratch, sl.d_unit_first, sl.d_unit_count, sl.d_unit_live, sl.d_class_bitmap,
                    sl.d_class_uncond, sl.d_class_final, sl.d_cand, sl.d_cand_count, sl.d_sweep_part,
                    sl.d_win, sl.d_win_part, sl.d_msg_pos,
@@ -995,9 +1004,11 @@ static int enqueue_convert(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
         launch_convert(cfg.format, cp, s);
         if (cfg.format != MGPU_FMT_UC8) {
             // mean level / power of the SC16 formats = the reference's sequential float sums: a chain per buffer, ~0.2 ms, on the second
-            // stream beside this chunk's sweep and slicer; whoever needs them (Mode A/C below, k_publish) waits for ev_fsum
+            // stream beside this chunk's kernels, into buffers of its own; whoever needs them (Mode A/C below, the fetcher) waits for ev_fsum
             HIPCHK(c, hipStreamWaitEvent(c->stream2, sl.ev_pre, 0));
-            launch_fsum_sc16(cfg.format, iq, n, cfg.buf_samples, sl.d_fsum_level, sl.d_fsum_power, c->stream2);
+            HIPCHK(c, hipMemsetAsync(sl.d_fsx, 0, 2 * c->cap_buffers * sizeof(double), c->stream2));
+            launch_fsum_sc16(cfg.format, iq, n, cfg.buf_samples, sl.d_fsum_level, sl.d_fsum_power, cfg.mode_ac ? 1 : 0, c->stream2);
+            HIPCHK(c, hipMemcpyAsync(sl.h_fsx, sl.d_fsx, 2 * c->cap_buffers * sizeof(double), hipMemcpyDeviceToHost, c->stream2));
             HIPCHK(c, hipEventRecord(sl.ev_fsum, c->stream2));
             sl.fsum_pending = true;
         }
@@ -1076,7 +1087,6 @@ static int enqueue_post(mgpu_ctx *c, Slot &sl) {
     q.keep_masks = true;
     q.fin_part = sl.d_sweep_part + (size_t) kSweepGridMax * 4;
     q.slice_part = sl.d_sweep_part; q.slice_blocks = sl.slice_blocks;       // k_slice's rows of counts (0 rows: the experiments build's fused kernel counts for itself)
-    if (sl.fsum_pending) { HIPCHK(c, hipStreamWaitEvent(s, sl.ev_fsum, 0)); sl.fsum_pending = false; }   // k_publish copies the sums out
     if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[6], s));
     if (launch_prescreen(q, s, s, sl.ev_scan) != 0) { c->err = "event ordering of the pre-screen passes failed"; return MGPU_E_HIP; }
     HIPCHK(c, hipEventRecord(sl.ev[3], s));
@@ -1176,6 +1186,7 @@ static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
     job.buffers = sl.buffers;
     job.given_mean_power = sl.given_mean_power;
     job.sums.assign(sl.h_sums, sl.h_sums + 2 * c->cap_buffers);
+    if (sl.fsum_pending) { HIPCHK(c, hipEventSynchronize(sl.ev_fsum)); sl.fsum_pending = false; }   // the float sums have their own pace
     job.fsums.assign(sl.h_fsums, sl.h_fsums + 2 * c->cap_buffers);
     // ---- counters that do not depend on the skip windows ----
     const unsigned long long *hc = sl.h_counters;
@@ -2137,7 +2148,7 @@ int mgpu_convert(mgpu_ctx *c, const void *iq_host, uint16_t *mag_host, uint32_t 
         cp.sum_level = sl.d_sum_level; cp.sum_power = sl.d_sum_power;
         cp.fsum_level = sl.d_fsum_level; cp.fsum_power = sl.d_fsum_power;
         launch_convert(c->cfg.format, cp, s);
-        launch_fsum_sc16(c->cfg.format, c->d_iq, len, 0x80000000u, sl.d_fsum_level, sl.d_fsum_power, s);   // (the call's one bucket: the state carries over)
+        launch_fsum_sc16(c->cfg.format, c->d_iq, len, 0x80000000u, sl.d_fsum_level, sl.d_fsum_power, 1, s);   // (the call's one bucket: the state carries over)
         HIPCHK(c, hipMemcpyAsync(mag_host + off, sl.d_mag + kTrailing, len * sizeof(uint16_t), hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
     }

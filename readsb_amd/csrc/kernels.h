@@ -132,7 +132,8 @@ struct ConvertParams {
 
 void launch_convert(int format, const ConvertParams &p, hipStream_t s);
 // SC16 formats: the per-buffer sequential float sums of mag / magsq (convert.c:225-249), exact; state in and out as doubles holding floats
-void launch_fsum_sc16(int format, const uint8_t *iq, uint64_t n, uint32_t buf_samples, double *fsum_level, double *fsum_power, hipStream_t s);
+void launch_fsum_sc16(int format, const uint8_t *iq, uint64_t n, uint32_t buf_samples, double *fsum_level, double *fsum_power, int want_level,
+                      hipStream_t s);
 unsigned launch_sweep(const SweepParams &p, hipStream_t s);        // k_sweep: preamble sweep -> per-step candidate lists; returns its grid size
 void sweep_pace_feedback(float kernel_us, uint64_t n, unsigned blocks);   // a timed k_sweep launch: feeds the pacing's step-time estimate
 unsigned launch_slice(const SweepParams &p, hipStream_t s);        // k_slice: slicer + CRC + scoring over the candidate lists -> record pool; returns its grid size (rows of sweep_part)

@@ -254,6 +254,11 @@ int mgpu_filter_expire(mgpu_ctx *ctx);
 int mgpu_filter_add(mgpu_ctx *ctx, uint32_t addr);
 
 int mgpu_last_timing(mgpu_ctx *ctx, struct mgpu_timing *t);
+/* What mgpu_timing's per-kernel figures (convert_ms, sweep_ms, slice_ms: a pair of timing HIP events around ONE kernel in a busy
+ * stream) contain beyond the kernel's own duration: measured here, now, with a kernel of known duration (it spins 20 us on the
+ * GPU's 100 MHz counter) between two such events — 4.0 us on an MI355X under ROCm 7.2, whatever the kernel's length
+ * (tools/micro/event_overhead.hip).  bench.py subtracts it from its per-launch figures and reports both. */
+int mgpu_event_bracket_us(mgpu_ctx *ctx, float *us);
 
 /* ---- the two plugin-surface pieces on their own ----------------------------------- */
 

@@ -159,6 +159,7 @@ def load_library():
     lib.mgpu_pending_messages.restype = u64
     lib.mgpu_last_timing.argtypes = [vp, C.POINTER(Timing)]
     lib.mgpu_debug_device_walk.argtypes = [vp, C.POINTER(u64)]
+    lib.mgpu_event_bracket_us.argtypes = [vp, C.POINTER(C.c_float)]
     lib.mgpu_convert.argtypes = [vp, vp, vp, u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.mgpu_demod_mag_buf.argtypes = [vp, vp, u32, i64, i64, C.c_double, u32]
     lib.mgpu_demod_mag_buf_ac.argtypes = [vp, vp, u32, i64, i64, C.c_double, C.c_double, u32]
@@ -434,6 +435,12 @@ class Demodulator:
         self._chk(self.lib.mgpu_debug_device_walk(self.ctx, out), "mgpu_debug_device_walk")
         keys = ("chunks", "device", "unsettled", "premises_failed", "not_modelled", "walks", "differences")
         return dict(zip(keys, [int(v) for v in out]))
+
+    def event_bracket_us(self):
+        """mgpu_event_bracket_us: what a pair of timing events around one kernel reports beyond the kernel itself (us)."""
+        v = C.c_float(0)
+        self._chk(self.lib.mgpu_event_bracket_us(self.ctx, C.byref(v)), "mgpu_event_bracket_us")
+        return float(v.value)
 
     def timing(self):
         t = Timing()

@@ -2112,6 +2112,33 @@ int mgpu_debug_device_walk(mgpu_ctx *c, uint64_t out[8]) {
     return MGPU_OK;
 }
 
+int mgpu_event_bracket_us(mgpu_ctx *c, float *us) {
+    if (!c || !us) return MGPU_E_INVAL;
+    { const int rc = drain(c); if (rc != MGPU_OK) return rc; }
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    hipEvent_t a = nullptr, b = nullptr;
+    HIPCHK(c, hipEventCreate(&a));
+    HIPCHK(c, hipEventCreate(&b));
+    std::vector<float> v;
+    const unsigned blocks = 1536, known_us = 20;
+    for (int r = 0; r < 24; ++r) {                  // | 50 us of something | ev | 20 us, exactly | ev | 50 us of something |
+        launch_spin(50, blocks, nullptr, c->stream);
+        (void) hipEventRecord(a, c->stream);
+        launch_spin(known_us, blocks, nullptr, c->stream);
+        (void) hipEventRecord(b, c->stream);
+        launch_spin(50, blocks, nullptr, c->stream);
+        if (hipStreamSynchronize(c->stream) != hipSuccess) break;
+        float ms = 0;
+        if (r >= 4 && hipEventElapsedTime(&ms, a, b) == hipSuccess) v.push_back(ms * 1e3f - (float) known_us);
+    }
+    (void) hipEventDestroy(a);
+    (void) hipEventDestroy(b);
+    if (v.empty()) { c->err = "mgpu_event_bracket_us: no measurement"; return MGPU_E_HIP; }
+    std::sort(v.begin(), v.end());
+    *us = v[v.size() / 2];
+    return MGPU_OK;
+}
+
 int mgpu_last_timing(mgpu_ctx *c, struct mgpu_timing *t) {
     if (!c || !t) return MGPU_E_INVAL;
     (void) drain(c);

@@ -1,3 +1,8 @@
 #!/bin/bash
 cd /root/repo
-timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+mkdir -p gpurun_out/s50
+timeout 600 python bench.py --no-extra-configs > gpurun_out/s50/bench.log 2>&1
+tail -1 gpurun_out/s50/bench.log | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.readline())
+print(d['value'], d['ms_per_step'], d['stage_ms']); print(d['roofline']); print(d['kernels'])"

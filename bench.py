@@ -174,6 +174,7 @@ def run_extra_config(name, fmt, nfix, kw, nsamples, device, steps=4):
     d.collect_feed(bufs[steps % 2], want_counters=True)
     elapsed = time.perf_counter() - t0
     tm = d.timing()
+    bracket_us = d.event_bracket_us()           # what a pair of timing events adds to what it brackets (see main())
     ev_scale = tm["n_chunks"] / max(1, tm["n_timed_chunks"])
     for key in ("convert_ms", "sweep_ms", "slice_ms", "prescreen_ms"):
         tm[key] *= ev_scale
@@ -204,8 +205,10 @@ def run_extra_config(name, fmt, nfix, kw, nsamples, device, steps=4):
            "samples_per_segment": nsamples, "segments_timed": steps, "messages_per_segment": int(len(msgs)),
            "candidates_per_1000_samples": round(tm["n_candidates"] / (nsamples * steps) * 1e3, 2),
            "records_per_1000_samples": round(tm["n_records"] / (nsamples * steps) * 1e3, 2),
-           "us_per_launch": {"convert": round(tm["convert_ms"] / nl * 1e3, 1), "k_sweep": round(tm["sweep_ms"] / nl * 1e3, 1),
-                             "k_slice": round(tm["slice_ms"] / nl * 1e3, 1), "post_sweep": round(tm["prescreen_ms"] / nl * 1e3, 1)},
+           # (per launch, the events' own constant taken off; stage_ms below: as the events report it)
+           "us_per_launch": {"convert": round(tm["convert_ms"] / nl * 1e3 - bracket_us, 1), "k_sweep": round(tm["sweep_ms"] / nl * 1e3 - bracket_us, 1),
+                             "k_slice": round(tm["slice_ms"] / nl * 1e3 - bracket_us, 1), "post_sweep": round(tm["prescreen_ms"] / nl * 1e3 - bracket_us, 1)},
+           "event_bracket_us": round(bracket_us, 2),
            "samples_per_launch": int(nsamples * steps // nl),
            # per segment: the GPU stages (HIP events, summed over the segment's launches) and the host stages behind them (wall
            # clock of the fetcher / walker / builder threads: they overlap each other and the GPU)

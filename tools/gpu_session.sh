@@ -1,8 +1,5 @@
 #!/bin/bash
 cd /root/repo
-mkdir -p gpurun_out/s50
-timeout 600 python bench.py --no-extra-configs > gpurun_out/s50/bench.log 2>&1
-tail -1 gpurun_out/s50/bench.log | python3 -c "
-import json,sys
-d=json.loads(sys.stdin.readline())
-print(d['value'], d['ms_per_step'], d['stage_ms']); print(d['roofline']); print(d['kernels'])"
+export GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+bash tools/profile_round.sh r03d 2>&1 | tail -40 | cut -c1-600
+timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -4

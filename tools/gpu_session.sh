@@ -1,5 +1,5 @@
 #!/bin/bash
 cd /root/repo
-export GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-bash tools/profile_round.sh r03d 2>&1 | tail -40 | cut -c1-600
-timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+mkdir -p gpurun_out/dump
+MGPU_DUMP_DIR=gpurun_out/dump timeout 300 python bench.py --no-extra-configs --no-cpu-baseline --steps 1 --warmup 0 2>&1 | tail -1 | cut -c1-200
+ls -la gpurun_out/dump

@@ -133,6 +133,26 @@ EXTRA_CONFIGS = {
 EXTRA_ENV = {"UC8 --fix, ordered walk on the device (MGPU_DEVICE_WALK=1)": {"MGPU_DEVICE_WALK": "1"}}
 
 
+try:
+    ORIG_AFFINITY = os.sched_getaffinity(0)
+except (AttributeError, OSError):
+    ORIG_AFFINITY = None
+
+
+def restore_affinity():
+    """A context pins its pipeline to cores it picks among those the CALLING thread may run on, and keep_other_threads_away() then takes
+    those cores (and their SMT siblings) away from every other thread of the process, the calling one included.  A context created
+    later by the same thread would pick among what is left — cores of other L3 groups, further from the device (measured: the
+    extra configurations' host walk 2 x slower than in a process of their own) — so the masks go back before the next context."""
+    if ORIG_AFFINITY is None:
+        return
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            os.sched_setaffinity(int(tid), ORIG_AFFINITY)
+        except OSError:
+            pass
+
+
 def run_extra_config(name, fmt, nfix, kw, nsamples, device, steps=4):
     """One more configuration on a fresh context: `steps` back-to-back segments of a resident stream with deferred feeds (timed),
     then two more deferred segments of a fresh stream, fed the same way, whose messages and counters must equal the reference's
@@ -140,6 +160,7 @@ def run_extra_config(name, fmt, nfix, kw, nsamples, device, steps=4):
     import helpers
     import readsb_amd
     iq = helpers.synth(nsamples=nsamples, fmt=fmt, seed=424242, threads=min(64, os.cpu_count() or 8), **kw)
+    restore_affinity()                          # (the previous context of this process is closed: its cores are free again)
     env = EXTRA_ENV.get(name, {})
     saved = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
@@ -356,7 +377,7 @@ def main():
                                                           "capture time-chunked over the GPUs (configs[4], strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the `configs` dict (other BASELINE configurations / input statistics)")
-    ap.add_argument("--extra-samples", type=int, default=2048 * BUF, help="samples per segment of the extra configurations")
+    ap.add_argument("--extra-samples", type=int, default=4096 * BUF, help="samples per segment of the extra configurations (default: the headline step)")
     ap.add_argument("--main-cpu", type=int, default=-1, help="experiment: pin the calling thread to this CPU after the context exists")
     ap.add_argument("--exercise-gather", action="store_true", help="run the N>1 aggregator exchange even with one rank (needs torchrun env)")
     ap.add_argument("--dryrun-gloo", action="store_true",

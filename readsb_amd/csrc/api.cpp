@@ -443,6 +443,18 @@ static void release_device_slot(int device, int slot) {
     g_device_slots[device & 63] &= ~(1u << slot);
 }
 
+// What the PROCESS may run on (cgroups, taskset): the mask of the thread that loaded the library, taken once, at load time.  Not the
+// calling thread's mask of the moment: an application that follows mgpu_host_cpus' advice keeps its own threads — the one that
+// creates the next context included — OFF the first context's cores, and a second context that picked its cores from that
+// thread's mask landed on other L3 groups, its walk 2-3 x slower (bench.py's extra configurations, rounds 2 and 3).
+static cpu_set_t g_process_cpus;
+static bool g_process_cpus_ok = false;
+__attribute__((constructor)) static void remember_process_cpus() { g_process_cpus_ok = sched_getaffinity(0, sizeof(g_process_cpus), &g_process_cpus) == 0; }
+static bool process_cpus(cpu_set_t *out) {
+    if (g_process_cpus_ok) { *out = g_process_cpus; return true; }
+    return sched_getaffinity(0, sizeof(*out), out) == 0;
+}
+
 // CPUs of the device's NUMA node that the process may use (empty set: unknown)
 static bool device_local_cpus(int device, cpu_set_t *out) {
     CPU_ZERO(out);
@@ -457,7 +469,7 @@ static bool device_local_cpus(int device, cpu_set_t *out) {
     fclose(f);
     if (!ok) return false;
     cpu_set_t allowed;
-    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return false;
+    if (!process_cpus(&allowed)) return false;
     int n = 0;
     for (char *tok = strtok(line, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
         int a = 0, b = 0;
@@ -505,7 +517,7 @@ static void bind_near_device(std::thread *const *walk, int nwalk, std::thread *c
     fclose(f);
     if (!ok) return;
     cpu_set_t allowed;                     // never step outside what the process may use (cgroups, taskset)
-    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
+    if (!process_cpus(&allowed)) return;
     std::vector<int> cpus;
     for (char *tok = strtok(line, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
         int a = 0, b = 0;

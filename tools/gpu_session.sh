@@ -1,10 +1,9 @@
 #!/bin/bash
 cd /root/repo
-mkdir -p gpurun_out/s62
-timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-timeout 900 python bench.py > gpurun_out/s62/bench.log 2> gpurun_out/s62/bench.err
-tail -1 gpurun_out/s62/bench.log | python3 -c "
+TR="python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533"
+for mode in "" "--exercise-gather" "" "--exercise-gather"; do
+timeout 600 $TR bench.py --gpus 1 $mode --no-extra-configs --no-cpu-baseline --steps 20 --warmup 3 2>/dev/null | tail -1 | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.readline())
-print(d['value'], d['ms_per_step'], d['stage_ms'], d['roofline']['frac'], d['roofline']['avg_launch_ms'], d['kernels']['k_slice']['avg_launch_ms'])
-for k,v in d.get('configs',{}).items(): print(k, v.get('msamples_s'), v.get('ms_per_segment'))"
+print('$mode', d['value'], d['ms_per_step'], d['stage_ms'])"
+done

@@ -159,7 +159,9 @@ void Resolver::reset(int64_t startup_ms, int clock_mode) {
 void Resolver::after_buffer() {
     // backgroundTasks(now = mstime()) after every buffer (readsb.c:899-902, 1227-1231)
     if (synthetic_now_ >= next_flip_) {
+        exp_lo_ = chunk_drops_.size();         // (what the expiry takes out of the union, when the changes are being tracked)
         filter_.expire();
+        exp_hi_ = chunk_drops_.size();
         next_flip_ = synthetic_now_ + kFilterTtlMs;
         ++nflips_;
     }
@@ -257,7 +259,10 @@ struct SpecPolicy {
         if (a >> 24) { w.odd = true; return flt.test(a); }
         if (w.added.test(a)) return true;
         w.q_pre.set(a);
-        return flt.test(a) || w.assumed.test(a);
+        // Behind the batch's expiry the generation that was inactive when the batch started is gone and the one that was active is
+        // the other, still known, one: exactly predictable, so a range does not have to be walked again because an expiry fell
+        // into the chunk (round 3; until then every range behind it failed its commit on the first address the expiry had dropped).
+        return (w.flipped ? flt.in_generation(a, true) : flt.test(a)) || w.assumed.test(a);
     }
     void add(uint32_t a) {
         w.added.set(a);
@@ -272,6 +277,7 @@ struct SpecPolicy {
             w.flip_at = (int32_t) (w.b_lo + w.end_clock.size() - 1);
             ++w.nflip;
             w.flip_clock = now + kFilterTtlMs;
+            w.flipped = true;
             w.recorded.clear();          // after an expiry the active generation is empty: every address counts again
         }
     }
@@ -382,7 +388,9 @@ void Resolver::collect_adders(const PhaseRec *recs, SegmentWalk &w) const {
     for (uint64_t i = w.rec_lo; i < w.rec_hi; ++i) {
         if (!(recs[i].flags & REC_ADDER)) continue;
         const uint32_t a = recs[i].addr & 0xffffffu;
-        if (filter_.test(a) || w.cand_seen.test(a)) continue;
+        // not in the ACTIVE generation: a new address, or one the expiry would drop had this frame not refreshed it (a range behind
+        // the expiry takes "known" from the active generation + these)
+        if (filter_.in_generation(a, true) || w.cand_seen.test(a)) continue;
         w.cand_seen.set(a);
         w.candidates.push_back(a);
     }
@@ -392,6 +400,7 @@ void Resolver::spec_walk(const PhaseRec *recs, const std::vector<BufferClock> &b
     w.added.ensure(); w.q_pre.ensure(); w.recorded.ensure();
     w.added.clear(); w.q_pre.clear(); w.recorded.clear();
     w.flip_at = -1; w.nflip = 0;
+    w.flipped = w.after_flip;
     w.adds.clear(); w.adds_end.clear(); w.end_clock.clear();
     w.counts = ResolveCounts();
     w.speculated = false;
@@ -414,7 +423,11 @@ bool Resolver::commit_segment(const PhaseRec *recs, const std::vector<BufferCloc
         const uint32_t a = w.assumed.list[i];
         if (!filter_.test(a) && w.q_pre.test(a)) ok = false;
     }
-    for (size_t i = 0; ok && i < chunk_drops_.size(); ++i) ok = !w.q_pre.test(chunk_drops_[i]);
+    // (what the batch's expiry dropped is what a range behind it left out of "known" itself)
+    for (size_t i = 0; ok && i < chunk_drops_.size(); ++i) {
+        if (w.after_flip && i >= exp_lo_ && i < exp_hi_) continue;
+        ok = !w.q_pre.test(chunk_drops_[i]);
+    }
     for (size_t i = 0; ok && i < chunk_news_.size(); ++i) {
         const uint32_t a = chunk_news_[i];
         if (!w.assumed.test(a) && w.q_pre.test(a)) ok = false;
@@ -423,7 +436,7 @@ bool Resolver::commit_segment(const PhaseRec *recs, const std::vector<BufferCloc
     //     expiry or a resize inside the range drops must not be something the range asked about; the expiry must
     //     come where the range itself put it (it restarted its list of first adds there), and only once (a
     //     second one could drop the range's own adds).
-    const size_t drops0 = chunk_drops_.size(), news0 = chunk_news_.size();
+    const size_t drops0 = chunk_drops_.size(), news0 = chunk_news_.size(), exp_lo0 = exp_lo_, exp_hi0 = exp_hi_;
     const int64_t now0 = synthetic_now_, flip0 = next_flip_;
     const uint64_t nflips0 = nflips_;
     if (ok) ok = w.nflip <= 1;
@@ -441,10 +454,22 @@ bool Resolver::commit_segment(const PhaseRec *recs, const std::vector<BufferCloc
             if (nflips_ != f) { if (flipped_at >= 0) ok = false; flipped_at = (int32_t) bi; }
         }
         if (flipped_at != w.flip_at) ok = false;
-        for (size_t i = drops0; ok && i < chunk_drops_.size(); ++i) ok = !w.q_pre.test(chunk_drops_[i]);
+        // the range's own expiry, where it put it itself: it answered from both generations before it and from the surviving one
+        // behind it — what the expiry drops is accounted for; what a resize drops is not
+        for (size_t i = drops0; ok && i < chunk_drops_.size(); ++i) {
+            if (flipped_at >= 0 && i >= exp_lo_ && i < exp_hi_) {
+                // ... except an address the range took for refreshed by an earlier range's frame (assumed) that was not: before
+                // its expiry both answers are "known", behind it only the assumption's
+                if (w.assumed.test(chunk_drops_[i]) && w.q_pre.test(chunk_drops_[i])) ok = false;
+                continue;
+            }
+            // (... nor is the range's own add of an address before its expiry, which a growing table behind the expiry drops
+            // with the rest of that generation: the range would go on answering "known" from its own set)
+            ok = !w.q_pre.test(chunk_drops_[i]) && !w.added.test(chunk_drops_[i]);
+        }
         if (!ok) {
             filter_.restore(snap);
-            chunk_drops_.resize(drops0); chunk_news_.resize(news0);
+            chunk_drops_.resize(drops0); chunk_news_.resize(news0); exp_lo_ = exp_lo0; exp_hi_ = exp_hi0;
             synthetic_now_ = now0; next_flip_ = flip0; nflips_ = nflips0;
         }
     }
@@ -477,6 +502,7 @@ void Resolver::adopt(Resolver &shadow) {
     synthetic_now_ = shadow.synthetic_now_; next_flip_ = shadow.next_flip_; nflips_ = shadow.nflips_;
     chunk_drops_.swap(shadow.chunk_drops_);
     chunk_news_.swap(shadow.chunk_news_);
+    exp_lo_ = shadow.exp_lo_; exp_hi_ = shadow.exp_hi_;
 }
 
 void Resolver::parallel_walk(const PhaseRec *recs, uint64_t nrecs, const std::vector<BufferClock> &buffers, std::vector<SegmentWalk> &segs,
@@ -490,6 +516,7 @@ void Resolver::parallel_walk(const PhaseRec *recs, uint64_t nrecs, const std::ve
         const int nb = K - t0;
         if (batches) ++*batches;
         run(nb, [&](int i) { collect_adders(recs, segs[t0 + i]); });
+        exp_lo_ = exp_hi_ = 0;
         for (int t = t0 + 1; t < K; ++t) {                   // assumed(t) = candidates of ranges t0 .. t-1
             SegmentWalk &w = segs[t];
             w.assumed.ensure();
@@ -501,15 +528,18 @@ void Resolver::parallel_walk(const PhaseRec *recs, uint64_t nrecs, const std::ve
             // not -> it watches for it itself; surely yes -> the next one is 60 s away; the buffer in between, or
             // a chunk longer than the filter's TTL -> no speculation.
             w.odd = false;
+            w.after_flip = false;
             const int64_t prev = buffers[w.b_lo - 1].sysTimestamp;
             if (prev + kBufferSpanMs < next_flip_) w.flip_clock = next_flip_;
-            else if (prev >= next_flip_ && buffers[w.b_hi - 1].sysTimestamp + kBufferSpanMs < next_flip_ + kFilterTtlMs - kBufferSpanMs)
+            else if (prev >= next_flip_ && buffers[w.b_hi - 1].sysTimestamp + kBufferSpanMs < next_flip_ + kFilterTtlMs - kBufferSpanMs) {
                 w.flip_clock = std::numeric_limits<int64_t>::max();
-            else w.odd = true;
+                w.after_flip = true;
+            } else w.odd = true;
         }
         shadow_->copy_state_from(*this);
         shadow_->chunk_drops_.clear();
         shadow_->chunk_news_.clear();
+        shadow_->exp_lo_ = shadow_->exp_hi_ = 0;
         shadow_->filter_.track_changes(&shadow_->chunk_drops_, &shadow_->chunk_news_);
         run(nb, [&](int i) {
             if (i == 0) shadow_->serial_segment(recs, buffers, segs[t0]);      // the true walk, on the private copy

@@ -128,6 +128,8 @@ struct SegmentWalk {
     // what the decisions assumed
     AddrSet added;                        // own adds so far
     AddrSet recorded;                     // own adds since the range's last expiry (what `adds` leaves out as repeats)
+    bool flipped = false;                 // the expiry lies behind: known = the batch's ACTIVE generation (+ adds), not both
+    bool after_flip = false;              // ... from the range's first buffer on (the expiry falls into an earlier range)
     int64_t flip_clock = 0;               // the range expires the filter at the first buffer end with clock >= this
     int32_t flip_at = -1;                 // buffer after which it did (-1: never), nflip = how often
     int32_t nflip = 0;
@@ -220,6 +222,7 @@ class Resolver {
     void after_buffer();
     IcaoFilter filter_;
     std::vector<uint32_t> chunk_drops_, chunk_news_;   // union changes since begin_chunk
+    size_t exp_lo_ = 0, exp_hi_ = 0;                   // ... of them, what the batch's expiry dropped: chunk_drops_[exp_lo_, exp_hi_)
     int64_t synthetic_now_ = 0, next_flip_ = 0;
     uint64_t nflips_ = 0;
 };

@@ -94,7 +94,12 @@ def test_host_uc8_table_matches_reference(built):
 
 
 WALK_CASES = [(1, 12, 256, 4, 50), (2, 12, 256, 8, 200), (3, 30, 128, 3, 20), (4, 8, 512, 6, 500), (5, 40, 64, 5, 10),
-              (6, 20, 300, 7, 100), (7, 6, 512, 2, 2000), (8, 50, 32, 4, 5), (9, 3, 2400, 4, 100), (10, 4, 1500, 16, 300)]
+              (6, 20, 300, 7, 100), (7, 6, 512, 2, 2000), (8, 50, 32, 4, 5), (9, 3, 2400, 4, 100), (10, 4, 1500, 16, 300),
+              # the pipeline's own shape (512 and 1024 buffers in 8 ranges), and streams on which a first version of the ranges'
+              # handling of an expiry inside the chunk went wrong: many aircraft, the table growing behind the expiry, an address
+              # taken for refreshed by an earlier range's frame that was not
+              (11, 40, 512, 8, 200), (12, 40, 1024, 8, 200), (314295693908, 30, 256, 5, 3000), (172793523793, 17, 1024, 6, 1000),
+              (1071970496161, 30, 512, 15, 1000), (947893337438, 12, 700, 16, 3000)]
 
 
 def test_parallel_walk_equals_serial_walk(built):

@@ -210,7 +210,9 @@ void *mgpu_device_iq_buffer(mgpu_ctx *ctx);
 
 /* The CPUs the context pinned its host threads to (one physical core each, one L3; 0 = not pinned, e.g. with
  * MGPU_NO_AFFINITY=1).  An application that wants the full speed keeps its own busy threads off these cores and
- * their SMT siblings: a thread of the application sharing a core with a pipeline stage costs up to 30 %. */
+ * their SMT siblings: a thread of the application sharing a core with a pipeline stage costs up to 30 %.
+ * The cores are chosen among the CPUs the process could run on when the library was LOADED (cgroups, taskset) — not among those
+ * the creating thread may use at the moment, so that an application following the advice above can create further contexts. */
 int mgpu_host_cpus(mgpu_ctx *ctx, int32_t *cpus, int32_t cap);
 
 /* Page-locked host memory placed on the device's NUMA node (hipHostMalloc while the calling thread sits on that node), for the

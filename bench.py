@@ -246,27 +246,32 @@ def run_extra_config(name, fmt, nfix, kw, nsamples, device, steps=4):
 
 def bench_config5(args, rank, local_rank, world):
     """BASELINE configs[4]: ONE dense-burst capture (overlapping 112-bit DF17 frames, --aggressive) time-chunked by whole buffers
-    over the ranks (readsb_amd/shard.py): rank 0 puts the first range through the ordinary pipeline; every other rank sweeps the
-    120 s before its range for their adder addresses, then its range against them, and ships the surviving records to rank 0
-    (gather), which continues its stream with them — the unsharded message list and counters, bit for bit.  Strong scaling: the
-    capture is fixed, a step = the whole capture once; every rank's samples are resident in its HBM (its own device
-    allocation: --samples 8640000000 = the one-hour capture of BASELINE.json, 17.3 GB, fits one MI355X).  With one rank the same
-    capture also runs through the deferred-feed loop of the headline benchmark in the same process: `unsharded` in the JSON line."""
+    over the ranks, every rank walking and building its OWN range (readsb_amd/shard.py: ShardWalkRank / run_walk_protocol; round 4
+    — rounds 2-3 shipped every range's records to rank 0, which walked the whole capture alone).  Strong scaling: the capture is
+    fixed, a step = the whole capture once; every rank's samples (its range + two filter generations of warm-up) are resident in
+    its HBM (--samples 8640000000 = the one-hour capture of BASELINE.json, 17.3 GB, fits one MI355X).
+      N = 1: the capture through the ordinary pipeline (one stream, deferred feeds) — with one rank sharding IS that;
+      N > 1: the protocol over torch.distributed (RCCL, or gloo with --dryrun-gloo);
+      --emulate-ranks K on ONE GPU: one context plays K ranks one after the other, every rank's phases timed on their own, the
+      all-gathers replaced by lists: what each rank would spend, what the combining rank does on top of its own share, and
+      the result checked against the unsharded run and the reference like any other."""
     import torch
     import torch.distributed as dist
     import helpers
     import readsb_amd
-    from readsb_amd.shard import demodulate_sharded, shard_ranges, needed_from, warmup_start
+    from readsb_amd import shard
+    from readsb_amd.shard import shard_ranges, needed_from, warmup_start
     dev = 0 if args.dryrun_gloo else local_rank
     torch.cuda.set_device(dev)
     coll = torch.device("cpu") if args.dryrun_gloo else torch.device("cuda", local_rank)
-    if not dist.is_initialized():
+    if world > 1 and not dist.is_initialized():
         if args.dryrun_gloo:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     helpers.ensure_built()
     n = args.samples - args.samples % BUF
+    emu = args.emulate_ranks if world == 1 else 0
     first, last = shard_ranges(n, world)[rank]
     lo = needed_from(first)
     threads = min(64, max(1, (os.cpu_count() or 8) // world))
@@ -274,96 +279,171 @@ def bench_config5(args, rank, local_rank, world):
     mine = helpers.synth(nsamples=last - lo, first=lo, seed=5150, rate=8000.0, dense=1, threads=threads)   # the rank's range, its warm-up and histories
     t_gen = time.time() - t_g0
     d_iq = torch.from_numpy(mine).to(torch.device("cuda", dev))            # resident: its own allocation, any length
-    wf = warmup_start(first)
-    histories = (None if wf == 0 else mine[(wf - 326 - lo) * 2:(wf - lo) * 2].copy(), None if first == 0 else mine[(first - 326 - lo) * 2:(first - lo) * 2].copy())
-    piece = min(8192 * BUF, max(BUF, last - first))                          # samples per feed call (rank 0 feeds synchronously: a drain per call)
+    piece = min(8192 * BUF, max(BUF, last - first))                          # samples per feed call
     d = readsb_amd.Demodulator(nfix_crc=2, max_samples=piece, device=dev, startup_time_ms=helpers.STARTUP_MS)
     resident = (lo, d_iq.data_ptr())
     d.keep_other_threads_away(confine_to_own_l3=world > 1)
-    out_buf = np.empty(int(n // 512 + 65536), dtype=readsb_amd.MSG_DTYPE) if rank == 0 else None   # rank 0 builds every message in place
-    res = None
-    for _ in range(max(0, args.warmup)):
-        res = demodulate_sharded(d, None, coll, resident=resident, nsamples=n, histories=histories, out=out_buf)
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    phases = {}
-    for _ in range(args.steps):
-        res = demodulate_sharded(d, None, coll, resident=resident, nsamples=n, histories=histories, phases=phases, out=out_buf)
-    dist.barrier()
-    torch.cuda.synchronize()
-    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=coll)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    if rank == 0:
-        msgs, counters = res
-        out = {"metric": "IQ Msamples/s demodulated, one dense-burst UC8 capture time-chunked over the GPUs (--aggressive), whole job",
-               "value": round(n * args.steps / elapsed / 1e6, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-               "dtype": "u16", "data": "synthetic",
-               "config": {"workload": f"configs[4]: one {n / 2.4e6:.1f} s dense-burst UC8 capture ({n} samples, 8000 overlapping DF17 frames/s, --aggressive) "
-                                      f"time-chunked by whole buffers over {world} GPU(s), each range (+ 120 s of warm-up before it) resident in its GPU's HBM; "
-                                      "rank 0: first range through the ordinary pipeline, then the other ranks' record packets (gathered) through the ordered walk",
-                          "samples": n, "shards": world, "parallelism": f"time-chunked x{world}"},
-               "messages_per_step": int(len(msgs)), "synth_gen_s": round(t_gen, 2),
-               "rank0_phase_ms_per_step": {k: round(v / args.steps, 3) for k, v in phases.items()}}
-        unsharded = None
-        if world == 1:
-            # the same capture through the headline benchmark's loop (one stream, deferred feeds of `piece` samples, resident IQ)
-            d.set_message_buffer(None)
-            bufs = [np.empty(int(piece // 64 + 65536), dtype=readsb_amd.MSG_DTYPE) for _ in range(2)]
-            offs = list(range(0, n, piece))
 
-            def unsharded_pass(keep):
-                d.reset()
-                d.set_deferred(True)
-                got, nm = [], 0
-                t1 = time.perf_counter()
-                for k, off in enumerate(offs):
-                    d.set_message_buffer(bufs[k % 2])
-                    d.feed_resident(min(piece, n - off), d_iq.data_ptr() + off * 2)
-                    if k >= 1:
-                        m, _ = d.collect_feed(bufs[(k - 1) % 2])
-                        nm += len(m)
-                        if keep:
-                            got.append(m.copy())
-                m, _ = d.collect_feed(bufs[(len(offs) - 1) % 2], want_counters=True)
+    def hist_of(sample):
+        return None if sample == 0 else mine[(sample - 326 - lo) * 2:(sample - lo) * 2].copy()
+
+    # ---- the capture through the ordinary pipeline (one stream, deferred feeds of `piece` samples, resident IQ): N = 1's value,
+    #      and the time everything else is measured against ----
+    def unsharded_pass(keep):
+        bufs = [np.empty(int(piece // 64 + 65536), dtype=readsb_amd.MSG_DTYPE) for _ in range(2)]
+        offs = list(range(0, n, piece))
+        d.reset()
+        d.set_deferred(True)
+        got, nm = [], 0
+        t1 = time.perf_counter()
+        for k, off in enumerate(offs):
+            d.set_message_buffer(bufs[k % 2])
+            d.feed_resident(min(piece, n - off), d_iq.data_ptr() + off * 2)
+            if k >= 1:
+                m, _ = d.collect_feed(bufs[(k - 1) % 2])
                 nm += len(m)
                 if keep:
                     got.append(m.copy())
-                dt = time.perf_counter() - t1
-                d.finish()                                   # end of file: ifileRun's last, empty buffer (sdr_ifile.c:223-237)
-                _, cnt = d.collect_feed(bufs[0], want_counters=True)
-                d.set_deferred(False)
-                return dt, nm, (np.concatenate(got) if keep else None), cnt
+        m, _ = d.collect_feed(bufs[(len(offs) - 1) % 2], want_counters=True)
+        nm += len(m)
+        if keep:
+            got.append(m.copy())
+        dt = time.perf_counter() - t1
+        d.finish()                                   # end of file: ifileRun's last, empty buffer (sdr_ifile.c:223-237)
+        _, cnt = d.collect_feed(bufs[0], want_counters=True)
+        d.set_deferred(False)
+        d.set_message_buffer(None)
+        return dt, nm, (np.concatenate(got) if keep else None), cnt
 
-            best = None
-            for _ in range(max(1, args.steps)):              # timed: the consumer takes each feed's messages where they are built
-                dt, nm, _, _ = unsharded_pass(False)
-                best = dt if best is None or dt < best else best
-            _, _, um, uc = unsharded_pass(True)              # checked: the same feeds, their messages kept
-            unsharded = {"msamples_s": round(n / best / 1e6, 1), "ms": round(best * 1e3, 3), "messages": int(len(um)),
-                         "sharded_over_unsharded": round((n * args.steps / elapsed) / (n / best), 3)}
-            assert len(um) == len(msgs) and um.tobytes() == msgs.tobytes(), "sharded and unsharded message lists differ"
-            unsharded["identical_to_sharded"] = True
-            out["unsharded"] = unsharded
+    out = {"metric": "IQ Msamples/s demodulated, one dense-burst UC8 capture time-chunked over the GPUs (--aggressive), whole job",
+           "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "u16", "data": "synthetic", "synth_gen_s": round(t_gen, 2)}
+    workload = (f"configs[4]: one {n / 2.4e6:.1f} s dense-burst UC8 capture ({n} samples, 8000 overlapping DF17 frames/s, --aggressive) "
+                f"time-chunked by whole buffers over {world} GPU(s), each range (+ {shard.WARMUP / 2.4e6:.1f} s of warm-up before it) resident in its GPU's HBM; ")
+    msgs = counters = None
+    um = uc = None
+    if world == 1:
+        for _ in range(max(0, args.warmup)):
+            unsharded_pass(False)
+        torch.cuda.synchronize()
+        best, total = None, 0.0
+        for _ in range(max(1, args.steps)):              # timed: the consumer takes each feed's messages where they are built
+            dt, nm, _, _ = unsharded_pass(False)
+            total += dt
+            best = dt if best is None or dt < best else best
+        _, _, um, uc = unsharded_pass(True)              # checked: the same feeds, their messages kept
+        msgs, counters = um, uc
+        elapsed = total
+        out.update(value=round(n * max(1, args.steps) / elapsed / 1e6, 1), ms_per_step=round(elapsed / max(1, args.steps) * 1e3, 3), messages_per_step=int(len(um)),
+                   best_step_ms=round(best * 1e3, 3))
+        out["config"] = {"workload": workload + "one rank: the ordinary pipeline over the whole capture (deferred feeds)", "samples": n, "shards": 1, "parallelism": "time-chunked x1"}
+    else:
+        stats, phases = {}, {}
+        for _ in range(max(0, args.warmup)):
+            shard.demodulate_sharded_walk(d, None, coll, resident=resident, nsamples=n, histories={warmup_start(first): hist_of(warmup_start(first))})
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = None
+        for _ in range(args.steps):
+            res = shard.demodulate_sharded_walk(d, None, coll, resident=resident, nsamples=n, histories={warmup_start(first): hist_of(warmup_start(first))},
+                                                phases=phases, stats=stats)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=coll)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        if rank == 0:
+            msgs, counters = res
+            out.update(value=round(n * args.steps / elapsed / 1e6, 1), ms_per_step=round(elapsed / args.steps * 1e3, 3), messages_per_step=int(len(msgs)),
+                       rank0_phase_ms_per_step={k: round(v / args.steps, 3) for k, v in phases.items()}, protocol=stats)
+            out["config"] = {"workload": workload + "every rank walks and builds its own range; per round an all-gather of every buffer's end clock and the "
+                                                    "filter state at every range's ends; at the end the ranges' messages gathered on rank 0",
+                             "samples": n, "shards": world, "parallelism": f"time-chunked x{world}"}
 
+    # ---- K emulated ranks on this one GPU: what each would spend, what the combining rank adds ----
+    if emu > 1:
+        ranks = [shard.ShardWalkRank(d, r, emu, n, keep_packets=True) for r in range(emu)]
+        stats = {}
+        t_ser = {}
+
+        def lap(name, t0):
+            t_ser[name] = t_ser.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
+
+        for r in ranks:
+            r.gpu_phase(None, resident=resident, histories={r.ws: hist_of(r.ws)})
+
+        def exchange(payloads):                      # the all-gather: nothing to do here; what EVERY rank computes from it is timed as rank 0's
+            return payloads
+
+        t0 = time.perf_counter()
+        ests = [shard._pack(r.estimate(), b"", b"") for r in ranks]
+        startup, fc = int(d.cfg.startup_time_ms), int(d.cfg.filter_clock)
+        t0 = time.perf_counter()
+        sched = shard.schedule_from_clocks([shard._unpack(b)[0] for b in ests], n, startup, fc)
+        lap("schedule_from_estimates", t0)
+        rounds = 0
+        while True:
+            rounds += 1
+            got = [shard._unpack(shard._pack(*r.walk(sched))) for r in ranks]
+            t0 = time.perf_counter()
+            done, nxt, imports = shard.protocol_round(sched, got, n, startup, fc)
+            lap("round_conclusions", t0)
+            stats["seam_failures"] = stats.get("seam_failures", 0) + len(imports)
+            if done:
+                break
+            sched = nxt
+            for r in ranks:
+                if r.rank in imports:
+                    r.import_state = imports[r.rank]
+            assert rounds < emu + 72
+        for r in ranks:
+            t0 = time.perf_counter()
+            r.blocks = shard.prepare_sum_blocks(r.msgs, [q.counters for q in ranks[:r.rank]])
+            r.ms["sum_blocks"] = (time.perf_counter() - t0) * 1e3
+        cstats = {}
+        t0 = time.perf_counter()
+        # (the concatenation of the message arrays stands in for the gather's receive side: RCCL lands them in rank 0's memory)
+        parts = [(r.msgs, r.counters, r.noise, r.blocks) for r in ranks]
+        t1 = time.perf_counter()
+        emsgs, ecnt = shard.combine_ranges(parts, n, len(sched) + (1 if fc == 1 else 0), cstats)
+        t_comb = (time.perf_counter() - t1) * 1e3
+        t_ser["combine_counters_and_sums"] = t_comb
+        assert um is not None and len(emsgs) == len(um) and emsgs.tobytes() == um.tobytes(), "emulated ranks and the unsharded run differ"
+        helpers.assert_same_counters(ecnt, uc)
+        per_rank = [{k: round(v, 3) for k, v in r.ms.items()} for r in ranks]
+        # a rank's critical path: GPU phase, clock estimate | round(s): walk + build + collect | its sum blocks; the combining rank's
+        # extra: conclusions per round, the combination (the gather itself is communication: bytes below)
+        crit = [r.ms.get("gpu_phase", 0) + r.ms.get("clock_estimate", 0) + r.ms.get("walk_call", 0) + r.ms.get("collect", 0) + r.ms.get("sum_blocks", 0) for r in ranks]
+        serial = sum(t_ser.values())
+        unsh_ms = out["ms_per_step"]
+        out["emulated_ranks"] = {
+            "ranks": emu, "per_rank_ms": per_rank, "rank_critical_path_ms": [round(c, 3) for c in crit],
+            "protocol": {"rounds": rounds, "walks": [r.walks for r in ranks], "seam_failures": stats.get("seam_failures", 0), "imported": [r.import_state is not None for r in ranks],
+                         "expiries": int(len(sched)), "sum_blocks": cstats.get("sum_blocks"), "sum_blocks_readded": cstats.get("sum_blocks_readded")},
+            "rank0_serial_ms": {k: round(v, 3) for k, v in t_ser.items()}, "rank0_serial_total_ms": round(serial, 3),
+            "rank0_serial_share_of_unsharded": round(serial / unsh_ms, 4),
+            "projected_ms_without_communication": round(max(crit) + serial, 3),
+            "projected_speedup_without_communication": round(unsh_ms / (max(crit) + serial), 2),
+            "gather_bytes_to_rank0": int(sum(r.msgs.nbytes + r.blocks.nbytes + r.noise.nbytes for r in ranks[1:])),
+            "allgather_bytes_per_round": int(sum(len(shard._pack(*g)) for g in got)),
+            "identical_to_unsharded": True, "note": "one context plays the ranks one after the other on ONE GPU: every rank's phases are what it would spend "
+                                                    "with the GPU to itself; the all-gathers are lists, the final gather is not timed (bytes given)"}
+
+    if rank == 0:
         if not args.no_cpu_baseline:
             iq = helpers.synth(nsamples=n, seed=5150, rate=8000.0, dense=1, threads=min(64, os.cpu_count() or 8)) if (world > 1 or lo != 0 or last != n) else mine
             kind, ref_msgs, st = cpu_reference(iq, n, 0, 2, 1, 58)
             helpers.assert_same_messages(msgs, ref_msgs)
-            full = getattr(d, "shard_counters_complete", False)   # (set by the library once the shards' sweep-side counters are merged)
-            if world == 1 and unsharded is not None:
-                helpers.assert_same_counters(uc, st)              # the unsharded run: every counter
-            for f in (helpers.COUNTER_FIELDS if full else ("demod_accepted", "demod_bestPhase", "samples_processed", "nbuffers", "nflips")):
-                assert (np.asarray(counters[f], dtype=np.uint64) == np.asarray(st[f], dtype=np.uint64)).all(), f
+            helpers.assert_same_counters(counters, st)            # every counter, the order-dependent double sums included
             cpu_s = float(st["t_convert_s"] + st["t_demod_s"])
             out["cpu_baseline"] = {"value": round(n / cpu_s / 1e6, 1), "unit": "Msamples/s", "cores": 1, "kind": kind,
                                    "sample": f"the whole capture ({n} samples) on one host core: convert {st['t_convert_s']:.1f} s + demodulate2400 {st['t_demod_s']:.1f} s",
-                                   "messages": int(len(ref_msgs)), "bit_identical_to_gpu": True, "counters_compared": "all" if full else "walk-side"}
+                                   "messages": int(len(ref_msgs)), "bit_identical_to_gpu": True, "counters_compared": "all"}
         emit(out)
     d.close()
-    dist.destroy_process_group()
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 def main():
@@ -375,6 +455,8 @@ def main():
     ap.add_argument("--msgs-per-sec", type=float, default=2000.0)
     ap.add_argument("--config", type=int, default=1, help="1 (default): one stream per GPU (BASELINE configs[1] / configs[3]); 5: one dense-burst "
                                                           "capture time-chunked over the GPUs (configs[4], strong scaling)")
+    ap.add_argument("--emulate-ranks", type=int, default=0, help="--config 5 on ONE GPU: one context plays this many ranks of the sharded walk one after "
+                                                                  "the other; per-rank phase times and the combining rank's serial share in the JSON line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the `configs` dict (other BASELINE configurations / input statistics)")
     ap.add_argument("--extra-samples", type=int, default=4096 * BUF, help="samples per segment of the extra configurations (default: the headline step)")

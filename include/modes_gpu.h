@@ -310,6 +310,64 @@ int mgpu_adder_bitmap_set(mgpu_ctx *ctx, const uint32_t *words /* 2^19 */);
 int mgpu_shard_packets(mgpu_ctx *ctx, const void **packets, uint64_t *bytes);   /* valid until the next reset */
 int mgpu_walk_packets(mgpu_ctx *ctx, const void *packets, uint64_t bytes);   /* continues the context's stream: the packets' first sample = where it stands */
 
+/* ---- config 5 with the ordered walk itself sharded across the ranks (round 4) ----
+ * The form above leaves the ordered walk and the message build of the WHOLE capture to the first rank; this one has every
+ * rank walk and build its own range.  What ties the ranges together is the ICAO filter (icao_filter.c:65-130: two generations,
+ * `occupied`, the table size with its grow / shrink hysteresis) and the clock of its expiry, which is data-dependent: after a
+ * buffer the reference tests Modes.synthetic_now — the timestamp of the buffer's last scored candidate, demod_2400.c:412-414 —
+ * against next_flip and re-arms it 60 s after THAT (readsb.c:1227-1231).  Protocol (readsb_amd/shard.py: ShardWalkRank):
+ *   1. rank r: mgpu_reset; mgpu_shard_begin(ctx, warmup_first, history, 2); mgpu_feed_iq*(warm-up: the two filter generations
+ *      before its range), mgpu_feed_iq*(its range) — two feeds, so that no packet straddles the range's first sample;
+ *   2. mgpu_shard_clock_estimate(): its buffers' end clocks, estimated from the records alone; all-gather;
+ *      mgpu_flip_schedule() over all buffers' clocks = the expiry schedule;
+ *   3. mgpu_shard_walk(): warm-up + range walked with that schedule imposed (rank 0, whose packets start at sample 0: from the
+ *      reference's initial state; the others: from an empty filter at the warm-up's first sample), the range's messages built,
+ *      its counters kept; out: the range's TRUE end clocks, the filter state at the range's first sample and at its end
+ *      (mgpu_shard_state);
+ *   4. all-gather clocks and states.  Done iff mgpu_flip_schedule over the true clocks reproduces the schedule and every rank's
+ *      state at its first sample equals the state the rank before it ended with (byte-equal blobs).  Otherwise again from 3 with
+ *      the new schedule, a rank whose seam failed starting from its predecessor's end state (args.start_state);
+ *   5. the last rank: mgpu_finish (the EOF buffer; its clock belongs to the schedule too); every rank: mgpu_collect — its range's
+ *      messages and counters.  Integer counters add up over the ranks; nflips is the last rank's; peak_signal_power the maximum;
+ *      signal_power_sum / noise_power_sum are sequential double sums in the reference (demod_2400.c:445-479): re-add them in
+ *      stream order with mgpu_seqsum_signal_power (over the gathered messages) / mgpu_seqsum (over mgpu_shard_noise_terms).
+ * At the fixed point every rank's walk is the serial walk's.  tests/test_gpu_shard.py, tests/test_shard_walk.py. */
+struct mgpu_shard_walk_args {
+    uint64_t own_first;          /* first sample of the rank's own range (a multiple of buf_samples); packets before it are warm-up */
+    const int64_t *flip_after;   /* the imposed expiry schedule: sampleTimestamp (12 MHz ticks = sample * 5) of every buffer of the
+                                  * CAPTURE after which the filter expires, ascending */
+    uint64_t nflips;
+    const void *start_state;     /* NULL: start at the first packet (see 3. above); else the filter state at own_first — the end
+                                  * state of the rank before — and the warm-up packets are skipped */
+    uint64_t start_state_bytes;
+    int32_t check_records;       /* 1: validate every record of the packets (packets that came over a network) */
+    int32_t reserved;
+};
+/* packets == NULL: the context's own (mgpu_shard_packets).  end_clocks[cap]: the range's buffers' end clocks (ms), *n of them. */
+int mgpu_shard_clock_estimate(mgpu_ctx *ctx, const void *packets, uint64_t bytes, uint64_t own_first,
+                              int64_t *end_clocks, uint64_t cap, uint64_t *n);
+int mgpu_shard_walk(mgpu_ctx *ctx, const void *packets, uint64_t bytes, const struct mgpu_shard_walk_args *args,
+                    int64_t *end_clocks, uint64_t cap, uint64_t *n);
+int mgpu_shard_state(mgpu_ctx *ctx, int which /* 0: at own_first, 1: at the range's end */, const void **blob, uint64_t *bytes);
+int mgpu_shard_noise_terms(mgpu_ctx *ctx, const double **terms, uint64_t *n);   /* per buffer of the range: its addend to noise_power_sum */
+/* The expiry schedule from every buffer's end clock, by the reference's rule (readsb.c:1227-1231; filter_clock as in
+ * mgpu_config): returns the number of expiries, flip_after[i < cap] = index of the buffer the i-th one follows. */
+uint64_t mgpu_flip_schedule(const int64_t *end_clock, uint64_t nbuf, int64_t startup_ms, int filter_clock,
+                            uint64_t *flip_after, uint64_t cap);
+double mgpu_seqsum(double start, const double *terms, uint64_t n);                               /* ((start + t0) + t1) + ... */
+double mgpu_seqsum_signal_power(double start, const struct mgpu_msg *msgs, uint64_t n);          /* ... of sig_sumsq / 65535^2 */
+/* The same sequential sum of the messages' signal powers, prepared by ranges and applied in O(blocks) (readsb_amd/csrc/seqsum.cpp):
+ * a block of `block` messages is ONE integer addition on the running sum's mantissa while the sum stays in the binade the block
+ * was prepared for (every addition then rounds to the same grid; ties carry the parity of the steps since the tie before).
+ * mgpu_seqsum_blocks (every rank, over its own messages): approx_start = roughly what the sum is where the range begins (the
+ * earlier ranges' totals, added any which way); out[ceil(n / block)].  mgpu_seqsum_apply (the combining rank, ranges in stream
+ * order, start = the exact sum so far): blocks whose premise fails — the sum is not in the predicted binade, or leaves it — are
+ * re-added message by message (*fallbacks counts them; may be NULL).  Returns exactly mgpu_seqsum_signal_power(start, msgs, n). */
+struct mgpu_sum_block { uint64_t total; int32_t e; uint32_t flags; };
+int    mgpu_seqsum_blocks(double approx_start, const struct mgpu_msg *msgs, uint64_t n, uint32_t block, struct mgpu_sum_block *out);
+double mgpu_seqsum_apply(double start, const struct mgpu_msg *msgs, uint64_t n, uint32_t block, const struct mgpu_sum_block *blocks,
+                         uint64_t *fallbacks);
+
 /* ---- beast wire output (modesSendBeastOutput, net_io.c:1655-1714) ------------------------------------
  * Per message: 0x1a, type '2' (56-bit) / '3' (112-bit) / '1' (Mode A/C), the 12 MHz timestamp as 6 bytes
  * big-endian, one signal byte clamp(nearbyint(sqrt(signalLevel) * 255), 1..255), the (corrected) message
@@ -464,6 +522,19 @@ int mgpu_selftest_walk(uint64_t seed, uint32_t nchunks, uint32_t buffers_per_chu
  * one chunk took. */
 int mgpu_selftest_device_walk(uint64_t seed, uint32_t nchunks, uint32_t buffers_per_chunk, uint32_t naircraft,
                               uint32_t max_walks, uint64_t stats[4]);
+
+/* The sharded walk's protocol (mgpu_shard_walk above), needs no GPU: a seeded synthetic record stream of nchunks chunks is dealt
+ * to `nranks` ranks in whole chunks; every rank walks warm-up + range (nsegments speculative buffer ranges per chunk, 1 = the
+ * serial loop) from an empty filter with the schedule from ESTIMATED end clocks imposed, and the rounds over (schedule, seam
+ * states) run as they would with all-gathers in between — against the serial walk of the whole stream: every decision of every
+ * chunk, every buffer's end clock, the counts, the final filter state.  front_extra more aircraft transmit during the first 150 s
+ * only (the filter's table grows for them and shrinks one size per expiry afterwards: state no warm-up can rebuild, so seams fail
+ * and ranks import).  flags bit 0: the first schedule from the buffers' start clocks; bit 1: a deliberately wrong first schedule.
+ * 0 = identical, k > 0 = first differing chunk + 1, -2 = the rounds did not settle.  stats (may be NULL): [0] rounds, [1] walks
+ * of a range in all, [2] seams that failed in some round, [3] rounds in which the schedule changed, [4] expiries, [5] ranges that
+ * ended up starting from an imported state. */
+int mgpu_selftest_shard_walk(uint64_t seed, uint32_t nchunks, uint32_t buffers_per_chunk, uint32_t naircraft, uint32_t front_extra,
+                             uint32_t nranks, uint32_t nsegments, uint32_t flags, uint64_t stats[6]);
 
 /* The ordered walk on the device (environment MGPU_DEVICE_WALK=1, or =check to run it beside the host walk and compare every
  * decision): out[0] chunks, [1] chunks whose decisions came from the device (check: were compared), [2] chunks the fixed point

@@ -91,8 +91,66 @@ class Timing(C.Structure):
         return {name: getattr(self, name) for name, _ in self._fields_}
 
 
+class ShardWalkArgs(C.Structure):
+    _fields_ = [
+        ("own_first", C.c_uint64), ("flip_after", C.c_void_p), ("nflips", C.c_uint64), ("start_state", C.c_void_p),
+        ("start_state_bytes", C.c_uint64), ("check_records", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
 class MgpuError(RuntimeError):
     pass
+
+
+def flip_schedule(end_clocks, startup_ms, filter_clock=0):
+    """Indices of the buffers the ICAO filter expires after, from every buffer's end clock (mgpu_flip_schedule: the reference's
+    rule, readsb.c:1227-1231)."""
+    lib = load_library()
+    clocks = np.ascontiguousarray(end_clocks, dtype=np.int64)
+    out = np.empty(clocks.size // 1000 + 16, dtype=np.uint64)      # an expiry per 60 s = per ~1099 buffers at least
+    n = int(lib.mgpu_flip_schedule(C.c_void_p(clocks.ctypes.data), clocks.size, int(startup_ms), int(filter_clock), C.c_void_p(out.ctypes.data), out.size))
+    if n > out.size:
+        out = np.empty(n, dtype=np.uint64)
+        n = int(lib.mgpu_flip_schedule(C.c_void_p(clocks.ctypes.data), clocks.size, int(startup_ms), int(filter_clock), C.c_void_p(out.ctypes.data), out.size))
+    return out[:n].copy()
+
+
+def seqsum(start, terms):
+    """((start + t0) + t1) + ... in doubles, in order (mgpu_seqsum)."""
+    terms = np.ascontiguousarray(terms, dtype=np.float64)
+    return float(load_library().mgpu_seqsum(float(start), C.c_void_p(terms.ctypes.data), terms.size))
+
+
+SUM_BLOCK_DTYPE = np.dtype([("total", "<u8"), ("e", "<i4"), ("flags", "<u4")])
+SUM_BLOCK = 1024                            # messages per block of the block-wise sequential sum
+
+
+def seqsum_blocks(approx_start, msgs, block=SUM_BLOCK):
+    """A range's messages prepared for the block-wise sequential sum of their signal powers (mgpu_seqsum_blocks)."""
+    if msgs.dtype != MSG_DTYPE or not msgs.flags["C_CONTIGUOUS"]:
+        raise ValueError("seqsum_blocks: need a contiguous mgpu_msg record array")
+    out = np.zeros((msgs.size + block - 1) // block, dtype=SUM_BLOCK_DTYPE)
+    rc = load_library().mgpu_seqsum_blocks(float(approx_start), C.c_void_p(msgs.ctypes.data), msgs.size, block, C.c_void_p(out.ctypes.data))
+    if rc != 0:
+        raise MgpuError("mgpu_seqsum_blocks failed")
+    return out
+
+
+def seqsum_apply(start, msgs, blocks, block=SUM_BLOCK):
+    """-> (the exact sequential sum continued over this range, blocks that had to be re-added message by message)."""
+    blocks = np.ascontiguousarray(blocks, dtype=SUM_BLOCK_DTYPE)
+    if msgs.dtype != MSG_DTYPE or not msgs.flags["C_CONTIGUOUS"] or blocks.size != (msgs.size + block - 1) // block:
+        raise ValueError("seqsum_apply: messages and blocks do not match")
+    fb = C.c_uint64(0)
+    s = load_library().mgpu_seqsum_apply(float(start), C.c_void_p(msgs.ctypes.data), msgs.size, block, C.c_void_p(blocks.ctypes.data), C.byref(fb))
+    return float(s), int(fb.value)
+
+
+def seqsum_signal_power(start, msgs):
+    """... of the messages' signal powers sig_sumsq / 65535^2, in order (mgpu_seqsum_signal_power; demod_2400.c:445-447)."""
+    if msgs.dtype != MSG_DTYPE or not msgs.flags["C_CONTIGUOUS"]:
+        raise ValueError("seqsum_signal_power: need a contiguous mgpu_msg record array")
+    return float(load_library().mgpu_seqsum_signal_power(float(start), C.c_void_p(msgs.ctypes.data), msgs.size))
 
 
 def lib_path():
@@ -156,6 +214,19 @@ def load_library():
     lib.mgpu_adder_bitmap_set.argtypes = [vp, vp]
     lib.mgpu_shard_packets.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
     lib.mgpu_walk_packets.argtypes = [vp, vp, u64]
+    lib.mgpu_shard_clock_estimate.argtypes = [vp, vp, u64, u64, vp, u64, C.POINTER(u64)]
+    lib.mgpu_shard_walk.argtypes = [vp, vp, u64, C.POINTER(ShardWalkArgs), vp, u64, C.POINTER(u64)]
+    lib.mgpu_shard_state.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(u64)]
+    lib.mgpu_shard_noise_terms.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
+    lib.mgpu_flip_schedule.argtypes = [vp, u64, i64, i32, vp, u64]
+    lib.mgpu_flip_schedule.restype = u64
+    lib.mgpu_seqsum.argtypes = [C.c_double, vp, u64]
+    lib.mgpu_seqsum.restype = C.c_double
+    lib.mgpu_seqsum_signal_power.argtypes = [C.c_double, vp, u64]
+    lib.mgpu_seqsum_signal_power.restype = C.c_double
+    lib.mgpu_seqsum_blocks.argtypes = [C.c_double, vp, u64, u32, vp]
+    lib.mgpu_seqsum_apply.argtypes = [C.c_double, vp, u64, u32, vp, C.POINTER(u64)]
+    lib.mgpu_seqsum_apply.restype = C.c_double
     lib.mgpu_pending_messages.restype = u64
     lib.mgpu_last_timing.argtypes = [vp, C.POINTER(Timing)]
     lib.mgpu_debug_device_walk.argtypes = [vp, C.POINTER(u64)]
@@ -285,6 +356,55 @@ class Demodulator:
     def walk_packets(self, packets):
         packets = np.ascontiguousarray(packets, dtype=np.uint8)
         self._chk(self.lib.mgpu_walk_packets(self.ctx, C.c_void_p(packets.ctypes.data), C.c_uint64(packets.size)), "mgpu_walk_packets")
+
+    # ---- ... with the ordered walk itself sharded over the ranks (include/modes_gpu.h, "round 4"; shard.py: ShardWalkRank) ----
+    @staticmethod
+    def _packets_arg(packets):
+        if packets is None:
+            return None, 0, None
+        packets = np.ascontiguousarray(packets, dtype=np.uint8)
+        return C.c_void_p(packets.ctypes.data), packets.size, packets
+
+    def shard_clock_estimate(self, own_first, nbuffers, packets=None):
+        """The range's buffers' end clocks estimated from the records alone (packets=None: the context's own packets)."""
+        ptr, size, keep = self._packets_arg(packets)
+        out = np.empty(int(nbuffers) + 1, dtype=np.int64)
+        n = C.c_uint64(0)
+        self._chk(self.lib.mgpu_shard_clock_estimate(self.ctx, ptr, size, int(own_first), C.c_void_p(out.ctypes.data), out.size, C.byref(n)),
+                  "mgpu_shard_clock_estimate")
+        return out[: n.value]
+
+    def shard_walk(self, own_first, nbuffers, flip_after_ts, start_state=None, packets=None, check_records=False):
+        """Walk warm-up + range with the expiry schedule imposed, build the range's messages (mgpu_shard_walk).
+        -> (end clocks of the range's buffers, state at own_first, state at the range's end) — the states as bytes."""
+        ptr, size, keep = self._packets_arg(packets)
+        sched = np.ascontiguousarray(flip_after_ts, dtype=np.int64)
+        a = ShardWalkArgs()
+        a.own_first = int(own_first)
+        a.flip_after = sched.ctypes.data if sched.size else None
+        a.nflips = sched.size
+        st = None
+        if start_state is not None:
+            st = np.frombuffer(start_state, dtype=np.uint8)
+            a.start_state, a.start_state_bytes = st.ctypes.data, st.size
+        a.check_records = 1 if check_records else 0
+        out = np.empty(int(nbuffers) + 1, dtype=np.int64)
+        n = C.c_uint64(0)
+        self._chk(self.lib.mgpu_shard_walk(self.ctx, ptr, size, C.byref(a), C.c_void_p(out.ctypes.data), out.size, C.byref(n)), "mgpu_shard_walk")
+        states = []
+        for which in (0, 1):
+            bp, bn = C.c_void_p(), C.c_uint64(0)
+            self._chk(self.lib.mgpu_shard_state(self.ctx, which, C.byref(bp), C.byref(bn)), "mgpu_shard_state")
+            states.append(C.string_at(bp, bn.value) if bn.value else b"")
+        return out[: n.value].copy(), states[0], states[1]
+
+    def shard_noise_terms(self):
+        """What each buffer of the walked range adds to noise_power_sum, in order (a copy)."""
+        tp, tn = C.c_void_p(), C.c_uint64(0)
+        self._chk(self.lib.mgpu_shard_noise_terms(self.ctx, C.byref(tp), C.byref(tn)), "mgpu_shard_noise_terms")
+        if not tn.value:
+            return np.zeros(0, dtype=np.float64)
+        return np.ctypeslib.as_array(C.cast(tp, C.POINTER(C.c_double)), shape=(tn.value,)).copy()
 
     def decode_fields(self, msgs):
         """Per-message field records (FIELDS_DTYPE) of a message record array, decoded on the GPU."""

@@ -178,6 +178,10 @@ struct Slot {
     hipEvent_t ev_pre = nullptr, ev_fsum = nullptr, ev_convdone = nullptr;
     bool fsum_pending = false;
     hipEvent_t ev_scan = nullptr;         // pre-screen offsets are final (main stream) -> the write pass may start (second stream)
+    // the second stream keeps out of k_sweep's way (walk_job: hold_behind_sweep): the chunk's k_sweep has run | which chunk that was
+    hipEvent_t ev_swept = nullptr;
+    std::atomic<uint64_t> swept_seq{~0ull};
+    uint64_t seq = 0;                     // the chunk's number in the context's life (slot = seq % kSlots)
     // the job
     uint64_t n = 0, stream_pos = 0;
     uint8_t *d_wk_in = nullptr;           // the walk on the device: its input blob (read again by k_build_messages: the buffer clocks) ...
@@ -316,6 +320,7 @@ struct mgpu_ctx {
     bool device_msgs = false;                                 // mgpu_set_device_messages
     bool sig_late = true;                                     // MGPU_SIG_LATE=0: signal power of every live record in the pre-screen write pass (as in shard passes) instead of the accepted frames' after the walk
     int timing_every = 4;                                     // MGPU_TIMING_EVERY: chunks per set of stage timing events (1 = every chunk)
+    float event_bracket_us = 4.5f;                            // what a pair of timing events adds to the kernel it brackets (mgpu_event_bracket_us measures it)
     uint64_t timing_seq = 0;
     bool accounting_open = false;                             // feed_begin has run, feed_end has not (deferred: spans several feeds)
     double acct_t0 = 0;
@@ -339,6 +344,11 @@ struct mgpu_ctx {
     // pre-screened records of every chunk as packets instead of walking them
     int shard_mode = 0;
     std::vector<uint8_t> shard_packets;
+    // the sharded walk (mgpu_shard_walk): the imposed expiry schedule (the resolver points into it), the range's end clocks, what
+    // each of its buffers adds to noise_power_sum, the filter state at the range's first sample / at its end
+    std::vector<int64_t> shard_sched;
+    std::vector<double> shard_noise;
+    ShardWalkOut shard_out;
     // beast encoder scratch (mgpu_beast_encode*): grown on demand
     uint16_t *d_beast_len = nullptr;        // per message: frame length | signal byte << 8
     uint8_t *d_beast_in = nullptr, *d_beast_out = nullptr;
@@ -684,6 +694,7 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
     HIPCHK(c, hipHostMalloc(&sl.h_live_sig, c->cap_pool * sizeof(unsigned long long)));
     HIPCHK(c, hipEventCreateWithFlags(&sl.ev_window, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&sl.ev_scan, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&sl.ev_swept, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&sl.ev_pre, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&sl.ev_fsum, hipEventDisableTiming));
@@ -715,6 +726,7 @@ static void free_slot(Slot &sl) {
         if (p) (void) hipFree(p);
     if (sl.ev_window) (void) hipEventDestroy(sl.ev_window);
     if (sl.ev_scan) (void) hipEventDestroy(sl.ev_scan);
+    if (sl.ev_swept) (void) hipEventDestroy(sl.ev_swept);
     if (sl.d_ac_noise) (void) hipFree(sl.d_ac_noise);
     if (sl.h_ac) (void) hipHostFree(sl.h_ac);
     if (sl.ev_h2d) (void) hipEventDestroy(sl.ev_h2d);
@@ -854,8 +866,12 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     if (const char *e = getenv("MGPU_SWEEP_VERSION")) { const int v = atoi(e); if (v == 3 || v == 5) c->sweep_version = v; }
 #endif
     if (hipSetDevice(cfg->device) != hipSuccess) { delete c; return MGPU_E_NODEVICE; }
+    // the second stream (what follows a chunk's walk; the SC16 formats' float sums) at the lowest priority the device offers: its
+    // kernels fill what the main stream leaves, they are not to take its slots
+    int prio_least = 0, prio_greatest = 0;
+    (void) hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream_w, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream_d2h, hipStreamNonBlocking) != hipSuccess) { mgpu_destroy(c); return MGPU_E_HIP; }
     // valid_df_*_bitset, init_bitsets() demod_2400.c:112-128 (ENABLE_DF24 off, readsb.h:303)
@@ -981,6 +997,8 @@ int mgpu_reset(mgpu_ctx *c) {
     c->worker_rc = MGPU_OK;
     c->shard_mode = 0;
     c->shard_packets.clear();
+    c->resolver.set_schedule(nullptr, 0);
+    c->resolver.log_end_clocks(nullptr);
     HIPCHK(c, hipMemsetAsync(c->d_adder_bitmap, 0, (1u << 24) / 8, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MGPU_OK;
@@ -1070,6 +1088,8 @@ static int enqueue_sweep(mgpu_ctx *c, Slot &sl) {
     {
         sl.sweep_blocks = launch_sweep(sp, s);
         if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[4], s));
+        HIPCHK(c, hipEventRecord(sl.ev_swept, s));
+        sl.swept_seq.store(sl.seq, std::memory_order_release);
         sl.slice_blocks = launch_slice(sp, s);
     }
     if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[2], s));
@@ -1170,7 +1190,7 @@ static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
     float ms;
     if (sl.timed) {
         if (hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]) == hipSuccess) c->acc.convert_ms += ms;
-        if (hipEventElapsedTime(&ms, sl.ev[5], sl.ev[4]) == hipSuccess) { c->acc.sweep_ms += ms; if (c->sweep_version == 5) sweep_pace_feedback(ms * 1e3f, sl.n, sl.sweep_blocks); }
+        if (hipEventElapsedTime(&ms, sl.ev[5], sl.ev[4]) == hipSuccess) { c->acc.sweep_ms += ms; if (c->sweep_version == 5) sweep_pace_feedback(ms * 1e3f, sl.n, sl.sweep_blocks, c->event_bracket_us); }
         if (hipEventElapsedTime(&ms, sl.ev[4], sl.ev[2]) == hipSuccess) c->acc.slice_ms += ms;
         if (hipEventElapsedTime(&ms, sl.ev[6], sl.ev[3]) == hipSuccess) c->acc.prescreen_ms += ms;
         c->acc.n_timed_chunks += 1;
@@ -1400,6 +1420,26 @@ static int64_t host_walk(mgpu_ctx *c, HostJob &job, const PhaseRec *recs, const 
     return wn;
 }
 
+// The second stream's work of a chunk (k_stage_in, k_msg_sig, k_window_stats, k_window_reduce, k_build_messages: ~125 us of small
+// latency-bound kernels) starts when the chunk's walk is done — at a random point of the main stream's convert | sweep | slice | post
+// cycle of a later chunk.  Beside k_slice or the converter it costs next to nothing; beside k_sweep, the kernel that streams at
+// half the HBM peak, it cost that kernel 4-5 of its 32 us (profiles/r03_slice_stages.txt: 31.7-32.0 us with the second stream idle,
+// 36.1 with it; round 4 A/B in the benchmark, profiles/r04_s2_behind_sweep.txt: k_sweep 39.9-42.5 -> 31.7-32.2 us, the step 1.94 ->
+// 1.80 ms; the stream's priority made no difference either way).  So: if the main stream is about to run, or is running, a later chunk's k_sweep (that chunk's converter has the
+// stream: the chunk before it is complete, its own sweep is not), the second stream waits for that sweep's event and runs beside
+// the k_slice that follows; otherwise it starts at once.  Timing only: no result depends on where these kernels run.
+static int hold_behind_sweep(mgpu_ctx *c, const Slot &sl, int slot_idx, hipStream_t s2) {
+    const Slot *prev = &sl;                                  // (its chunk is complete: the walker has its records)
+    for (int d = 1; d < mgpu_ctx::kSlots; ++d) {
+        const Slot &o = c->slot[(slot_idx + d) % mgpu_ctx::kSlots];
+        if (o.swept_seq.load(std::memory_order_acquire) != sl.seq + (uint64_t) d) break;   // not enqueued (yet)
+        if (hipEventQuery(o.ev_swept) == hipSuccess) { prev = &o; continue; }              // that sweep is behind us
+        if (prev == &sl || hipEventQuery(prev->ev[3]) == hipSuccess) HIPCHK(c, hipStreamWaitEvent(s2, o.ev_swept, 0));
+        break;
+    }
+    return MGPU_OK;
+}
+
 // ---- part 2 (walker thread): the ordered accept walk, then the window statistics of what it hid ----
 static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
     const uint64_t n = sl.n;
@@ -1440,6 +1480,7 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
     // accumulated on the device and read once at the end of the feed
     const double t_sig0 = wall_ms();
     hipStream_t s2 = c->s_post;
+    if (nmsg) { const int rc = hold_behind_sweep(c, sl, job.slot, s2); if (rc != MGPU_OK) return rc; }
     if (nmsg)
         launch_stage_in(sl.h_msg_pos, sl.h_msg_limit, sl.h_msg_skip, sl.d_msg_pos, sl.d_msg_limit, sl.d_msg_skip, nmsg, s2);
     if (nmsg && job.sig_late) {    // the accepted frames' signal powers, now that it is known which frames they are: first, the builder waits for them
@@ -1829,8 +1870,10 @@ static int feed_common(mgpu_ctx *c, const void *src, bool src_is_device, uint64_
     hipEvent_t last_h2d = nullptr;
     for (uint64_t off = 0; off < n && rc == MGPU_OK; off += c->chunk_samples) {
         const uint64_t len = n - off < c->chunk_samples ? n - off : c->chunk_samples;
-        const int k = (int) (c->chunk_seq++ % mgpu_ctx::kSlots);
+        const uint64_t seq = c->chunk_seq++;
+        const int k = (int) (seq % mgpu_ctx::kSlots);
         Slot &sl = acquire_slot(c, k);
+        sl.seq = seq;
         sl.n = len;
         sl.stream_pos = c->stream_pos + off;
         sl.feed = fidx;
@@ -1967,7 +2010,7 @@ int mgpu_finish(mgpu_ctx *c) {
     // file length an exact multiple of the buffer size: one more zero-length buffer, whose
     // converter call divides 0 by 0 (convert.c:101-107) -> noise_power_sum becomes NaN
     const int64_t st = (int64_t) c->stream_pos * 5;
-    c->resolver.tick_empty(st / 12000 + c->cfg.startup_time_ms);
+    c->resolver.tick_empty(st / 12000 + c->cfg.startup_time_ms, st);
     c->counters.noise_power_sum += std::numeric_limits<double>::quiet_NaN();
     c->counters.samples_lost += c->cfg.buf_samples;
     c->counters.nbuffers++;
@@ -2130,9 +2173,13 @@ int mgpu_event_bracket_us(mgpu_ctx *c, float *us) {
     HIPCHK(c, hipSetDevice(c->cfg.device));
     hipEvent_t a = nullptr, b = nullptr;
     HIPCHK(c, hipEventCreate(&a));
-    HIPCHK(c, hipEventCreate(&b));
+    if (hipEventCreate(&b) != hipSuccess) { (void) hipEventDestroy(a); c->err = "hipEventCreate failed"; return MGPU_E_HIP; }
     std::vector<float> v;
-    const unsigned blocks = 1536, known_us = 20;
+    // one workgroup per CU: every one of them is resident from the start, so the kernel lasts exactly what each of them spins
+    // (a grid that does not fit spins in waves and reads longer than `known_us`: the bracket would come out inflated)
+    hipDeviceProp_t prop;
+    const unsigned blocks = hipGetDeviceProperties(&prop, c->cfg.device) == hipSuccess && prop.multiProcessorCount > 0 ? (unsigned) prop.multiProcessorCount : 256u;
+    const unsigned known_us = 20;
     for (int r = 0; r < 24; ++r) {                  // | 50 us of something | ev | 20 us, exactly | ev | 50 us of something |
         launch_spin(50, blocks, nullptr, c->stream);
         (void) hipEventRecord(a, c->stream);
@@ -2148,6 +2195,7 @@ int mgpu_event_bracket_us(mgpu_ctx *c, float *us) {
     if (v.empty()) { c->err = "mgpu_event_bracket_us: no measurement"; return MGPU_E_HIP; }
     std::sort(v.begin(), v.end());
     *us = v[v.size() / 2];
+    if (*us > 0.5f && *us < 20.0f) c->event_bracket_us = *us;   // (k_sweep's pacing feedback takes it off the timed launches)
     return MGPU_OK;
 }
 
@@ -2247,8 +2295,10 @@ static int demod_mag_buf(mgpu_ctx *c, const uint16_t *data, uint32_t length, int
     }
     const double t_start = wall_ms();
     { int brc = feed_begin(c); if (brc != MGPU_OK) return brc; }
-    const int slot_idx = (int) (c->chunk_seq++ % mgpu_ctx::kSlots);
+    const uint64_t seq = c->chunk_seq++;
+    const int slot_idx = (int) (seq % mgpu_ctx::kSlots);
     Slot &sl = acquire_slot(c, slot_idx);
+    sl.seq = seq;
     sl.n = length;
     sl.feed = -1;
     // demod_2400.c:335-338: after dropped samples the reference raises the threshold to at least PREAMBLE_THRESHOLD_PIZERO
@@ -2349,105 +2399,143 @@ int mgpu_shard_packets(mgpu_ctx *c, const void **packets, uint64_t *bytes) {
     return MGPU_OK;
 }
 
-// The packets come from other ranks over a gather: nothing in a header is trusted before it is checked against the bytes
-// that are really there (record count without a 64-bit overflow), the context's capacity, and the order the walk relies on.
-// Per packet = per chunk of some rank's range: the ordered walk (the walker's team, as for a chunk of an unsharded stream), the
-// messages, and every statistic an unsharded run keeps — the sweep-side tallies and the per-buffer sums ride in the packet,
-// what the accepted frames' skip windows hide is the sum of the accepted records' window counts.
-static int walk_packets_checked(mgpu_ctx *c, const void *packets, uint64_t bytes) {
-    const uint8_t *p = (const uint8_t *) packets, *end = p + bytes;
-    HostJob &job = c->job[0];
+// One packet = one chunk of some rank's range, as fetcher_main lays it out.
+struct PacketView {
+    uint64_t pos = 0, n = 0, nrecs = 0, nbuf = 0;
+    uint64_t hdr[kPacketWords] = {};
+    const PhaseRec *recs = nullptr;                            // nrecs records + the walk's sentinel
+    const unsigned long long *sig = nullptr, *win = nullptr;    // per record: its would-be signal power, the counts of its would-be skip window
+    const unsigned long long *sums = nullptr;                   // level[nbuf], power[nbuf]: integers (UC8) or doubles, eight bytes each
+};
+
+// The packets may come from other ranks over a gather: nothing in a header is trusted before it is checked against the bytes
+// that are really there (record count without a 64-bit overflow) and the context's capacity; `check_records`: the order the walk
+// relies on, record by record (a rank's own packets, made by this library in this process, are taken as they are).
+static int parse_packet(mgpu_ctx *c, const uint8_t *&p, const uint8_t *end, PacketView &v, bool check_records) {
     constexpr uint64_t kRecBytes = sizeof(PhaseRec) + 16;       // record + its signal power + its window counts
-    if ((uintptr_t) packets & 7) { c->err = "mgpu_walk_packets: the packets must be 8-byte aligned"; return MGPU_E_INVAL; }
-    mgpu_counters &k = c->counters;
-    while (p < end) {
-        uint64_t hdr[kPacketWords];
-        if ((size_t) (end - p) < sizeof(hdr)) { c->err = "mgpu_walk_packets: truncated packet header"; return MGPU_E_INVAL; }
-        std::memcpy(hdr, p, sizeof(hdr));
-        p += sizeof(hdr);
-        const uint64_t pos = hdr[0], n = hdr[1], nrecs = hdr[2], nbuf = hdr[10];
-        if (hdr[3] != kPacketMagic || pos != c->stream_pos || n == 0 || n > c->cap_samples || n > 0xFFFFFFF0ull ||
-            nbuf != (n + c->cfg.buf_samples - 1) / c->cfg.buf_samples || (uint64_t) (end - p) < sizeof(PhaseRec) || nrecs > ((uint64_t) (end - p) - sizeof(PhaseRec)) / kRecBytes ||
-            (uint64_t) (end - p) - sizeof(PhaseRec) - nrecs * kRecBytes < nbuf * 16) {
-            c->err = "mgpu_walk_packets: packets must continue the stream in order, within max_samples, with all their records present";
-            return MGPU_E_INVAL;
-        }
-        // the records are walked where they lie (packets are 8-byte aligned and a sentinel record follows the last one)
-        const PhaseRec *recs = (const PhaseRec *) p;
-        p += (nrecs + 1) * sizeof(PhaseRec);
-        const unsigned long long *sig = (const unsigned long long *) p;
-        p += nrecs * 8;
-        const unsigned long long *win = (const unsigned long long *) p;
-        p += nrecs * 8;
-        const unsigned long long *sums = (const unsigned long long *) p;    // level[nbuf], power[nbuf]: integers (UC8) or doubles, eight bytes each
-        p += nbuf * 16;
-        if (recs[nrecs].pos != 0xFFFFFFFFu) { c->err = "mgpu_walk_packets: malformed record list"; return MGPU_E_INVAL; }
-        for (uint64_t i = 0; i < nrecs; ++i) {                   // sorted by position, inside the packet's samples, a real phase
-            const PhaseRec &r = recs[i];
-            if (r.pos >= n || (i && r.pos < recs[i - 1].pos) || r.phase < 4 || r.phase > 8) {
-                c->err = "mgpu_walk_packets: malformed record list";
+    if ((size_t) (end - p) < sizeof(v.hdr)) { c->err = "shard packets: truncated packet header"; return MGPU_E_INVAL; }
+    std::memcpy(v.hdr, p, sizeof(v.hdr));
+    p += sizeof(v.hdr);
+    v.pos = v.hdr[0]; v.n = v.hdr[1]; v.nrecs = v.hdr[2]; v.nbuf = v.hdr[10];
+    if (v.hdr[3] != kPacketMagic || v.n == 0 || v.n > c->cap_samples || v.n > 0xFFFFFFF0ull ||
+        v.nbuf != (v.n + c->cfg.buf_samples - 1) / c->cfg.buf_samples || (uint64_t) (end - p) < sizeof(PhaseRec) ||
+        v.nrecs > ((uint64_t) (end - p) - sizeof(PhaseRec)) / kRecBytes ||
+        (uint64_t) (end - p) - sizeof(PhaseRec) - v.nrecs * kRecBytes < v.nbuf * 16) {
+        c->err = "shard packets: a packet must lie within max_samples, with all its records present";
+        return MGPU_E_INVAL;
+    }
+    // the records are walked where they lie (packets are 8-byte aligned and a sentinel record follows the last one)
+    v.recs = (const PhaseRec *) p;
+    p += (v.nrecs + 1) * sizeof(PhaseRec);
+    v.sig = (const unsigned long long *) p;
+    p += v.nrecs * 8;
+    v.win = (const unsigned long long *) p;
+    p += v.nrecs * 8;
+    v.sums = (const unsigned long long *) p;
+    p += v.nbuf * 16;
+    if (v.recs[v.nrecs].pos != 0xFFFFFFFFu) { c->err = "shard packets: malformed record list"; return MGPU_E_INVAL; }
+    if (check_records)
+        for (uint64_t i = 0; i < v.nrecs; ++i) {                 // sorted by position, inside the packet's samples, a real phase
+            const PhaseRec &r = v.recs[i];
+            if (r.pos >= v.n || (i && r.pos < v.recs[i - 1].pos) || r.phase < 4 || r.phase > 8) {
+                c->err = "shard packets: malformed record list";
                 return MGPU_E_INVAL;
             }
         }
-        ifile_grid(c, pos, n, job.buffers);
-        const uint64_t cap = nrecs + 1;
-        job.pos.resize(cap); c->w_limit.resize(cap); c->w_skip.resize(cap);
-        job.rc = ResolveCounts();
-        const int64_t wn = host_walk(c, job, recs, job.buffers, nrecs, cap);
-        if (wn < 0) return MGPU_E_OVERFLOW;
-        const size_t first = c->pending.size();
-        if (!c->pending.grow_for((size_t) wn)) return c->pending.external ? MGPU_E_OVERFLOW : MGPU_E_NOMEM;
-        {
-            mgpu_msg *dst = c->pending.data() + first;
-            const int parts = wn >= 4096 ? c->build_threads : 1;
-            c->build_team.run(parts, [&](int i) {
-                const uint64_t lo = (uint64_t) wn * i / parts, hi = (uint64_t) wn * (i + 1) / parts;
-                Resolver::build_messages(recs, sig, nullptr, job.buffers, job.acc.data() + lo, hi - lo, dst + lo);
-            });
-        }
-        c->pending.n = first + (size_t) wn;
-        // ---- the statistics: feed_end's and build_job's, from what the packet carries ----
-        const ResolveCounts &rc = job.rc;
-        for (int i = 0; i < 3; ++i) k.demod_accepted[i] += rc.accepted[i];
-        for (int i = 0; i < 5; ++i) k.demod_bestPhase[i] += rc.best_phase[i];
-        uint64_t hw[5] = {0, 0, 0, 0, 0};                        // what the accepted frames' skip windows hide: candidates, phases 4/5, 6/7, 8, conditional-only
-        std::vector<uint64_t> buf_scaled(nbuf, 0);
-        for (int64_t i = 0; i < wn; ++i) {
-            const Accepted &a = job.acc[(size_t) i];
-            const unsigned long long w = win[a.rec];
-            hw[0] += w & 0xff; hw[1] += (w >> 8) & 0xff; hw[2] += (w >> 16) & 0xff; hw[3] += (w >> 24) & 0xff; hw[4] += (w >> 32) & 0xff;
-            const unsigned long long sumsq = sig[a.rec];
-            const unsigned sig_len = (recs[a.rec].msg[0] & 0x80) ? 268u : 134u;    // msglen * 12 / 5, demod_2400.c:439
-            const double signal_power = (double) sumsq / 65535.0 / 65535.0, level = signal_power / sig_len;
-            k.signal_power_sum += signal_power;
-            k.signal_power_count += sig_len;
-            if (level > k.peak_signal_power) k.peak_signal_power = level;
-            if (level > 0.50119) k.strong_signal_count++;
-            if (a.buffer < nbuf) buf_scaled[a.buffer] += sumsq;
-        }
-        const uint64_t C = hdr[4], U = hdr[8], R = hdr[9], cW = hw[0], uW = hw[4];
-        k.demod_preambles += C - cW;
-        k.demod_preamblePhase[0] += hdr[5] - hw[1];
-        k.demod_preamblePhase[1] += hdr[5] - hw[1];
-        k.demod_preamblePhase[2] += hdr[6] - hw[2];
-        k.demod_preamblePhase[3] += hdr[6] - hw[2];
-        k.demod_preamblePhase[4] += hdr[7] - hw[3];
-        k.demod_rejected_bad += (C - U - R) - (cW - uW - rc.skipped_uncond_groups) + rc.rejected_bad;
-        k.demod_rejected_unknown_icao += rc.rejected_unknown + (U - rc.visited_cond_groups - uW);
-        for (uint64_t b = 0; b < nbuf; ++b) {                    // noise power per buffer (demod_2400.c:474-479)
-            const BufferClock &bc = job.buffers[b];
-            double mean_power;
-            if (c->cfg.format == MGPU_FMT_UC8) mean_power = (double) sums[nbuf + b] / 65535.0 / 65535.0 / bc.length;   // convert.c:105-107
-            else { double f; std::memcpy(&f, &sums[nbuf + b], 8); mean_power = (double) ((float) f / (float) bc.length); }
-            k.noise_power_sum += (mean_power * bc.length - (double) buf_scaled[b] / 65535.0 / 65535.0);
-            k.noise_power_count += bc.length;
-            k.samples_lost += c->cfg.buf_samples - bc.length;    // readsb.c:886
-        }
-        k.samples_processed += n;
-        k.nbuffers += nbuf;
-        k.nflips = c->resolver.nflips();
-        c->stream_pos += n;
-        if (n % c->cfg.buf_samples) c->eof = true;
+    return MGPU_OK;
+}
+
+// A packet's ordered walk (the walker's team, as for a chunk of an unsharded stream); build: its messages appended to
+// c->pending and every statistic an unsharded run keeps — the sweep-side tallies and the per-buffer sums ride in the packet,
+// what the accepted frames' skip windows hide is the sum of the accepted records' window counts; noise_terms (when given): what
+// each buffer adds to noise_power_sum, in order (a double sum is order-dependent: the rank that combines ranges re-adds them).
+static int walk_one_packet(mgpu_ctx *c, const PacketView &v, bool build, std::vector<double> *noise_terms) {
+    HostJob &job = c->job[0];
+    mgpu_counters &k = c->counters;
+    const uint64_t nrecs = v.nrecs, nbuf = v.nbuf, n = v.n;
+    const PhaseRec *recs = v.recs;
+    const unsigned long long *sig = v.sig, *win = v.win, *sums = v.sums;
+    ifile_grid(c, v.pos, n, job.buffers);
+    const uint64_t cap = nrecs + 1;
+    job.pos.resize(cap); c->w_limit.resize(cap); c->w_skip.resize(cap);
+    job.rc = ResolveCounts();
+    const double t0 = wall_ms();
+    const int64_t wn = host_walk(c, job, recs, job.buffers, nrecs, cap);
+    c->acc.resolve_ms += (float) (wall_ms() - t0);
+    if (wn < 0) return MGPU_E_OVERFLOW;
+    if (!build) return MGPU_OK;
+    const double t1 = wall_ms();
+    const size_t first = c->pending.size();
+    if (!c->pending.grow_for((size_t) wn)) return c->pending.external ? MGPU_E_OVERFLOW : MGPU_E_NOMEM;
+    {
+        mgpu_msg *dst = c->pending.data() + first;
+        const int parts = wn >= 4096 ? c->build_threads : 1;
+        c->build_team.run(parts, [&](int i) {
+            const uint64_t lo = (uint64_t) wn * i / parts, hi = (uint64_t) wn * (i + 1) / parts;
+            Resolver::build_messages(recs, sig, nullptr, job.buffers, job.acc.data() + lo, hi - lo, dst + lo);
+        });
+    }
+    c->pending.n = first + (size_t) wn;
+    // ---- the statistics: feed_end's and build_job's, from what the packet carries ----
+    const ResolveCounts &rc = job.rc;
+    for (int i = 0; i < 3; ++i) k.demod_accepted[i] += rc.accepted[i];
+    for (int i = 0; i < 5; ++i) k.demod_bestPhase[i] += rc.best_phase[i];
+    uint64_t hw[5] = {0, 0, 0, 0, 0};                        // what the accepted frames' skip windows hide: candidates, phases 4/5, 6/7, 8, conditional-only
+    std::vector<uint64_t> buf_scaled(nbuf, 0);
+    for (int64_t i = 0; i < wn; ++i) {
+        const Accepted &a = job.acc[(size_t) i];
+        const unsigned long long w = win[a.rec];
+        hw[0] += w & 0xff; hw[1] += (w >> 8) & 0xff; hw[2] += (w >> 16) & 0xff; hw[3] += (w >> 24) & 0xff; hw[4] += (w >> 32) & 0xff;
+        const unsigned long long sumsq = sig[a.rec];
+        const unsigned sig_len = (recs[a.rec].msg[0] & 0x80) ? 268u : 134u;    // msglen * 12 / 5, demod_2400.c:439
+        const double signal_power = (double) sumsq / 65535.0 / 65535.0, level = signal_power / sig_len;
+        k.signal_power_sum += signal_power;
+        k.signal_power_count += sig_len;
+        if (level > k.peak_signal_power) k.peak_signal_power = level;
+        if (level > 0.50119) k.strong_signal_count++;
+        if (a.buffer < nbuf) buf_scaled[a.buffer] += sumsq;
+    }
+    const uint64_t C = v.hdr[4], U = v.hdr[8], R = v.hdr[9], cW = hw[0], uW = hw[4];
+    k.demod_preambles += C - cW;
+    k.demod_preamblePhase[0] += v.hdr[5] - hw[1];
+    k.demod_preamblePhase[1] += v.hdr[5] - hw[1];
+    k.demod_preamblePhase[2] += v.hdr[6] - hw[2];
+    k.demod_preamblePhase[3] += v.hdr[6] - hw[2];
+    k.demod_preamblePhase[4] += v.hdr[7] - hw[3];
+    k.demod_rejected_bad += (C - U - R) - (cW - uW - rc.skipped_uncond_groups) + rc.rejected_bad;
+    k.demod_rejected_unknown_icao += rc.rejected_unknown + (U - rc.visited_cond_groups - uW);
+    for (uint64_t b = 0; b < nbuf; ++b) {                    // noise power per buffer (demod_2400.c:474-479)
+        const BufferClock &bc = job.buffers[b];
+        double mean_power;
+        if (c->cfg.format == MGPU_FMT_UC8) mean_power = (double) sums[nbuf + b] / 65535.0 / 65535.0 / bc.length;   // convert.c:105-107
+        else { double f; std::memcpy(&f, &sums[nbuf + b], 8); mean_power = (double) ((float) f / (float) bc.length); }
+        const double term = mean_power * bc.length - (double) buf_scaled[b] / 65535.0 / 65535.0;
+        k.noise_power_sum += term;
+        if (noise_terms) noise_terms->push_back(term);
+        k.noise_power_count += bc.length;
+        k.samples_lost += c->cfg.buf_samples - bc.length;    // readsb.c:886
+    }
+    k.samples_processed += n;
+    k.nbuffers += nbuf;
+    k.nflips = c->resolver.nflips();
+    c->acc.build_ms += (float) (wall_ms() - t1);
+    c->acc.n_messages += (uint64_t) wn;
+    return MGPU_OK;
+}
+
+// Packets that continue the context's stream: per packet the ordered walk, the messages, the statistics.
+static int walk_packets_checked(mgpu_ctx *c, const void *packets, uint64_t bytes) {
+    const uint8_t *p = (const uint8_t *) packets, *end = p + bytes;
+    if ((uintptr_t) packets & 7) { c->err = "mgpu_walk_packets: the packets must be 8-byte aligned"; return MGPU_E_INVAL; }
+    while (p < end) {
+        PacketView v;
+        int rc = parse_packet(c, p, end, v, true);
+        if (rc != MGPU_OK) return rc;
+        if (v.pos != c->stream_pos) { c->err = "mgpu_walk_packets: packets must continue the stream in order"; return MGPU_E_INVAL; }
+        rc = walk_one_packet(c, v, true, nullptr);
+        if (rc != MGPU_OK) return rc;
+        c->stream_pos += v.n;
+        if (v.n % c->cfg.buf_samples) c->eof = true;
     }
     return MGPU_OK;
 }
@@ -2462,6 +2550,133 @@ int mgpu_walk_packets(mgpu_ctx *c, const void *packets, uint64_t bytes) {
     const int rc = guarded(c, [&] { return walk_packets_checked(c, packets, bytes); });
     c->hot.store(false, std::memory_order_relaxed);
     return rc;
+}
+
+// ---- config 5 with the ordered walk itself sharded: every rank walks its OWN range (include/modes_gpu.h) ----------------------
+//
+// What ties the ranges of one capture together is the ICAO filter: its two generations, `occupied`, the table size, and the clock
+// of its 60 s expiry — which is data-dependent at millisecond granularity (the expiry after a buffer is tested against the
+// timestamp of the buffer's last scored candidate, and the next is due 60 s after THAT: demod_2400.c:412-414, readsb.c:1227-1231),
+// so a rank cannot know the schedule from the buffer grid.  The protocol (readsb_amd/shard.py):
+//   1. every rank puts warm-up (two filter generations before its range) + range through the GPU pipeline and keeps the packets;
+//   2. every rank ESTIMATES its buffers' end clocks from the records alone (mgpu_shard_clock_estimate); all-gather; the schedule
+//      is the chain over all end clocks (mgpu_flip_schedule);
+//   3. every rank walks warm-up + range with that schedule IMPOSED, from an empty filter at the warm-up's first sample (rank 0:
+//      from the reference's initial state), and reports its true end clocks, the state it had at its range's first sample, the
+//      state it ended with;
+//   4. all-gather; done iff the chain over the true end clocks reproduces the schedule and every rank's state at its first
+//      sample equals the state the rank before it ended with.  Otherwise: the new schedule, and a rank whose seam failed starts
+//      its range from the imported state of its predecessor instead of its own warm-up; again from 3.
+// At the fixed point every rank's walk IS the serial walk's (induction over buffers: rank 0 starts from the true state; the true
+// rule expires the filter after buffer b iff the chain says so, because the chain runs the same rule on the same end clocks).
+// Every range's messages are built by its own rank; integer counters add up; the two order-dependent double sums are re-added in
+// stream order by whoever combines the ranges (mgpu_seqsum*, from the per-buffer terms / the messages themselves).
+
+uint64_t mgpu_flip_schedule(const int64_t *end_clock, uint64_t nbuf, int64_t startup_ms, int filter_clock, uint64_t *flip_after, uint64_t cap) {
+    std::vector<uint64_t> f;
+    flip_schedule(end_clock, nbuf, startup_ms, filter_clock, f);
+    for (size_t i = 0; i < f.size() && i < cap; ++i) flip_after[i] = f[i];
+    return f.size();
+}
+
+static int shard_packets_span(mgpu_ctx *c, const void *&packets, uint64_t &bytes) {
+    if (!packets) { packets = c->shard_packets.data(); bytes = c->shard_packets.size(); }
+    if ((uintptr_t) packets & 7) { c->err = "shard packets must be 8-byte aligned"; return MGPU_E_INVAL; }
+    return MGPU_OK;
+}
+
+int mgpu_shard_clock_estimate(mgpu_ctx *c, const void *packets, uint64_t bytes, uint64_t own_first, int64_t *end_clocks, uint64_t cap, uint64_t *n_out) {
+    if (!c || !end_clocks || !n_out) return MGPU_E_INVAL;
+    *n_out = 0;
+    { const int rc = shard_packets_span(c, packets, bytes); if (rc != MGPU_OK) return rc; }
+    const uint8_t *p = (const uint8_t *) packets, *end = p + bytes;
+    std::vector<BufferClock> bufs;
+    std::vector<int64_t> clocks;
+    while (p < end) {
+        PacketView v;
+        const int rc = parse_packet(c, p, end, v, false);
+        if (rc != MGPU_OK) return rc;
+        if (v.pos < own_first) continue;
+        ifile_grid(c, v.pos, v.n, bufs);
+        estimate_end_clocks(v.recs, v.nrecs, bufs, clocks);
+    }
+    if (clocks.size() > cap) { c->err = "mgpu_shard_clock_estimate: more buffers than the caller's array holds"; return MGPU_E_CAPACITY; }
+    std::memcpy(end_clocks, clocks.data(), clocks.size() * sizeof(int64_t));
+    *n_out = clocks.size();
+    return MGPU_OK;
+}
+
+static int shard_walk_checked(mgpu_ctx *c, const void *packets, uint64_t bytes, const mgpu_shard_walk_args *a, int64_t *end_clocks, uint64_t cap, uint64_t *n_out) {
+    const uint8_t *p = (const uint8_t *) packets, *end = p + bytes;
+    const double t_all = wall_ms();
+    std::vector<PacketView> views;
+    while (p < end) {
+        PacketView v;
+        const int rc = parse_packet(c, p, end, v, a->check_records != 0);
+        if (rc != MGPU_OK) return rc;
+        views.push_back(v);
+    }
+    c->pending.clear();
+    std::memset(&c->counters, 0, sizeof(c->counters));
+    std::memset(&c->acc, 0, sizeof(c->acc));
+    c->shard_noise.clear();
+    c->eof = false;
+    c->spec_segments = c->spec_batches = 0;
+    c->shard_sched.assign(a->flip_after, a->flip_after + a->nflips);
+    ShardWalkPlan plan;
+    plan.own_first = a->own_first; plan.buf_samples = c->cfg.buf_samples; plan.startup_ms = c->cfg.startup_time_ms; plan.clock_mode = (int) c->cfg.filter_clock;
+    plan.sched = c->shard_sched.data(); plan.nsched = c->shard_sched.size();
+    plan.start_state = (const uint8_t *) a->start_state; plan.start_state_bytes = a->start_state_bytes;
+    ShardWalkOut &out = c->shard_out;
+    const char *err = "";
+    double t_own = 0;
+    const int rc = shard_walk_core(c->resolver, plan, views.size(),
+        [&](size_t i, uint64_t &pos, uint64_t &n) { pos = views[i].pos; n = views[i].n; },
+        [&](size_t i, bool own) {
+            if (own && t_own == 0) { t_own = wall_ms(); c->acc.resolve_ms = 0; }          // (resolve_ms: the own range's walk; d2h_ms below: the warm-up's)
+            const int wrc = walk_one_packet(c, views[i], own, own ? &c->shard_noise : nullptr);
+            if (wrc == MGPU_OK && own) { c->stream_pos = views[i].pos + views[i].n; if (views[i].n % c->cfg.buf_samples) c->eof = true; }
+            return wrc;
+        }, out, &err);
+    if (rc == -1) { c->err = std::string("mgpu_shard_walk: ") + err; return MGPU_E_INVAL; }
+    if (rc != MGPU_OK) return rc;
+    c->counters.nflips = c->resolver.nflips();
+    if (out.clocks.size() > cap) { c->err = "mgpu_shard_walk: more buffers than the caller's array holds"; return MGPU_E_CAPACITY; }
+    std::memcpy(end_clocks, out.clocks.data(), out.clocks.size() * sizeof(int64_t));
+    *n_out = out.clocks.size();
+    c->acc.d2h_ms = t_own > 0 ? (float) (t_own - t_all) : 0;
+    c->acc.total_ms = (float) (wall_ms() - t_all);
+    c->timing = c->acc;
+    return MGPU_OK;
+}
+
+int mgpu_shard_walk(mgpu_ctx *c, const void *packets, uint64_t bytes, const struct mgpu_shard_walk_args *a, int64_t *end_clocks, uint64_t cap, uint64_t *n_out) {
+    if (!c || !a || !end_clocks || !n_out || (a->nflips && !a->flip_after) || (a->start_state && !a->start_state_bytes)) return MGPU_E_INVAL;
+    *n_out = 0;
+    if (c->deferred || c->cfg.mode_ac || c->cfg.filter_clock == MGPU_FILTER_CLOCK_EXTERNAL || a->own_first % c->cfg.buf_samples) {
+        c->err = "mgpu_shard_walk: not in deferred mode, not with Mode A/C or an external filter clock; ranges are whole buffers";
+        return MGPU_E_INVAL;
+    }
+    { const int rc = wait_all(c); if (rc != MGPU_OK) return rc; }
+    { const int rc = shard_packets_span(c, packets, bytes); if (rc != MGPU_OK) return rc; }
+    { std::lock_guard<std::mutex> lk(c->mu); c->hot.store(true, std::memory_order_relaxed); }
+    c->cv.notify_all();                      // the walker's team polls instead of sleeping while the packets are walked
+    const int rc = guarded(c, [&] { return shard_walk_checked(c, packets, bytes, a, end_clocks, cap, n_out); });
+    c->hot.store(false, std::memory_order_relaxed);
+    return rc;
+}
+
+int mgpu_shard_state(mgpu_ctx *c, int which, const void **blob, uint64_t *bytes) {
+    if (!c || !blob || !bytes || which < 0 || which > 1) return MGPU_E_INVAL;
+    const std::vector<uint8_t> &st = which ? c->shard_out.state_end : c->shard_out.state_first;
+    *blob = st.data(); *bytes = st.size();
+    return MGPU_OK;
+}
+
+int mgpu_shard_noise_terms(mgpu_ctx *c, const double **terms, uint64_t *n) {
+    if (!c || !terms || !n) return MGPU_E_INVAL;
+    *terms = c->shard_noise.data(); *n = c->shard_noise.size();
+    return MGPU_OK;
 }
 
 // ---- beast wire format (net_io.c:1655-1714) for message records that already are in HBM -----------------------
@@ -2601,16 +2816,20 @@ const uint16_t *mgpu_uc8_table(void) { return uc8_table(); }
 // seconds — quiet spells longer than two filter generations make addresses expire, short ones do not — and the record kinds the
 // kernels emit (clean adders, repaired frames, address-parity replies that only count when the address is known).
 struct SelftestStream {
-    struct Plane { uint32_t addr; double on, off, period; };
+    struct Plane { uint32_t addr; double on, off, period, until; };
     uint64_t x;
     std::vector<Plane> planes;
     uint64_t rnd() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; }
-    SelftestStream(uint64_t seed, uint32_t naircraft) : x(seed ? seed : 88172645463325252ull), planes(naircraft) {
-        for (uint32_t i = 0; i < naircraft; ++i) {
+    // front_extra more aircraft transmit during the first front_s seconds only: the filter's table grows for them and shrinks by one
+    // size per expiry afterwards (icao_filter.c:96-110) — state that a rank starting later cannot rebuild from a warm-up
+    SelftestStream(uint64_t seed, uint32_t naircraft, uint32_t front_extra = 0, double front_s = 0) : x(seed ? seed : 88172645463325252ull), planes(naircraft + front_extra) {
+        for (uint32_t i = 0; i < naircraft + front_extra; ++i) {
+            planes[i].until = i < naircraft ? 1e300 : front_s;
             planes[i].addr = 0x400000u + (uint32_t) (rnd() % 4096) * 7u + i;
             planes[i].period = 40.0 + (double) (rnd() % 400);
             planes[i].on = (double) (rnd() % 1000) / 1000.0 * planes[i].period;
             planes[i].off = planes[i].on + 5.0 + (double) (rnd() % 1000) / 1000.0 * planes[i].period;
+            if (i >= naircraft) { planes[i].on = 0; planes[i].off = planes[i].period; }
         }
     }
     // one chunk of `nbuf` 131072-sample buffers starting at stream position `stream_pos`: its buffer grid and its records
@@ -2631,7 +2850,7 @@ struct SelftestStream {
             const double t = (double) (stream_pos + pos) / 2.4e6;
             const Plane &pl = planes[rnd() % naircraft];
             const double ph = std::fmod(t, pl.period);
-            const bool active = ph >= pl.on && ph < pl.off;
+            const bool active = ph >= pl.on && ph < pl.off && t < pl.until;
             const int nrec = 1 + (int) (rnd() % 3);
             int phase = 4 + (int) (rnd() % 3);
             for (int k = 0; k < nrec && phase <= 8; ++k, phase += 1 + (int) (rnd() % 2)) {
@@ -2756,6 +2975,145 @@ int mgpu_selftest_walk(uint64_t seed, uint32_t nchunks, uint32_t buffers_per_chu
         stream_pos += npos;
     }
     if (speculated_permille) *speculated_permille = ranges ? (uint32_t) (held * 1000 / ranges) : 0;
+    return 0;
+}
+
+// The sharded walk's protocol (mgpu_shard_walk, readsb_amd/shard.py) on a synthetic record stream, without a GPU: the capture's
+// chunks are dealt to `nranks` ranks (whole chunks, contiguous), every rank walks warm-up + range from an empty filter with the
+// schedule derived from ESTIMATED end clocks imposed, and the fixed point over (schedule, seam states) is iterated exactly as the
+// ranks would with all-gathers in between.  Against the serial walk of the whole stream: every decision of every chunk (from the
+// rank that owns it), every buffer's end clock, the counts, the number of expiries, the last rank's final state.
+// 0 = identical; k > 0 = first differing chunk + 1; -2 = the iteration did not settle.  stats: [0] protocol rounds, [1] walks of a
+// range in all, [2] seams that failed in some round, [3] rounds in which the schedule changed, [4] expiries, [5] ranges that started
+// from an imported state in the end.  flags bit 0: the first schedule from the buffers' START clocks instead of the estimate;
+// bit 1: a deliberately wrong first schedule (the rounds over the schedule have work to do).
+int mgpu_selftest_shard_walk(uint64_t seed, uint32_t nchunks, uint32_t buffers_per_chunk, uint32_t naircraft, uint32_t front_extra,
+                             uint32_t nranks, uint32_t nsegments, uint32_t flags, uint64_t stats[6]) {
+    if (nchunks == 0 || buffers_per_chunk == 0 || naircraft == 0 || nranks == 0 || nranks > nchunks) return -1;
+    const uint32_t B = 131072;
+    const int64_t startup = 1000000;
+    struct Chunk { std::vector<BufferClock> bufs; std::vector<PhaseRec> recs; uint64_t pos, n; uint64_t nrecs; };
+    std::vector<Chunk> chunks(nchunks);
+    {
+        SelftestStream gen(seed, naircraft, front_extra, 150.0);
+        uint64_t pos = 0;
+        for (auto &ch : chunks) {
+            ch.pos = pos;
+            ch.n = gen.chunk(pos, buffers_per_chunk, ch.bufs, ch.recs);
+            ch.nrecs = ch.recs.size();
+            PhaseRec sentinel{}; sentinel.pos = 0xFFFFFFFFu; ch.recs.push_back(sentinel);
+            pos += ch.n;
+        }
+    }
+    struct Decisions { std::vector<Accepted> acc; ResolveCounts rc; };
+    auto walk_chunk = [&](Resolver &res, const Chunk &ch, Decisions &d, bool parallel) {
+        const uint64_t n = ch.nrecs;
+        std::vector<uint32_t> pos(n + 1), lim(n + 1);
+        std::vector<uint16_t> skip(n + 1);
+        d.rc = ResolveCounts();
+        const uint32_t K = nsegments < buffers_per_chunk ? nsegments : buffers_per_chunk;
+        if (!parallel || K < 2) {
+            const int64_t na = res.decide(ch.recs.data(), n, ch.bufs, d.acc, pos.data(), skip.data(), lim.data(), n + 1, d.rc);
+            d.acc.resize((size_t) (na < 0 ? 0 : na));
+            return;
+        }
+        std::vector<SegmentWalk> segs(K);
+        for (uint32_t k = 0; k < K; ++k) {
+            segs[k].b_lo = (uint32_t) ((uint64_t) buffers_per_chunk * k / K);
+            segs[k].b_hi = (uint32_t) ((uint64_t) buffers_per_chunk * (k + 1) / K);
+            segs[k].rec_lo = k == 0 ? 0 : segment_first_record(ch.recs.data(), n, ch.bufs[segs[k].b_lo].first);
+        }
+        for (uint32_t k = 0; k < K; ++k) segs[k].rec_hi = k + 1 < K ? segs[k + 1].rec_lo : n;
+        res.parallel_walk(ch.recs.data(), n, ch.bufs, segs, [&](int ntasks, const std::function<void(int)> &task) {
+            std::vector<std::thread> th;
+            for (int i = 0; i < ntasks; ++i) th.emplace_back([&task, i] { task(i); });
+            for (auto &t : th) t.join();
+        });
+        d.acc.clear();
+        for (uint32_t k = 0; k < K; ++k) {
+            d.rc.add(segs[k].counts);
+            d.acc.insert(d.acc.end(), segs[k].acc.begin(), segs[k].acc.begin() + (std::ptrdiff_t) segs[k].nacc);
+        }
+    };
+    // ---- the serial walk of the whole stream ----
+    Resolver truth;
+    truth.reset(startup, 0);
+    std::vector<int64_t> true_clocks;
+    truth.log_end_clocks(&true_clocks);
+    std::vector<Decisions> want(nchunks);
+    for (uint32_t i = 0; i < nchunks; ++i) walk_chunk(truth, chunks[i], want[i], false);
+    truth.log_end_clocks(nullptr);
+    std::vector<uint8_t> true_end;
+    truth.export_state(true_end);
+    // ---- the ranks ----
+    const double chunk_s = (double) buffers_per_chunk * B / 2.4e6;
+    const uint32_t warm = (uint32_t) (120.3 / chunk_s) + 2;                    // two generations (+ the expiry's slack) in whole chunks, one to spare
+    struct Rank { uint32_t c0, c1, w0; Resolver res; ShardWalkOut out; std::vector<Decisions> got; std::vector<uint8_t> import; bool walked = false; };
+    std::vector<Rank> ranks(nranks);
+    for (uint32_t r = 0; r < nranks; ++r) {
+        ranks[r].c0 = (uint32_t) ((uint64_t) nchunks * r / nranks);
+        ranks[r].c1 = (uint32_t) ((uint64_t) nchunks * (r + 1) / nranks);
+        ranks[r].w0 = ranks[r].c0 > warm ? ranks[r].c0 - warm : 0;
+        ranks[r].got.resize(ranks[r].c1 - ranks[r].c0);
+    }
+    std::vector<int64_t> clocks;
+    for (uint32_t i = 0; i < nchunks; ++i) {
+        if (flags & 1u) for (const BufferClock &b : chunks[i].bufs) clocks.push_back(b.sysTimestamp);   // a crude first guess: the iteration over the schedule has work to do
+        else estimate_end_clocks(chunks[i].recs.data(), chunks[i].nrecs, chunks[i].bufs, clocks);
+    }
+    std::vector<uint64_t> fl;
+    flip_schedule(clocks.data(), clocks.size(), startup, 0, fl);
+    std::vector<int64_t> sched(fl.size());
+    for (size_t i = 0; i < fl.size(); ++i) sched[i] = (int64_t) (fl[i] * B) * 5;
+    if (flags & 2u) for (size_t i = 1; i < sched.size(); i += 2) sched[i] += (int64_t) B * 5 * (int64_t) (1 + i % 3);   // a WRONG first schedule: some expiries 1-3 buffers late
+    uint64_t st[6] = {0, 0, 0, 0, 0, 0};
+    bool done = false;
+    std::vector<int64_t> used_sched;
+    for (uint32_t round = 0; round < nranks + 70 && !done; ++round) {
+        ++st[0];
+        const bool sched_changed = used_sched != sched;
+        used_sched = sched;
+        for (uint32_t r = 0; r < nranks; ++r) {
+            Rank &R = ranks[r];
+            if (R.walked && !sched_changed && (R.import.empty() || R.import == R.out.state_first)) continue;   // nothing it depends on has changed
+            ShardWalkPlan plan;
+            plan.own_first = chunks[R.c0].pos; plan.buf_samples = B; plan.startup_ms = startup; plan.clock_mode = 0;
+            plan.sched = used_sched.data(); plan.nsched = used_sched.size();
+            if (!R.import.empty()) { plan.start_state = R.import.data(); plan.start_state_bytes = R.import.size(); }
+            const char *err = "";
+            const int rc = shard_walk_core(R.res, plan, R.c1 - R.w0,
+                [&](size_t i, uint64_t &pos, uint64_t &n) { pos = chunks[R.w0 + i].pos; n = chunks[R.w0 + i].n; },
+                [&](size_t i, bool own) { Decisions scratch; walk_chunk(R.res, chunks[R.w0 + i], own ? R.got[R.w0 + i - R.c0] : scratch, true); return 0; },
+                R.out, &err);
+            if (rc != 0) { fprintf(stderr, "mgpu_selftest_shard_walk: rank %u: %s\n", r, err); return -1; }
+            R.walked = true;
+            ++st[1];
+        }
+        // ---- what the all-gather would hand every rank: all clocks, all states ----
+        clocks.clear();
+        for (auto &R : ranks) clocks.insert(clocks.end(), R.out.clocks.begin(), R.out.clocks.end());
+        flip_schedule(clocks.data(), clocks.size(), startup, 0, fl);
+        std::vector<int64_t> next(fl.size());
+        for (size_t i = 0; i < fl.size(); ++i) next[i] = (int64_t) (fl[i] * B) * 5;
+        bool seams = true;
+        for (uint32_t r = 1; r < nranks; ++r)
+            if (ranks[r].out.state_first != ranks[r - 1].out.state_end) { seams = false; ++st[2]; ranks[r].import = ranks[r - 1].out.state_end; }
+        if (next != sched) ++st[3];
+        done = seams && next == sched;
+        sched.swap(next);
+    }
+    if (stats) { st[4] = sched.size(); for (auto &R : ranks) st[5] += R.import.empty() ? 0 : 1; std::memcpy(stats, st, sizeof(st)); }
+    if (!done) return -2;
+    // ---- against the serial walk ----
+    if (clocks != true_clocks) return (int) nchunks + 1;
+    for (uint32_t r = 0; r < nranks; ++r)
+        for (uint32_t i = ranks[r].c0; i < ranks[r].c1; ++i) {
+            const Decisions &g = ranks[r].got[i - ranks[r].c0], &w = want[i];
+            bool same = g.acc.size() == w.acc.size() && std::memcmp(&g.rc, &w.rc, sizeof(g.rc)) == 0;
+            for (size_t k = 0; same && k < g.acc.size(); ++k) same = g.acc[k].rec == w.acc[k].rec && g.acc[k].buffer == w.acc[k].buffer && g.acc[k].score == w.acc[k].score;
+            if (!same) return (int) i + 1;
+        }
+    if (ranks[nranks - 1].out.state_end != true_end) return (int) nchunks + 2;
     return 0;
 }
 

@@ -136,7 +136,7 @@ void launch_spin(unsigned us, unsigned blocks, unsigned long long *sink, hipStre
 void launch_fsum_sc16(int format, const uint8_t *iq, uint64_t n, uint32_t buf_samples, double *fsum_level, double *fsum_power, int want_level,
                       hipStream_t s);
 unsigned launch_sweep(const SweepParams &p, hipStream_t s);        // k_sweep: preamble sweep -> per-step candidate lists; returns its grid size
-void sweep_pace_feedback(float kernel_us, uint64_t n, unsigned blocks);   // a timed k_sweep launch: feeds the pacing's step-time estimate
+void sweep_pace_feedback(float kernel_us, uint64_t n, unsigned blocks, float bracket_us);   // a timed k_sweep launch: feeds the pacing's step-time estimate
 unsigned launch_slice(const SweepParams &p, hipStream_t s);        // k_slice: slicer + CRC + scoring over the candidate lists -> record pool; returns its grid size (rows of sweep_part)
 #if MGPU_EXPERIMENTS
 void launch_sweep_slice(const SweepParams &p, hipStream_t s);      // generation 3: both in one kernel (cross-check build only)

@@ -19,6 +19,7 @@
 #include "kernels.h"
 #include "tables.h"
 
+#include <atomic>
 #include <cstdlib>
 
 namespace mgpu {

@@ -156,9 +156,21 @@ void Resolver::reset(int64_t startup_ms, int clock_mode) {
     if (clock_mode == 2) next_flip_ = std::numeric_limits<int64_t>::max();
 }
 
-void Resolver::after_buffer() {
+bool Resolver::scheduled(int64_t buffer_ts) const {
+    const int64_t *e = std::lower_bound(sched_, sched_ + nsched_, buffer_ts);
+    return e != sched_ + nsched_ && *e == buffer_ts;
+}
+
+void Resolver::after_buffer(int64_t buffer_ts) {
     // backgroundTasks(now = mstime()) after every buffer (readsb.c:899-902, 1227-1231)
-    if (synthetic_now_ >= next_flip_) {
+    if (clock_log_) clock_log_->push_back(synthetic_now_);
+    bool due = synthetic_now_ >= next_flip_;
+    if (sched_ && buffer_ts != kNoBufferTs) {       // an imposed schedule (several ranks walk one capture): it decides, the rule is only compared
+        const bool imposed = scheduled(buffer_ts);
+        if (imposed != due) ++sched_mismatch_;
+        due = imposed;
+    }
+    if (due) {
         exp_lo_ = chunk_drops_.size();         // (what the expiry takes out of the union, when the changes are being tracked)
         filter_.expire();
         exp_hi_ = chunk_drops_.size();
@@ -167,9 +179,62 @@ void Resolver::after_buffer() {
     }
 }
 
-void Resolver::tick_empty(int64_t sysTimestamp) {
+void Resolver::tick_empty(int64_t sysTimestamp, int64_t sampleTimestamp) {
     synthetic_now_ = sysTimestamp;   // demod_2400.c:283-285
-    after_buffer();
+    after_buffer(sampleTimestamp);
+}
+
+void Resolver::reset_empty(int64_t startup_ms) {
+    filter_.init();
+    synthetic_now_ = startup_ms;
+    next_flip_ = 0;
+    nflips_ = 0;
+}
+
+// state blob: magic | synthetic_now | next_flip | nflips | occupied, table bits | four counts | active members (< 2^24), inactive
+// members, active big, inactive big — each list ascending
+static constexpr uint64_t kStateMagic = 0x3154415453524c46ull;   // "FLRSTAT1"
+
+void Resolver::export_state(std::vector<uint8_t> &blob) const {
+    IcaoFilter::Snapshot sn;
+    filter_.snapshot(sn);
+    const int a = sn.active;
+    std::vector<uint32_t> lists[4] = {sn.members[a], sn.members[a ^ 1], sn.big[a], sn.big[a ^ 1]};
+    for (auto &l : lists) std::sort(l.begin(), l.end());
+    const uint64_t head[5] = {kStateMagic, (uint64_t) synthetic_now_, (uint64_t) next_flip_, nflips_, (uint64_t) sn.occupied | ((uint64_t) sn.filter_bits << 32)};
+    const uint32_t counts[4] = {(uint32_t) lists[0].size(), (uint32_t) lists[1].size(), (uint32_t) lists[2].size(), (uint32_t) lists[3].size()};
+    blob.clear();
+    auto put = [&](const void *p, size_t n) { blob.insert(blob.end(), (const uint8_t *) p, (const uint8_t *) p + n); };
+    put(head, sizeof(head));
+    put(counts, sizeof(counts));
+    for (auto &l : lists) if (!l.empty()) put(l.data(), l.size() * sizeof(uint32_t));
+    while (blob.size() % 8) blob.push_back(0);
+}
+
+bool Resolver::import_state(const uint8_t *blob, size_t bytes) {
+    uint64_t head[5];
+    uint32_t counts[4];
+    if (!blob || bytes < sizeof(head) + sizeof(counts)) return false;
+    std::memcpy(head, blob, sizeof(head));
+    std::memcpy(counts, blob + sizeof(head), sizeof(counts));
+    const uint64_t total = (uint64_t) counts[0] + counts[1] + counts[2] + counts[3];
+    const uint32_t bits = (uint32_t) (head[4] >> 32);
+    if (head[0] != kStateMagic || bits < 8 || bits > 20 || total > (bytes - sizeof(head) - sizeof(counts)) / sizeof(uint32_t)) return false;
+    const uint8_t *p = blob + sizeof(head) + sizeof(counts);
+    IcaoFilter::Snapshot sn;
+    sn.active = 0;
+    std::vector<uint32_t> *dst[4] = {&sn.members[0], &sn.members[1], &sn.big[0], &sn.big[1]};
+    for (int i = 0; i < 4; ++i) {
+        dst[i]->resize(counts[i]);
+        if (counts[i]) std::memcpy(dst[i]->data(), p, (size_t) counts[i] * sizeof(uint32_t));
+        p += (size_t) counts[i] * sizeof(uint32_t);
+        for (uint32_t a : *dst[i]) if ((i < 2) != (a < (1u << 24))) return false;      // a list in the wrong place: not one of ours
+    }
+    sn.occupied = (uint32_t) head[4];
+    sn.filter_bits = bits;
+    filter_.restore(sn);
+    synthetic_now_ = (int64_t) head[1]; next_flip_ = (int64_t) head[2]; nflips_ = head[3];
+    return true;
 }
 
 static inline int frame_bits(const PhaseRec &r) { return (r.msg[0] & 0x80) ? 112 : 56; }   // demod_2400.c:399, DF as sliced
@@ -233,7 +298,7 @@ int64_t Resolver::walk_range(Policy &pol, const PhaseRec *recs, uint64_t rec_lo,
             ++nout;
             skip_until = (int64_t) pos + msglen * 8 / 4;
         }
-        pol.buffer_end(now);
+        pol.buffer_end(now, b.sampleTimestamp);
     }
     counts.add(c);
     return (int64_t) nout;
@@ -245,10 +310,10 @@ struct LivePolicy {
     IcaoFilter &flt;
     int64_t &synthetic_now;
     Resolver &res;
-    void (Resolver::*tick)();
+    void (Resolver::*tick)(int64_t);
     bool test(uint32_t a) const { return flt.test(a); }
     void add(uint32_t a) { flt.add(a); }
-    void buffer_end(int64_t now) { synthetic_now = now; (res.*tick)(); }
+    void buffer_end(int64_t now, int64_t buffer_ts) { synthetic_now = now; (res.*tick)(buffer_ts); }
 };
 
 // speculation: membership as it was when the chunk started, plus the range's own adds
@@ -270,10 +335,10 @@ struct SpecPolicy {
     }
     // the 60 s expiry clock (readsb.c:1227-1231) with the threshold the batch started with: exact as long as
     // the decisions are, which is what commit_segment establishes
-    void buffer_end(int64_t now) {
+    void buffer_end(int64_t now, int64_t buffer_ts) {
         w.adds_end.push_back((uint32_t) w.adds.size());
         w.end_clock.push_back(now);
-        if (now >= w.flip_clock) {
+        if (w.sched ? buffer_ts == w.flip_ts : now >= w.flip_clock) {
             w.flip_at = (int32_t) (w.b_lo + w.end_clock.size() - 1);
             ++w.nflip;
             w.flip_clock = now + kFilterTtlMs;
@@ -307,7 +372,7 @@ struct ModelPolicy {
         return it != first_cur.end() && it->first == a && it->second < b;
     }
     void add(uint32_t a) { own.set(a); }
-    void buffer_end(int64_t now) { end_clock = now; }
+    void buffer_end(int64_t now, int64_t) { end_clock = now; }
 };
 }  // namespace
 
@@ -414,7 +479,7 @@ void Resolver::spec_walk(const PhaseRec *recs, const std::vector<BufferClock> &b
 }
 
 bool Resolver::commit_segment(const PhaseRec *recs, const std::vector<BufferClock> &buffers, SegmentWalk &w) {
-    (void) recs; (void) buffers;
+    (void) recs;
     bool ok = !w.odd;
     // (1) what the range assumed about the state at its start against the true filter: adds it expected from
     //     earlier ranges that did not happen, and anything the earlier ranges of the batch dropped (or dropped
@@ -438,7 +503,8 @@ bool Resolver::commit_segment(const PhaseRec *recs, const std::vector<BufferCloc
     //     second one could drop the range's own adds).
     const size_t drops0 = chunk_drops_.size(), news0 = chunk_news_.size(), exp_lo0 = exp_lo_, exp_hi0 = exp_hi_;
     const int64_t now0 = synthetic_now_, flip0 = next_flip_;
-    const uint64_t nflips0 = nflips_;
+    const uint64_t nflips0 = nflips_, mism0 = sched_mismatch_;
+    const size_t log0 = clock_log_ ? clock_log_->size() : 0;
     if (ok) ok = w.nflip <= 1;
     if (ok) {
         IcaoFilter::Snapshot snap;
@@ -450,7 +516,7 @@ bool Resolver::commit_segment(const PhaseRec *recs, const std::vector<BufferCloc
             for (; k < e; ++k) filter_.add(w.adds[k]);
             synthetic_now_ = w.end_clock[bi - w.b_lo];
             const uint64_t f = nflips_;
-            after_buffer();
+            after_buffer(buffers[bi].sampleTimestamp);
             if (nflips_ != f) { if (flipped_at >= 0) ok = false; flipped_at = (int32_t) bi; }
         }
         if (flipped_at != w.flip_at) ok = false;
@@ -470,7 +536,8 @@ bool Resolver::commit_segment(const PhaseRec *recs, const std::vector<BufferCloc
         if (!ok) {
             filter_.restore(snap);
             chunk_drops_.resize(drops0); chunk_news_.resize(news0); exp_lo_ = exp_lo0; exp_hi_ = exp_hi0;
-            synthetic_now_ = now0; next_flip_ = flip0; nflips_ = nflips0;
+            synthetic_now_ = now0; next_flip_ = flip0; nflips_ = nflips0; sched_mismatch_ = mism0;
+            if (clock_log_) clock_log_->resize(log0);
         }
     }
     w.speculated = ok;
@@ -493,13 +560,14 @@ void Resolver::copy_state_from(const Resolver &o) {
     o.filter_.snapshot(snap);
     filter_.restore(snap);
     synthetic_now_ = o.synthetic_now_; next_flip_ = o.next_flip_; nflips_ = o.nflips_;
+    sched_ = o.sched_; nsched_ = o.nsched_; sched_mismatch_ = o.sched_mismatch_; clock_log_ = o.clock_log_;
 }
 
 void Resolver::adopt(Resolver &shadow) {
     std::swap(filter_, shadow.filter_);        // vectors change hands, nothing is copied
     filter_.track_changes(nullptr, nullptr);
     shadow.filter_.track_changes(nullptr, nullptr);
-    synthetic_now_ = shadow.synthetic_now_; next_flip_ = shadow.next_flip_; nflips_ = shadow.nflips_;
+    synthetic_now_ = shadow.synthetic_now_; next_flip_ = shadow.next_flip_; nflips_ = shadow.nflips_; sched_mismatch_ = shadow.sched_mismatch_;
     chunk_drops_.swap(shadow.chunk_drops_);
     chunk_news_.swap(shadow.chunk_news_);
     exp_lo_ = shadow.exp_lo_; exp_hi_ = shadow.exp_hi_;
@@ -529,6 +597,19 @@ void Resolver::parallel_walk(const PhaseRec *recs, uint64_t nrecs, const std::ve
             // a chunk longer than the filter's TTL -> no speculation.
             w.odd = false;
             w.after_flip = false;
+            w.sched = sched_ != nullptr;
+            if (w.sched) {
+                // an imposed schedule says exactly where the expiry falls: in an earlier range of the batch, in this one, or nowhere near
+                const int64_t *lo = std::lower_bound(sched_, sched_ + nsched_, buffers[segs[t0].b_lo].sampleTimestamp);
+                const int64_t *mid = std::lower_bound(lo, sched_ + nsched_, buffers[w.b_lo].sampleTimestamp);
+                const int64_t *hi = std::upper_bound(mid, sched_ + nsched_, buffers[w.b_hi - 1].sampleTimestamp);
+                w.flip_ts = kNoBufferTs;
+                w.flip_clock = std::numeric_limits<int64_t>::max();
+                if ((mid - lo) + (hi - mid) > 1) w.odd = true;         // two expiries inside one chunk: a chunk longer than the filter's TTL
+                else if (mid - lo == 1) w.after_flip = true;
+                else if (hi - mid == 1) w.flip_ts = *mid;
+                continue;
+            }
             const int64_t prev = buffers[w.b_lo - 1].sysTimestamp;
             if (prev + kBufferSpanMs < next_flip_) w.flip_clock = next_flip_;
             else if (prev >= next_flip_ && buffers[w.b_hi - 1].sysTimestamp + kBufferSpanMs < next_flip_ + kFilterTtlMs - kBufferSpanMs) {
@@ -556,6 +637,85 @@ void Resolver::parallel_walk(const PhaseRec *recs, uint64_t nrecs, const std::ve
 }
 
 uint64_t segment_first_record(const PhaseRec *recs, uint64_t nrecs, uint32_t pos) { return first_record_at(recs, nrecs, pos); }
+
+void flip_schedule(const int64_t *end_clock, uint64_t nbuf, int64_t startup_ms, int clock_mode, std::vector<uint64_t> &flip_after) {
+    // Resolver::reset + after_buffer, nothing else: next_flip = 0 (static, readsb.c:1227); clock mode 1 = one expiry before buffer 0
+    int64_t next_flip = clock_mode == 1 ? startup_ms + kFilterTtlMs : 0;
+    flip_after.clear();
+    for (uint64_t b = 0; b < nbuf; ++b)
+        if (end_clock[b] >= next_flip) { flip_after.push_back(b); next_flip = end_clock[b] + kFilterTtlMs; }
+}
+
+void estimate_end_clocks(const PhaseRec *recs, uint64_t nrecs, const std::vector<BufferClock> &buffers, std::vector<int64_t> &out) {
+    uint64_t i = 0;
+    for (const BufferClock &b : buffers) {
+        int64_t now = b.sysTimestamp;
+        const uint64_t bend = (uint64_t) b.first + b.length;
+        while (i < nrecs && recs[i].pos < bend) {
+            const uint32_t pos = recs[i].pos;
+            int best = -2;
+            uint32_t phase = 0;
+            bool uncond = false;
+            for (; i < nrecs && recs[i].pos == pos; ++i) {
+                const PhaseRec &r = recs[i];
+                if (!(r.flags & REC_COND)) uncond = true;
+                if (r.score_known > best) { best = r.score_known; phase = r.phase; }
+            }
+            if (uncond && best >= 0) now = b.sysTimestamp + ((int64_t) (pos - b.first) * 5 + (8 + 56) * 12 + phase) / 12000;
+        }
+        out.push_back(now);
+    }
+}
+
+int shard_walk_core(Resolver &res, const ShardWalkPlan &plan, size_t nchunks, const std::function<void(size_t, uint64_t &, uint64_t &)> &chunk,
+                    const std::function<int(size_t, bool)> &walk, ShardWalkOut &out, const char **err) {
+    static const char *none = "";
+    *err = none;
+    out.clocks.clear(); out.state_first.clear(); out.state_end.clear();
+    for (size_t i = 1; i < plan.nsched; ++i)
+        if (plan.sched[i] <= plan.sched[i - 1]) { *err = "the expiry schedule must be ascending"; return -1; }
+    res.log_end_clocks(nullptr);
+    bool own_started = false, have_state = false;
+    uint64_t expect = 0;
+    for (size_t i = 0; i < nchunks; ++i) {
+        uint64_t pos = 0, n = 0;
+        chunk(i, pos, n);
+        if (i == 0) {
+            if (pos > plan.own_first || pos % plan.buf_samples) { *err = "the chunks start behind the range's first sample"; return -1; }
+            if (plan.start_state) {
+                if (!res.import_state(plan.start_state, plan.start_state_bytes)) { *err = "not a filter state"; return -1; }
+                have_state = true;
+            } else if (pos == 0) res.reset(plan.startup_ms, plan.clock_mode);    // the stream's own start: the reference's initial state
+            else res.reset_empty(plan.startup_ms);
+            res.set_schedule(plan.sched, plan.nsched);
+        } else if (pos != expect) { *err = "the chunks must be consecutive"; return -1; }
+        expect = pos + n;
+        if (pos < plan.own_first) {                            // warm-up: walked for the filter's state only
+            if (expect > plan.own_first) { *err = "a chunk straddles the range's first sample (feed warm-up and range separately)"; return -1; }
+            if (have_state) continue;                          // ... or not at all: the state at the range's first sample was given
+            const int rc = walk(i, false);
+            if (rc != 0) return rc;
+            continue;
+        }
+        if (!own_started) {
+            own_started = true;
+            if (pos != plan.own_first) { *err = "no chunk starts at the range's first sample"; return -1; }
+            if (!have_state) {
+                // the expiries before the range, counted from the schedule (a cold start counted only those of its warm-up)
+                const int64_t ts0 = (int64_t) plan.own_first * 5;
+                res.set_nflips((uint64_t) (std::lower_bound(plan.sched, plan.sched + plan.nsched, ts0) - plan.sched) + (plan.clock_mode == 1 ? 1u : 0u));
+            }
+            res.export_state(out.state_first);
+            res.log_end_clocks(&out.clocks);
+        }
+        const int rc = walk(i, true);
+        if (rc != 0) { res.log_end_clocks(nullptr); return rc; }
+    }
+    res.log_end_clocks(nullptr);
+    if (!own_started) { *err = "no chunk of the range itself"; return -1; }
+    res.export_state(out.state_end);
+    return 0;
+}
 
 void Resolver::build_messages(const PhaseRec *recs, const unsigned long long *sig, const unsigned long long *msig, const std::vector<BufferClock> &buffers,
                               const Accepted *acc, uint64_t nacc, mgpu_msg *out) {

@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <functional>
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "../../include/modes_gpu.h"
@@ -40,6 +41,7 @@ class IcaoFilter {
     };
     void snapshot(Snapshot &s) const;
     void restore(const Snapshot &s);
+    int active_index() const { return active_; }
     void union_sorted(std::vector<uint32_t> &out) const;      // addresses < 2^24 in either generation, ascending
     const std::vector<uint32_t> &members(bool active) const { return members_[active ? active_ : active_ ^ 1]; }   // addresses < 2^24
     bool same_as(const IcaoFilter &o) const;                  // membership per generation, occupied, table size
@@ -131,6 +133,8 @@ struct SegmentWalk {
     bool flipped = false;                 // the expiry lies behind: known = the batch's ACTIVE generation (+ adds), not both
     bool after_flip = false;              // ... from the range's first buffer on (the expiry falls into an earlier range)
     int64_t flip_clock = 0;               // the range expires the filter at the first buffer end with clock >= this
+    bool sched = false;                   // an imposed expiry schedule (Resolver::set_schedule): the range expires the filter after the
+    int64_t flip_ts = 0;                  // buffer whose sampleTimestamp is flip_ts (INT64_MIN: after none), whatever the clock says
     int32_t flip_at = -1;                 // buffer after which it did (-1: never), nflip = how often
     int32_t nflip = 0;
     AddrSet q_pre;                        // addresses asked about before their own first add in this range
@@ -145,6 +149,23 @@ class Resolver {
   public:
     // clock_mode = mgpu_config.filter_clock: 0 first expiry after buffer 0, 1 before it, 2 never (external_expire only)
     void reset(int64_t startup_ms, int clock_mode = 0);
+    // --- one capture walked by several ranks (config 5; api.cpp: mgpu_shard_walk, readsb_amd/shard.py) ---
+    // A rank that starts in the middle of the stream: nothing known (not even modesInit's show_only entry, which is two expiries
+    // gone by then), the clock wherever the first buffer puts it.
+    void reset_empty(int64_t startup_ms);
+    // An imposed expiry schedule: the filter expires after exactly the buffers whose sampleTimestamp is listed (ascending; the
+    // array must outlive its use; nullptr = the reference's own rule, readsb.c:1227-1231).  The clock state (next_flip) is still
+    // kept as the reference keeps it, so a schedule that is the fixed point of the walk's own end clocks reproduces the
+    // reference's expiries exactly; mismatches() counts the buffers where the rule and the schedule disagreed.
+    void set_schedule(const int64_t *buffer_ts, size_t n) { sched_ = buffer_ts; nsched_ = n; sched_mismatch_ = 0; }
+    uint64_t schedule_mismatches() const { return sched_mismatch_; }
+    void set_nflips(uint64_t n) { nflips_ = n; }
+    // every buffer's end clock (Modes.synthetic_now when backgroundTasks looks at it), in stream order, appended to *log
+    void log_end_clocks(std::vector<int64_t> *log) { clock_log_ = log; }
+    // The whole state as bytes, canonical (members sorted: bucket placement never shows in results, icao_filter.c): equal states
+    // <=> equal blobs.  import_state: false = not a state blob (nothing changed).
+    void export_state(std::vector<uint8_t> &blob) const;
+    bool import_state(const uint8_t *blob, size_t bytes);
     void external_expire() { filter_.expire(); ++nflips_; }   // the host's icaoFilterExpire(), forwarded
     // The serial part: walk the ordered live records of one chunk and decide which frames the
     // reference accepts (best phase, ICAO filter, skip-ahead, filter clock).  Fills acc[0..return) (the
@@ -183,7 +204,7 @@ class Resolver {
                  const std::vector<BufferClock> &buffers, std::vector<mgpu_msg> &out, uint32_t *aux_pos,
                  uint16_t *aux_skip, uint32_t *aux_limit, uint64_t aux_cap, ResolveCounts &counts);
     // the per-buffer filter clock for a buffer that produced no walk (zero-length EOF buffer)
-    void tick_empty(int64_t sysTimestamp);
+    void tick_empty(int64_t sysTimestamp, int64_t sampleTimestamp = kNoBufferTs);
     IcaoFilter &filter() { return filter_; }
     uint64_t nflips() const { return nflips_; }
 
@@ -219,13 +240,45 @@ class Resolver {
     int64_t walk_range(Policy &pol, const PhaseRec *recs, uint64_t rec_lo, const BufferClock *bufs, uint32_t b_lo, uint32_t b_hi,
                        Accepted *out, uint32_t *aux_pos, uint16_t *aux_skip, uint32_t *aux_limit, uint64_t aux_cap,
                        ResolveCounts &c) const;
-    void after_buffer();
+    static constexpr int64_t kNoBufferTs = INT64_MIN;  // "which buffer this is, is not known": the reference's rule applies
+    void after_buffer(int64_t buffer_ts = kNoBufferTs);
+    bool scheduled(int64_t buffer_ts) const;           // does the imposed schedule expire the filter after this buffer
+    const int64_t *sched_ = nullptr;
+    size_t nsched_ = 0;
+    uint64_t sched_mismatch_ = 0;
+    std::vector<int64_t> *clock_log_ = nullptr;
     IcaoFilter filter_;
     std::vector<uint32_t> chunk_drops_, chunk_news_;   // union changes since begin_chunk
     size_t exp_lo_ = 0, exp_hi_ = 0;                   // ... of them, what the batch's expiry dropped: chunk_drops_[exp_lo_, exp_hi_)
     int64_t synthetic_now_ = 0, next_flip_ = 0;
     uint64_t nflips_ = 0;
 };
+
+// ---- one capture walked by several ranks (config 5): what a rank does with its chunks, free of the GPU side (api.cpp:
+// mgpu_shard_walk adapts packets to it; mgpu_selftest_shard_walk runs the whole protocol on synthetic record streams) ----
+struct ShardWalkPlan {
+    uint64_t own_first = 0;                 // first sample of the rank's own range; chunks before it are warm-up
+    uint32_t buf_samples = 131072;
+    int64_t startup_ms = 0;
+    int clock_mode = 0;                     // mgpu_config.filter_clock (0 / 1)
+    const int64_t *sched = nullptr;         // imposed expiry schedule: sampleTimestamps of the buffers the filter expires after (must outlive the walk)
+    size_t nsched = 0;
+    const uint8_t *start_state = nullptr;   // the filter state at own_first (then the warm-up is skipped), or null: start at the first chunk
+    size_t start_state_bytes = 0;
+};
+struct ShardWalkOut {
+    std::vector<int64_t> clocks;            // end clock of every buffer of the own range
+    std::vector<uint8_t> state_first, state_end;
+};
+// chunk(i) = (first sample, samples) of the i-th chunk, consecutive; walk(i, own) walks it on `res` (own: the caller also builds
+// messages / keeps statistics), returns 0 or an error code that ends the walk.  Returns 0, a walk's code, or -1 with *err set.
+int shard_walk_core(Resolver &res, const ShardWalkPlan &plan, size_t nchunks, const std::function<void(size_t, uint64_t &, uint64_t &)> &chunk,
+                    const std::function<int(size_t, bool)> &walk, ShardWalkOut &out, const char **err);
+// A buffer's end clock (Modes.synthetic_now when backgroundTasks looks at it after the buffer, demod_2400.c:412-414) estimated from
+// the records alone: the last candidate with an unconditional record, its best phase by the "known" scores.  Appends one per buffer.
+void estimate_end_clocks(const PhaseRec *recs, uint64_t nrecs, const std::vector<BufferClock> &buffers, std::vector<int64_t> &out);
+// readsb.c:1227-1231 over a list of end clocks: indices of the buffers the filter expires after
+void flip_schedule(const int64_t *end_clock, uint64_t nbuf, int64_t startup_ms, int clock_mode, std::vector<uint64_t> &flip_after);
 
 // index of the first of nrecs position-sorted records with position >= pos
 uint64_t segment_first_record(const PhaseRec *recs, uint64_t nrecs, uint32_t pos);

@@ -25,13 +25,17 @@ OR-ed the adder bitmaps of the whole capture over the ranks: twice the GPU work,
 `nccl` with device tensors)."""
 import numpy as np
 
-from .binding import _FMT_BYTES
+from .binding import _FMT_BYTES, MSG_DTYPE
 
 BUF = 131072
 TRAILING = 326
 SAMPLE_RATE = 2400000
 FILTER_TTL_S = 60                       # MODES_ICAO_FILTER_TTL, readsb.h:315: one generation
-WARMUP = (2 * FILTER_TTL_S * SAMPLE_RATE + BUF - 1) // BUF * BUF + BUF   # two generations of samples, whole buffers, one to spare
+# Two generations of samples in whole buffers.  A generation is not 60 s sharp: the expiry is tested after a buffer against the
+# timestamp of the buffer's last scored candidate (anywhere within the buffer's 54.6 ms) and re-armed 60 s after THAT
+# (readsb.c:1227-1231, demod_2400.c:412-414), so two consecutive expiries lie up to 60 s + two buffers apart: 2 x (60 s + 2 buffers),
+# one buffer to spare.  (Rounds 2-3 took 120 s + 1 buffer: 0.11 s short of the bound.)
+WARMUP = (2 * FILTER_TTL_S * SAMPLE_RATE + BUF - 1) // BUF * BUF + 5 * BUF
 
 
 def shard_ranges(nsamples, nshards, buf=BUF):
@@ -189,4 +193,318 @@ def demodulate_sharded(d, iq, device=None, resident=None, nsamples=None, histori
     d.finish()
     res = d.collect(out=out) if out is not None else d.collect()
     lap("collect")
+    return res
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Round 4: the ordered walk itself sharded.  Every rank walks and builds its OWN range; what crosses ranks is a few KB per round
+# (every buffer's end clock, the filter state at every range's two ends) and, at the end, the messages — as in config 4.
+# include/modes_gpu.h ("config 5 with the ordered walk itself sharded") states the protocol; DESIGN.md §5 why it is exact.
+# ---------------------------------------------------------------------------------------------------------------------------
+
+def _pack(clocks, state_first, state_end):
+    head = np.array([clocks.size, len(state_first), len(state_end)], dtype=np.int64)
+    return head.tobytes() + np.ascontiguousarray(clocks, dtype=np.int64).tobytes() + state_first + state_end
+
+
+def _unpack(b):
+    b = bytes(b)
+    nc, n0, n1 = (int(x) for x in np.frombuffer(b[:24], dtype=np.int64))
+    o = 24
+    clocks = np.frombuffer(b[o:o + 8 * nc], dtype=np.int64)
+    o += 8 * nc
+    return clocks, b[o:o + n0], b[o + n0:o + n0 + n1]
+
+
+class ShardWalkRank:
+    """One rank of a capture of `nsamples` samples walked by `world` ranks (whole-buffer ranges, shard_ranges)."""
+
+    def __init__(self, d, rank, world, nsamples, keep_packets=False):
+        self.d, self.rank, self.world, self.n = d, rank, world, int(nsamples)
+        self.first, self.last = shard_ranges(self.n, world)[rank]
+        self.ws = warmup_start(self.first)
+        self.nbuf = (self.last - self.first + BUF - 1) // BUF
+        self.keep_packets = keep_packets       # one context plays several ranks (tests, bench --emulate-ranks): its packets are copied out
+        self.packets = None
+        self.import_state = None               # the state at `first`, from the rank before, once this rank's own warm-up proved wrong
+        self.result = None                     # (clocks, state_first, state_end) of the last walk
+        self.used = None                       # (schedule within the rank's window, imported state) of the last walk
+        self.msgs = self.counters = self.noise = None
+        self.walks = 0
+        self.ms = {}
+
+    def _lap(self, name, t0):
+        import time
+        self.ms[name] = self.ms.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
+
+    def gpu_phase(self, iq=None, resident=None, histories=None):
+        """Warm-up + range through convert / sweep / slice / pre-screen; the live records stay on the host as packets.
+        iq: the capture (host bytes), or resident = (first sample held, device address) with histories = {sample: the 326
+        IQ samples before it, as bytes} for the warm-up's first sample."""
+        import time
+        t0 = time.perf_counter()
+        d = self.d
+        if self.last <= self.first:
+            self.packets = np.zeros(0, dtype=np.uint8)
+            return
+        bps = _FMT_BYTES[d.fmt]
+        d.reset()
+        hist = None
+        if self.ws > 0:
+            hist = histories[self.ws] if histories is not None else iq[(self.ws - TRAILING) * bps:self.ws * bps]
+        d.shard_begin(self.ws, hist, 2)
+        for a, b in ((self.ws, self.first), (self.first, self.last)):     # two feeds: no packet straddles the range's first sample
+            if b > a:
+                if resident is not None:
+                    _feed_resident(d, a, b, bps, resident)
+                else:
+                    _feed_host(d, iq, a, b, bps)
+        self._lap("gpu_phase", t0)
+        if self.keep_packets:
+            self.packets = d.shard_packets().copy()
+
+    def estimate(self):
+        import time
+        t0 = time.perf_counter()
+        out = self.d.shard_clock_estimate(self.first, self.nbuf, self.packets) if self.nbuf else np.zeros(0, dtype=np.int64)
+        self._lap("clock_estimate", t0)
+        return out
+
+    def walk(self, sched_ts, out=None):
+        """Walk (unless nothing this rank depends on has changed since its last walk) and collect the range's messages."""
+        import time
+        if self.nbuf == 0:
+            self.result = (np.zeros(0, dtype=np.int64), b"", b"")
+            self.msgs, self.counters, self.noise = np.zeros(0, dtype=MSG_DTYPE), None, np.zeros(0)
+            return self.result
+        lo, hi = self.ws * 5, self.last * 5
+        mine = sched_ts[(sched_ts >= lo) & (sched_ts < hi)]
+        nbefore = int((sched_ts < self.first * 5).sum())         # (a cold start numbers its expiries from the schedule)
+        key = (mine.tobytes(), nbefore, self.import_state)
+        if self.used == key:
+            return self.result
+        t0 = time.perf_counter()
+        d = self.d
+        if out is not None:
+            d.set_message_buffer(out)
+        self.result = d.shard_walk(self.first, self.nbuf, sched_ts, self.import_state, self.packets)
+        self.used = key
+        self.walks += 1
+        tm = d.timing()
+        self.ms["walk_warmup"] = self.ms.get("walk_warmup", 0.0) + tm["d2h_ms"]
+        self.ms["walk_range"] = self.ms.get("walk_range", 0.0) + tm["resolve_ms"]
+        self.ms["build_range"] = self.ms.get("build_range", 0.0) + tm["build_ms"]
+        self._lap("walk_call", t0)
+        t0 = time.perf_counter()
+        self.msgs, self.counters = d.collect(out=out) if out is not None else d.collect()
+        self.noise = d.shard_noise_terms()
+        self._lap("collect", t0)
+        return self.result
+
+
+def eof_clock(nsamples, startup_ms):
+    """The zero-length buffer ifileRun pushes after a capture that is a whole number of buffers (sdr_ifile.c:223-237): its clock."""
+    return (nsamples * 5) // 12000 + startup_ms if nsamples % BUF == 0 else None
+
+
+def schedule_from_clocks(per_rank_clocks, nsamples, startup_ms, filter_clock=0):
+    """All buffers' end clocks (rank order = stream order) -> the sampleTimestamps of the buffers the filter expires after."""
+    from .binding import flip_schedule
+    clocks = np.concatenate([np.asarray(c, dtype=np.int64) for c in per_rank_clocks] + [np.zeros(0, dtype=np.int64)])
+    e = eof_clock(nsamples, startup_ms)
+    if e is not None:
+        clocks = np.concatenate([clocks, np.array([e], dtype=np.int64)])
+    return flip_schedule(clocks, startup_ms, filter_clock).astype(np.int64) * (BUF * 5)
+
+
+def protocol_round(sched_ts, gathered, nsamples, startup_ms, filter_clock=0):
+    """What every rank concludes from a round's all-gather (the same on every rank: no further exchange needed).
+    gathered[r] = (clocks, state_first, state_end) of rank r.  -> (done, next schedule, {rank: state to import})."""
+    nxt = schedule_from_clocks([g[0] for g in gathered], nsamples, startup_ms, filter_clock)
+    imports = {}
+    prev_end = None
+    for r, (clocks, s0, s1) in enumerate(gathered):
+        if len(clocks) == 0:                        # an empty range (more ranks than buffers): the seam passes through
+            continue
+        if prev_end is not None and s0 != prev_end:
+            imports[r] = prev_end
+        prev_end = s1
+    done = not imports and nxt.size == sched_ts.size and bool((nxt == sched_ts).all())
+    return done, nxt, imports
+
+
+_INT_FIELDS = ["demod_preambles", "demod_rejected_bad", "demod_rejected_unknown_icao", "demod_accepted", "demod_preamblePhase",
+               "demod_bestPhase", "strong_signal_count", "signal_power_count", "noise_power_count", "samples_processed",
+               "samples_lost", "nbuffers", "demod_modeac"]
+
+
+def prepare_sum_blocks(msgs, earlier_counters):
+    """What a rank adds to its range's results so that the combining rank need not re-add every message's signal power one by
+    one: the block-wise form of that sequential sum (readsb_amd/csrc/seqsum.cpp), predicted from the earlier ranges' own totals."""
+    from .binding import seqsum_blocks
+    approx = float(sum(c["signal_power_sum"] for c in earlier_counters if c is not None))
+    return seqsum_blocks(approx, np.ascontiguousarray(msgs))
+
+
+def combine_ranges(parts, nsamples, nflips, stats=None):
+    """parts[r] = (messages, counters, noise terms[, sum blocks]) of rank r, in rank order -> the unsharded run's (messages,
+    counters).  Integer counters add up; the two double sums are the reference's SEQUENTIAL sums (demod_2400.c:445-447, 474-479),
+    re-added in stream order: the per-buffer noise terms one by one (one per buffer), the messages' signal powers block-wise
+    (prepare_sum_blocks) or, without blocks, message by message."""
+    from .binding import seqsum, seqsum_signal_power, seqsum_apply
+    total = None
+    sig = noise = 0.0
+    peak = 0.0
+    for part in parts:
+        msgs, cnt, terms = part[:3]
+        blocks = part[3] if len(part) > 3 else None
+        if cnt is None:
+            continue
+        if total is None:
+            total = {k: (list(v) if isinstance(v, list) else v) for k, v in cnt.items()}
+            for k in _INT_FIELDS:
+                total[k] = [0] * len(cnt[k]) if isinstance(cnt[k], list) else 0
+        for k in _INT_FIELDS:
+            if isinstance(cnt[k], list):
+                total[k] = [a + b for a, b in zip(total[k], cnt[k])]
+            else:
+                total[k] += cnt[k]
+        if blocks is not None:
+            sig, fb = seqsum_apply(sig, np.ascontiguousarray(msgs), blocks)
+            if stats is not None:
+                stats["sum_blocks"] = stats.get("sum_blocks", 0) + len(blocks)
+                stats["sum_blocks_readded"] = stats.get("sum_blocks_readded", 0) + fb
+        else:
+            sig = seqsum_signal_power(sig, np.ascontiguousarray(msgs))
+        noise = seqsum(noise, terms)
+        peak = max(peak, cnt["peak_signal_power"])
+    if nsamples % BUF == 0:                         # the EOF buffer: 0 / 0 in the converter (convert.c:101-107), mgpu_finish
+        noise += float("nan")
+        total["samples_lost"] += BUF
+        total["nbuffers"] += 1
+    total["nflips"] = int(nflips)
+    total["signal_power_sum"], total["noise_power_sum"], total["peak_signal_power"] = sig, noise, peak
+    msgs = np.concatenate([p[0] for p in parts]) if len(parts) > 1 else parts[0][0]
+    return msgs, total
+
+
+def run_walk_protocol(ranks, exchange, nsamples, startup_ms, filter_clock=0, max_rounds=None, stats=None):
+    """The rounds of the protocol for the ranks this process plays.  exchange(list of bytes, one per own rank) -> list of bytes
+    of ALL ranks in rank order (an all-gather).  -> the final schedule (sampleTimestamps)."""
+    est = exchange([_pack(r.estimate(), b"", b"") for r in ranks])
+    sched = schedule_from_clocks([_unpack(b)[0] for b in est], nsamples, startup_ms, filter_clock)
+    world = len(est)
+    rounds = 0
+    while True:
+        rounds += 1
+        if max_rounds is None:
+            max_rounds = world + 72
+        if rounds > max_rounds:
+            raise RuntimeError("sharded walk: the schedule / seam iteration did not settle")
+        got = [_unpack(b) for b in exchange([_pack(*r.walk(sched)) for r in ranks])]
+        done, nxt, imports = protocol_round(sched, got, nsamples, startup_ms, filter_clock)
+        if stats is not None:
+            stats.setdefault("rounds", 0)
+            stats["rounds"] = rounds
+            stats["seam_failures"] = stats.get("seam_failures", 0) + len(imports)
+            stats["schedule_changes"] = stats.get("schedule_changes", 0) + (0 if (nxt.size == sched.size and (nxt == sched).all()) else 1)
+        if done:
+            return sched
+        sched = nxt
+        for r in ranks:
+            if r.rank in imports:
+                r.import_state = imports[r.rank]
+
+
+def demodulate_sharded_walk_local(d, iq, nshards, stats=None):
+    """All ranks of the sharded walk played by ONE Demodulator, one after the other (tests, single GPU): the same protocol, the
+    all-gather replaced by a list."""
+    iq = np.ascontiguousarray(iq).view(np.uint8).reshape(-1)
+    n = iq.size // _FMT_BYTES[d.fmt]
+    ranks = [ShardWalkRank(d, r, nshards, n, keep_packets=True) for r in range(nshards)]
+    for r in ranks:
+        r.gpu_phase(iq)
+    startup = int(d.cfg.startup_time_ms)
+    fc = int(d.cfg.filter_clock)
+    sched = run_walk_protocol(ranks, lambda payloads: payloads, n, startup, fc, stats=stats)
+    if stats is not None:
+        stats["walks"] = [r.walks for r in ranks]
+        stats["imported"] = [r.import_state is not None for r in ranks]
+    parts = [(r.msgs, r.counters, r.noise, prepare_sum_blocks(r.msgs, [q.counters for q in ranks[:r.rank]])) for r in ranks]
+    return combine_ranges(parts, n, len(sched) + (1 if fc == 1 else 0), stats)
+
+
+def _all_gather_bytes(payload, device):
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    size = torch.tensor([len(payload)], dtype=torch.int64, device=device)
+    sizes = [torch.zeros_like(size) for _ in range(world)]
+    dist.all_gather(sizes, size)
+    sizes = [int(x.item()) for x in sizes]
+    buf = torch.zeros(max(max(sizes), 1), dtype=torch.uint8, device=device)
+    if payload:
+        buf[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(device)
+    parts = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf)
+    return [bytes(parts[r][:sizes[r]].cpu().numpy().tobytes()) for r in range(world)]
+
+
+def demodulate_sharded_walk(d, iq, device=None, resident=None, nsamples=None, histories=None, phases=None, out=None, stats=None):
+    """torch.distributed version: this process is ONE rank.  Collectives: an all-gather of a few KB per protocol round (clocks and
+    states), then the gather of every range's messages, counters and noise terms to rank 0.  Returns (messages, counters) on rank
+    0, None elsewhere."""
+    import time
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    device = device or torch.device("cpu")
+    if iq is not None:
+        iq = np.ascontiguousarray(iq).view(np.uint8).reshape(-1)
+    n = nsamples if nsamples is not None else iq.size // _FMT_BYTES[d.fmt]
+    me = ShardWalkRank(d, rank, world, n)
+    me.gpu_phase(iq, resident, histories)
+    startup, fc = int(d.cfg.startup_time_ms), int(d.cfg.filter_clock)
+    t0 = time.perf_counter()
+    sched = run_walk_protocol([me], lambda payloads: _all_gather_bytes(payloads[0], device), n, startup, fc, stats=stats)
+    t1 = time.perf_counter()
+    # ---- the ranges' results to rank 0 ----
+    import pickle
+    cnt = me.counters
+    blob = b""
+    if cnt is not None:
+        blob = pickle.dumps((cnt, me.noise.tobytes()))
+    metas = _all_gather_bytes(np.array([me.msgs.size], dtype=np.int64).tobytes() + blob, device)
+    counts = [int(np.frombuffer(m[:8], dtype=np.int64)[0]) for m in metas]
+    earlier = [pickle.loads(m[8:])[0] if len(m) > 8 else None for m in metas[:rank]]
+    from .binding import SUM_BLOCK, SUM_BLOCK_DTYPE
+    blocks = prepare_sum_blocks(me.msgs, earlier)                 # (every rank at once: its part of the sequential signal-power sum)
+    rec, brec = MSG_DTYPE.itemsize, SUM_BLOCK_DTYPE.itemsize
+    nblk = [(c + SUM_BLOCK - 1) // SUM_BLOCK for c in counts]
+    buf = torch.zeros(max(max(c * rec + b * brec for c, b in zip(counts, nblk)), 1), dtype=torch.uint8, device=device)
+    if me.msgs.size:
+        mine = np.concatenate([np.ascontiguousarray(me.msgs).view(np.uint8).reshape(-1), blocks.view(np.uint8).reshape(-1)])
+        buf[:mine.size] = torch.from_numpy(mine).to(device)
+    gathered = [torch.zeros_like(buf) for _ in range(world)] if rank == 0 else None
+    dist.gather(buf, gathered, dst=0)
+    t2 = time.perf_counter()
+    if phases is not None:
+        for k, v in me.ms.items():
+            phases[k] = phases.get(k, 0.0) + v
+        phases["protocol_rounds_wall"] = phases.get("protocol_rounds_wall", 0.0) + (t1 - t0) * 1e3
+        phases["gather_results"] = phases.get("gather_results", 0.0) + (t2 - t1) * 1e3
+    if rank != 0:
+        return None
+    parts = []
+    for r in range(world):
+        raw = gathered[r][:counts[r] * rec + nblk[r] * brec].cpu().numpy()
+        msgs = raw[:counts[r] * rec].view(MSG_DTYPE)
+        if len(metas[r]) > 8:
+            c, terms = pickle.loads(metas[r][8:])
+            parts.append((msgs, c, np.frombuffer(terms, dtype=np.float64), raw[counts[r] * rec:].view(SUM_BLOCK_DTYPE)))
+        else:
+            parts.append((msgs, None, np.zeros(0)))
+    res = combine_ranges(parts, n, len(sched) + (1 if fc == 1 else 0), stats)
+    if phases is not None:
+        phases["combine"] = phases.get("combine", 0.0) + (time.perf_counter() - t2) * 1e3
     return res

@@ -75,6 +75,13 @@ def _cases():
     x[:3000] = 0
     x[9000:9050] = 1.0
     yield "zeros, burst, noise", x
+    #  ONE isolated strong sample while the running sum is still small: its grid steps are 2^22 and more, the block
+    # must be added in order (the kernel once clamped the count and took the one-addition path: 0.0511 for 1.0355)
+    for k, (quiet, strong) in enumerate(((0.033, (1.0,)), (0.033, (0.02,)), (0.3, (1.0, 1.0)), (0.07, (0.5, 1.0, 0.25)))):
+        x = np.full(4096, F(quiet / 2048), dtype=F)
+        for j, v in enumerate(strong):
+            x[2048 + 600 + 37 * j] = F(v)
+        yield f"isolated strong samples {k}", x
     # exact ties by construction against a sum that sits in [4, 8): every sample is half a grid step
     yield "all ties", np.concatenate([np.full(4, F(1.0)), np.full(5000, F(2.0 ** -22))]).astype(F)
 

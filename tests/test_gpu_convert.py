@@ -79,3 +79,24 @@ def test_sc16_random_and_extremes(built, fmt):
         w2, wml2, wmp2 = helpers.oracle_convert(blk, fmt)
         assert np.array_equal(m2, w2) and ml2 == wml2 and mp2 == wmp2, (k, ml2, wml2, mp2, wmp2)
     d.close()
+
+
+@pytest.mark.parametrize("fmt", [1, 2])
+@pytest.mark.parametrize("nstrong", [1, 2, 3])
+def test_sc16_isolated_strong_samples_after_a_quiet_stretch(built, fmt, nstrong):
+    """one to three full-scale samples in a 512-sample block while the running float sum is still small — each is
+    2^22 grid steps and more of the binade the sum is in; the block has to be added in order, not as one integer addition."""
+    rng = np.random.default_rng(90 + fmt + nstrong)
+    n = 131072
+    full = 32767 if fmt == 1 else 2047
+    for quiet_amp, where in ((3, 700), (12, 5000), (40, 60000)):
+        iq = rng.integers(-quiet_amp, quiet_amp + 1, size=2 * n, dtype=np.int32).astype("<i2")
+        for j in range(nstrong):
+            iq[2 * (where + 37 * j)] = full
+            iq[2 * (where + 37 * j) + 1] = -full
+        d = _dem(fmt, n)
+        mag, ml, mp = d.convert(iq)
+        d.close()
+        want, wml, wmp = helpers.oracle_convert(iq, fmt)
+        assert np.array_equal(mag, want)
+        assert ml == wml and mp == wmp, (quiet_amp, where, ml, wml, mp, wmp)

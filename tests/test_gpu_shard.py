@@ -34,6 +34,77 @@ def test_sharded_capture_equals_unsharded(built, nshards, seconds, dense, rate, 
     helpers.assert_same_counters(cnt, wst)          # every demodulator statistic, the ones the skip windows and the samples feed included
 
 
+@pytest.mark.parametrize("nshards,seconds,dense,rate,nfix,naircraft", [(2, 8.0, 1, 8000.0, 2, 200), (3, 8.0, 0, 2000.0, 1, 200), (8, 70.0, 1, 6000.0, 1, 200),
+                                                                       (2, 290.0, 0, 1500.0, 1, 200),      # second range from 145 s: its warm-up [24.7 s, 145 s) starts from an empty filter
+                                                                       (3, 400.0, 0, 1200.0, 1, 3000)])    # many aircraft: the table grows early, the later ranks' warm-ups must find its size
+def test_sharded_walk_equals_unsharded(built, nshards, seconds, dense, rate, nfix, naircraft):
+    """Round 4: every rank walks and builds its OWN range (shard.py: ShardWalkRank, run_walk_protocol) — the unsharded message
+    list and every counter, the order-dependent double sums included, bit for bit."""
+    import readsb_amd
+    from readsb_amd import shard
+    iq = helpers.synth(seconds=seconds, seed=1900 + nshards + int(seconds), rate=rate, dense=dense, naircraft=naircraft, threads=16)
+    want, wst = helpers.ref_run(iq, 0, nfix, 1, 58) if helpers.have_ref() else helpers.oracle_run(iq, 0, nfix, 1, 58)
+    d = readsb_amd.Demodulator(nfix_crc=nfix, startup_time_ms=helpers.STARTUP_MS, max_samples=256 * 131072)
+    stats = {}
+    try:
+        got, cnt = shard.demodulate_sharded_walk_local(d, iq, nshards, stats)
+    finally:
+        d.close()
+    assert len(want) > 5000
+    helpers.assert_same_messages(got, want)
+    helpers.assert_same_counters(cnt, wst)
+    assert stats["rounds"] >= 1 and min(stats["walks"]) >= 1 and stats["sum_blocks"] >= 1
+    if seconds < 100:
+        assert stats["rounds"] == 1 and not any(stats["imported"])  # every warm-up reaches back to the start: one walk per rank
+
+
+def _rank_walk(rank, world, port, q, seconds, seed):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, helpers.ROOT)
+    sys.path.insert(0, os.path.join(helpers.ROOT, "tests"))
+    import readsb_amd
+    from readsb_amd.shard import demodulate_sharded_walk
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    iq = helpers.synth(seconds=seconds, seed=seed, rate=4000.0, dense=1, threads=8)
+    d = readsb_amd.Demodulator(startup_time_ms=helpers.STARTUP_MS, max_samples=128 * 131072)
+    stats = {}
+    res = demodulate_sharded_walk(d, iq, torch.device("cpu"), stats=stats)
+    d.close()
+    ok = True
+    if rank == 0:
+        want, wst = helpers.oracle_run(iq)
+        got, cnt = res
+        try:
+            helpers.assert_same_messages(got, want)
+            helpers.assert_same_counters(cnt, wst)
+            ok = len(want) > 5000 and stats["rounds"] >= 1
+        except AssertionError as e:
+            sys.stderr.write(f"sharded walk, rank 0: {e}\n")
+            ok = False
+    else:
+        ok = res is None
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_walk_two_ranks_gloo(built):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 36500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_rank_walk, args=(r, 2, port, q, 6.0, 4243)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert results == {0: True, 1: True}
+
+
 def _rank(rank, world, port, q, seconds, seed):
     import torch
     import torch.distributed as dist

@@ -20,7 +20,8 @@ def test_ranges_tile_the_capture_in_whole_buffers(n, world):
 
 def test_warmup_covers_two_filter_generations():
     two_generations = 2 * shard.FILTER_TTL_S * shard.SAMPLE_RATE
-    assert shard.WARMUP % shard.BUF == 0 and two_generations + shard.BUF <= shard.WARMUP < two_generations + 2 * shard.BUF
+    # a generation lasts up to 60 s + two buffers (the expiry's clock is data-dependent within a buffer, and tested per buffer)
+    assert shard.WARMUP % shard.BUF == 0 and two_generations + 4 * shard.BUF <= shard.WARMUP <= two_generations + 6 * shard.BUF
     for first in (0, shard.BUF, 100 * shard.BUF, shard.WARMUP, shard.WARMUP + shard.BUF, 40000 * shard.BUF):
         w = shard.warmup_start(first)
         assert w % shard.BUF == 0 and 0 <= w <= first

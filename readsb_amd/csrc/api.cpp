@@ -347,6 +347,8 @@ struct mgpu_ctx {
     // the sharded walk (mgpu_shard_walk): the imposed expiry schedule (the resolver points into it), the range's end clocks, what
     // each of its buffers adds to noise_power_sum, the filter state at the range's first sample / at its end
     std::vector<int64_t> shard_sched;
+    std::vector<int64_t> shard_est;                           // the fetcher's estimate of every buffer's end clock, packet by packet
+    std::vector<uint64_t> shard_est_pos, shard_est_off;       // ... the packets' first samples / offsets into shard_est
     std::vector<double> shard_noise;
     ShardWalkOut shard_out;
     // beast encoder scratch (mgpu_beast_encode*): grown on demand
@@ -997,6 +999,7 @@ int mgpu_reset(mgpu_ctx *c) {
     c->worker_rc = MGPU_OK;
     c->shard_mode = 0;
     c->shard_packets.clear();
+    c->shard_est.clear(); c->shard_est_pos.clear(); c->shard_est_off.clear();
     c->resolver.set_schedule(nullptr, 0);
     c->resolver.log_end_clocks(nullptr);
     HIPCHK(c, hipMemsetAsync(c->d_adder_bitmap, 0, (1u << 24) / 8, c->stream));
@@ -1737,6 +1740,10 @@ static void fetcher_main(mgpu_ctx *c) {
             // (UC8: exact integer sums; SC16*: the converter's double sums — eight bytes per buffer either way, level then power)
             if (c->cfg.format == MGPU_FMT_UC8) { put(sl.h_sums, nbuf * 8); put(sl.h_sums + c->cap_buffers, nbuf * 8); }
             else { put(sl.h_fsums, nbuf * 8); put(sl.h_fsums + c->cap_buffers, nbuf * 8); }
+            // ... and, while the GPU works on the next chunk, what the buffers' end clocks will be (mgpu_shard_clock_estimate)
+            c->shard_est_pos.push_back(job.stream_pos);
+            c->shard_est_off.push_back(c->shard_est.size());
+            estimate_end_clocks(job.recs.data(), job.nlive, sl.buffers, c->shard_est);
         }
         {
             std::lock_guard<std::mutex> lk(c->mu);
@@ -2352,6 +2359,7 @@ int mgpu_shard_begin(mgpu_ctx *c, uint64_t first_sample, const void *history_iq,
                 HIPCHK(c, hipHostMalloc(&sl.h_live_win, c->cap_pool * sizeof(unsigned long long)));
             }
     c->shard_packets.clear();
+    c->shard_est.clear(); c->shard_est_pos.clear(); c->shard_est_off.clear();
     c->stream_pos = first_sample;
     c->eof = false;
     c->tail_src = nullptr;
@@ -2588,6 +2596,17 @@ static int shard_packets_span(mgpu_ctx *c, const void *&packets, uint64_t &bytes
 int mgpu_shard_clock_estimate(mgpu_ctx *c, const void *packets, uint64_t bytes, uint64_t own_first, int64_t *end_clocks, uint64_t cap, uint64_t *n_out) {
     if (!c || !end_clocks || !n_out) return MGPU_E_INVAL;
     *n_out = 0;
+    if (!packets && !c->shard_est_pos.empty()) {              // the context's own packets: the fetcher has estimated them as they came
+        { const int rc = wait_all(c); if (rc != MGPU_OK) return rc; }
+        size_t k = 0;
+        while (k < c->shard_est_pos.size() && c->shard_est_pos[k] < own_first) ++k;
+        const size_t off = k < c->shard_est_off.size() ? (size_t) c->shard_est_off[k] : c->shard_est.size();
+        const size_t cnt = c->shard_est.size() - off;
+        if (cnt > cap) { c->err = "mgpu_shard_clock_estimate: more buffers than the caller's array holds"; return MGPU_E_CAPACITY; }
+        std::memcpy(end_clocks, c->shard_est.data() + off, cnt * sizeof(int64_t));
+        *n_out = cnt;
+        return MGPU_OK;
+    }
     { const int rc = shard_packets_span(c, packets, bytes); if (rc != MGPU_OK) return rc; }
     const uint8_t *p = (const uint8_t *) packets, *end = p + bytes;
     std::vector<BufferClock> bufs;

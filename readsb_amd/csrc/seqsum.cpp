@@ -16,6 +16,9 @@
 // by term, only the blocks whose premise fails (the ~20 in which the sum crosses into the next binade, the stream's first).
 #include <cmath>
 #include <cstdint>
+#include <functional>
+#include <thread>
+#include <vector>
 
 #include "../../include/modes_gpu.h"
 
@@ -40,11 +43,10 @@ double mgpu_seqsum_signal_power(double start, const struct mgpu_msg *msgs, uint6
     return s;
 }
 
-int mgpu_seqsum_blocks(double approx_start, const struct mgpu_msg *msgs, uint64_t n, uint32_t block, struct mgpu_sum_block *out) {
-    if (!block || (n && (!msgs || !out))) return MGPU_E_INVAL;
-    double pred = approx_start;                                 // where the sum roughly is: decides the binade a block is prepared for
-    for (uint64_t lo = 0, b = 0; lo < n; lo += block, ++b) {
-        const uint64_t hi = lo + block < n ? lo + block : n;
+// One part of a range: its blocks against the binades `pred` (the approximate running sum where the part begins) predicts.
+static void prepare_part(double pred, const struct mgpu_msg *msgs, uint64_t lo0, uint64_t hi0, uint32_t block, struct mgpu_sum_block *out) {
+    for (uint64_t lo = lo0, b = lo0 / block; lo < hi0; lo += block, ++b) {
+        const uint64_t hi = lo + block < hi0 ? lo + block : hi0;
         mgpu_sum_block sb{0, 0, 0};
         if (!(pred > 0.0) || !std::isfinite(pred)) {            // no binade yet (the stream's first block): re-added term by term
             for (uint64_t i = lo; i < hi; ++i) if (has_power(msgs[i])) pred += power_of(msgs[i]);
@@ -76,6 +78,30 @@ int mgpu_seqsum_blocks(double approx_start, const struct mgpu_msg *msgs, uint64_
         sb.total = total; sb.e = e; sb.flags = flags;
         out[b] = sb;
     }
+}
+
+int mgpu_seqsum_blocks(double approx_start, const struct mgpu_msg *msgs, uint64_t n, uint32_t block, struct mgpu_sum_block *out) {
+    if (!block || (n && (!msgs || !out))) return MGPU_E_INVAL;
+    // the prediction only has to be roughly right, so a range splits into parts prepared side by side: plain part sums first (any
+    // order), then every part against the prefix of those
+    const uint64_t nblocks = (n + block - 1) / block;
+    unsigned parts = std::thread::hardware_concurrency() >= 16 ? 8u : 2u;
+    if (nblocks < 64) parts = 1;
+    std::vector<double> sums(parts, 0.0);
+    std::vector<uint64_t> cut(parts + 1);
+    for (unsigned p = 0; p <= parts; ++p) { const uint64_t c = nblocks * p / parts * block; cut[p] = c < n ? c : n; }
+    cut[parts] = n;
+    auto run = [&](const std::function<void(unsigned)> &f) {
+        std::vector<std::thread> th;
+        for (unsigned p = 1; p < parts; ++p) th.emplace_back(f, p);
+        f(0);
+        for (auto &t : th) t.join();
+    };
+    if (parts > 1)
+        run([&](unsigned p) { double s = 0; for (uint64_t i = cut[p]; i < cut[p + 1]; ++i) if (has_power(msgs[i])) s += power_of(msgs[i]); sums[p] = s; });
+    std::vector<double> start(parts, approx_start);
+    for (unsigned p = 1; p < parts; ++p) start[p] = start[p - 1] + sums[p - 1];
+    run([&](unsigned p) { prepare_part(start[p], msgs, cut[p], cut[p + 1], block, out); });
     return MGPU_OK;
 }
 

@@ -219,8 +219,10 @@ def _unpack(b):
 class ShardWalkRank:
     """One rank of a capture of `nsamples` samples walked by `world` ranks (whole-buffer ranges, shard_ranges)."""
 
-    def __init__(self, d, rank, world, nsamples, keep_packets=False):
+    def __init__(self, d, rank, world, nsamples, keep_packets=False, out=None):
         self.d, self.rank, self.world, self.n = d, rank, world, int(nsamples)
+        self.out = out                         # a standing mgpu_msg array the range's messages are built into (none: the library's list, copied out)
+        self.est = None
         self.first, self.last = shard_ranges(self.n, world)[rank]
         self.ws = warmup_start(self.first)
         self.nbuf = (self.last - self.first + BUF - 1) // BUF
@@ -260,17 +262,16 @@ class ShardWalkRank:
                 else:
                     _feed_host(d, iq, a, b, bps)
         self._lap("gpu_phase", t0)
+        t0 = time.perf_counter()
+        self.est = d.shard_clock_estimate(self.first, self.nbuf).copy()     # (the fetcher estimated every chunk as it came)
+        self._lap("clock_estimate", t0)
         if self.keep_packets:
             self.packets = d.shard_packets().copy()
 
     def estimate(self):
-        import time
-        t0 = time.perf_counter()
-        out = self.d.shard_clock_estimate(self.first, self.nbuf, self.packets) if self.nbuf else np.zeros(0, dtype=np.int64)
-        self._lap("clock_estimate", t0)
-        return out
+        return self.est if self.est is not None else np.zeros(0, dtype=np.int64)
 
-    def walk(self, sched_ts, out=None):
+    def walk(self, sched_ts):
         """Walk (unless nothing this rank depends on has changed since its last walk) and collect the range's messages."""
         import time
         if self.nbuf == 0:
@@ -284,9 +285,8 @@ class ShardWalkRank:
         if self.used == key:
             return self.result
         t0 = time.perf_counter()
-        d = self.d
-        if out is not None:
-            d.set_message_buffer(out)
+        d, out = self.d, self.out
+        d.set_message_buffer(out)
         self.result = d.shard_walk(self.first, self.nbuf, sched_ts, self.import_state, self.packets)
         self.used = key
         self.walks += 1
@@ -346,11 +346,12 @@ def prepare_sum_blocks(msgs, earlier_counters):
     return seqsum_blocks(approx, np.ascontiguousarray(msgs))
 
 
-def combine_ranges(parts, nsamples, nflips, stats=None):
+def combine_ranges(parts, nsamples, nflips, stats=None, concat=True):
     """parts[r] = (messages, counters, noise terms[, sum blocks]) of rank r, in rank order -> the unsharded run's (messages,
     counters).  Integer counters add up; the two double sums are the reference's SEQUENTIAL sums (demod_2400.c:445-447, 474-479),
     re-added in stream order: the per-buffer noise terms one by one (one per buffer), the messages' signal powers block-wise
-    (prepare_sum_blocks) or, without blocks, message by message."""
+    (prepare_sum_blocks) or, without blocks, message by message.  concat=False: the messages stay the list of per-range arrays
+    they arrived as (an aggregator's gather lands them in one buffer anyway)."""
     from .binding import seqsum, seqsum_signal_power, seqsum_apply
     total = None
     sig = noise = 0.0
@@ -384,6 +385,8 @@ def combine_ranges(parts, nsamples, nflips, stats=None):
         total["nbuffers"] += 1
     total["nflips"] = int(nflips)
     total["signal_power_sum"], total["noise_power_sum"], total["peak_signal_power"] = sig, noise, peak
+    if not concat:
+        return [p[0] for p in parts], total
     msgs = np.concatenate([p[0] for p in parts]) if len(parts) > 1 else parts[0][0]
     return msgs, total
 

@@ -127,10 +127,11 @@ EXTRA_CONFIGS = {
     "configs[2]: SC16Q11 --aggressive (2-bit repair)": (2, 2, dict(rate=2000.0)),
     "dense bursts, 8000 frames/s, overlapping DF17, --aggressive": (0, 2, dict(rate=8000.0, dense=1)),
     "UC8 --fix, Gaussian noise (sigma 3 LSB)": (0, 1, dict(rate=2000.0, dense=4)),
-    "UC8 --fix, ordered walk on the device (MGPU_DEVICE_WALK=1)": (0, 1, dict(rate=2000.0)),
 }
-# ... and the environment a configuration's context is created under (library switches are read by mgpu_create)
-EXTRA_ENV = {"UC8 --fix, ordered walk on the device (MGPU_DEVICE_WALK=1)": {"MGPU_DEVICE_WALK": "1"}}
+# (rounds 2-3 also ran the UC8 stream with the ordered walk on the device, MGPU_DEVICE_WALK=1: 78 Gsamples/s on the driver's box against
+# 223 on the builder's, the same code — since round 4 that walk lives in the experiments build only and the product has one walk,
+# the host's)
+EXTRA_ENV = {}
 
 
 try:
@@ -153,7 +154,7 @@ def restore_affinity():
             pass
 
 
-def run_extra_config(name, fmt, nfix, kw, nsamples, device, steps=4):
+def run_extra_config(name, fmt, nfix, kw, nsamples, device, steps=4, bracket_us=None):
     """One more configuration on a fresh context: `steps` back-to-back segments of a resident stream with deferred feeds (timed),
     then two more deferred segments of a fresh stream, fed the same way, whose messages and counters must equal the reference's
     own code on the same two-segment stream."""
@@ -195,7 +196,8 @@ def run_extra_config(name, fmt, nfix, kw, nsamples, device, steps=4):
     d.collect_feed(bufs[steps % 2], want_counters=True)
     elapsed = time.perf_counter() - t0
     tm = d.timing()
-    bracket_us = d.event_bracket_us()           # what a pair of timing events adds to what it brackets (see main())
+    if bracket_us is None:
+        bracket_us = d.event_bracket_us()       # what a pair of timing events adds to what it brackets (see main())
     ev_scale = tm["n_chunks"] / max(1, tm["n_timed_chunks"])
     for key in ("convert_ms", "sweep_ms", "slice_ms", "prescreen_ms"):
         tm[key] *= ev_scale
@@ -238,8 +240,6 @@ def run_extra_config(name, fmt, nfix, kw, nsamples, device, steps=4):
                                                                    ("build_ms", "build_host"), ("sigpower_ms", "sigpower"))},
            "cpu_reference_msamples_s": round(2 * nsamples / float(st["t_convert_s"] + st["t_demod_s"]) / 1e6, 1),
            "bit_identical_to_reference": True, "checked": "two deferred segments of a fresh stream, fed as in the timed region", "checker": kind}
-    if env.get("MGPU_DEVICE_WALK"):
-        out["device_walk"] = d.device_walk_stats()          # chunks decided on the device / walked on the host after all, walks run
     d.close()
     return out
 
@@ -279,7 +279,7 @@ def bench_config5(args, rank, local_rank, world):
     mine = helpers.synth(nsamples=last - lo, first=lo, seed=5150, rate=8000.0, dense=1, threads=threads)   # the rank's range, its warm-up and histories
     t_gen = time.time() - t_g0
     d_iq = torch.from_numpy(mine).to(torch.device("cuda", dev))            # resident: its own allocation, any length
-    piece = min(8192 * BUF, max(BUF, last - first))                          # samples per feed call
+    piece = min(16384 * BUF, max(BUF, ((last - first) // max(1, args.emulate_ranks if world == 1 else 1) // BUF + 512) * BUF))   # samples per feed call: a rank's range in one
     d = readsb_amd.Demodulator(nfix_crc=2, max_samples=piece, device=dev, startup_time_ms=helpers.STARTUP_MS)
     resident = (lo, d_iq.data_ptr())
     d.keep_other_threads_away(confine_to_own_l3=world > 1)
@@ -462,6 +462,9 @@ def main():
                                                           "capture time-chunked over the GPUs (configs[4], strong scaling)")
     ap.add_argument("--emulate-ranks", type=int, default=0, help="--config 5 on ONE GPU: one context plays this many ranks of the sharded walk one after "
                                                                   "the other; per-rank phase times and the combining rank's serial share in the JSON line")
+    ap.add_argument("--event-bracket-us", type=float, default=None, help="what a pair of timing events adds to the kernel it brackets, as measured by an "
+                    "earlier run (`event_bracket_us` of its line): skips the calibration (k_spin launches) — for rocprofv3 runs, whose kernel statistics "
+                    "then hold the pipeline's kernels only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the `configs` dict (other BASELINE configurations / input statistics)")
     ap.add_argument("--extra-samples", type=int, default=4096 * BUF, help="samples per segment of the extra configurations (default: the headline step)")
@@ -600,7 +603,8 @@ def main():
     if os.environ.get("MGPU_DBG_BENCH"):
         sys.stderr.write(f"dbg bench rank {rank}: main thread, warm-up + timed steps: {dbg_t}\n")
     tm = d.timing()                             # sums over the timed region's launches (everything since the last drain)
-    bracket_us = d.event_bracket_us()           # what two timing events around one kernel report beyond the kernel (include/modes_gpu.h)
+    # what two timing events around one kernel report beyond the kernel (include/modes_gpu.h): measured here, or taken from an earlier run
+    bracket_us = args.event_bracket_us if args.event_bracket_us is not None else d.event_bracket_us()
     # the stage events ride on every 4th chunk only (an event costs ~5 us of idle stream): scale the sampled sums to all chunks
     ev_scale = tm["n_chunks"] / max(1, tm["n_timed_chunks"])
     for key in ("convert_ms", "sweep_ms", "slice_ms", "prescreen_ms"):
@@ -619,8 +623,14 @@ def main():
         nm = torch.tensor([nmsgs_last], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(nm)
         total_msgs = int(nm.item())
+        # every rank's host stages (wall clock of the work itself, per step): do N pipelines' polling threads get in each other's way?
+        hs = torch.tensor([resolve_ms[0], tm["build_ms"], tm["d2h_ms"], len(d.host_cpus())], dtype=torch.float64, device=coll_dev)
+        hparts = [torch.zeros_like(hs) for _ in range(world)]
+        dist.all_gather(hparts, hs)
+        per_rank_host = [{"resolve_host": round(float(x[0]), 3), "build_host": round(float(x[1]), 3), "d2h": round(float(x[2]), 3), "pinned_cpus": int(x[3])} for x in hparts]
     else:
         total_msgs = nmsgs_last
+        per_rank_host = None
 
     # ---- bit-identity + CPU baseline, same run.  Every rank checks its own stream: the first two segments, fed exactly as in
     #      the timed region (deferred, into the consumer's arrays), against the reference's own code on the 2-segment stream, on
@@ -726,6 +736,8 @@ def main():
                                     "valu_issue": valu_issue("k_slice", slice_ / nlaunch, n / nlaunch) if per_launch == 134217728 else None}},
             "synth_gen_s": round(t_gen, 2),
         }
+        if per_rank_host is not None:
+            out["per_rank_host_ms"] = per_rank_host
         # the boundary handing over HOST buffers (mgpu_feed_iq from page-locked memory): never `value`, see DESIGN.md §4
         try:
             d.host_register(iq)
@@ -749,7 +761,7 @@ def main():
             out["configs"] = {}
             for name, (fmt, nfix, kw) in EXTRA_CONFIGS.items():
                 try:
-                    out["configs"][name] = run_extra_config(name, fmt, nfix, kw, args.extra_samples - args.extra_samples % BUF, local_rank_dev)
+                    out["configs"][name] = run_extra_config(name, fmt, nfix, kw, args.extra_samples - args.extra_samples % BUF, local_rank_dev, bracket_us=args.event_bracket_us)
                 except AssertionError as e:                      # a mismatch is a failed run, not a missing number
                     raise SystemExit(f"extra configuration '{name}': GPU result differs from the reference: {e}")
                 except Exception as e:                           # anything else (an allocation, the checker's binary): this entry is missing, the line is not

@@ -56,7 +56,7 @@ class Config(C.Structure):
         ("preamble_threshold", C.c_int32), ("buf_samples", C.c_uint32), ("trailing_samples", C.c_uint32),
         ("mode_ac", C.c_uint32), ("max_samples", C.c_uint64), ("startup_time_ms", C.c_int64),
         ("record_pool_records", C.c_uint64), ("max_messages", C.c_uint64),
-        ("filter_clock", C.c_uint32), ("streams_on_device", C.c_uint32),
+        ("filter_clock", C.c_uint32), ("streams_on_device", C.c_uint32), ("chunk_buffers", C.c_uint32), ("reserved", C.c_uint32),
     ]
 
 
@@ -96,6 +96,9 @@ class ShardWalkArgs(C.Structure):
         ("own_first", C.c_uint64), ("flip_after", C.c_void_p), ("nflips", C.c_uint64), ("start_state", C.c_void_p),
         ("start_state_bytes", C.c_uint64), ("check_records", C.c_int32), ("reserved", C.c_int32),
     ]
+
+
+DEFAULT_CHUNK_BUFFERS = 0                   # mgpu_config.chunk_buffers of Demodulators created without one (tests lower it: more chunks per feed)
 
 
 class MgpuError(RuntimeError):
@@ -249,7 +252,7 @@ class Demodulator:
 
     def __init__(self, fmt=FMT_UC8, nfix_crc=1, fix_df=1, preamble_threshold=58, max_samples=64 * 131072,
                  device=0, startup_time_ms=0, record_pool_records=0, max_messages=0, buf_samples=131072, mode_ac=0,
-                 filter_clock=0):
+                 filter_clock=0, chunk_buffers=None):
         self.lib = load_library()
         cfg = Config()
         self.lib.mgpu_config_defaults(C.byref(cfg))
@@ -258,6 +261,7 @@ class Demodulator:
         cfg.record_pool_records, cfg.max_messages, cfg.buf_samples = record_pool_records, max_messages, buf_samples
         cfg.mode_ac = 1 if mode_ac else 0
         cfg.filter_clock = filter_clock          # FILTER_CLOCK_*: who runs icaoFilterExpire (modes_gpu.h)
+        cfg.chunk_buffers = DEFAULT_CHUNK_BUFFERS if chunk_buffers is None else chunk_buffers   # buffers per pipeline chunk (0 = 512)
         self.cfg = cfg
         self.fmt = fmt
         self._collect_buf = None

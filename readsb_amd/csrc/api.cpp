@@ -747,9 +747,8 @@ static int alloc_all(mgpu_ctx *c) {
     const mgpu_config &cfg = c->cfg;
     const uint64_t n = cfg.max_samples;
     c->cap_samples = n;
-    // pipeline chunk: a whole number of 131072-sample buffers; MGPU_CHUNK_BUFFERS overrides (experiments)
-    uint64_t chunk_buffers = 512;
-    if (const char *e = getenv("MGPU_CHUNK_BUFFERS")) { long v = atol(e); if (v >= 1) chunk_buffers = (uint64_t) v; }
+    // pipeline chunk: a whole number of 131072-sample buffers (cfg.chunk_buffers)
+    uint64_t chunk_buffers = cfg.chunk_buffers ? cfg.chunk_buffers : 512;
     c->chunk_samples = chunk_buffers * cfg.buf_samples;
     const uint64_t nmax_buffers = (n + cfg.buf_samples - 1) / cfg.buf_samples;
     if (c->chunk_samples > nmax_buffers * cfg.buf_samples) c->chunk_samples = nmax_buffers * cfg.buf_samples;
@@ -783,6 +782,7 @@ static int alloc_all(mgpu_ctx *c) {
         HIPCHK(c, hipHostMalloc(&j.h_msig, c->cap_msgs * sizeof(unsigned long long)));
         HIPCHK(c, hipEventCreateWithFlags(&j.ev_copied, hipEventDisableTiming));
     }
+#if MGPU_EXPERIMENTS
     if (c->device_walk) {
         WalkBuffers &w = c->wk;
         const size_t nb = c->cap_buffers + 1;
@@ -825,6 +825,7 @@ static int alloc_all(mgpu_ctx *c) {
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_wk, hipEventDisableTiming));
     }
 
+#endif
     // constant tables
     const CrcTables &crc = crc_tables();
     HIPCHK(c, hipMalloc(&c->d_bit_syndrome, 112 * sizeof(uint32_t)));
@@ -881,6 +882,7 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     c->valid_long = (1u << 16) | (1u << 17) | (1u << 18) | (1u << 20) | (1u << 21);
     if (cfg->fixDF && cfg->nfix_crc)
         for (int b = 0; b < 5; ++b) c->valid_long |= 1u << (17 ^ (1 << b));
+#if MGPU_EXPERIMENTS   // the ordered walk on the device (kernels/walk.inc): the experiments build only — DESIGN.md §3 says why the host owns the walk
     if (const char *e = getenv("MGPU_DEVICE_WALK")) c->device_walk = !strcmp(e, "check") ? 2 : atoi(e) != 0;
     c->wk_serial_only = getenv("MGPU_DBG_WK_SERIAL") != nullptr;
     if (c->device_walk) {
@@ -888,6 +890,7 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
         (void) hipDeviceGetStreamPriorityRange(&lo, &hi);
         if (hipStreamCreateWithPriority(&c->stream_wk, hipStreamNonBlocking, hi) != hipSuccess) { mgpu_destroy(c); return MGPU_E_HIP; }
     }
+#endif
     c->s_post = c->stream2;
     int rc;
     {
@@ -900,20 +903,22 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
         return rc;
     }
     c->resolver.reset(cfg->startup_time_ms, (int) cfg->filter_clock);
+#if MGPU_EXPERIMENTS   // debug / experiment switches: the experiments build only; the product reads MGPU_NO_AFFINITY and nothing else
     c->dbg_print = getenv("MGPU_DEBUG_PRINT") != nullptr;
-#if MGPU_EXPERIMENTS
     if (const char *e = getenv("MGPU_DEBUG_STAGE")) c->dbg_stage = atoi(e);   // (generation 3 only)
-#endif
     if (const char *e = getenv("MGPU_TIMING_EVERY")) { const int v = atoi(e); if (v >= 1) c->timing_every = v; }
     if (const char *e = getenv("MGPU_DUMP_DIR")) { c->dump_dir = e; c->sig_late = false; }   // (the dump holds per-record signal powers)
+#endif
     c->device_slot = take_device_slot(cfg->device);
     // the first context of a device has two L3 groups to itself (bind_near_device): a walk team of 8 and a builder team of 6;
     // further contexts of the device share one group: 4 + 3 as before
     if (c->device_slot == 0 && cfg->streams_on_device <= 1 && !getenv("MGPU_NO_AFFINITY")) { c->walk_threads = 8; c->build_threads = 6; }
     // with the walk on the device the walker only waits for the GPU and replays the adds; the builder copies and sums
     if (c->device_walk == 1) { c->walk_threads = 1; c->build_threads = 2; }
+#if MGPU_EXPERIMENTS   // (8 + 6 is the best of 6..16 + 6..8; tools/stress.py varies them)
     if (const char *e = getenv("MGPU_WALK_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) c->walk_threads = v; }
     if (const char *e = getenv("MGPU_BUILD_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) c->build_threads = v; }
+#endif
     c->fetcher = std::thread(fetcher_main, c);
     c->worker = std::thread(worker_main, c);
     c->builder = std::thread(builder_main, c);
@@ -1238,6 +1243,7 @@ static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
     return MGPU_OK;
 }
 
+#if MGPU_EXPERIMENTS
 // ---- the ordered walk on the device (kernels/walk.inc) ----
 // Enqueues the walk of the slot's chunk on `s` against the filter as it stands now.  false = this chunk is not one the device
 // walk models (a buffer longer than the context's buffer size, generations too large for the input blob): the host walks it.
@@ -1371,6 +1377,8 @@ static int walk_job_device(mgpu_ctx *c, Slot &sl, HostJob &job) {
     return MGPU_OK;
 }
 
+#endif  // MGPU_EXPERIMENTS
+
 // The ordered walk of one chunk's live records on the host: buffer ranges walked in parallel against the filter as it stands
 // now and committed in stream order (resolve.h: Resolver::parallel_walk) — exact, serial only where speculation fails — or the
 // plain serial walk for small chunks.  Decisions into job.acc / job.pos / c->w_limit / c->w_skip, counts into job.rc.
@@ -1452,6 +1460,7 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
     job.pos.resize(aux_cap); c->w_limit.resize(aux_cap); c->w_skip.resize(aux_cap);
     job.rc = ResolveCounts();
     int64_t wn;
+#if MGPU_EXPERIMENTS
     bool wk_running = false;
     if (c->device_walk == 1) {
         const int rc = walk_job_device(c, sl, job);
@@ -1466,6 +1475,7 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
         wk_running = device_walk_enqueue(c, sl, nlive, c->stream2);
         if (!wk_running) c->wk_stats[4] += 1;
     }
+#endif
     wn = host_walk(c, job, job.recs.data(), sl.buffers, nlive, aux_cap);
     if (wn > 0) {
         std::memcpy(sl.h_msg_pos, job.pos.data(), (size_t) wn * sizeof(uint32_t));
@@ -1477,7 +1487,9 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
     if (wn < 0) { c->err = "max_messages exceeded"; return MGPU_E_OVERFLOW; }
     const uint32_t nmsg = (uint32_t) wn;
     c->feed_rc.add(job.rc);
+#if MGPU_EXPERIMENTS
     if (wk_running) { const int rc = device_walk_compare(c, sl, job, nmsg); if (rc != MGPU_OK) return rc; }
+#endif
 
     // what the skip windows hid from the counters: asynchronous on the second stream, totals are
     // accumulated on the device and read once at the end of the feed
@@ -1733,17 +1745,20 @@ static void fetcher_main(mgpu_ctx *c) {
                                                 hc[CNT_PHASE0 + 4], hc[CNT_CLASS_COND], hc[CNT_CLASS_UNCOND], nbuf, 0};
             std::vector<uint8_t> &pk = c->shard_packets;
             auto put = [&](const void *p8, size_t bytes) { pk.insert(pk.end(), (const uint8_t *) p8, (const uint8_t *) p8 + bytes); };
-            put(hdr, sizeof(hdr));
-            put(job.recs.data(), (job.nlive + 1) * sizeof(PhaseRec));      // (with the walk's sentinel record)
-            put(job.sig.data(), job.nlive * sizeof(unsigned long long));
-            put(job.win.data(), job.nlive * sizeof(unsigned long long));
-            // (UC8: exact integer sums; SC16*: the converter's double sums — eight bytes per buffer either way, level then power)
-            if (c->cfg.format == MGPU_FMT_UC8) { put(sl.h_sums, nbuf * 8); put(sl.h_sums + c->cap_buffers, nbuf * 8); }
-            else { put(sl.h_fsums, nbuf * 8); put(sl.h_fsums + c->cap_buffers, nbuf * 8); }
-            // ... and, while the GPU works on the next chunk, what the buffers' end clocks will be (mgpu_shard_clock_estimate)
             c->shard_est_pos.push_back(job.stream_pos);
             c->shard_est_off.push_back(c->shard_est.size());
-            estimate_end_clocks(job.recs.data(), job.nlive, sl.buffers, c->shard_est);
+            // two things, side by side (the walker's team has nothing else to do during a shard pass): the packet, and what the buffers'
+            // end clocks will be (mgpu_shard_clock_estimate) — on this thread alone they made the fetcher the pass's slowest stage
+            c->walk_team.run(2, [&](int task) {
+                if (task == 1) { estimate_end_clocks(job.recs.data(), job.nlive, sl.buffers, c->shard_est); return; }
+                put(hdr, sizeof(hdr));
+                put(job.recs.data(), (job.nlive + 1) * sizeof(PhaseRec));      // (with the walk's sentinel record)
+                put(job.sig.data(), job.nlive * sizeof(unsigned long long));
+                put(job.win.data(), job.nlive * sizeof(unsigned long long));
+                // (UC8: exact integer sums; SC16*: the converter's double sums — eight bytes per buffer either way, level then power)
+                if (c->cfg.format == MGPU_FMT_UC8) { put(sl.h_sums, nbuf * 8); put(sl.h_sums + c->cap_buffers, nbuf * 8); }
+                else { put(sl.h_fsums, nbuf * 8); put(sl.h_fsums + c->cap_buffers, nbuf * 8); }
+            });
         }
         {
             std::lock_guard<std::mutex> lk(c->mu);

@@ -112,7 +112,9 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 #include "kernels/modeac.inc"
 #include "kernels/window_stats.inc"
 #include "kernels/build.inc"
-#include "kernels/walk.inc"
+#if MGPU_EXPERIMENTS
+#include "kernels/walk.inc"      // the ordered walk on the device: experiments build only (the host owns the walk)
+#endif
 #include "kernels/beast.inc"
 #include "kernels/fields.inc"
 

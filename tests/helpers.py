@@ -109,6 +109,15 @@ def oracle_run(iq, fmt=0, nfix=1, fixdf=1, thr=58, want_mag=False, mode_ac=0, fi
     return (msgs, st[0], mag) if want_mag else (msgs, st[0])
 
 
+def reference_run(iq, fmt=0, nfix=1, fixdf=1, thr=58):
+    """The checker of the -m gpu parity tests on the BASELINE configurations: the reference's OWN objects (oracle/_ref, compiled from
+    /root/reference in place; the prebuilt files travel to the GPU box) where they are there, the restatement otherwise — one hop
+    less between the HIP path and the reference (tests/test_oracle.py pins the restatement to _ref either way)."""
+    if have_ref():
+        return ref_run(iq, fmt, nfix, fixdf, thr)
+    return oracle_run(iq, fmt, nfix, fixdf, thr)
+
+
 def oracle_convert(iq, fmt):
     lib = oracle_lib()
     iq = np.ascontiguousarray(iq).view(np.uint8).reshape(-1)

@@ -23,7 +23,7 @@ def _blocks(iq, sizes):
 @pytest.mark.parametrize("external", [False, True])
 def test_deferred_feeds_equal_synchronous_feeds(built, external, monkeypatch):
     import readsb_amd
-    monkeypatch.setenv("MGPU_CHUNK_BUFFERS", "16")             # several pipeline chunks per feed
+    monkeypatch.setattr(readsb_amd.binding, "DEFAULT_CHUNK_BUFFERS", 16)             # several pipeline chunks per feed
     sizes = [40 * B, 56 * B, 24 * B, 33 * B + 4321]            # several 16-buffer chunks per feed; the last block ends the stream short
     iq = helpers.synth(nsamples=sum(sizes), seed=909, rate=3000.0)
     want, wst = helpers.oracle_run(iq, 0, 2, 1, 58)
@@ -86,7 +86,7 @@ def test_device_messages_equal_host_messages(built, monkeypatch):
     """mgpu_set_device_messages: the records k_build_messages leaves in HBM, feed by feed, are byte for byte the records the
     host builder writes (and therefore the oracle's messages); the field decoder and the beast encoder take them where they are."""
     import readsb_amd
-    monkeypatch.setenv("MGPU_CHUNK_BUFFERS", "16")
+    monkeypatch.setattr(readsb_amd.binding, "DEFAULT_CHUNK_BUFFERS", 16)
     sizes = [48 * B, 40 * B, 19 * B + 999]
     iq = helpers.synth(nsamples=sum(sizes), seed=1234, rate=3500.0)
     want, wst = helpers.oracle_run(iq, 0, 2, 1, 58)
@@ -137,7 +137,7 @@ def test_one_chunk_host_feeds_on_a_busy_gpu(built, monkeypatch):
     and the caller's block must have been read when mgpu_feed_iq returns."""
     import threading
     import readsb_amd
-    monkeypatch.setenv("MGPU_CHUNK_BUFFERS", "64")
+    monkeypatch.setattr(readsb_amd.binding, "DEFAULT_CHUNK_BUFFERS", 64)
     nfeeds, per = 12, 48 * B                                   # one chunk per feed
     iq = helpers.synth(nsamples=nfeeds * per, seed=31337, rate=4000.0)
     want, wst = helpers.oracle_run(iq, 0, 1, 1, 58)

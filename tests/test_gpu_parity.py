@@ -1,4 +1,5 @@
-"""-m gpu: the HIP path (through the C ABI) against the CPU oracle on the same seeded captures.
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle on the same seeded captures — on the BASELINE configurations
+(test_uc8_options, test_uc8_10s_config2, test_dense_bursts) against the reference's own objects (oracle/_ref) where they are present.
 Bit-exact bar: every accepted message (timestamp, frame bytes raw and corrected, score,
 corrected bits, address, signal level) and every demod counter."""
 import numpy as np
@@ -24,7 +25,7 @@ def _demod(iq, **kw):
 @pytest.mark.parametrize("nfix,fixdf,thr", [(1, 1, 58), (2, 1, 58), (0, 1, 58), (1, 0, 58), (1, 1, 75), (2, 1, 40)])
 def test_uc8_options(built, nfix, fixdf, thr):
     iq = helpers.synth(seconds=3.0, seed=101)
-    want, wst = helpers.oracle_run(iq, 0, nfix, fixdf, thr)
+    want, wst = helpers.reference_run(iq, 0, nfix, fixdf, thr)         # the reference's own objects (oracle/_ref) where they travel
     got, cnt, _ = _demod(iq, nfix_crc=nfix, fix_df=fixdf, preamble_threshold=thr)
     assert len(want) > 1000
     helpers.assert_same_messages(got, want)
@@ -34,7 +35,7 @@ def test_uc8_options(built, nfix, fixdf, thr):
 def test_uc8_10s_config2(built):
     """BASELINE config 2: single 10 s UC8 stream, --fix."""
     iq = helpers.synth(seconds=10.0, seed=88172645463325252)
-    want, wst = helpers.oracle_run(iq)
+    want, wst = helpers.reference_run(iq)
     got, cnt, tm = _demod(iq)
     helpers.assert_same_messages(got, want)
     helpers.assert_same_counters(cnt, wst)
@@ -56,7 +57,7 @@ def test_chunked_feeds_equal_single_feed(built):
 def test_dense_bursts(built):
     """Config 5 flavour: overlapping 112-bit DF17 frames at 8000 msg/s."""
     iq = helpers.synth(seconds=2.0, seed=5, rate=8000.0, dense=1)
-    want, wst = helpers.oracle_run(iq, 0, 2, 1, 58)
+    want, wst = helpers.reference_run(iq, 0, 2, 1, 58)
     got, cnt, _ = _demod(iq, nfix_crc=2)
     helpers.assert_same_messages(got, want)
     helpers.assert_same_counters(cnt, wst)

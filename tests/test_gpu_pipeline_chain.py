@@ -16,7 +16,7 @@ B = 131072
 
 def test_messages_fields_and_beast_frames_without_leaving_the_device(built, monkeypatch):
     import readsb_amd
-    monkeypatch.setenv("MGPU_CHUNK_BUFFERS", "16")
+    monkeypatch.setattr(readsb_amd.binding, "DEFAULT_CHUNK_BUFFERS", 16)
     hip = C.CDLL("libamdhip64.so")
     hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]

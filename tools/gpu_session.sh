@@ -1,21 +1,33 @@
 #!/bin/bash
 # What one gpurun call of this round usually ran.  (Scratch: edited per call.)
 cd /root/repo
-mkdir -p gpurun_out/r04b
-echo skip tests
-timeout 600 python bench.py --config 5 --emulate-ranks 8 --samples 8640000000 --steps 3 --warmup 1 > gpurun_out/r04b/config5_emulate8.json 2> gpurun_out/r04b/config5_emulate8.err
-tail -c 3000 gpurun_out/r04b/config5_emulate8.err
+O=gpurun_out/r04c
+mkdir -p $O
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -6
+timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_full.json 2> $O/bench_full.err
 python - <<'PY'
 import json
 try:
-    o = json.loads(open("gpurun_out/r04b/config5_emulate8.json").read().strip().splitlines()[-1])
-    print("unsharded", o["value"], o["ms_per_step"], "msgs", o["messages_per_step"])
-    e = o["emulated_ranks"]
-    for k in ("rank_critical_path_ms", "protocol", "rank0_serial_ms", "rank0_serial_total_ms", "rank0_serial_share_of_unsharded", "projected_ms_without_communication", "projected_speedup_without_communication", "gather_bytes_to_rank0", "allgather_bytes_per_round"):
-        print(k, e[k])
-    for r, p in enumerate(e["per_rank_ms"]):
-        print(r, p)
-    print(o.get("cpu_baseline"))
-except Exception as ex:
-    print("no line:", ex)
+    o = json.loads(open("gpurun_out/r04c/bench_full.json").read().strip().splitlines()[-1])
+    r = o["roofline"]
+    print(round(o["value"]), o["ms_per_step"], "sweep", r["avg_launch_ms"], r["frac"], "raw", r["avg_launch_ms_between_events"], "slice", o["kernels"]["k_slice"]["avg_launch_ms"], o["stage_ms"], "pcie", o.get("pcie_inclusive_msamples_s"))
+    print(o["cpu_baseline"])
+    for k, v in o.get("configs", {}).items():
+        print(k, {kk: v.get(kk) for kk in ("msamples_s", "ms_per_segment", "us_per_launch", "stage_ms", "error")})
+except Exception as e:
+    print("no line:", e)
 PY
+tail -3 $O/bench_full.err
+# four ranks' host pipelines on ONE socket (what an 8-GPU node's socket carries), all on GPU 0: do their polling threads coexist?
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 4 --dryrun-gloo --steps 10 --warmup 3 --samples 134217728 --no-cpu-baseline > $O/host_4rank.json 2> $O/host_4rank.err
+timeout 300 python bench.py --steps 10 --warmup 3 --samples 134217728 --no-cpu-baseline --no-extra-configs > $O/host_1rank.json 2> $O/host_1rank.err
+python - <<'PY'
+import json
+for f in ("host_4rank", "host_1rank"):
+    try:
+        o = json.loads(open(f"gpurun_out/r04c/{f}.json").read().strip().splitlines()[-1])
+        print(f, round(o["value"]), o["ms_per_step"], o["stage_ms"], o.get("per_rank_host_ms"))
+    except Exception as e:
+        print(f, "no line:", e)
+PY
+tail -5 $O/host_4rank.err

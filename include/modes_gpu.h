@@ -62,8 +62,9 @@ struct mgpu_config {
                                    * keeps its host stages small (4 walkers, 3 builders): the stage threads poll while a feed runs, and eight
                                    * contexts with a lone stream's teams (8 + 6) oversubscribe the device's two L3 groups — measured, 8 streams:
                                    * 9.4 Gsamples/s, with small teams 18.7 (profiles/r03_fanin.txt) */
-    uint32_t chunk_buffers;       /* buffers per pipeline chunk (one launch of every kernel); 0 = 512.  Throughput is flat between 384 and
-                                   * 1024; a host that wants its messages sooner takes fewer (latency = three chunks) */
+    uint32_t chunk_buffers;       /* buffers per pipeline chunk (one launch of every kernel); 0 = 1024 (half as many kernel boundaries and tails
+                                   * as 512: 325 against 300 Gsamples/s, profiles/r04_chunk_buffers.txt); a host that wants its messages sooner
+                                   * takes fewer (latency = three chunks) */
     uint32_t reserved;
 };
 

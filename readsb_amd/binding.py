@@ -261,7 +261,7 @@ class Demodulator:
         cfg.record_pool_records, cfg.max_messages, cfg.buf_samples = record_pool_records, max_messages, buf_samples
         cfg.mode_ac = 1 if mode_ac else 0
         cfg.filter_clock = filter_clock          # FILTER_CLOCK_*: who runs icaoFilterExpire (modes_gpu.h)
-        cfg.chunk_buffers = DEFAULT_CHUNK_BUFFERS if chunk_buffers is None else chunk_buffers   # buffers per pipeline chunk (0 = 512)
+        cfg.chunk_buffers = DEFAULT_CHUNK_BUFFERS if chunk_buffers is None else chunk_buffers   # buffers per pipeline chunk (0 = the library's 1024)
         self.cfg = cfg
         self.fmt = fmt
         self._collect_buf = None

@@ -177,6 +177,7 @@ struct Slot {
     // for | the sums are there | the converter has read the samples too
     hipEvent_t ev_pre = nullptr, ev_fsum = nullptr, ev_convdone = nullptr;
     bool fsum_pending = false;
+    const uint8_t *fsum_iq = nullptr;     // the chunk's IQ samples (SC16 formats), for the float sums enqueued behind k_sweep
     hipEvent_t ev_scan = nullptr;         // pre-screen offsets are final (main stream) -> the write pass may start (second stream)
     // the second stream keeps out of k_sweep's way (walk_job: hold_behind_sweep): the chunk's k_sweep has run | which chunk that was
     hipEvent_t ev_swept = nullptr;
@@ -278,6 +279,7 @@ struct mgpu_ctx {
     mgpu_config cfg{};
     hipStream_t stream = nullptr, stream2 = nullptr, stream_w = nullptr;   // main | window statistics | pre-screen write pass / IQ uploads
     hipStream_t stream_d2h = nullptr;                                      // the fetcher's record copies
+    hipStream_t stream_f = nullptr;                                        // SC16 formats: the float sums' chains (k_fsum_sc16), so that what follows a walk does not queue behind them
     hipStream_t s_post = nullptr;                                          // what follows the walk (window statistics, messages on the device): stream2, or stream_wk
     hipStream_t stream_wk = nullptr;                                       // the walk on the device: highest priority, its small kernels must not queue behind the main stream's
     std::string err;
@@ -748,7 +750,7 @@ static int alloc_all(mgpu_ctx *c) {
     const uint64_t n = cfg.max_samples;
     c->cap_samples = n;
     // pipeline chunk: a whole number of 131072-sample buffers (cfg.chunk_buffers)
-    uint64_t chunk_buffers = cfg.chunk_buffers ? cfg.chunk_buffers : 512;
+    uint64_t chunk_buffers = cfg.chunk_buffers ? cfg.chunk_buffers : 1024;   // (round 4: 512 -> 1024, 300 -> 325 Gsamples/s once the builder kept up; profiles/r04_chunk_buffers.txt)
     c->chunk_samples = chunk_buffers * cfg.buf_samples;
     const uint64_t nmax_buffers = (n + cfg.buf_samples - 1) / cfg.buf_samples;
     if (c->chunk_samples > nmax_buffers * cfg.buf_samples) c->chunk_samples = nmax_buffers * cfg.buf_samples;
@@ -876,7 +878,8 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream_w, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->stream_d2h, hipStreamNonBlocking) != hipSuccess) { mgpu_destroy(c); return MGPU_E_HIP; }
+        hipStreamCreateWithFlags(&c->stream_d2h, hipStreamNonBlocking) != hipSuccess ||
+        (cfg->format != MGPU_FMT_UC8 && hipStreamCreateWithPriority(&c->stream_f, hipStreamNonBlocking, prio_least) != hipSuccess)) { mgpu_destroy(c); return MGPU_E_HIP; }
     // valid_df_*_bitset, init_bitsets() demod_2400.c:112-128 (ENABLE_DF24 off, readsb.h:303)
     c->valid_short = (1u << 0) | (1u << 4) | (1u << 5) | (1u << 11);
     c->valid_long = (1u << 16) | (1u << 17) | (1u << 18) | (1u << 20) | (1u << 21);
@@ -950,6 +953,7 @@ void mgpu_destroy(mgpu_ctx *c) {
     if (c->stream) (void) hipStreamSynchronize(c->stream);
     if (c->stream2) (void) hipStreamSynchronize(c->stream2);
     if (c->stream_w) (void) hipStreamSynchronize(c->stream_w);
+    if (c->stream_f) (void) hipStreamSynchronize(c->stream_f);
     if (c->stream_wk) (void) hipStreamSynchronize(c->stream_wk);
     for (auto &sl : c->slot) free_slot(sl);
     for (auto &f : c->feed) {
@@ -982,6 +986,7 @@ void mgpu_destroy(mgpu_ctx *c) {
     if (c->stream2) (void) hipStreamDestroy(c->stream2);
     if (c->stream_w) (void) hipStreamDestroy(c->stream_w);
     if (c->stream_d2h) (void) hipStreamDestroy(c->stream_d2h);
+    if (c->stream_f) (void) hipStreamDestroy(c->stream_f);
     if (c->stream_wk) (void) hipStreamDestroy(c->stream_wk);
     delete c;
 }
@@ -1020,6 +1025,18 @@ int mgpu_reset(mgpu_ctx *c) {
 // would meet k_sweep instead of the converter: k_sweep then took 68 us instead of 37 and the step 2.85 ms instead of 2.52.)
 // HIP events with timing cost ~5 us of idle stream each (the next kernel waits for the marker): only every
 // `timing_every`-th chunk carries the stage events (sl.timed); the others record the completion event alone.
+// k_fsum_sc16 of the slot's chunk on the second stream, behind `after` (an event of the main stream)
+static int enqueue_fsum(mgpu_ctx *c, Slot &sl, const uint8_t *iq, hipEvent_t after) {
+    const mgpu_config &cfg = c->cfg;
+    HIPCHK(c, hipStreamWaitEvent(c->stream_f, after, 0));
+    HIPCHK(c, hipMemsetAsync(sl.d_fsx, 0, 2 * c->cap_buffers * sizeof(double), c->stream_f));
+    launch_fsum_sc16(cfg.format, iq, sl.n, cfg.buf_samples, sl.d_fsum_level, sl.d_fsum_power, cfg.mode_ac ? 1 : 0, c->stream_f);
+    HIPCHK(c, hipMemcpyAsync(sl.h_fsx, sl.d_fsx, 2 * c->cap_buffers * sizeof(double), hipMemcpyDeviceToHost, c->stream_f));
+    HIPCHK(c, hipEventRecord(sl.ev_fsum, c->stream_f));
+    sl.fsum_pending = true;
+    return MGPU_OK;
+}
+
 static int enqueue_convert(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
     const mgpu_config &cfg = c->cfg;
     const uint64_t n = sl.n;
@@ -1040,16 +1057,13 @@ static int enqueue_convert(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
         cp.fsum_level = sl.d_fsum_level; cp.fsum_power = sl.d_fsum_power;
         if (cfg.format != MGPU_FMT_UC8) HIPCHK(c, hipEventRecord(sl.ev_pre, s));
         launch_convert(cfg.format, cp, s);
-        if (cfg.format != MGPU_FMT_UC8) {
-            // mean level / power of the SC16 formats = the reference's sequential float sums: a chain per buffer, ~0.2 ms, on the second
-            // stream beside this chunk's kernels, into buffers of its own; whoever needs them (Mode A/C below, the fetcher) waits for ev_fsum
-            HIPCHK(c, hipStreamWaitEvent(c->stream2, sl.ev_pre, 0));
-            HIPCHK(c, hipMemsetAsync(sl.d_fsx, 0, 2 * c->cap_buffers * sizeof(double), c->stream2));
-            launch_fsum_sc16(cfg.format, iq, n, cfg.buf_samples, sl.d_fsum_level, sl.d_fsum_power, cfg.mode_ac ? 1 : 0, c->stream2);
-            HIPCHK(c, hipMemcpyAsync(sl.h_fsx, sl.d_fsx, 2 * c->cap_buffers * sizeof(double), hipMemcpyDeviceToHost, c->stream2));
-            HIPCHK(c, hipEventRecord(sl.ev_fsum, c->stream2));
-            sl.fsum_pending = true;
+        if (cfg.format != MGPU_FMT_UC8 && cfg.mode_ac) {
+            // mean level / power of the SC16 formats = the reference's sequential float sums: a chain per buffer, ~0.35 ms, on the second
+            // stream, into buffers of its own.  Mode A/C needs them before its scan (the noise floor): beside the converter, at once
+            int rc = enqueue_fsum(c, sl, iq, sl.ev_pre);
+            if (rc != MGPU_OK) return rc;
         }
+        sl.fsum_iq = iq;
         // lastbuf->length < trailing_samples -> zeros (only possible for a stream shorter than 326 samples)
         c->tail_src = n >= (uint64_t) kTrailing ? sl.d_mag + n : nullptr;
     } else {
@@ -1098,6 +1112,13 @@ static int enqueue_sweep(mgpu_ctx *c, Slot &sl) {
         if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[4], s));
         HIPCHK(c, hipEventRecord(sl.ev_swept, s));
         sl.swept_seq.store(sl.seq, std::memory_order_release);
+        // Without Mode A/C nobody needs the float sums before the builder: their chain (one wave per buffer at s_setprio 3, ~0.35 ms,
+        // which doubled k_sweep's time while it ran beside it: 59 against 33 us) starts when the chunk's k_sweep is through and
+        // runs beside k_slice — with chunks of 1024 buffers it is over before the chunk's post-sweep kernels are.
+        if (cfg.format != MGPU_FMT_UC8 && !cfg.mode_ac && !sl.have_mag && sl.fsum_iq) {
+            const int rc = enqueue_fsum(c, sl, sl.fsum_iq, sl.ev_swept);
+            if (rc != MGPU_OK) return rc;
+        }
         sl.slice_blocks = launch_slice(sp, s);
     }
     if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[2], s));
@@ -1136,14 +1157,20 @@ static int enqueue_post(mgpu_ctx *c, Slot &sl) {
 // one chunk on its own (struct mag_buf entry, shard passes)
 static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq, hipEvent_t after_convert = nullptr) {
     int rc = enqueue_convert(c, sl, iq);
-    if (rc == MGPU_OK && after_convert) {                                                        // the chunk's IQ samples have been read
-        if (sl.fsum_pending) {               // ... by the converter AND by the float sums on the second stream
+    // `after_convert`: the chunk's IQ samples have been read — by the converter AND, for the SC16 formats, by the float sums on the
+    // second stream, which run beside the converter (Mode A/C) or start behind the chunk's k_sweep (enqueue_sweep)
+    const bool fsum_late = c->cfg.format != MGPU_FMT_UC8 && !c->cfg.mode_ac && !sl.have_mag;
+    auto mark_read = [&]() -> int {
+        if (sl.fsum_pending) {
             HIPCHK(c, hipEventRecord(sl.ev_convdone, c->stream));
-            HIPCHK(c, hipStreamWaitEvent(c->stream2, sl.ev_convdone, 0));
-            HIPCHK(c, hipEventRecord(after_convert, c->stream2));
+            HIPCHK(c, hipStreamWaitEvent(c->stream_f, sl.ev_convdone, 0));
+            HIPCHK(c, hipEventRecord(after_convert, c->stream_f));
         } else HIPCHK(c, hipEventRecord(after_convert, c->stream));
-    }
+        return MGPU_OK;
+    };
+    if (rc == MGPU_OK && after_convert && !fsum_late) rc = mark_read();
     if (rc == MGPU_OK) rc = enqueue_sweep(c, sl);
+    if (rc == MGPU_OK && after_convert && fsum_late) rc = mark_read();
     if (rc == MGPU_OK) rc = enqueue_post(c, sl);
     return rc;
 }
@@ -1583,6 +1610,47 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
         job.buf_nacc.assign(nbuf, 0);
         for (uint32_t i = 0; i < nmsg; ++i) job.buf_nacc[job.acc[i].buffer]++;
     }
+    // per-message signal level, per-buffer noise power (demod_2400.c:436-457, 474-479): in stream order (double sums are order-dependent)
+    auto build_statistics = [&]() {
+        mgpu_counters &k = c->counters;
+        for (int i = 0; i < 3; ++i) k.demod_accepted[i] += job.rc.accepted[i];
+        for (int i = 0; i < 5; ++i) k.demod_bestPhase[i] += job.rc.best_phase[i];
+        // per-message signal level, per-buffer noise power (demod_2400.c:436-457, 474-479)
+        uint32_t mi = 0;
+        for (uint32_t b = 0; b < nbuf; ++b) {
+            const BufferClock &bc = job.buffers[b];
+            uint64_t sum_scaled = 0;
+            for (const uint32_t mend = mi + job.buf_nacc[b]; mi < mend;) {
+                unsigned long long sumsq;
+                unsigned sig_len;                                 // msglen * 12 / 5, demod_2400.c:439
+                if (job.from_device || job.sig_late) { sumsq = job.h_msig[mi] & ~(1ull << 63); sig_len = (job.h_msig[mi] >> 63) ? 268u : 134u; }
+                else {
+                    const uint32_t ri = job.acc[mi].rec;          // not from the message: those went out with streaming stores
+                    sumsq = job.sig[ri];
+                    sig_len = (job.recs[ri].msg[0] & 0x80) ? 268u : 134u;
+                }
+                const double signal_power = (double) sumsq / 65535.0 / 65535.0;
+                const double level = signal_power / sig_len;
+                k.signal_power_sum += signal_power;
+                k.signal_power_count += sig_len;
+                sum_scaled += sumsq;
+                if (level > k.peak_signal_power) k.peak_signal_power = level;
+                if (level > 0.50119) k.strong_signal_count++;
+                ++mi;
+            }
+            double mean_power;
+            if (!job.given_mean_power.empty()) mean_power = job.given_mean_power[b];
+            else if (cfg.format == MGPU_FMT_UC8) mean_power = (double) job.sums[c->cap_buffers + b] / 65535.0 / 65535.0 / bc.length;   // convert.c:105-107
+            else mean_power = (double) ((float) job.fsums[c->cap_buffers + b] / (float) bc.length);   // convert.c:246-248: a float sum, a float division
+            const double sum_signal_power = (double) sum_scaled / 65535.0 / 65535.0;
+            k.noise_power_sum += (mean_power * bc.length - sum_signal_power);
+            k.noise_power_count += bc.length;
+            k.samples_processed += bc.length;
+            k.samples_lost += cfg.buf_samples - bc.length;        // readsb.c:886
+            k.nbuffers++;
+        }
+    };
+    bool stats_done = false;
     if (!on_device && !job.from_device) {
         const int parts = nmsg >= 4096 ? c->build_threads : 1;
         mgpu_msg *dst = nac ? stage.data() : out;
@@ -1590,11 +1658,19 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
         // statistics.  Building first and filling the field in afterwards was slower: the messages leave with streaming stores,
         // and touching 27 000 of their lines again costs more than the wait.)
         if (job.sig_late && nmsg) HIPCHK(c, hipEventSynchronize(job.ev_copied));
-        c->build_team.run(parts, [&](int i) {
-            const uint64_t lo = (uint64_t) nmsg * i / parts, hi = (uint64_t) nmsg * (i + 1) / parts;
+        // The signal / noise statistics — one chain of dependent double additions over the chunk's messages, a third of this stage's
+        // time on one thread — ride beside the message build as one more task of the team (they read the accept list and the signal
+        // powers only): with chunks of 1024 buffers the builder was the pipeline's slowest stage (round 4: 1.6-1.77 ms per step
+        // against 1.59 ms of kernels).
+        const bool split = parts > 1;
+        c->build_team.run(parts + (split ? 1 : 0), [&](int i) {
+            if (split && i == 0) { build_statistics(); return; }
+            const int p = split ? i - 1 : i;
+            const uint64_t lo = (uint64_t) nmsg * p / parts, hi = (uint64_t) nmsg * (p + 1) / parts;
             Resolver::build_messages(job.recs.data(), job.sig_late ? nullptr : job.sig.data(), job.sig_late ? job.h_msig + lo : nullptr, job.buffers,
                                      job.acc.data() + lo, hi - lo, dst + lo);
         });
+        stats_done = split;
     } else if (!job.from_device && job.sig_late && nmsg) HIPCHK(c, hipEventSynchronize(job.ev_copied));   // (messages on the device: statistics only)
     if (nac) {   // netUseMessage order: per buffer the Mode S messages of demodulate2400, then the replies of demodulate2400AC
         size_t si = 0, ai = 0, o = 0;
@@ -1620,43 +1696,7 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
     if (!on_device) pending.n = first_msg + nmsg + nac;
     const double t2 = wall_ms();
 
-    mgpu_counters &k = c->counters;
-    for (int i = 0; i < 3; ++i) k.demod_accepted[i] += job.rc.accepted[i];
-    for (int i = 0; i < 5; ++i) k.demod_bestPhase[i] += job.rc.best_phase[i];
-    // per-message signal level, per-buffer noise power (demod_2400.c:436-457, 474-479)
-    uint32_t mi = 0;
-    for (uint32_t b = 0; b < nbuf; ++b) {
-        const BufferClock &bc = job.buffers[b];
-        uint64_t sum_scaled = 0;
-        for (const uint32_t mend = mi + job.buf_nacc[b]; mi < mend;) {
-            unsigned long long sumsq;
-            unsigned sig_len;                                 // msglen * 12 / 5, demod_2400.c:439
-            if (job.from_device || job.sig_late) { sumsq = job.h_msig[mi] & ~(1ull << 63); sig_len = (job.h_msig[mi] >> 63) ? 268u : 134u; }
-            else {
-                const uint32_t ri = job.acc[mi].rec;          // not from the message: those went out with streaming stores
-                sumsq = job.sig[ri];
-                sig_len = (job.recs[ri].msg[0] & 0x80) ? 268u : 134u;
-            }
-            const double signal_power = (double) sumsq / 65535.0 / 65535.0;
-            const double level = signal_power / sig_len;
-            k.signal_power_sum += signal_power;
-            k.signal_power_count += sig_len;
-            sum_scaled += sumsq;
-            if (level > k.peak_signal_power) k.peak_signal_power = level;
-            if (level > 0.50119) k.strong_signal_count++;
-            ++mi;
-        }
-        double mean_power;
-        if (!job.given_mean_power.empty()) mean_power = job.given_mean_power[b];
-        else if (cfg.format == MGPU_FMT_UC8) mean_power = (double) job.sums[c->cap_buffers + b] / 65535.0 / 65535.0 / bc.length;   // convert.c:105-107
-        else mean_power = (double) ((float) job.fsums[c->cap_buffers + b] / (float) bc.length);   // convert.c:246-248: a float sum, a float division
-        const double sum_signal_power = (double) sum_scaled / 65535.0 / 65535.0;
-        k.noise_power_sum += (mean_power * bc.length - sum_signal_power);
-        k.noise_power_count += bc.length;
-        k.samples_processed += bc.length;
-        k.samples_lost += cfg.buf_samples - bc.length;        // readsb.c:886
-        k.nbuffers++;
-    }
+    if (!stats_done) build_statistics();
     c->acc.build_ms += (float) (wall_ms() - t0);
     if (c->dbg_print) fprintf(stderr, "dbg: timeline: build %.3f .. %.3f\n", t0 - c->feed_t0, wall_ms() - c->feed_t0);
     if (c->dbg_print) fprintf(stderr, "dbg: build: grow %.3f ms, messages %.3f ms, statistics %.3f ms for %u msgs\n", t1 - t0, t2 - t1, wall_ms() - t2, nmsg);

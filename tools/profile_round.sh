@@ -23,8 +23,8 @@ sha=$(python -c "import bench; print(bench.kernel_source_sha())")
 python tools/pmc_summary.py $(find $out/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $out/pmc_write -name "*counter_collection.csv" | head -1) $out/pmc_hbm.json $sha > /dev/null 2> $out/pmc_hbm.err
 timeout 400 python bench.py --steps 20 --warmup 3 > $out/bench_plain.log 2>&1
 # the micro harnesses (make -C tools micro): k_sweep alone over a cold > 1 GiB array (and its stages), instruction issue rates, atomics; k_slice's parts
-for v in "" _s1 _s2 _s3; do timeout 120 tools/micro/sweep_cold$v 512 9 4 > $out/sweep_cold$v.json 2> $out/sweep_cold$v.err; done
-timeout 120 tools/micro/sweep_cold 512 9 4 0 2000 0 0 0 > $out/sweep_cold_unpaced.json 2>/dev/null
+for v in "" _s1 _s2 _s3; do timeout 120 tools/micro/sweep_cold$v 1024 5 4 > $out/sweep_cold$v.json 2> $out/sweep_cold$v.err; done
+timeout 120 tools/micro/sweep_cold 1024 5 4 0 2000 0 0 0 > $out/sweep_cold_unpaced.json 2>/dev/null
 timeout 120 tools/micro/valu_issue $out/valu_issue.json > $out/valu_issue.txt 2>&1
 timeout 120 tools/micro/atomic_cost > $out/atomic_cost.txt 2>&1
 timeout 300 bash tools/slice_stages.sh > $out/slice_stages.txt 2>&1

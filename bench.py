@@ -189,13 +189,14 @@ def run_extra_config(name, fmt, nfix, kw, nsamples, device, steps=4, bracket_us=
         d.set_message_buffer(bufs[k % 2])
         d.feed_resident(nsamples)
 
-    submit(0)
-    d.collect_feed(bufs[0], want_counters=True)              # warm-up segment, drained
+    for k in range(2):                                       # two warm-up segments, drained (every job and slot of the pipeline has run at full size)
+        submit(k)
+        d.collect_feed(bufs[k % 2], want_counters=True)
     # the timed region, twice: a single host stage of a freshly created context now and then runs 2-4 x slower for one repetition
     # (r04c: the builder, r04f: the fetcher — never the same stage, never the headline's long-lived context); both rates are
     # reported, the better one with its stage times is the entry's figure
     runs = []
-    for _ in range(2):
+    for _ in range(int(os.environ.get("MGPU_DBG_BENCH_REPS", "2"))):
         d.timing()
         t0 = time.perf_counter()
         submit(1)
@@ -235,9 +236,11 @@ def run_extra_config(name, fmt, nfix, kw, nsamples, device, steps=4, bracket_us=
     nl = max(1, tm["n_chunks"])
     out = {"msamples_s": round(nsamples * steps / elapsed / 1e6, 1), "ms_per_segment": round(elapsed / steps * 1e3, 3),
            "msamples_s_both_repetitions": [round(nsamples * steps / r[0] / 1e6, 1) for r in runs],
+           "host_stage_ms_both_repetitions": [{k2: round(r[1][k1] / steps, 3) for k1, k2 in (("d2h_ms", "d2h"), ("resolve_ms", "resolve_host"), ("build_ms", "build_host"))} for r in runs],
            "samples_per_segment": nsamples, "segments_timed": steps, "messages_per_segment": int(len(msgs)),
            "candidates_per_1000_samples": round(tm["n_candidates"] / (nsamples * steps) * 1e3, 2),
            "records_per_1000_samples": round(tm["n_records"] / (nsamples * steps) * 1e3, 2),
+           "live_records_per_1000_samples": round(tm["n_live_records"] / (nsamples * steps) * 1e3, 2),
            # (per launch, the events' own constant taken off; stage_ms below: as the events report it)
            "us_per_launch": {"convert": round(tm["convert_ms"] / nl * 1e3 - bracket_us, 1), "k_sweep": round(tm["sweep_ms"] / nl * 1e3 - bracket_us, 1),
                              "k_slice": round(tm["slice_ms"] / nl * 1e3 - bracket_us, 1), "post_sweep": round(tm["prescreen_ms"] / nl * 1e3 - bracket_us, 1)},

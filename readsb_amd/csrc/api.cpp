@@ -178,6 +178,7 @@ struct Slot {
     hipEvent_t ev_pre = nullptr, ev_fsum = nullptr, ev_convdone = nullptr;
     bool fsum_pending = false;
     const uint8_t *fsum_iq = nullptr;     // the chunk's IQ samples (SC16 formats), for the float sums enqueued behind k_sweep
+    int fsum_idx = -1;                    // which entry of mgpu_ctx::fsum_ring holds the chunk's float sums
     hipEvent_t ev_scan = nullptr;         // pre-screen offsets are final (main stream) -> the write pass may start (second stream)
     // the second stream keeps out of k_sweep's way (walk_job: hold_behind_sweep): the chunk's k_sweep has run | which chunk that was
     hipEvent_t ev_swept = nullptr;
@@ -244,6 +245,7 @@ struct HostJob {
     std::vector<double> given_mean_power;
     std::vector<unsigned long long> sums;    // per-buffer level / power sums of the converter
     std::vector<double> fsums;
+    int fsum_idx = -1;                       // >= 0: the float sums are still on their way (mgpu_ctx::fsum_ring): the builder waits for them, not the fetcher
     std::vector<AcCand> ac;                  // Mode A/C candidates of the chunk (cfg.mode_ac)
     ResolveCounts rc;
     uint64_t nlive = 0;
@@ -276,9 +278,18 @@ struct FeedSlot {
 };
 
 struct mgpu_ctx {
+    // Four slots (round 4; three before): a slot is held from the chunk's first kernel until its walk is done — with chunks of 1024
+    // buffers GPU 0.4-0.6 ms + fetch 0.25-0.6 + walk 0.25-0.35 = 2.2-2.5 chunk periods, and with three slots the GPU idled whenever a
+    // host stage took a little longer (SC16Q11 --aggressive: 110 or 180 Gsamples/s from one repetition to the next)
+    static constexpr int kSlots = 4;
+    static constexpr int kJobs = 6;                           // fetched -> walked -> built: a job outlives its slot by the builder's stage
+    static constexpr int kFsumRing = 12;                      // > kSlots + kJobs: an entry is free again before its index comes round
     mgpu_config cfg{};
     hipStream_t stream = nullptr, stream2 = nullptr, stream_w = nullptr;   // main | window statistics | pre-screen write pass / IQ uploads
     hipStream_t stream_d2h = nullptr;                                      // the fetcher's record copies
+    // SC16 formats: the float sums of the chunks in flight — a ring, not the slots' own buffers, so that nobody has to wait for a chunk's
+    // sums before the chunk's slot goes back to the GPU (chunk seq uses entry seq % kFsumRing)
+    struct FsumRing { double *d = nullptr, *h = nullptr; void *scratch = nullptr; hipEvent_t ev = nullptr; } fsum_ring[kFsumRing];
     hipStream_t stream_f = nullptr;                                        // SC16 formats: the float sums' chains (k_fsum_sc16), so that what follows a walk does not queue behind them
     hipStream_t s_post = nullptr;                                          // what follows the walk (window statistics, messages on the device): stream2, or stream_wk
     hipStream_t stream_wk = nullptr;                                       // the walk on the device: highest priority, its small kernels must not queue behind the main stream's
@@ -300,14 +311,13 @@ struct mgpu_ctx {
     uint64_t *d_parity = nullptr, *d_tab_long = nullptr, *d_tab_short = nullptr;
     uint16_t *d_uc8_folded = nullptr;
     int n_long = 0, n_short = 0;
-    static constexpr int kSlots = 3;
     Slot slot[kSlots];
     unsigned long long *d_win = nullptr, *h_win = nullptr;   // skip-window totals of the current feed
     uint64_t feed_cand[8] = {0, 0, 0, 0, 0, 0, 0, 0};         // C, phase[5], U, R of the current feed
     ResolveCounts feed_rc;
     std::vector<uint32_t> w_limit;                            // walker scratch (ordinary memory)
     std::vector<uint16_t> w_skip;
-    HostJob job[4];                                           // fetcher -> walker -> builder hand-off ring
+    HostJob job[kJobs];                                         // fetcher -> walker -> builder hand-off ring
     uint64_t job_seq = 0;
 
     std::vector<SyndromeEntry> tab_long, tab_short;
@@ -322,6 +332,7 @@ struct mgpu_ctx {
     bool device_msgs = false;                                 // mgpu_set_device_messages
     bool sig_late = true;                                     // MGPU_SIG_LATE=0: signal power of every live record in the pre-screen write pass (as in shard passes) instead of the accepted frames' after the walk
     int timing_every = 4;                                     // MGPU_TIMING_EVERY: chunks per set of stage timing events (1 = every chunk)
+    bool fsum_wide = false;                                   // (experiments build: MGPU_FSUM_WIDE=1) the float sums as three wide kernels instead of one chain per buffer
     float event_bracket_us = 4.5f;                            // what a pair of timing events adds to the kernel it brackets (mgpu_event_bracket_us measures it)
     uint64_t timing_seq = 0;
     bool accounting_open = false;                             // feed_begin has run, feed_end has not (deferred: spans several feeds)
@@ -780,6 +791,13 @@ static int alloc_all(mgpu_ctx *c) {
         if (rc != MGPU_OK) return rc;
     }
 
+    if (cfg.format != MGPU_FMT_UC8)
+        for (auto &r : c->fsum_ring) {
+            HIPCHK(c, hipMalloc(&r.d, 2 * c->cap_buffers * sizeof(double)));
+            HIPCHK(c, hipHostMalloc(&r.h, 2 * c->cap_buffers * sizeof(double)));
+            HIPCHK(c, hipMalloc(&r.scratch, fsum_wide_scratch_bytes(c->chunk_samples, cfg.buf_samples)));
+            HIPCHK(c, hipEventCreateWithFlags(&r.ev, hipEventDisableTiming));
+        }
     for (auto &j : c->job) {
         HIPCHK(c, hipHostMalloc(&j.h_msig, c->cap_msgs * sizeof(unsigned long long)));
         HIPCHK(c, hipEventCreateWithFlags(&j.ev_copied, hipEventDisableTiming));
@@ -911,6 +929,7 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     if (const char *e = getenv("MGPU_DEBUG_STAGE")) c->dbg_stage = atoi(e);   // (generation 3 only)
     if (const char *e = getenv("MGPU_TIMING_EVERY")) { const int v = atoi(e); if (v >= 1) c->timing_every = v; }
     if (const char *e = getenv("MGPU_DUMP_DIR")) { c->dump_dir = e; c->sig_late = false; }   // (the dump holds per-record signal powers)
+    c->fsum_wide = getenv("MGPU_FSUM_WIDE") != nullptr;   // (measured, r04k: no faster than the chain per buffer, twice its HBM traffic)
 #endif
     c->device_slot = take_device_slot(cfg->device);
     // the first context of a device has two L3 groups to itself (bind_near_device): a walk team of 8 and a builder team of 6;
@@ -964,6 +983,12 @@ void mgpu_destroy(mgpu_ctx *c) {
     if (c->h_wk_in) (void) hipHostFree(c->h_wk_in);
     if (c->h_wk_sum) (void) hipHostFree(c->h_wk_sum);
     if (c->ev_wk) (void) hipEventDestroy(c->ev_wk);
+    for (auto &r : c->fsum_ring) {
+        if (r.d) (void) hipFree(r.d);
+        if (r.scratch) (void) hipFree(r.scratch);
+        if (r.h) (void) hipHostFree(r.h);
+        if (r.ev) (void) hipEventDestroy(r.ev);
+    }
     for (auto &j : c->job) {
         if (j.h_msgs) (void) hipHostFree(j.h_msgs);
         if (j.h_msig) (void) hipHostFree(j.h_msig);
@@ -1028,11 +1053,16 @@ int mgpu_reset(mgpu_ctx *c) {
 // k_fsum_sc16 of the slot's chunk on the second stream, behind `after` (an event of the main stream)
 static int enqueue_fsum(mgpu_ctx *c, Slot &sl, const uint8_t *iq, hipEvent_t after) {
     const mgpu_config &cfg = c->cfg;
+    sl.fsum_idx = (int) (sl.seq % mgpu_ctx::kFsumRing);
+    mgpu_ctx::FsumRing &r = c->fsum_ring[sl.fsum_idx];
+    const size_t nb = c->cap_buffers;
     HIPCHK(c, hipStreamWaitEvent(c->stream_f, after, 0));
-    HIPCHK(c, hipMemsetAsync(sl.d_fsx, 0, 2 * c->cap_buffers * sizeof(double), c->stream_f));
-    launch_fsum_sc16(cfg.format, iq, sl.n, cfg.buf_samples, sl.d_fsum_level, sl.d_fsum_power, cfg.mode_ac ? 1 : 0, c->stream_f);
-    HIPCHK(c, hipMemcpyAsync(sl.h_fsx, sl.d_fsx, 2 * c->cap_buffers * sizeof(double), hipMemcpyDeviceToHost, c->stream_f));
-    HIPCHK(c, hipEventRecord(sl.ev_fsum, c->stream_f));
+    HIPCHK(c, hipMemsetAsync(r.d, 0, 2 * nb * sizeof(double), c->stream_f));
+    // (Mode A/C waits for the sums on the main stream: their chain runs at s_setprio 3; otherwise nobody is waiting and it yields)
+    if (c->fsum_wide) launch_fsum_sc16_wide(cfg.format, iq, sl.d_mag, sl.n, cfg.buf_samples, r.d, r.d + nb, cfg.mode_ac ? 1 : 0, r.scratch, c->stream_f);
+    else launch_fsum_sc16(cfg.format, iq, sl.n, cfg.buf_samples, r.d, r.d + nb, cfg.mode_ac ? 1 : 0, c->stream_f);
+    HIPCHK(c, hipMemcpyAsync(r.h, r.d, 2 * nb * sizeof(double), hipMemcpyDeviceToHost, c->stream_f));
+    HIPCHK(c, hipEventRecord(r.ev, c->stream_f));
     sl.fsum_pending = true;
     return MGPU_OK;
 }
@@ -1055,11 +1085,12 @@ static int enqueue_convert(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
         cp.uc8_folded = c->d_uc8_folded;
         cp.sum_level = sl.d_sum_level; cp.sum_power = sl.d_sum_power;
         cp.fsum_level = sl.d_fsum_level; cp.fsum_power = sl.d_fsum_power;
-        if (cfg.format != MGPU_FMT_UC8) HIPCHK(c, hipEventRecord(sl.ev_pre, s));
         launch_convert(cfg.format, cp, s);
         if (cfg.format != MGPU_FMT_UC8 && cfg.mode_ac) {
-            // mean level / power of the SC16 formats = the reference's sequential float sums: a chain per buffer, ~0.35 ms, on the second
-            // stream, into buffers of its own.  Mode A/C needs them before its scan (the noise floor): beside the converter, at once
+            // mean level / power of the SC16 formats = the reference's sequential float sums (k_fsum_*, kernels/convert.inc), on a stream
+            // of their own, into buffers of their own.  Mode A/C needs them before its scan (the noise floor): behind the converter
+            // (they predict from its magnitudes), at once; the main stream waits for them below
+            HIPCHK(c, hipEventRecord(sl.ev_pre, s));
             int rc = enqueue_fsum(c, sl, iq, sl.ev_pre);
             if (rc != MGPU_OK) return rc;
         }
@@ -1074,9 +1105,10 @@ static int enqueue_convert(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
         launch_modeac_scan(sl.d_mag, n, cfg.buf_samples, sl.d_ac_noise, sl.h_ac, (uint32_t) c->cap_ac,
                            sl.d_scratch + CNT_NUM + 1 + 4 * c->cap_buffers, sl.d_counters, s);
     }
-    if (cfg.mode_ac && !sl.have_mag && sl.fsum_pending) HIPCHK(c, hipStreamWaitEvent(s, sl.ev_fsum, 0));
+    if (cfg.mode_ac && !sl.have_mag && sl.fsum_pending) HIPCHK(c, hipStreamWaitEvent(s, c->fsum_ring[sl.fsum_idx].ev, 0));
     if (cfg.mode_ac && !sl.have_mag)       // Mode A/C candidates (needs the converter's per-buffer sums); a few us, streaming
-        launch_modeac(sl.d_mag, n, cfg.buf_samples, cfg.format, sl.d_sum_level, sl.d_sum_power, sl.d_fsum_level, sl.d_fsum_power,
+        launch_modeac(sl.d_mag, n, cfg.buf_samples, cfg.format, sl.d_sum_level, sl.d_sum_power,
+                      sl.fsum_pending ? c->fsum_ring[sl.fsum_idx].d : sl.d_fsum_level, sl.fsum_pending ? c->fsum_ring[sl.fsum_idx].d + c->cap_buffers : sl.d_fsum_power,
                       sl.d_ac_noise, sl.h_ac, (uint32_t) c->cap_ac, sl.d_scratch + CNT_NUM + 1 + 4 * c->cap_buffers, sl.d_counters, s);
     if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[1], s));
     return MGPU_OK;
@@ -1177,6 +1209,22 @@ static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq, hipEvent_t aft
 
 // ---- host half of a chunk, part 1 (fetcher thread): wait for the GPU, copy the live records out of pinned memory ----
 // The chunk's live records and their would-be signal powers, HBM -> the job's ordinary memory.
+static void unpin_records(mgpu_ctx *c, Slot &sl, HostJob &job, bool team) {
+    const uint64_t nlive = job.nlive;
+    job.recs.resize(nlive + 1);
+    job.recs[nlive].pos = 0xFFFFFFFFu;          // sentinel for the walk
+    if (!sl.sig_late) job.sig.resize(nlive);
+    const int parts = team && nlive >= 65536 ? c->walk_threads : 1;
+    auto copy = [&](int i) {
+        const uint64_t lo = nlive * (uint64_t) i / parts, hi = nlive * (uint64_t) (i + 1) / parts;
+        std::memcpy(job.recs.data() + lo, sl.h_live + lo, (hi - lo) * sizeof(PhaseRec));
+        if (!sl.sig_late) std::memcpy(job.sig.data() + lo, sl.h_live_sig + lo, (hi - lo) * sizeof(unsigned long long));
+    };
+    if (parts > 1) c->walk_team.run(parts, copy); else copy(0);
+    if (c->shard_mode == 2) job.win.assign(sl.h_live_win, sl.h_live_win + nlive);
+    job.fetched = true;
+}
+
 static int fetch_records(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
     const uint64_t nlive = job.nlive;
     // exactly nlive records + signal powers, HBM -> page-locked host memory over the copy engine (its own stream: the next
@@ -1203,15 +1251,11 @@ static int fetch_records(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
             f = fopen((base + "bufs.bin").c_str(), "wb"); fwrite(sl.buffers.data(), sizeof(BufferClock), sl.buffers.size(), f); fclose(f);
         }
     }
-    job.recs.resize(nlive + 1);
-    job.recs[nlive].pos = 0xFFFFFFFFu;          // sentinel for the walk
-    std::memcpy(job.recs.data(), sl.h_live, nlive * sizeof(PhaseRec));
-    if (!sl.sig_late) {
-        job.sig.resize(nlive);
-        std::memcpy(job.sig.data(), sl.h_live_sig, nlive * sizeof(unsigned long long));
-    }
-    if (c->shard_mode == 2) job.win.assign(sl.h_live_win, sl.h_live_win + nlive);
-    job.fetched = true;
+    // Out of the page-locked buffer into ordinary memory: GPU-written pinned memory is 4x slower for the walk's small scattered reads.
+    // (Round 4 tried the copy on the walker's team instead, in parallel: it takes as long there — reading the pinned pages is the
+    // cost, not the copying thread — and the walker is the stage with less slack: dense bursts 2.1-2.7 ms of walk per 537 M samples
+    // against 1.4, the rate unchanged.  So: here.)
+    unpin_records(c, sl, job, false);
     return MGPU_OK;
 }
 
@@ -1253,8 +1297,19 @@ static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
     job.buffers = sl.buffers;
     job.given_mean_power = sl.given_mean_power;
     job.sums.assign(sl.h_sums, sl.h_sums + 2 * c->cap_buffers);
-    if (sl.fsum_pending) { HIPCHK(c, hipEventSynchronize(sl.ev_fsum)); sl.fsum_pending = false; }   // the float sums have their own pace
-    job.fsums.assign(sl.h_fsums, sl.h_fsums + 2 * c->cap_buffers);
+    // the float sums have their own pace: a chain of ~0.4 ms per chunk that starts behind the chunk's k_sweep.  Only the noise statistics
+    // need them, so it is the builder that waits (build_job), two pipeline stages later — unless this is a shard pass, whose packets
+    // carry them: then here
+    job.fsum_idx = -1;
+    if (sl.fsum_pending) {
+        sl.fsum_pending = false;
+        if (c->shard_mode == 0) job.fsum_idx = sl.fsum_idx;
+        else {
+            HIPCHK(c, hipEventSynchronize(c->fsum_ring[sl.fsum_idx].ev));
+            std::memcpy(sl.h_fsums, c->fsum_ring[sl.fsum_idx].h, 2 * c->cap_buffers * sizeof(double));
+        }
+    }
+    if (job.fsum_idx < 0) job.fsums.assign(sl.h_fsums, sl.h_fsums + 2 * c->cap_buffers);
     // ---- counters that do not depend on the skip windows ----
     const unsigned long long *hc = sl.h_counters;
     c->feed_cand[0] += hc[CNT_CANDIDATES];
@@ -1487,6 +1542,7 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
     job.pos.resize(aux_cap); c->w_limit.resize(aux_cap); c->w_skip.resize(aux_cap);
     job.rc = ResolveCounts();
     int64_t wn;
+    if (!job.fetched && c->device_walk != 1) unpin_records(c, sl, job, true);
 #if MGPU_EXPERIMENTS
     bool wk_running = false;
     if (c->device_walk == 1) {
@@ -1495,6 +1551,7 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
         // not this chunk (see mgpu_debug_device_walk): its records come over after all and it is walked here
         const int frc = fetch_records(c, sl, job, nullptr);
         if (frc != MGPU_OK) return frc;
+        if (!job.fetched) unpin_records(c, sl, job, true);
     }
     if (c->device_walk == 2) {
         c->wk_stats[0] += 1;
@@ -1613,6 +1670,11 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
     // per-message signal level, per-buffer noise power (demod_2400.c:436-457, 474-479): in stream order (double sums are order-dependent)
     auto build_statistics = [&]() {
         mgpu_counters &k = c->counters;
+        const double *fsums = job.fsums.data();
+        if (job.fsum_idx >= 0) {                                  // SC16 formats: the chunk's float sums arrive here at the latest
+            (void) hipEventSynchronize(c->fsum_ring[job.fsum_idx].ev);
+            fsums = c->fsum_ring[job.fsum_idx].h;
+        }
         for (int i = 0; i < 3; ++i) k.demod_accepted[i] += job.rc.accepted[i];
         for (int i = 0; i < 5; ++i) k.demod_bestPhase[i] += job.rc.best_phase[i];
         // per-message signal level, per-buffer noise power (demod_2400.c:436-457, 474-479)
@@ -1641,7 +1703,7 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
             double mean_power;
             if (!job.given_mean_power.empty()) mean_power = job.given_mean_power[b];
             else if (cfg.format == MGPU_FMT_UC8) mean_power = (double) job.sums[c->cap_buffers + b] / 65535.0 / 65535.0 / bc.length;   // convert.c:105-107
-            else mean_power = (double) ((float) job.fsums[c->cap_buffers + b] / (float) bc.length);   // convert.c:246-248: a float sum, a float division
+            else mean_power = (double) ((float) fsums[c->cap_buffers + b] / (float) bc.length);   // convert.c:246-248: a float sum, a float division
             const double sum_signal_power = (double) sum_scaled / 65535.0 / 65535.0;
             k.noise_power_sum += (mean_power * bc.length - sum_signal_power);
             k.noise_power_count += bc.length;
@@ -1766,7 +1828,7 @@ static void fetcher_main(mgpu_ctx *c) {
             if (c->queue.empty()) return;   // stop requested and nothing left
             idx = c->queue.front();
             next_idx = c->queue.size() >= 2 ? c->queue[1] : -1;
-            jidx = (int) (c->job_seq++ % 4);
+            jidx = (int) (c->job_seq++ % mgpu_ctx::kJobs);
             stage_wait(c, lk, [&] { return !c->job[jidx].busy; });
             c->job[jidx].busy = true;
         }
@@ -1870,7 +1932,7 @@ static void submit_slot(mgpu_ctx *c, int idx) {
 
 static int wait_all(mgpu_ctx *c) {
     std::unique_lock<std::mutex> lk(c->mu);
-    c->cv.wait(lk, [&] { return !c->slot[0].busy && !c->slot[1].busy && !c->slot[2].busy && c->queue.empty() && c->walk_queue.empty() && c->build_queue.empty(); });
+    c->cv.wait(lk, [&] { bool idle = true; for (const Slot &sl : c->slot) idle = idle && !sl.busy; return idle && c->queue.empty() && c->walk_queue.empty() && c->build_queue.empty(); });
     return c->worker_rc;
 }
 

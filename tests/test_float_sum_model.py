@@ -92,3 +92,45 @@ def test_block_sum_equals_sequential_float_sum(name, xs):
     for block in (256, 512):
         got = model_sum(xs, block)
         assert got.view(np.uint32) == want.view(np.uint32), (name, block, float(got), float(want))
+
+
+def model_sum_wide(xs, block=512, rel_err=1e-4, seed=0):
+    """Round 4's wide form (k_fsum_approx / k_fsum_prep / k_fsum_apply): every block is summarised against the binade an APPROXIMATE
+    prefix of block sums predicts — independently of the others —, and the chain only applies the summaries; a block whose
+    premise fails (the sum is not in the predicted binade, the block leaves it, an oversized sample) is added exactly."""
+    rng = np.random.default_rng(seed)
+    nblk = (len(xs) + block - 1) // block
+    approx = np.array([float(np.sum(xs[b * block:(b + 1) * block].astype(np.float64))) * (1 + rel_err * rng.uniform(-1, 1)) for b in range(nblk)], dtype=F)
+    summaries = []
+    for b in range(nblk):                                  # (on the device: all at once)
+        pre = F(np.sum(approx[:b].astype(F), dtype=F)) if b else F(0)
+        e_bits = int(F(pre).view(np.uint32)) & 0x7f800000
+        res = block_steps(xs[b * block:(b + 1) * block], e_bits) if e_bits else None
+        summaries.append((e_bits, res))
+    s, exact = F(0), 0
+    for b in range(nblk):
+        sbits = int(np.float32(s).view(np.uint32))
+        e_bits = sbits & 0x7f800000
+        pe, res = summaries[b]
+        if res is not None and e_bits and pe == e_bits:
+            total, has_tie, z_first = res
+            S = (sbits & 0x7fffff) | 0x800000
+            if has_tie and (S & 1):
+                total += -1 if z_first else 1
+            if S + total < (1 << 24):
+                s = np.uint32(e_bits | ((S + total) & 0x7fffff)).view(F)
+                continue
+        exact += 1
+        s = model_sum(xs[b * block:(b + 1) * block], block, s)      # k_fsum_sc16's step for this one block
+    return s, exact, nblk
+
+
+@pytest.mark.parametrize("name,xs", list(_cases()), ids=[c[0] for c in _cases()])
+def test_wide_form_equals_sequential_float_sum(name, xs):
+    want = sequential(xs)
+    for rel_err in (1e-4, 0.3):                            # a prediction as good as the magnitudes give it / a poor one: speed, never the result
+        got, exact, nblk = model_sum_wide(xs, 512, rel_err)
+        assert got.view(np.uint32) == want.view(np.uint32), (name, rel_err, float(got), float(want))
+    got, exact, nblk = model_sum_wide(xs, 512, 1e-4)
+    if name.startswith("magsq small integers") or name == "sc16 magsq":
+        assert exact <= 26 + nblk // 8, (name, exact, nblk)         # the binade crossings and the first block, not much more

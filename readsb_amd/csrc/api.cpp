@@ -795,7 +795,9 @@ static int alloc_all(mgpu_ctx *c) {
         for (auto &r : c->fsum_ring) {
             HIPCHK(c, hipMalloc(&r.d, 2 * c->cap_buffers * sizeof(double)));
             HIPCHK(c, hipHostMalloc(&r.h, 2 * c->cap_buffers * sizeof(double)));
+#if MGPU_EXPERIMENTS
             HIPCHK(c, hipMalloc(&r.scratch, fsum_wide_scratch_bytes(c->chunk_samples, cfg.buf_samples)));
+#endif
             HIPCHK(c, hipEventCreateWithFlags(&r.ev, hipEventDisableTiming));
         }
     for (auto &j : c->job) {
@@ -1059,8 +1061,11 @@ static int enqueue_fsum(mgpu_ctx *c, Slot &sl, const uint8_t *iq, hipEvent_t aft
     HIPCHK(c, hipStreamWaitEvent(c->stream_f, after, 0));
     HIPCHK(c, hipMemsetAsync(r.d, 0, 2 * nb * sizeof(double), c->stream_f));
     // (Mode A/C waits for the sums on the main stream: their chain runs at s_setprio 3; otherwise nobody is waiting and it yields)
+#if MGPU_EXPERIMENTS
     if (c->fsum_wide) launch_fsum_sc16_wide(cfg.format, iq, sl.d_mag, sl.n, cfg.buf_samples, r.d, r.d + nb, cfg.mode_ac ? 1 : 0, r.scratch, c->stream_f);
-    else launch_fsum_sc16(cfg.format, iq, sl.n, cfg.buf_samples, r.d, r.d + nb, cfg.mode_ac ? 1 : 0, c->stream_f);
+    else
+#endif
+    launch_fsum_sc16(cfg.format, iq, sl.n, cfg.buf_samples, r.d, r.d + nb, cfg.mode_ac ? 1 : 0, c->stream_f);
     HIPCHK(c, hipMemcpyAsync(r.h, r.d, 2 * nb * sizeof(double), hipMemcpyDeviceToHost, c->stream_f));
     HIPCHK(c, hipEventRecord(r.ev, c->stream_f));
     sl.fsum_pending = true;

@@ -135,11 +135,13 @@ void launch_spin(unsigned us, unsigned blocks, unsigned long long *sink, hipStre
 // SC16 formats: the per-buffer sequential float sums of mag / magsq (convert.c:225-249), exact; state in and out as doubles holding floats
 void launch_fsum_sc16(int format, const uint8_t *iq, uint64_t n, uint32_t buf_samples, double *fsum_level, double *fsum_power, int want_level,
                       hipStream_t s);
+#if MGPU_EXPERIMENTS
 // the same sums for the pipeline's chunks, wide: approximate block sums from the magnitudes -> per-block summaries against predicted
 // binades -> a short apply chain per buffer (kernels/convert.inc); scratch = fsum_wide_scratch_bytes()
 size_t fsum_wide_scratch_bytes(uint64_t max_samples, uint32_t buf_samples);
 void launch_fsum_sc16_wide(int format, const uint8_t *iq, const uint16_t *mag, uint64_t n, uint32_t buf_samples, double *fsum_level, double *fsum_power,
                            int want_level, void *scratch, hipStream_t s);
+#endif
 unsigned launch_sweep(const SweepParams &p, hipStream_t s);        // k_sweep: preamble sweep -> per-step candidate lists; returns its grid size
 void sweep_pace_feedback(float kernel_us, uint64_t n, unsigned blocks, float bracket_us);   // a timed k_sweep launch: feeds the pacing's step-time estimate
 unsigned launch_slice(const SweepParams &p, hipStream_t s);        // k_slice: slicer + CRC + scoring over the candidate lists -> record pool; returns its grid size (rows of sweep_part)

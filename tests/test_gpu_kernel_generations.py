@@ -38,6 +38,36 @@ def test_generation_matches_oracle(built, version):
     assert r.stdout.strip().startswith("OK")
 
 
+WIDE_SCRIPT = r"""
+import sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+import numpy as np
+import helpers, readsb_amd
+for fmt, mode_ac in ((2, 0), (1, 0), (2, 1)):
+    iq = helpers.synth(seconds=1.5, seed=606 + fmt, rate=2500.0, fmt=fmt)
+    iq = np.ascontiguousarray(iq).view("<i2").copy()
+    iq[2 * 200000: 2 * 200003] = 32767 if fmt == 1 else 2047            # isolated strong samples after a quiet stretch, inside a stream
+    want, wst = helpers.oracle_run(iq, fmt, 2, 1, 58, mode_ac=mode_ac)
+    d = readsb_amd.Demodulator(fmt=fmt, nfix_crc=2, mode_ac=mode_ac, startup_time_ms=helpers.STARTUP_MS, max_samples=64 * 131072)
+    got, cnt = d.demodulate_capture(iq)
+    d.close()
+    helpers.assert_same_messages(got, want)
+    helpers.assert_same_counters(cnt, wst)                             # float_tol 0.0: the noise statistics are made of the float sums
+print("OK")
+"""
+
+
+def test_wide_float_sums_are_exact(built):
+    """MGPU_FSUM_WIDE=1 (experiments build): k_fsum_approx / k_fsum_prep / k_fsum_apply in place of k_fsum_sc16 — the same sequential
+    float sums, bit for bit (Mode S noise statistics, Mode A/C's noise floor)."""
+    exp = os.path.join(helpers.ROOT, "readsb_amd", "csrc", "libmodes_gpu_exp.so")
+    env = dict(os.environ, MGPU_FSUM_WIDE="1", MGPU_LIBRARY="libmodes_gpu_exp.so")
+    code = WIDE_SCRIPT.format(root=helpers.ROOT, tests=os.path.join(helpers.ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.stdout.strip().endswith("OK")
+
+
 @pytest.mark.parametrize("buffers,ragged,dense", [(16, 0, 0), (5, 1025, 1), (3, 7 * 1024 + 1, 0), (1, 0, 1)])
 def test_sweep_kernel_alone_matches_cpu_scan(built, buffers, ragged, dense):
     """k_sweep on its own (tools/micro/sweep_cold.hip includes the product's kernels.hip): the candidate lists of a chunk — an

@@ -352,15 +352,26 @@ def bench_config5(args, rank, local_rank, world):
         out["config"] = {"workload": workload + "one rank: the ordinary pipeline over the whole capture (deferred feeds)", "samples": n, "shards": 1, "parallelism": "time-chunked x1"}
     else:
         stats, phases = {}, {}
+        wf = warmup_start(first)
+        hists = {wf: hist_of(wf), first: hist_of(first)}
+
+        def gather_ranges(ranges):                   # the pre-pass's buffers, gathered into one device buffer (HBM -> HBM)
+            t = torch.cat([d_iq[(a - lo) * 2:(b - lo) * 2] for a, b in ranges])
+            return t, t.data_ptr()
+
+        def one_pass(ph=None, st=None):
+            if args.config5_form == "stream":
+                return shard.demodulate_sharded_stream(d, None, coll, resident=resident, nsamples=n, histories=hists, gather=gather_ranges, phases=ph, stats=st)
+            return shard.demodulate_sharded_walk(d, None, coll, resident=resident, nsamples=n, histories=hists, phases=ph, stats=st)
+
         for _ in range(max(0, args.warmup)):
-            shard.demodulate_sharded_walk(d, None, coll, resident=resident, nsamples=n, histories={warmup_start(first): hist_of(warmup_start(first))})
+            one_pass()
         dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         res = None
         for _ in range(args.steps):
-            res = shard.demodulate_sharded_walk(d, None, coll, resident=resident, nsamples=n, histories={warmup_start(first): hist_of(warmup_start(first))},
-                                                phases=phases, stats=stats)
+            res = one_pass(phases, stats)
         dist.barrier()
         torch.cuda.synchronize()
         t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=coll)
@@ -370,8 +381,8 @@ def bench_config5(args, rank, local_rank, world):
             msgs, counters = res
             out.update(value=round(n * args.steps / elapsed / 1e6, 1), ms_per_step=round(elapsed / args.steps * 1e3, 3), messages_per_step=int(len(msgs)),
                        rank0_phase_ms_per_step={k: round(v / args.steps, 3) for k, v in phases.items()}, protocol=stats)
-            out["config"] = {"workload": workload + "every rank walks and builds its own range; per round an all-gather of every buffer's end clock and the "
-                                                    "filter state at every range's ends; at the end the ranges' messages gathered on rank 0",
+            out["config"] = {"workload": workload + f"every rank walks and builds its own range ({args.config5_form} form); per round an all-gather of every buffer's "
+                                                    "end clock and the filter state at every range's ends; at the end the ranges' messages gathered on rank 0",
                              "samples": n, "shards": world, "parallelism": f"time-chunked x{world}"}
 
     # ---- K emulated ranks on this one GPU: what each would spend, what the combining rank adds ----
@@ -384,36 +395,48 @@ def bench_config5(args, rank, local_rank, world):
 
         # every rank's standing message array (an aggregator keeps one; page faults of a fresh one are not the rank's work)
         outs = [np.zeros(int((b - a) // 512 + 65536), dtype=readsb_amd.MSG_DTYPE) for a, b in shard_ranges(n, emu)]
-        for trial in range(2):                       # the first time round warms the context's buffers up (its numbers are dropped)
-            ranks = [shard.ShardWalkRank(d, r, emu, n, keep_packets=True, out=outs[r]) for r in range(emu)]
-            for r in ranks:
-                r.gpu_phase(None, resident=resident, histories={r.ws: hist_of(r.ws)})
-            if trial == 0:
-                ranks[0].walk(shard.schedule_from_clocks([r.estimate() for r in ranks], n, int(d.cfg.startup_time_ms), int(d.cfg.filter_clock)))
-
-        def exchange(payloads):                      # the all-gather: nothing to do here; what EVERY rank computes from it is timed as rank 0's
-            return payloads
-
-        ests = [shard._pack(r.estimate(), b"", b"") for r in ranks]
         startup, fc = int(d.cfg.startup_time_ms), int(d.cfg.filter_clock)
-        t0 = time.perf_counter()
-        sched = shard.schedule_from_clocks([shard._unpack(b)[0] for b in ests], n, startup, fc)
-        lap("schedule_from_estimates", t0)
+        stream = args.config5_form == "stream"
+        if stream:
+            def gather(ranges):                      # the pre-pass's buffers, gathered into one device buffer (HBM -> HBM)
+                t = torch.cat([d_iq[(a - lo) * 2:(b - lo) * 2] for a, b in ranges])
+                return t, t.data_ptr()
+            src = shard._Source(d, resident=resident, histories=None, gather=gather)
+            src.history = lambda sample: hist_of(sample)
         rounds = 0
-        while True:
-            rounds += 1
-            got = [shard._unpack(shard._pack(*r.walk(sched))) for r in ranks]
-            t0 = time.perf_counter()
-            done, nxt, imports = shard.protocol_round(sched, got, n, startup, fc)
-            lap("round_conclusions", t0)
-            stats["seam_failures"] = stats.get("seam_failures", 0) + len(imports)
-            if done:
-                break
-            sched = nxt
-            for r in ranks:
-                if r.rank in imports:
-                    r.import_state = imports[r.rank]
-            assert rounds < emu + 72
+        for trial in range(2):                       # the first time round warms the context's buffers up (its numbers are dropped)
+            t_ser.clear()
+            if stream:
+                ranks = [shard.ShardStreamRank(d, r, emu, n, src, out=outs[r]) for r in range(emu)]
+                pre = [r.prepass(startup, fc) for r in ranks]
+                t0 = time.perf_counter()
+                sched = shard.schedule_from_window_estimates(pre, n, startup, fc)
+                lap("schedule_from_estimates", t0)
+                step = lambda r, sc: r.stream_pass(sc)
+            else:
+                ranks = [shard.ShardWalkRank(d, r, emu, n, keep_packets=True, out=outs[r]) for r in range(emu)]
+                for r in ranks:
+                    r.gpu_phase(None, resident=resident, histories={r.ws: hist_of(r.ws)})
+                t0 = time.perf_counter()
+                sched = shard.schedule_from_clocks([r.estimate() for r in ranks], n, startup, fc)
+                lap("schedule_from_estimates", t0)
+                step = lambda r, sc: r.walk(sc)
+            rounds = 0
+            while True:
+                rounds += 1
+                got = [shard._unpack(shard._pack(*step(r, sched))) for r in ranks]
+                t0 = time.perf_counter()
+                done, nxt, imports = shard.protocol_round(sched, got, n, startup, fc)
+                lap("round_conclusions", t0)
+                if trial == 1:
+                    stats["seam_failures"] = stats.get("seam_failures", 0) + len(imports)
+                if done:
+                    break
+                sched = nxt
+                for r in ranks:
+                    if r.rank in imports:
+                        r.import_state = imports[r.rank]
+                assert rounds < emu + 72
         for r in ranks:
             t0 = time.perf_counter()
             r.blocks = shard.prepare_sum_blocks(r.msgs, [q.counters for q in ranks[:r.rank]])
@@ -432,11 +455,11 @@ def bench_config5(args, rank, local_rank, world):
         per_rank = [{k: round(v, 3) for k, v in r.ms.items()} for r in ranks]
         # a rank's critical path: GPU phase, clock estimate | round(s): walk + build + collect | its sum blocks; the combining rank's
         # extra: conclusions per round, the combination (the gather itself is communication: bytes below)
-        crit = [r.ms.get("gpu_phase", 0) + r.ms.get("clock_estimate", 0) + r.ms.get("walk_call", 0) + r.ms.get("collect", 0) + r.ms.get("sum_blocks", 0) for r in ranks]
+        crit = [r.ms.get("prepass", 0) + r.ms.get("stream_pass", 0) + r.ms.get("gpu_phase", 0) + r.ms.get("clock_estimate", 0) + r.ms.get("walk_call", 0) + r.ms.get("collect", 0) + r.ms.get("sum_blocks", 0) for r in ranks]
         serial = sum(t_ser.values())
         unsh_ms = out["ms_per_step"]
         out["emulated_ranks"] = {
-            "ranks": emu, "per_rank_ms": per_rank, "rank_critical_path_ms": [round(c, 3) for c in crit],
+            "ranks": emu, "form": args.config5_form, "per_rank_ms": per_rank, "rank_critical_path_ms": [round(c, 3) for c in crit],
             "protocol": {"rounds": rounds, "walks": [r.walks for r in ranks], "seam_failures": stats.get("seam_failures", 0), "imported": [r.import_state is not None for r in ranks],
                          "expiries": int(len(sched)), "sum_blocks": cstats.get("sum_blocks"), "sum_blocks_readded": cstats.get("sum_blocks_readded")},
             "rank0_serial_ms": {k: round(v, 3) for k, v in t_ser.items()}, "rank0_serial_total_ms": round(serial, 3),
@@ -479,6 +502,9 @@ def main():
     ap.add_argument("--event-bracket-us", type=float, default=None, help="what a pair of timing events adds to the kernel it brackets, as measured by an "
                     "earlier run (`event_bracket_us` of its line): skips the calibration (k_spin launches) — for rocprofv3 runs, whose kernel statistics "
                     "then hold the pipeline's kernels only")
+    ap.add_argument("--config5-form", choices=["stream", "packets"], default="stream",
+                    help="--emulate-ranks: `stream` = every rank's pass through the ordinary pipeline, the schedule from a pre-pass over the expiry "
+                         "windows (walk and build overlap the kernels); `packets` = GPU pass first, then the walk of its packets")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the `configs` dict (other BASELINE configurations / input statistics)")
     ap.add_argument("--extra-samples", type=int, default=4096 * BUF, help="samples per segment of the extra configurations (default: the headline step)")

@@ -354,6 +354,25 @@ int mgpu_shard_walk(mgpu_ctx *ctx, const void *packets, uint64_t bytes, const st
                     int64_t *end_clocks, uint64_t cap, uint64_t *n);
 int mgpu_shard_state(mgpu_ctx *ctx, int which /* 0: at own_first, 1: at the range's end */, const void **blob, uint64_t *bytes);
 int mgpu_shard_noise_terms(mgpu_ctx *ctx, const double **terms, uint64_t *n);   /* per buffer of the range: its addend to noise_power_sum */
+/* The same rank with its pass through the ORDINARY pipeline — ordered walk and message build overlapped with the kernels, as for any
+ * stream — for when the schedule is known before the pass (shard.py derives it from a pre-pass over the few buffers around every
+ * expiry's possible positions):  mgpu_shard_stream_begin (resets the context; first_sample = the warm-up's first sample, or own_first
+ * with start_state) | mgpu_feed_iq*(warm-up), synchronous | mgpu_shard_stream_mark (the warm-up's messages and statistics are dropped,
+ * the state at own_first kept, clocks logged from here) | mgpu_feed_iq*(range) with mgpu_collect as for any stream, deferred feeds
+ * allowed | mgpu_shard_stream_end -> the range's true end clocks; states by mgpu_shard_state, noise terms by mgpu_shard_noise_terms.
+ * The rounds that follow are those of mgpu_shard_walk; a rank whose premise failed runs its pass again. */
+struct mgpu_shard_stream_args {
+    uint64_t first_sample;       /* where the pass starts (a multiple of buf_samples) */
+    const void *history_iq;      /* the 326 IQ samples before it (NULL for 0) */
+    uint64_t own_first;          /* first sample of the rank's own range */
+    const int64_t *flip_after;   /* the imposed expiry schedule (as in mgpu_shard_walk_args) */
+    uint64_t nflips;
+    const void *start_state;     /* NULL, or the filter state at own_first (then first_sample == own_first) */
+    uint64_t start_state_bytes;
+};
+int mgpu_shard_stream_begin(mgpu_ctx *ctx, const struct mgpu_shard_stream_args *args);
+int mgpu_shard_stream_mark(mgpu_ctx *ctx);
+int mgpu_shard_stream_end(mgpu_ctx *ctx, int64_t *end_clocks, uint64_t cap, uint64_t *n);
 /* The expiry schedule from every buffer's end clock, by the reference's rule (readsb.c:1227-1231; filter_clock as in
  * mgpu_config): returns the number of expiries, flip_after[i < cap] = index of the buffer the i-th one follows. */
 uint64_t mgpu_flip_schedule(const int64_t *end_clock, uint64_t nbuf, int64_t startup_ms, int filter_clock,

@@ -101,6 +101,13 @@ class ShardWalkArgs(C.Structure):
 DEFAULT_CHUNK_BUFFERS = 0                   # mgpu_config.chunk_buffers of Demodulators created without one (tests lower it: more chunks per feed)
 
 
+class ShardStreamArgs(C.Structure):
+    _fields_ = [
+        ("first_sample", C.c_uint64), ("history_iq", C.c_void_p), ("own_first", C.c_uint64), ("flip_after", C.c_void_p), ("nflips", C.c_uint64),
+        ("start_state", C.c_void_p), ("start_state_bytes", C.c_uint64),
+    ]
+
+
 class MgpuError(RuntimeError):
     pass
 
@@ -220,6 +227,9 @@ def load_library():
     lib.mgpu_shard_clock_estimate.argtypes = [vp, vp, u64, u64, vp, u64, C.POINTER(u64)]
     lib.mgpu_shard_walk.argtypes = [vp, vp, u64, C.POINTER(ShardWalkArgs), vp, u64, C.POINTER(u64)]
     lib.mgpu_shard_state.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(u64)]
+    lib.mgpu_shard_stream_begin.argtypes = [vp, C.POINTER(ShardStreamArgs)]
+    lib.mgpu_shard_stream_mark.argtypes = [vp]
+    lib.mgpu_shard_stream_end.argtypes = [vp, vp, u64, C.POINTER(u64)]
     lib.mgpu_shard_noise_terms.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
     lib.mgpu_flip_schedule.argtypes = [vp, u64, i64, i32, vp, u64]
     lib.mgpu_flip_schedule.restype = u64
@@ -401,6 +411,39 @@ class Demodulator:
             self._chk(self.lib.mgpu_shard_state(self.ctx, which, C.byref(bp), C.byref(bn)), "mgpu_shard_state")
             states.append(C.string_at(bp, bn.value) if bn.value else b"")
         return out[: n.value].copy(), states[0], states[1]
+
+    def _shard_states(self):
+        states = []
+        for which in (0, 1):
+            bp, bn = C.c_void_p(), C.c_uint64(0)
+            self._chk(self.lib.mgpu_shard_state(self.ctx, which, C.byref(bp), C.byref(bn)), "mgpu_shard_state")
+            states.append(C.string_at(bp, bn.value) if bn.value else b"")
+        return states
+
+    def shard_stream_begin(self, first_sample, history_iq, own_first, flip_after_ts, start_state=None):
+        """A rank's pass through the ordinary pipeline (mgpu_shard_stream_*): resets the context, cold start or imported state."""
+        hist = None if history_iq is None else np.ascontiguousarray(history_iq, dtype=np.uint8)
+        sched = np.ascontiguousarray(flip_after_ts, dtype=np.int64)
+        a = ShardStreamArgs()
+        a.first_sample, a.own_first = int(first_sample), int(own_first)
+        a.history_iq = None if hist is None else hist.ctypes.data
+        a.flip_after, a.nflips = (sched.ctypes.data if sched.size else None), sched.size
+        st = None
+        if start_state is not None:
+            st = np.frombuffer(start_state, dtype=np.uint8)
+            a.start_state, a.start_state_bytes = st.ctypes.data, st.size
+        self._chk(self.lib.mgpu_shard_stream_begin(self.ctx, C.byref(a)), "mgpu_shard_stream_begin")
+
+    def shard_stream_mark(self):
+        self._chk(self.lib.mgpu_shard_stream_mark(self.ctx), "mgpu_shard_stream_mark")
+
+    def shard_stream_end(self, nbuffers):
+        """-> (the range's true end clocks, state at own_first, state at the range's end)."""
+        out = np.empty(int(nbuffers) + 1, dtype=np.int64)
+        n = C.c_uint64(0)
+        self._chk(self.lib.mgpu_shard_stream_end(self.ctx, C.c_void_p(out.ctypes.data), out.size, C.byref(n)), "mgpu_shard_stream_end")
+        s0, s1 = self._shard_states()
+        return out[: n.value].copy(), s0, s1
 
     def shard_noise_terms(self):
         """What each buffer of the walked range adds to noise_power_sum, in order (a copy)."""

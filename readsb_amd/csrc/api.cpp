@@ -364,6 +364,9 @@ struct mgpu_ctx {
     std::vector<uint64_t> shard_est_pos, shard_est_off;       // ... the packets' first samples / offsets into shard_est
     std::vector<double> shard_noise;
     ShardWalkOut shard_out;
+    bool shard_noise_on = false;                              // a rank's pass through the ordinary pipeline (mgpu_shard_stream_*): the builder logs every buffer's noise term
+    uint64_t shard_stream_own_first = 0;
+    bool shard_stream = false, shard_stream_cold = false;
     // beast encoder scratch (mgpu_beast_encode*): grown on demand
     uint16_t *d_beast_len = nullptr;        // per message: frame length | signal byte << 8
     uint8_t *d_beast_in = nullptr, *d_beast_out = nullptr;
@@ -1039,6 +1042,7 @@ int mgpu_reset(mgpu_ctx *c) {
     c->shard_est.clear(); c->shard_est_pos.clear(); c->shard_est_off.clear();
     c->resolver.set_schedule(nullptr, 0);
     c->resolver.log_end_clocks(nullptr);
+    c->shard_noise_on = c->shard_stream = false;
     HIPCHK(c, hipMemsetAsync(c->d_adder_bitmap, 0, (1u << 24) / 8, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MGPU_OK;
@@ -1647,6 +1651,7 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
         ac.resize(keep);
     }
     const uint32_t nac = (uint32_t) ac.size();
+    if (c->shard_stream && job.stream_pos < c->shard_stream_own_first) return MGPU_OK;   // a rank's warm-up: walked for the filter's state only
     const bool on_device = c->device_msgs && job.feed >= 0;   // the walker had k_build_messages make the records: statistics only here
     MsgBuf &pending = job.feed >= 0 ? c->feed[job.feed].msgs : c->pending;
     const size_t first_msg = pending.size();
@@ -1711,6 +1716,7 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
             else mean_power = (double) ((float) fsums[c->cap_buffers + b] / (float) bc.length);   // convert.c:246-248: a float sum, a float division
             const double sum_signal_power = (double) sum_scaled / 65535.0 / 65535.0;
             k.noise_power_sum += (mean_power * bc.length - sum_signal_power);
+            if (c->shard_noise_on) c->shard_noise.push_back(mean_power * bc.length - sum_signal_power);
             k.noise_power_count += bc.length;
             k.samples_processed += bc.length;
             k.samples_lost += cfg.buf_samples - bc.length;        // readsb.c:886
@@ -2469,24 +2475,13 @@ static int demod_mag_buf(mgpu_ctx *c, const uint16_t *data, uint32_t length, int
 // chunk's live records as a packet.  The packets of all shards, in stream order, go through mgpu_walk_packets on
 // one context: the ordered walk and the message build, exactly as for an unsharded stream.
 
-int mgpu_shard_begin(mgpu_ctx *c, uint64_t first_sample, const void *history_iq, int mode) {
-    if (!c || mode < 1 || mode > 2 || first_sample % c->cfg.buf_samples || c->deferred) return MGPU_E_INVAL;
-    if (first_sample && !history_iq) return MGPU_E_INVAL;
-    HIPCHK(c, hipSetDevice(c->cfg.device));
-    c->shard_mode = mode;
-    if (mode == 2)                           // the packets carry every live record's would-be skip-window counts
-        for (auto &sl : c->slot)
-            if (!sl.d_live_win) {
-                HIPCHK(c, hipMalloc(&sl.d_live_win, c->cap_pool * sizeof(unsigned long long)));
-                HIPCHK(c, hipHostMalloc(&sl.h_live_win, c->cap_pool * sizeof(unsigned long long)));
-            }
-    c->shard_packets.clear();
-    c->shard_est.clear(); c->shard_est_pos.clear(); c->shard_est_off.clear();
+// A context that starts (or continues) in the middle of a capture: its sample clock, and the 326 magnitudes that precede the first
+// sample (sdr_ifile.c:209-213) from the 326 IQ samples before it.
+static int start_mid_stream(mgpu_ctx *c, uint64_t first_sample, const void *history_iq) {
     c->stream_pos = first_sample;
     c->eof = false;
     c->tail_src = nullptr;
     if (first_sample) {
-        // the 326 magnitudes that precede the shard (sdr_ifile.c:209-213), from the 326 IQ samples before it
         const size_t bps = c->cfg.format == MGPU_FMT_UC8 ? 2 : 4;
         if (!c->d_hist) {
             HIPCHK(c, hipMalloc(&c->d_hist, (2 * kTrailing + 64) * sizeof(uint16_t)));
@@ -2505,6 +2500,23 @@ int mgpu_shard_begin(mgpu_ctx *c, uint64_t first_sample, const void *history_iq,
         HIPCHK(c, hipStreamSynchronize(s));
         c->tail_src = c->d_hist + kTrailing;   // d_hist[326 + i] = magnitude of history sample i
     }
+    return MGPU_OK;
+}
+
+int mgpu_shard_begin(mgpu_ctx *c, uint64_t first_sample, const void *history_iq, int mode) {
+    if (!c || mode < 1 || mode > 2 || first_sample % c->cfg.buf_samples || c->deferred) return MGPU_E_INVAL;
+    if (first_sample && !history_iq) return MGPU_E_INVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    c->shard_mode = mode;
+    if (mode == 2)                           // the packets carry every live record's would-be skip-window counts
+        for (auto &sl : c->slot)
+            if (!sl.d_live_win) {
+                HIPCHK(c, hipMalloc(&sl.d_live_win, c->cap_pool * sizeof(unsigned long long)));
+                HIPCHK(c, hipHostMalloc(&sl.h_live_win, c->cap_pool * sizeof(unsigned long long)));
+            }
+    c->shard_packets.clear();
+    c->shard_est.clear(); c->shard_est_pos.clear(); c->shard_est_off.clear();
+    { const int rc = start_mid_stream(c, first_sample, history_iq); if (rc != MGPU_OK) return rc; }
     return MGPU_OK;
 }
 
@@ -2805,6 +2817,72 @@ int mgpu_shard_walk(mgpu_ctx *c, const void *packets, uint64_t bytes, const stru
     const int rc = guarded(c, [&] { return shard_walk_checked(c, packets, bytes, a, end_clocks, cap, n_out); });
     c->hot.store(false, std::memory_order_relaxed);
     return rc;
+}
+
+// ---- the same rank, its pass through the ORDINARY pipeline (walk and build overlapped with the GPU) ----
+// mgpu_shard_walk above walks a range's packets after its GPU pass: nothing overlaps, and of a rank's 26 ms for an eighth of the
+// one-hour capture 14 were walk and build (profiles/r04_config5_one_hour_emulate8.json).  When the schedule is known BEFORE the pass
+// (readsb_amd/shard.py: it is the chain over end clocks of a few buffers around every expiry's possible positions — a pre-pass over
+// ~5 % of the capture), warm-up and range go through the pipeline every other stream goes through: begin (cold start or imported
+// state, schedule imposed), feed the warm-up, mark, feed the range, end.  Same outputs as mgpu_shard_walk: true end clocks, the
+// states at the range's two ends, per-buffer noise terms; messages and counters by mgpu_collect.
+int mgpu_shard_stream_begin(mgpu_ctx *c, const struct mgpu_shard_stream_args *a) {
+    if (!c || !a || (a->nflips && !a->flip_after) || (a->start_state && !a->start_state_bytes)) return MGPU_E_INVAL;
+    if (c->cfg.mode_ac || c->cfg.filter_clock == MGPU_FILTER_CLOCK_EXTERNAL || a->own_first % c->cfg.buf_samples || a->first_sample % c->cfg.buf_samples ||
+        a->first_sample > a->own_first || (a->first_sample && !a->history_iq) || (a->start_state && a->first_sample != a->own_first)) {
+        c->err = "mgpu_shard_stream_begin: whole-buffer ranges, no Mode A/C, no external filter clock; an imported state starts at the range's first sample";
+        return MGPU_E_INVAL;
+    }
+    { const int rc = mgpu_reset(c); if (rc != MGPU_OK) return rc; }
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    { const int rc = start_mid_stream(c, a->first_sample, a->history_iq); if (rc != MGPU_OK) return rc; }
+    c->shard_sched.assign(a->flip_after, a->flip_after + a->nflips);
+    for (size_t i = 1; i < c->shard_sched.size(); ++i)
+        if (c->shard_sched[i] <= c->shard_sched[i - 1]) { c->err = "mgpu_shard_stream_begin: the schedule must be ascending"; return MGPU_E_INVAL; }
+    Resolver &res = c->resolver;
+    c->shard_stream_cold = false;
+    if (a->start_state) {
+        if (!res.import_state((const uint8_t *) a->start_state, a->start_state_bytes)) { c->err = "mgpu_shard_stream_begin: not a filter state"; return MGPU_E_INVAL; }
+    } else if (a->first_sample == 0) res.reset(c->cfg.startup_time_ms, (int) c->cfg.filter_clock);
+    else { res.reset_empty(c->cfg.startup_time_ms); c->shard_stream_cold = true; }
+    res.set_schedule(c->shard_sched.data(), c->shard_sched.size());
+    c->shard_stream = true;
+    c->shard_stream_own_first = a->own_first;
+    c->shard_out.clocks.clear(); c->shard_out.state_first.clear(); c->shard_out.state_end.clear();
+    c->shard_noise.clear();
+    return MGPU_OK;
+}
+
+int mgpu_shard_stream_mark(mgpu_ctx *c) {
+    if (!c || !c->shard_stream) return MGPU_E_INVAL;
+    { const int rc = drain(c); if (rc != MGPU_OK) return rc; }
+    if (c->deferred || c->stream_pos != c->shard_stream_own_first) { c->err = "mgpu_shard_stream_mark: after the warm-up's (synchronous) feeds, at the range's first sample"; return MGPU_E_INVAL; }
+    c->pending.clear();                                        // the warm-up's messages and statistics are nobody's
+    std::memset(&c->counters, 0, sizeof(c->counters));
+    Resolver &res = c->resolver;
+    if (c->shard_stream_cold) {                                // the expiries before the range, counted from the schedule
+        const int64_t ts0 = (int64_t) c->shard_stream_own_first * 5;
+        res.set_nflips((uint64_t) (std::lower_bound(c->shard_sched.begin(), c->shard_sched.end(), ts0) - c->shard_sched.begin()) +
+                       (c->cfg.filter_clock == MGPU_FILTER_CLOCK_BEFORE_FIRST ? 1u : 0u));
+    }
+    res.export_state(c->shard_out.state_first);
+    res.log_end_clocks(&c->shard_out.clocks);
+    c->shard_noise_on = true;
+    return MGPU_OK;
+}
+
+int mgpu_shard_stream_end(mgpu_ctx *c, int64_t *end_clocks, uint64_t cap, uint64_t *n_out) {
+    if (!c || !c->shard_stream || !end_clocks || !n_out) return MGPU_E_INVAL;
+    *n_out = 0;
+    { const int rc = drain(c); if (rc != MGPU_OK) return rc; }
+    c->resolver.log_end_clocks(nullptr);
+    c->shard_noise_on = false;
+    c->resolver.export_state(c->shard_out.state_end);
+    c->counters.nflips = c->resolver.nflips();
+    if (c->shard_out.clocks.size() > cap) { c->err = "mgpu_shard_stream_end: more buffers than the caller's array holds"; return MGPU_E_CAPACITY; }
+    std::memcpy(end_clocks, c->shard_out.clocks.data(), c->shard_out.clocks.size() * sizeof(int64_t));
+    *n_out = c->shard_out.clocks.size();
+    return MGPU_OK;
 }
 
 int mgpu_shard_state(mgpu_ctx *c, int which, const void **blob, uint64_t *bytes) {

@@ -470,6 +470,16 @@ def demodulate_sharded_walk(d, iq, device=None, resident=None, nsamples=None, hi
     startup, fc = int(d.cfg.startup_time_ms), int(d.cfg.filter_clock)
     t0 = time.perf_counter()
     sched = run_walk_protocol([me], lambda payloads: _all_gather_bytes(payloads[0], device), n, startup, fc, stats=stats)
+    return _gather_and_combine(me, sched, n, fc, device, phases, stats, t0)
+
+
+def _gather_and_combine(me, sched, n, fc, device, phases, stats, t0):
+    """Every range's messages, counters, noise terms and sum blocks to rank 0 (an all-gather of the small parts, a gather of the
+    messages), combined there.  -> (messages, counters) on rank 0, None elsewhere."""
+    import time
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
     t1 = time.perf_counter()
     # ---- the ranges' results to rank 0 ----
     import pickle
@@ -511,3 +521,220 @@ def demodulate_sharded_walk(d, iq, device=None, resident=None, nsamples=None, hi
     if phases is not None:
         phases["combine"] = phases.get("combine", 0.0) + (time.perf_counter() - t2) * 1e3
     return res
+
+
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# ... and the form in which a rank's walk and build OVERLAP its kernels: the schedule is derived before the pass, from a pre-pass
+# over the few buffers an expiry can follow, and warm-up + range then go through the ordinary pipeline (mgpu_shard_stream_*).
+# ---------------------------------------------------------------------------------------------------------------------------
+
+def buffer_sys_ms(b, startup_ms):
+    """sysTimestamp of buffer b (sdr_ifile.c:216): where its clock starts; its end clock lies within the 55 ms after."""
+    return (np.asarray(b, dtype=np.int64) * (BUF * 5)) // 12000 + int(startup_ms)
+
+
+def expiry_windows(nbuf_total, startup_ms, filter_clock=0):
+    """The buffers an expiry of the ICAO filter CAN follow, as a boolean mask.  The k-th expiry follows the first buffer whose end
+    clock reaches T_k, and T_(k+1) = (that buffer's end clock) + 60 s (readsb.c:1227-1231) with the end clock anywhere in the
+    buffer's own 55 ms: T_k + 60 000 <= T_(k+1) < T_k + 60 111 (the buffer that reaches T_k starts within 55.6 ms of it).  So T_k lies in a window that widens by 110 ms per expiry, and only
+    buffers whose 55 ms touch a window matter to the schedule: ~2 k of them for the k-th expiry."""
+    mask = np.zeros(int(nbuf_total), dtype=bool)
+    if nbuf_total == 0:
+        return mask
+    s = buffer_sys_ms(np.arange(nbuf_total), startup_ms)
+    span = 56
+    if filter_clock == 1:
+        lo, hi = startup_ms + 60000, startup_ms + 60000           # one expiry before buffer 0, the next due 60 s after start-up
+    else:
+        mask[0] = True                                            # next_flip = 0: the first expiry follows buffer 0
+        lo, hi = int(s[0]) + 60000, int(s[0]) + span + 60000
+    end = int(s[-1]) + span
+    while lo <= end:
+        a = int(np.searchsorted(s, lo - span, side="left"))       # buffers whose [s, s + 55] reaches lo ...
+        b = int(np.searchsorted(s, hi, side="right"))             # ... and starts by hi
+        mask[max(0, a - 1):min(nbuf_total, b + 1)] = True         # (a buffer to spare on either side)
+        lo, hi = lo + 60000, hi + 60111
+    return mask
+
+
+class _Source:
+    """Where a rank's samples are: host bytes, or resident in HBM (first sample held, device address, a function that gathers
+    sample ranges into one device buffer)."""
+
+    def __init__(self, d, iq=None, resident=None, histories=None, gather=None):
+        self.d, self.iq, self.resident, self.histories, self.gather_fn = d, iq, resident, histories, gather
+        self.bps = _FMT_BYTES[d.fmt]
+
+    def history(self, sample):
+        if sample == 0:
+            return None
+        if self.iq is not None:
+            return self.iq[(sample - TRAILING) * self.bps:sample * self.bps]
+        return self.histories[sample]
+
+    def feed(self, a, b):
+        if b <= a:
+            return
+        if self.resident is not None:
+            _feed_resident(self.d, a, b, self.bps, self.resident)
+        else:
+            _feed_host(self.d, self.iq, a, b, self.bps)
+
+    def feed_gathered(self, ranges):
+        """The sample ranges as ONE stream (for the pre-pass: whole buffers, their order kept)."""
+        total = sum(b - a for a, b in ranges)
+        if self.iq is not None:
+            fake = np.concatenate([self.iq[a * self.bps:b * self.bps] for a, b in ranges])
+            _feed_host(self.d, fake, 0, total, self.bps)
+        else:
+            keep, ptr = self.gather_fn(ranges)
+            _feed_resident(self.d, 0, total, self.bps, (0, ptr))
+            del keep
+
+
+class ShardStreamRank(ShardWalkRank):
+    """A rank whose pass goes through the ordinary pipeline (mgpu_shard_stream_*): `prepass` estimates the end clocks of its buffers
+    inside the expiry windows, `stream_pass` runs warm-up + range with the schedule imposed."""
+
+    def __init__(self, d, rank, world, nsamples, source, out=None):
+        super().__init__(d, rank, world, nsamples, keep_packets=False, out=out)
+        self.src = source
+
+    def prepass(self, startup_ms, filter_clock=0):
+        """-> (global indices of this rank's buffers inside the expiry windows, their estimated end clocks)."""
+        import time
+        t0 = time.perf_counter()
+        nb_total = (self.n + BUF - 1) // BUF
+        mask = expiry_windows(nb_total, startup_ms, filter_clock)
+        b0, b1 = self.first // BUF, (self.last + BUF - 1) // BUF
+        idx = np.flatnonzero(mask[b0:b1]) + b0
+        if idx.size and idx[-1] == nb_total - 1 and self.n % BUF:
+            idx = idx[:-1]                                       # (a short last buffer does not fit the gathered stream's grid: its clock is guessed)
+        if idx.size == 0:
+            return idx, np.zeros(0, dtype=np.int64)
+        runs, start = [], idx[0]
+        for k in range(1, idx.size + 1):
+            if k == idx.size or idx[k] != idx[k - 1] + 1:
+                runs.append((int(start) * BUF, (int(idx[k - 1]) + 1) * BUF))
+                if k < idx.size:
+                    start = idx[k]
+        d = self.d
+        d.reset()
+        d.shard_begin(0, None, 2)
+        self.src.feed_gathered(runs)
+        est = d.shard_clock_estimate(0, idx.size).copy()
+        # the gathered stream's buffer i stands for buffer idx[i]: what counts is how far into its own 55 ms the clock ends
+        clocks = buffer_sys_ms(idx, startup_ms) + (est - buffer_sys_ms(np.arange(idx.size), startup_ms))
+        self._lap("prepass", t0)
+        self.ms["prepass_buffers"] = int(idx.size)
+        return idx, clocks
+
+    def stream_pass(self, sched_ts):
+        import time
+        if self.nbuf == 0:
+            self.result = (np.zeros(0, dtype=np.int64), b"", b"")
+            self.msgs, self.counters, self.noise = np.zeros(0, dtype=MSG_DTYPE), None, np.zeros(0)
+            return self.result
+        lo, hi = self.ws * 5, self.last * 5
+        mine = sched_ts[(sched_ts >= lo) & (sched_ts < hi)]
+        nbefore = int((sched_ts < self.first * 5).sum())
+        key = (mine.tobytes(), nbefore, self.import_state)
+        if self.used == key:
+            return self.result
+        t0 = time.perf_counter()
+        d = self.d
+        start = self.first if self.import_state is not None else self.ws
+        d.shard_stream_begin(start, self.src.history(start), self.first, sched_ts, self.import_state)
+        self.src.feed(start, self.first)                         # the warm-up (nothing with an imported state)
+        d.shard_stream_mark()
+        d.set_message_buffer(self.out)
+        self.src.feed(self.first, self.last)
+        self.result = d.shard_stream_end(self.nbuf)
+        self.used = key
+        self.walks += 1
+        self._lap("stream_pass", t0)
+        t0 = time.perf_counter()
+        self.msgs, self.counters = d.collect(out=self.out) if self.out is not None else d.collect()
+        self.noise = d.shard_noise_terms()
+        self._lap("collect", t0)
+        return self.result
+
+
+def schedule_from_window_estimates(parts, nsamples, startup_ms, filter_clock=0):
+    """parts = every rank's (buffer indices, estimated end clocks) inside the expiry windows -> the schedule.  Buffers outside the
+    windows cannot be followed by an expiry: their clocks are filled in with their start (anything within their 55 ms would do)."""
+    nb_total = (nsamples + BUF - 1) // BUF
+    clocks = buffer_sys_ms(np.arange(nb_total), startup_ms)
+    for idx, c in parts:
+        if len(idx):
+            clocks[np.asarray(idx, dtype=np.int64)] = c
+    return schedule_from_clocks([clocks], nsamples, startup_ms, filter_clock)
+
+
+def run_stream_protocol(ranks, exchange, nsamples, startup_ms, filter_clock=0, stats=None):
+    """The rounds for ShardStreamRanks.  exchange as in run_walk_protocol."""
+    pre = [r.prepass(startup_ms, filter_clock) for r in ranks]
+    got = exchange([np.array([len(i)], dtype=np.int64).tobytes() + np.asarray(i, dtype=np.int64).tobytes() + np.asarray(c, dtype=np.int64).tobytes() for i, c in pre])
+    parts = []
+    for b in got:
+        b = bytes(b)
+        k = int(np.frombuffer(b[:8], dtype=np.int64)[0])
+        parts.append((np.frombuffer(b[8:8 + 8 * k], dtype=np.int64), np.frombuffer(b[8 + 8 * k:8 + 16 * k], dtype=np.int64)))
+    sched = schedule_from_window_estimates(parts, nsamples, startup_ms, filter_clock)
+    world = len(got)
+    rounds = 0
+    while True:
+        rounds += 1
+        if rounds > world + 72:
+            raise RuntimeError("sharded walk: the schedule / seam iteration did not settle")
+        res = [_unpack(b) for b in exchange([_pack(*r.stream_pass(sched)) for r in ranks])]
+        done, nxt, imports = protocol_round(sched, res, nsamples, startup_ms, filter_clock)
+        if stats is not None:
+            stats["rounds"] = rounds
+            stats["seam_failures"] = stats.get("seam_failures", 0) + len(imports)
+            stats["schedule_changes"] = stats.get("schedule_changes", 0) + (0 if (nxt.size == sched.size and (nxt == sched).all()) else 1)
+            stats["prepass_buffers"] = int(sum(len(p[0]) for p in parts))
+        if done:
+            return sched
+        sched = nxt
+        for r in ranks:
+            if r.rank in imports:
+                r.import_state = imports[r.rank]
+
+
+def demodulate_sharded_stream_local(d, iq, nshards, stats=None):
+    """All ranks of the stream form played by ONE Demodulator, one after the other (tests, single GPU)."""
+    iq = np.ascontiguousarray(iq).view(np.uint8).reshape(-1)
+    n = iq.size // _FMT_BYTES[d.fmt]
+    src = _Source(d, iq=iq)
+    ranks = [ShardStreamRank(d, r, nshards, n, src) for r in range(nshards)]
+    startup, fc = int(d.cfg.startup_time_ms), int(d.cfg.filter_clock)
+    sched = run_stream_protocol(ranks, lambda payloads: payloads, n, startup, fc, stats=stats)
+    if stats is not None:
+        stats["walks"] = [r.walks for r in ranks]
+        stats["imported"] = [r.import_state is not None for r in ranks]
+    parts = [(r.msgs, r.counters, r.noise, prepare_sum_blocks(r.msgs, [q.counters for q in ranks[:r.rank]])) for r in ranks]
+    return combine_ranges(parts, n, len(sched) + (1 if fc == 1 else 0), stats)
+
+
+def demodulate_sharded_stream(d, iq=None, device=None, resident=None, nsamples=None, histories=None, gather=None, phases=None, out=None, stats=None):
+    """torch.distributed version of the stream form: this process is ONE rank.  iq = the capture as host bytes, or resident = (first
+    sample held, device address) with histories = {sample: the 326 IQ samples before it} for the samples this rank starts passes at
+    (its warm-up's first, its range's first) and gather(ranges) -> (keep-alive, device address of those sample ranges made contiguous).
+    Collectives: an all-gather of the pre-pass's clocks (a few KB), one of clocks + states per round, the gather of the results."""
+    import time
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    device = device or torch.device("cpu")
+    if iq is not None:
+        iq = np.ascontiguousarray(iq).view(np.uint8).reshape(-1)
+    n = nsamples if nsamples is not None else iq.size // _FMT_BYTES[d.fmt]
+    src = _Source(d, iq=iq, resident=resident, histories=histories, gather=gather)
+    me = ShardStreamRank(d, rank, world, n, src, out=out)
+    startup, fc = int(d.cfg.startup_time_ms), int(d.cfg.filter_clock)
+    t0 = time.perf_counter()
+    sched = run_stream_protocol([me], lambda payloads: _all_gather_bytes(payloads[0], device), n, startup, fc, stats=stats)
+    return _gather_and_combine(me, sched, n, fc, device, phases, stats, t0)

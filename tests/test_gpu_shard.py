@@ -58,20 +58,43 @@ def test_sharded_walk_equals_unsharded(built, nshards, seconds, dense, rate, nfi
         assert stats["rounds"] == 1 and not any(stats["imported"])  # every warm-up reaches back to the start: one walk per rank
 
 
-def _rank_walk(rank, world, port, q, seconds, seed):
+@pytest.mark.parametrize("nshards,seconds,dense,rate,nfix,naircraft", [(2, 8.0, 1, 8000.0, 2, 200), (8, 70.0, 1, 6000.0, 1, 200), (2, 290.0, 0, 1500.0, 1, 200),
+                                                                       (3, 400.0, 0, 1200.0, 1, 3000)])
+def test_sharded_stream_equals_unsharded(built, nshards, seconds, dense, rate, nfix, naircraft):
+    """... and the form whose walk and build overlap the kernels: the schedule from a pre-pass over the buffers an expiry can follow
+    (shard.expiry_windows), every rank's warm-up + range through the ordinary pipeline (mgpu_shard_stream_*)."""
+    import readsb_amd
+    from readsb_amd import shard
+    iq = helpers.synth(seconds=seconds, seed=2900 + nshards + int(seconds), rate=rate, dense=dense, naircraft=naircraft, threads=16)
+    want, wst = helpers.ref_run(iq, 0, nfix, 1, 58) if helpers.have_ref() else helpers.oracle_run(iq, 0, nfix, 1, 58)
+    d = readsb_amd.Demodulator(nfix_crc=nfix, startup_time_ms=helpers.STARTUP_MS, max_samples=256 * 131072)
+    stats = {}
+    try:
+        got, cnt = shard.demodulate_sharded_stream_local(d, iq, nshards, stats)
+    finally:
+        d.close()
+    assert len(want) > 5000
+    helpers.assert_same_messages(got, want)
+    helpers.assert_same_counters(cnt, wst)
+    assert stats["rounds"] >= 1 and min(stats["walks"]) >= 1
+    if seconds < 100:
+        assert stats["rounds"] == 1 and not any(stats["imported"])
+
+
+def _rank_walk(rank, world, port, q, seconds, seed, form="packets"):
     import torch
     import torch.distributed as dist
     sys.path.insert(0, helpers.ROOT)
     sys.path.insert(0, os.path.join(helpers.ROOT, "tests"))
     import readsb_amd
-    from readsb_amd.shard import demodulate_sharded_walk
+    from readsb_amd.shard import demodulate_sharded_walk, demodulate_sharded_stream
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     iq = helpers.synth(seconds=seconds, seed=seed, rate=4000.0, dense=1, threads=8)
     d = readsb_amd.Demodulator(startup_time_ms=helpers.STARTUP_MS, max_samples=128 * 131072)
     stats = {}
-    res = demodulate_sharded_walk(d, iq, torch.device("cpu"), stats=stats)
+    res = (demodulate_sharded_stream if form == "stream" else demodulate_sharded_walk)(d, iq, torch.device("cpu"), stats=stats)
     d.close()
     ok = True
     if rank == 0:
@@ -91,11 +114,12 @@ def _rank_walk(rank, world, port, q, seconds, seed):
     dist.destroy_process_group()
 
 
-def test_sharded_walk_two_ranks_gloo(built):
+@pytest.mark.parametrize("form", ["packets", "stream"])
+def test_sharded_walk_two_ranks_gloo(built, form):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 36500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_rank_walk, args=(r, 2, port, q, 6.0, 4243)) for r in range(2)]
+    port = 36500 + (os.getpid() % 2000) + (7 if form == "stream" else 0)
+    procs = [ctx.Process(target=_rank_walk, args=(r, 2, port, q, 6.0, 4243, form)) for r in range(2)]
     for p in procs:
         p.start()
     results = dict(q.get(timeout=300) for _ in range(2))

@@ -78,6 +78,36 @@ def test_flip_schedule_is_the_reference_rule(built, mode):
     assert list(flip_schedule(np.zeros(0, dtype=np.int64), startup, mode)) == []
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_expiry_windows_hold_every_expiry(built, mode):
+    """The stream form's pre-pass looks only at the buffers inside shard.expiry_windows: every expiry of every legal clock
+    assignment (each buffer's end clock anywhere in its own 55 ms) must follow one of them; and they are a small part of a capture."""
+    from readsb_amd import shard
+    from readsb_amd.binding import flip_schedule
+    rng = np.random.default_rng(11 + mode)
+    startup = 1_700_000_123_456
+    for nb in (1, 5, 1098, 1099, 1100, 1101, 2500, 66000):
+        mask = shard.expiry_windows(nb, startup, mode)
+        s = shard.buffer_sys_ms(np.arange(nb), startup)
+        for trial in range(40 if nb < 60000 else 6):
+            kind = trial % 4
+            off = rng.integers(0, 55, size=nb) if kind == 0 else np.full(nb, 54) if kind == 1 else np.zeros(nb, dtype=np.int64) if kind == 2 else rng.choice([0, 54], size=nb)
+            f = flip_schedule(s + off, startup, mode).astype(np.int64)
+            assert mask[f].all(), (nb, kind, f[~mask[f]][:5])
+    assert shard.expiry_windows(66000, startup, mode).mean() < 0.07          # the one-hour capture: ~6 % of its buffers
+    # the schedule from window estimates alone = the schedule from all clocks
+    nb = 30000
+    s = shard.buffer_sys_ms(np.arange(nb), startup)
+    clocks = s + rng.integers(0, 55, size=nb)
+    mask = shard.expiry_windows(nb, startup, mode)
+    idx = np.flatnonzero(mask)
+    halves = [(idx[: idx.size // 3], clocks[idx[: idx.size // 3]]), (idx[idx.size // 3:], clocks[idx[idx.size // 3:]])]
+    n = nb * 131072 - 5
+    got = shard.schedule_from_window_estimates(halves, n, startup, mode)
+    want = shard.schedule_from_clocks([clocks], n, startup, mode)
+    assert list(got) == list(want) and len(got) >= 25
+
+
 def test_round_conclusions_and_combination(built):
     from readsb_amd import shard
     n = 131072 * 6

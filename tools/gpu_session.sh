@@ -1,22 +1,20 @@
 #!/bin/bash
 cd /root/repo
-O=gpurun_out/r04m
+O=gpurun_out/r04n
 mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_deferred.py tests/test_gpu_device_walk.py tests/test_gpu_shard.py tests/test_gpu_golden.py -m gpu -x -q 2>&1 | tail -3
-export MGPU_DBG_BENCH_REPS=4
-for i in 0 1; do timeout 300 python tools/profile_extra.py $i 2>/dev/null | tail -1 | python -c "
-import json,sys
-o=json.loads(sys.stdin.readline())
-for k,v in o.items(): print(k[:20], v['msamples_s_both_repetitions'], v['live_records_per_1000_samples'], [ (h['d2h'],h['resolve_host'],h['build_host']) for h in v['host_stage_ms_both_repetitions']][:2])"; done
-unset MGPU_DBG_BENCH_REPS
-timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
+timeout 900 python -m pytest tests/test_gpu_shard.py -m gpu -x -q -k "stream" 2>&1 | tail -8
+timeout 600 python bench.py --config 5 --emulate-ranks 8 --samples 8640000000 --steps 3 --warmup 1 --no-cpu-baseline > $O/config5_stream8.json 2> $O/config5_stream8.err
+tail -c 1500 $O/config5_stream8.err
 python - <<'PY'
-import json, sys
+import json
 try:
-    o = json.loads(open("gpurun_out/r04m/bench.json").read().strip().splitlines()[-1])
-    print("headline", round(o["value"]), o["ms_per_step"], o["stage_ms"])
-    for k, v in o.get("configs", {}).items():
-        print("   ", k[:22], v.get("msamples_s_both_repetitions"), v.get("host_stage_ms_both_repetitions"), v.get("us_per_launch"))
-except Exception as e:
-    print("no line:", e)
+    o = json.loads(open("gpurun_out/r04n/config5_stream8.json").read().strip().splitlines()[-1])
+    print("unsharded", o["value"], o["ms_per_step"], "msgs", o["messages_per_step"])
+    e = o["emulated_ranks"]
+    for k in ("form", "rank_critical_path_ms", "protocol", "rank0_serial_ms", "rank0_serial_share_of_unsharded", "projected_ms_without_communication", "projected_speedup_without_communication"):
+        print(k, e[k])
+    for r, p in enumerate(e["per_rank_ms"]):
+        print(r, p)
+except Exception as ex:
+    print("no line:", ex)
 PY

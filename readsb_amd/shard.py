@@ -473,7 +473,7 @@ def demodulate_sharded_walk(d, iq, device=None, resident=None, nsamples=None, hi
     return _gather_and_combine(me, sched, n, fc, device, phases, stats, t0)
 
 
-def _gather_and_combine(me, sched, n, fc, device, phases, stats, t0):
+def _gather_and_combine(me, sched, n, fc, device, phases, stats, t0, concat=True):
     """Every range's messages, counters, noise terms and sum blocks to rank 0 (an all-gather of the small parts, a gather of the
     messages), combined there.  -> (messages, counters) on rank 0, None elsewhere."""
     import time
@@ -510,14 +510,15 @@ def _gather_and_combine(me, sched, n, fc, device, phases, stats, t0):
         return None
     parts = []
     for r in range(world):
-        raw = gathered[r][:counts[r] * rec + nblk[r] * brec].cpu().numpy()
+        raw = gathered[r][:counts[r] * rec + nblk[r] * brec]
+        raw = raw.numpy() if raw.device.type == "cpu" else raw.cpu().numpy()      # (gloo: a view; RCCL: the D2H copy a host-side consumer needs anyway)
         msgs = raw[:counts[r] * rec].view(MSG_DTYPE)
         if len(metas[r]) > 8:
             c, terms = pickle.loads(metas[r][8:])
             parts.append((msgs, c, np.frombuffer(terms, dtype=np.float64), raw[counts[r] * rec:].view(SUM_BLOCK_DTYPE)))
         else:
             parts.append((msgs, None, np.zeros(0)))
-    res = combine_ranges(parts, n, len(sched) + (1 if fc == 1 else 0), stats)
+    res = combine_ranges(parts, n, len(sched) + (1 if fc == 1 else 0), stats, concat=concat)
     if phases is not None:
         phases["combine"] = phases.get("combine", 0.0) + (time.perf_counter() - t2) * 1e3
     return res
@@ -719,11 +720,13 @@ def demodulate_sharded_stream_local(d, iq, nshards, stats=None):
     return combine_ranges(parts, n, len(sched) + (1 if fc == 1 else 0), stats)
 
 
-def demodulate_sharded_stream(d, iq=None, device=None, resident=None, nsamples=None, histories=None, gather=None, phases=None, out=None, stats=None):
+def demodulate_sharded_stream(d, iq=None, device=None, resident=None, nsamples=None, histories=None, gather=None, phases=None, out=None, stats=None,
+                              concat=True):
     """torch.distributed version of the stream form: this process is ONE rank.  iq = the capture as host bytes, or resident = (first
     sample held, device address) with histories = {sample: the 326 IQ samples before it} for the samples this rank starts passes at
     (its warm-up's first, its range's first) and gather(ranges) -> (keep-alive, device address of those sample ranges made contiguous).
-    Collectives: an all-gather of the pre-pass's clocks (a few KB), one of clocks + states per round, the gather of the results."""
+    Collectives: an all-gather of the pre-pass's clocks (a few KB), one of clocks + states per round, the gather of the results.
+    concat=False: rank 0 gets the messages as the list of per-range arrays they arrived as (no 0.5 GB copy for the one-hour capture)."""
     import time
     import torch
     import torch.distributed as dist
@@ -737,4 +740,4 @@ def demodulate_sharded_stream(d, iq=None, device=None, resident=None, nsamples=N
     startup, fc = int(d.cfg.startup_time_ms), int(d.cfg.filter_clock)
     t0 = time.perf_counter()
     sched = run_stream_protocol([me], lambda payloads: _all_gather_bytes(payloads[0], device), n, startup, fc, stats=stats)
-    return _gather_and_combine(me, sched, n, fc, device, phases, stats, t0)
+    return _gather_and_combine(me, sched, n, fc, device, phases, stats, t0, concat)

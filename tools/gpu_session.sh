@@ -1,20 +1,17 @@
 #!/bin/bash
 cd /root/repo
-O=gpurun_out/r04n
+O=gpurun_out/r04o
 mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_shard.py -m gpu -x -q -k "stream" 2>&1 | tail -8
-timeout 600 python bench.py --config 5 --emulate-ranks 8 --samples 8640000000 --steps 3 --warmup 1 --no-cpu-baseline > $O/config5_stream8.json 2> $O/config5_stream8.err
-tail -c 1500 $O/config5_stream8.err
-python - <<'PY'
-import json
+timeout 900 python -m pytest tests/test_gpu_shard.py -m gpu -x -q 2>&1 | tail -4
+for form in stream packets; do
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --config 5 --gpus 2 --dryrun-gloo --samples 1440000000 --steps 2 --warmup 1 --config5-form $form > $O/config5_2rank_$form.json 2> $O/config5_2rank_$form.err
+tail -c 600 $O/config5_2rank_$form.err | grep -v "socket.cpp"
+python - $form <<'PY'
+import json, sys
 try:
-    o = json.loads(open("gpurun_out/r04n/config5_stream8.json").read().strip().splitlines()[-1])
-    print("unsharded", o["value"], o["ms_per_step"], "msgs", o["messages_per_step"])
-    e = o["emulated_ranks"]
-    for k in ("form", "rank_critical_path_ms", "protocol", "rank0_serial_ms", "rank0_serial_share_of_unsharded", "projected_ms_without_communication", "projected_speedup_without_communication"):
-        print(k, e[k])
-    for r, p in enumerate(e["per_rank_ms"]):
-        print(r, p)
+    o = json.loads(open(f"gpurun_out/r04o/config5_2rank_{sys.argv[1]}.json").read().strip().splitlines()[-1])
+    print(sys.argv[1], o["value"], o["ms_per_step"], o["n_gpus"], o.get("rank0_phase_ms_per_step"), o.get("protocol"), (o.get("cpu_baseline") or {}).get("bit_identical_to_gpu"), (o.get("cpu_baseline") or {}).get("counters_compared"))
 except Exception as ex:
     print("no line:", ex)
 PY
+done

@@ -796,9 +796,9 @@ static int alloc_all(mgpu_ctx *c) {
 
     if (cfg.format != MGPU_FMT_UC8)
         for (auto &r : c->fsum_ring) {
-            HIPCHK(c, hipMalloc(&r.d, 2 * c->cap_buffers * sizeof(double)));
             HIPCHK(c, hipHostMalloc(&r.h, 2 * c->cap_buffers * sizeof(double)));
 #if MGPU_EXPERIMENTS
+            HIPCHK(c, hipMalloc(&r.d, 2 * c->cap_buffers * sizeof(double)));
             HIPCHK(c, hipMalloc(&r.scratch, fsum_wide_scratch_bytes(c->chunk_samples, cfg.buf_samples)));
 #endif
             HIPCHK(c, hipEventCreateWithFlags(&r.ev, hipEventDisableTiming));
@@ -1063,14 +1063,18 @@ static int enqueue_fsum(mgpu_ctx *c, Slot &sl, const uint8_t *iq, hipEvent_t aft
     mgpu_ctx::FsumRing &r = c->fsum_ring[sl.fsum_idx];
     const size_t nb = c->cap_buffers;
     HIPCHK(c, hipStreamWaitEvent(c->stream_f, after, 0));
-    HIPCHK(c, hipMemsetAsync(r.d, 0, 2 * nb * sizeof(double), c->stream_f));
-    // (Mode A/C waits for the sums on the main stream: their chain runs at s_setprio 3; otherwise nobody is waiting and it yields)
+    // The chain's waves store their results straight into the ring entry's page-locked host memory (one double per buffer).  A
+    // hipMemcpyAsync behind the kernel goes to the copy engine as a packet that waits for the kernel's signal — and every later copy
+    // of the process on that engine, the fetcher's record copies first of all, waits behind it: the fetch stage read 2-3.6 ms per
+    // 537 M samples for 4.6 MB of records per chunk (r04g-r04p), whatever the chain ran beside.
 #if MGPU_EXPERIMENTS
-    if (c->fsum_wide) launch_fsum_sc16_wide(cfg.format, iq, sl.d_mag, sl.n, cfg.buf_samples, r.d, r.d + nb, cfg.mode_ac ? 1 : 0, r.scratch, c->stream_f);
-    else
+    if (c->fsum_wide) {
+        HIPCHK(c, hipMemsetAsync(r.d, 0, 2 * nb * sizeof(double), c->stream_f));
+        launch_fsum_sc16_wide(cfg.format, iq, sl.d_mag, sl.n, cfg.buf_samples, r.d, r.d + nb, cfg.mode_ac ? 1 : 0, r.scratch, c->stream_f);
+        HIPCHK(c, hipMemcpyAsync(r.h, r.d, 2 * nb * sizeof(double), hipMemcpyDeviceToHost, c->stream_f));
+    } else
 #endif
-    launch_fsum_sc16(cfg.format, iq, sl.n, cfg.buf_samples, r.d, r.d + nb, cfg.mode_ac ? 1 : 0, c->stream_f);
-    HIPCHK(c, hipMemcpyAsync(r.h, r.d, 2 * nb * sizeof(double), hipMemcpyDeviceToHost, c->stream_f));
+    launch_fsum_sc16(cfg.format, iq, sl.n, cfg.buf_samples, r.h, r.h + nb, cfg.mode_ac ? 1 : 0, c->stream_f, 1);
     HIPCHK(c, hipEventRecord(r.ev, c->stream_f));
     sl.fsum_pending = true;
     return MGPU_OK;
@@ -1117,7 +1121,7 @@ static int enqueue_convert(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
     if (cfg.mode_ac && !sl.have_mag && sl.fsum_pending) HIPCHK(c, hipStreamWaitEvent(s, c->fsum_ring[sl.fsum_idx].ev, 0));
     if (cfg.mode_ac && !sl.have_mag)       // Mode A/C candidates (needs the converter's per-buffer sums); a few us, streaming
         launch_modeac(sl.d_mag, n, cfg.buf_samples, cfg.format, sl.d_sum_level, sl.d_sum_power,
-                      sl.fsum_pending ? c->fsum_ring[sl.fsum_idx].d : sl.d_fsum_level, sl.fsum_pending ? c->fsum_ring[sl.fsum_idx].d + c->cap_buffers : sl.d_fsum_power,
+                      sl.fsum_pending ? c->fsum_ring[sl.fsum_idx].h : sl.d_fsum_level, sl.fsum_pending ? c->fsum_ring[sl.fsum_idx].h + c->cap_buffers : sl.d_fsum_power,
                       sl.d_ac_noise, sl.h_ac, (uint32_t) c->cap_ac, sl.d_scratch + CNT_NUM + 1 + 4 * c->cap_buffers, sl.d_counters, s);
     if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[1], s));
     return MGPU_OK;
@@ -1153,9 +1157,10 @@ static int enqueue_sweep(mgpu_ctx *c, Slot &sl) {
         if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[4], s));
         HIPCHK(c, hipEventRecord(sl.ev_swept, s));
         sl.swept_seq.store(sl.seq, std::memory_order_release);
-        // Without Mode A/C nobody needs the float sums before the builder: their chain (one wave per buffer at s_setprio 3, ~0.35 ms,
-        // which doubled k_sweep's time while it ran beside it: 59 against 33 us) starts when the chunk's k_sweep is through and
-        // runs beside k_slice — with chunks of 1024 buffers it is over before the chunk's post-sweep kernels are.
+        // Without Mode A/C nobody needs the float sums before the builder's statistics: their chain (one wave per buffer for ~0.35 ms at
+        // s_setprio 3; beside k_sweep it doubled that kernel's time: 59 against 33 us per 512 buffers, round 3) starts when the chunk's
+        // k_sweep is through and runs beside k_slice.  (Behind k_slice instead — beside the post-sweep kernels and the next chunk's
+        // converter and k_sweep: 173-183 Gsamples/s against 191-203, gpurun r04q.)
         if (cfg.format != MGPU_FMT_UC8 && !cfg.mode_ac && !sl.have_mag && sl.fsum_iq) {
             const int rc = enqueue_fsum(c, sl, sl.fsum_iq, sl.ev_swept);
             if (rc != MGPU_OK) return rc;

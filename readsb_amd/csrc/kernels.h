@@ -134,7 +134,7 @@ void launch_convert(int format, const ConvertParams &p, hipStream_t s);
 void launch_spin(unsigned us, unsigned blocks, unsigned long long *sink, hipStream_t s);   // a kernel that lasts `us` microseconds (event calibration)
 // SC16 formats: the per-buffer sequential float sums of mag / magsq (convert.c:225-249), exact; state in and out as doubles holding floats
 void launch_fsum_sc16(int format, const uint8_t *iq, uint64_t n, uint32_t buf_samples, double *fsum_level, double *fsum_power, int want_level,
-                      hipStream_t s);
+                      hipStream_t s, int fresh = 0);   // fresh: the sums start at zero (else they continue what fsum_* holds)
 #if MGPU_EXPERIMENTS
 // the same sums for the pipeline's chunks, wide: approximate block sums from the magnitudes -> per-block summaries against predicted
 // binades -> a short apply chain per buffer (kernels/convert.inc); scratch = fsum_wide_scratch_bytes()

@@ -1,17 +1,17 @@
 #!/bin/bash
 cd /root/repo
-O=gpurun_out/r04o
+O=gpurun_out/r04q
 mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_shard.py -m gpu -x -q 2>&1 | tail -4
-for form in stream packets; do
-timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --config 5 --gpus 2 --dryrun-gloo --samples 1440000000 --steps 2 --warmup 1 --config5-form $form > $O/config5_2rank_$form.json 2> $O/config5_2rank_$form.err
-tail -c 600 $O/config5_2rank_$form.err | grep -v "socket.cpp"
-python - $form <<'PY'
+for w in 0 1 0 1; do
+  if [ $w = 1 ]; then export MGPU_X_FSUM_AFTER_SLICE=1; else unset MGPU_X_FSUM_AFTER_SLICE; fi
+  timeout 300 python bench.py --steps 5 --warmup 2 > $O/bench_$w.json 2> $O/bench_$w.err
+  python - $w <<'PY'
 import json, sys
 try:
-    o = json.loads(open(f"gpurun_out/r04o/config5_2rank_{sys.argv[1]}.json").read().strip().splitlines()[-1])
-    print(sys.argv[1], o["value"], o["ms_per_step"], o["n_gpus"], o.get("rank0_phase_ms_per_step"), o.get("protocol"), (o.get("cpu_baseline") or {}).get("bit_identical_to_gpu"), (o.get("cpu_baseline") or {}).get("counters_compared"))
-except Exception as ex:
-    print("no line:", ex)
+    o = json.loads(open(f"gpurun_out/r04q/bench_{sys.argv[1]}.json").read().strip().splitlines()[-1])
+    for k, v in list(o.get("configs", {}).items())[:1]:
+        print("after_slice", sys.argv[1], k[:22], v.get("msamples_s_both_repetitions"), v.get("host_stage_ms_both_repetitions"), v.get("us_per_launch"))
+except Exception as e:
+    print("no line:", e)
 PY
 done

@@ -39,6 +39,10 @@ extern "C" {
 #define MGPU_E_CAPACITY     -6   /* more samples than cfg.max_samples in one call */
 #define MGPU_E_EOF          -7   /* stream already ended on a short buffer (sdr_ifile.c:223-237) */
 
+/* Bumped whenever a struct of this header grows or an entry point changes meaning.  4 (round 4): mgpu_config.chunk_buffers;
+ * with MGPU_FILTER_CLOCK_EXTERNAL the filter starts EMPTY since 3 (the host mirrors modesInit's icaoFilterAdd(Modes.show_only)). */
+#define MGPU_ABI_VERSION 4
+
 typedef struct mgpu_ctx mgpu_ctx;
 
 /* Options of the hot path, named after the struct _Modes fields they mirror. */
@@ -158,7 +162,11 @@ struct mgpu_timing {
 /* ---- lifecycle -------------------------------------------------------------------- */
 
 /* Replaces modesInit()'s hot-path part: modesChecksumInit(nfix_crc), icaoFilterInit(),
- * icaoFilterAdd(show_only), init_converter() (readsb.c:306-310, sdr_ifile.c:156). */
+ * icaoFilterAdd(show_only), init_converter() (readsb.c:306-310, sdr_ifile.c:156).
+ * The filter starts holding show_only's default (0xff123456, readsb.h:296) — EXCEPT with cfg.filter_clock ==
+ * MGPU_FILTER_CLOCK_EXTERNAL, where it starts EMPTY and the host mirrors its own icaoFilterAdd(Modes.show_only) with mgpu_filter_add
+ * like every other add: with a user --show-only a default entry added here as well would leave `occupied` one ahead of the host's
+ * and the table resizes (icao_filter.c:65-93) on different adds (readsb_tree/demod_gpu_wrap.c replays the host's early adds). */
 int  mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out);
 void mgpu_destroy(mgpu_ctx *ctx);
 /* Back to the state right after mgpu_create (sample clock 0, filter = {show_only's default}; empty with the EXTERNAL clock). */

@@ -95,7 +95,11 @@ void demodulate2400_gpu(struct gpu_demod *g, struct mag_buf *mag) {
     /* with --modeac the decode thread runs demodulate2400AC(buf) right after demodulate2400(buf) (readsb.c:871-874) */
     /* `dropped` of the library entry = "Modes.stats_15min.samples_dropped != 0" (demod_2400.c:335-338), not this buffer's
      * own count: the host adds mag->dropped to its statistics (readsb.c:884-887) and the 15-minute window holds it for 15
-     * minutes.  Stand-alone there is no struct stats: the window is kept here, on the buffers' own clock. */
+     * minutes.  Stand-alone there is no struct stats: the window is kept here, on the buffers' own clock.
+     * AN APPROXIMATION of the reference's timing, not its restatement: readsb's stats_15min is rebuilt when the periodic statistics
+     * rotation folds the current one-minute bucket in (stats.c), so there the raised threshold starts at the first rotation AFTER the
+     * drop and ends on a bucket boundary 15 buckets later; here it starts with the dropping buffer itself and ends exactly 15 minutes
+     * on.  The link-time drop-in (readsb_tree/demod_gpu_wrap.c) reads the host's own Modes.stats_15min and is exact. */
     if (mag->dropped) { g->dropped_seen = 1; g->dropped_until_ms = mag->sysTimestamp + 15 * 60 * 1000; }
     const uint32_t dropped15 = g->dropped_seen && mag->sysTimestamp < g->dropped_until_ms;
     int rc = g->mode_ac ? mgpu_demod_mag_buf_ac(g->ctx, mag->data, mag->length, mag->sampleTimestamp, mag->sysTimestamp,

@@ -385,6 +385,18 @@ int mgpu_shard_stream_end(mgpu_ctx *ctx, int64_t *end_clocks, uint64_t cap, uint
  * mgpu_config): returns the number of expiries, flip_after[i < cap] = index of the buffer the i-th one follows. */
 uint64_t mgpu_flip_schedule(const int64_t *end_clock, uint64_t nbuf, int64_t startup_ms, int filter_clock,
                             uint64_t *flip_after, uint64_t cap);
+/* The buffers an expiry of the filter CAN follow, whatever the data (mask[b] = 1; returns how many): what the stream form's pre-pass
+ * looks at.  T_k + 60 000 <= T_(k+1) < T_k + 60 111 ms for the clocks T_k the expiries are due at, so the windows widen by 111 ms per
+ * expiry: ~6 % of a one-hour capture's buffers. */
+uint64_t mgpu_expiry_windows(uint64_t nbuf_total, uint32_t buf_samples, int64_t startup_ms, int filter_clock, uint8_t *mask);
+/* What every rank concludes from a round's all-gather (step 4 above; the same on every rank): the schedule the true clocks give
+ * (next_sched[cap], *n_next entries), *done = it is the imposed one AND every range's state at its first sample equals the state the
+ * range before it ended with; import_from[r] = the rank whose end state rank r has to start its next pass from, or -1.  clocks[r] /
+ * nclocks[r]: rank r's end clocks (an empty range: 0 of them; its states are ignored). */
+int mgpu_shard_round(const int64_t *sched, uint64_t nsched, uint32_t world, const int64_t *const *clocks, const uint64_t *nclocks,
+                     const void *const *state_first, const uint64_t *state_first_bytes, const void *const *state_end, const uint64_t *state_end_bytes,
+                     uint64_t nsamples, uint32_t buf_samples, int64_t startup_ms, int filter_clock,
+                     int64_t *next_sched, uint64_t cap, uint64_t *n_next, int32_t *import_from, int32_t *done);
 double mgpu_seqsum(double start, const double *terms, uint64_t n);                               /* ((start + t0) + t1) + ... */
 double mgpu_seqsum_signal_power(double start, const struct mgpu_msg *msgs, uint64_t n);          /* ... of sig_sumsq / 65535^2 */
 /* The same sequential sum of the messages' signal powers, prepared by ranges and applied in O(blocks) (readsb_amd/csrc/seqsum.cpp):

@@ -125,6 +125,37 @@ def flip_schedule(end_clocks, startup_ms, filter_clock=0):
     return out[:n].copy()
 
 
+def expiry_windows(nbuf_total, startup_ms, filter_clock=0, buf_samples=131072):
+    """Boolean mask of the buffers an expiry of the ICAO filter can follow (mgpu_expiry_windows)."""
+    mask = np.zeros(int(nbuf_total), dtype=np.uint8)
+    if nbuf_total:
+        load_library().mgpu_expiry_windows(int(nbuf_total), int(buf_samples), int(startup_ms), int(filter_clock), C.c_void_p(mask.ctypes.data))
+    return mask.astype(bool)
+
+
+def shard_round(sched_ts, gathered, nsamples, startup_ms, filter_clock=0, buf_samples=131072):
+    """mgpu_shard_round: gathered[r] = (clocks, state_first, state_end) -> (done, next schedule, {rank: rank to import the end state of})."""
+    lib = load_library()
+    world = len(gathered)
+    sched = np.ascontiguousarray(sched_ts, dtype=np.int64)
+    clocks = [np.ascontiguousarray(g[0], dtype=np.int64) for g in gathered]
+    sf = [np.frombuffer(bytes(g[1]) or b"\0", dtype=np.uint8) for g in gathered]
+    se = [np.frombuffer(bytes(g[2]) or b"\0", dtype=np.uint8) for g in gathered]
+    ptrs = lambda arrs: (C.c_void_p * world)(*[a.ctypes.data for a in arrs])
+    lens = lambda xs: np.array(xs, dtype=np.uint64)
+    ncl, nsf, nse = lens([c.size for c in clocks]), lens([len(g[1]) for g in gathered]), lens([len(g[2]) for g in gathered])
+    cap = sum(c.size for c in clocks) // 1000 + 64
+    nxt = np.empty(cap, dtype=np.int64)
+    n_next, done = C.c_uint64(0), C.c_int32(0)
+    imp = np.empty(world, dtype=np.int32)
+    rc = lib.mgpu_shard_round(sched.ctypes.data if sched.size else None, sched.size, world, ptrs(clocks), C.c_void_p(ncl.ctypes.data), ptrs(sf),
+                              C.c_void_p(nsf.ctypes.data), ptrs(se), C.c_void_p(nse.ctypes.data), int(nsamples), int(buf_samples), int(startup_ms),
+                              int(filter_clock), C.c_void_p(nxt.ctypes.data), cap, C.byref(n_next), C.c_void_p(imp.ctypes.data), C.byref(done))
+    if rc != 0:
+        raise MgpuError("mgpu_shard_round failed")
+    return bool(done.value), nxt[: n_next.value].copy(), {r: int(imp[r]) for r in range(world) if imp[r] >= 0}
+
+
 def seqsum(start, terms):
     """((start + t0) + t1) + ... in doubles, in order (mgpu_seqsum)."""
     terms = np.ascontiguousarray(terms, dtype=np.float64)
@@ -233,6 +264,9 @@ def load_library():
     lib.mgpu_shard_noise_terms.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
     lib.mgpu_flip_schedule.argtypes = [vp, u64, i64, i32, vp, u64]
     lib.mgpu_flip_schedule.restype = u64
+    lib.mgpu_expiry_windows.argtypes = [u64, u32, i64, i32, vp]
+    lib.mgpu_expiry_windows.restype = u64
+    lib.mgpu_shard_round.argtypes = [vp, u64, u32, vp, vp, vp, vp, vp, vp, u64, u32, i64, i32, vp, u64, C.POINTER(u64), vp, C.POINTER(i32)]
     lib.mgpu_seqsum.argtypes = [C.c_double, vp, u64]
     lib.mgpu_seqsum.restype = C.c_double
     lib.mgpu_seqsum_signal_power.argtypes = [C.c_double, vp, u64]

@@ -2726,6 +2726,46 @@ uint64_t mgpu_flip_schedule(const int64_t *end_clock, uint64_t nbuf, int64_t sta
     return f.size();
 }
 
+uint64_t mgpu_expiry_windows(uint64_t nbuf_total, uint32_t buf_samples, int64_t startup_ms, int filter_clock, uint8_t *mask) {
+    if (!mask && nbuf_total) return 0;
+    return expiry_windows(nbuf_total, buf_samples ? buf_samples : 131072u, startup_ms, filter_clock, mask);
+}
+
+// What every rank concludes from a round's all-gather — the same on every rank, so no further exchange is needed.
+int mgpu_shard_round(const int64_t *sched, uint64_t nsched, uint32_t world, const int64_t *const *clocks, const uint64_t *nclocks,
+                     const void *const *state_first, const uint64_t *state_first_bytes, const void *const *state_end, const uint64_t *state_end_bytes,
+                     uint64_t nsamples, uint32_t buf_samples, int64_t startup_ms, int filter_clock,
+                     int64_t *next_sched, uint64_t cap, uint64_t *n_next, int32_t *import_from, int32_t *done) {
+    if (!world || !clocks || !nclocks || !n_next || !import_from || !done || (nsched && !sched)) return MGPU_E_INVAL;
+    if (!buf_samples) buf_samples = 131072;
+    std::vector<int64_t> all;
+    for (uint32_t r = 0; r < world; ++r) all.insert(all.end(), clocks[r], clocks[r] + nclocks[r]);
+    if (nsamples % buf_samples == 0) all.push_back((int64_t) ((nsamples * 5) / 12000) + startup_ms);   // the EOF buffer (sdr_ifile.c:223-237): mgpu_finish's clock
+    std::vector<uint64_t> f;
+    flip_schedule(all.data(), all.size(), startup_ms, filter_clock, f);
+    *n_next = f.size();
+    bool same = f.size() == nsched;
+    for (size_t i = 0; i < f.size(); ++i) {
+        const int64_t ts = (int64_t) (f[i] * buf_samples) * 5;
+        if (i < cap && next_sched) next_sched[i] = ts;
+        if (same && sched[i] != ts) same = false;
+    }
+    if (f.size() > cap) return MGPU_E_CAPACITY;
+    bool seams = true;
+    int32_t prev = -1;                                          // the last rank with a range of its own (an empty range passes its neighbour's state through)
+    for (uint32_t r = 0; r < world; ++r) {
+        import_from[r] = -1;
+        if (nclocks[r] == 0) continue;
+        if (prev >= 0 && (state_first_bytes[r] != state_end_bytes[prev] || std::memcmp(state_first[r], state_end[prev], (size_t) state_end_bytes[prev]) != 0)) {
+            import_from[r] = prev;
+            seams = false;
+        }
+        prev = (int32_t) r;
+    }
+    *done = same && seams;
+    return MGPU_OK;
+}
+
 static int shard_packets_span(mgpu_ctx *c, const void *&packets, uint64_t &bytes) {
     if (!packets) { packets = c->shard_packets.data(); bytes = c->shard_packets.size(); }
     if ((uintptr_t) packets & 7) { c->err = "shard packets must be 8-byte aligned"; return MGPU_E_INVAL; }

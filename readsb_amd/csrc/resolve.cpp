@@ -646,6 +646,29 @@ void flip_schedule(const int64_t *end_clock, uint64_t nbuf, int64_t startup_ms, 
         if (end_clock[b] >= next_flip) { flip_after.push_back(b); next_flip = end_clock[b] + kFilterTtlMs; }
 }
 
+uint64_t expiry_windows(uint64_t nbuf_total, uint32_t buf_samples, int64_t startup_ms, int clock_mode, uint8_t *mask) {
+    if (nbuf_total == 0) return 0;
+    std::memset(mask, 0, (size_t) nbuf_total);
+    auto sys_ms = [&](uint64_t b) { return (int64_t) ((b * (uint64_t) buf_samples * 5) / 12000) + startup_ms; };
+    // the first buffer whose clock start is >= t (the starts ascend)
+    auto lower = [&](int64_t t) { uint64_t lo = 0, hi = nbuf_total; while (lo < hi) { const uint64_t mid = (lo + hi) / 2; if (sys_ms(mid) < t) lo = mid + 1; else hi = mid; } return lo; };
+    const int64_t span = 56;
+    int64_t lo, hi;
+    if (clock_mode == 1) lo = hi = startup_ms + kFilterTtlMs;          // one expiry before buffer 0, the next due 60 s after start-up
+    else { mask[0] = 1; lo = sys_ms(0) + kFilterTtlMs; hi = sys_ms(0) + span + kFilterTtlMs; }   // next_flip = 0: the first expiry follows buffer 0
+    const int64_t end = sys_ms(nbuf_total - 1) + span;
+    while (lo <= end) {
+        uint64_t a = lower(lo - span), b = lower(hi + 1);              // buffers whose [start, start + 55] reaches lo and starts by hi
+        a = a > 0 ? a - 1 : 0;                                          // (a buffer to spare on either side)
+        b = b + 1 < nbuf_total ? b + 1 : nbuf_total;
+        for (uint64_t i = a; i < b; ++i) mask[i] = 1;
+        lo += kFilterTtlMs; hi += kFilterTtlMs + 111;
+    }
+    uint64_t n = 0;
+    for (uint64_t i = 0; i < nbuf_total; ++i) n += mask[i];
+    return n;
+}
+
 void estimate_end_clocks(const PhaseRec *recs, uint64_t nrecs, const std::vector<BufferClock> &buffers, std::vector<int64_t> &out) {
     uint64_t i = 0;
     for (const BufferClock &b : buffers) {

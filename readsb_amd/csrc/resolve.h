@@ -280,6 +280,12 @@ void estimate_end_clocks(const PhaseRec *recs, uint64_t nrecs, const std::vector
 // readsb.c:1227-1231 over a list of end clocks: indices of the buffers the filter expires after
 void flip_schedule(const int64_t *end_clock, uint64_t nbuf, int64_t startup_ms, int clock_mode, std::vector<uint64_t> &flip_after);
 
+// The buffers an expiry CAN follow (mask[b] = 1), whatever the data: the k-th expiry follows the first buffer whose end clock reaches T_k,
+// T_k + 60 000 <= T_(k+1) < T_k + 60 111 ms (the buffer that reaches T_k starts within 55.6 ms of it, its clock ends within its own 55 ms),
+// so T_k lies in a window that widens by 111 ms per expiry and only buffers whose 55 ms touch a window matter to the schedule.
+// Buffer b's clock starts at (b * buf_samples * 5) / 12000 + startup_ms (sdr_ifile.c:216).  Returns how many are set.
+uint64_t expiry_windows(uint64_t nbuf_total, uint32_t buf_samples, int64_t startup_ms, int clock_mode, uint8_t *mask);
+
 // index of the first of nrecs position-sorted records with position >= pos
 uint64_t segment_first_record(const PhaseRec *recs, uint64_t nrecs, uint32_t pos);
 

@@ -318,19 +318,12 @@ def schedule_from_clocks(per_rank_clocks, nsamples, startup_ms, filter_clock=0):
 
 
 def protocol_round(sched_ts, gathered, nsamples, startup_ms, filter_clock=0):
-    """What every rank concludes from a round's all-gather (the same on every rank: no further exchange needed).
-    gathered[r] = (clocks, state_first, state_end) of rank r.  -> (done, next schedule, {rank: state to import})."""
-    nxt = schedule_from_clocks([g[0] for g in gathered], nsamples, startup_ms, filter_clock)
-    imports = {}
-    prev_end = None
-    for r, (clocks, s0, s1) in enumerate(gathered):
-        if len(clocks) == 0:                        # an empty range (more ranks than buffers): the seam passes through
-            continue
-        if prev_end is not None and s0 != prev_end:
-            imports[r] = prev_end
-        prev_end = s1
-    done = not imports and nxt.size == sched_ts.size and bool((nxt == sched_ts).all())
-    return done, nxt, imports
+    """What every rank concludes from a round's all-gather (the same on every rank: no further exchange needed) — the library's
+    mgpu_shard_round, which a C host calls too.  gathered[r] = (clocks, state_first, state_end) of rank r.
+    -> (done, next schedule, {rank: state to import})."""
+    from .binding import shard_round
+    done, nxt, imp = shard_round(sched_ts, gathered, nsamples, startup_ms, filter_clock)
+    return done, nxt, {r: gathered[src][2] for r, src in imp.items()}
 
 
 _INT_FIELDS = ["demod_preambles", "demod_rejected_bad", "demod_rejected_unknown_icao", "demod_accepted", "demod_preamblePhase",
@@ -537,27 +530,13 @@ def buffer_sys_ms(b, startup_ms):
 
 
 def expiry_windows(nbuf_total, startup_ms, filter_clock=0):
-    """The buffers an expiry of the ICAO filter CAN follow, as a boolean mask.  The k-th expiry follows the first buffer whose end
-    clock reaches T_k, and T_(k+1) = (that buffer's end clock) + 60 s (readsb.c:1227-1231) with the end clock anywhere in the
-    buffer's own 55 ms: T_k + 60 000 <= T_(k+1) < T_k + 60 111 (the buffer that reaches T_k starts within 55.6 ms of it).  So T_k lies in a window that widens by 110 ms per expiry, and only
-    buffers whose 55 ms touch a window matter to the schedule: ~2 k of them for the k-th expiry."""
-    mask = np.zeros(int(nbuf_total), dtype=bool)
-    if nbuf_total == 0:
-        return mask
-    s = buffer_sys_ms(np.arange(nbuf_total), startup_ms)
-    span = 56
-    if filter_clock == 1:
-        lo, hi = startup_ms + 60000, startup_ms + 60000           # one expiry before buffer 0, the next due 60 s after start-up
-    else:
-        mask[0] = True                                            # next_flip = 0: the first expiry follows buffer 0
-        lo, hi = int(s[0]) + 60000, int(s[0]) + span + 60000
-    end = int(s[-1]) + span
-    while lo <= end:
-        a = int(np.searchsorted(s, lo - span, side="left"))       # buffers whose [s, s + 55] reaches lo ...
-        b = int(np.searchsorted(s, hi, side="right"))             # ... and starts by hi
-        mask[max(0, a - 1):min(nbuf_total, b + 1)] = True         # (a buffer to spare on either side)
-        lo, hi = lo + 60000, hi + 60111
-    return mask
+    """The buffers an expiry of the ICAO filter CAN follow, as a boolean mask (mgpu_expiry_windows).  The k-th expiry follows the
+    first buffer whose end clock reaches T_k, and T_(k+1) = (that buffer's end clock) + 60 s (readsb.c:1227-1231) with the end clock
+    anywhere in the buffer's own 55 ms: T_k + 60 000 <= T_(k+1) < T_k + 60 111 (the buffer that reaches T_k starts within 55.6 ms of
+    it).  So T_k lies in a window that widens by 111 ms per expiry, and only buffers whose 55 ms touch a window matter to the
+    schedule: ~2 k of them for the k-th expiry."""
+    from .binding import expiry_windows as _w
+    return _w(nbuf_total, startup_ms, filter_clock, BUF)
 
 
 class _Source:

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Host code under the sanitizers, no GPU: the file reader / fan-in / stand-alone CLI against the test stand-ins
 # (tests/host_stub) with ASan + UBSan, and the ordered walk (readsb_amd/csrc/resolve.cpp) replayed from a dumped chunk
-# (MGPU_DUMP_DIR=… during any GPU run; default gpurun_out/dump) with TSan and ASan + UBSan.
+# (MGPU_DUMP_DIR=… during any GPU run; default gpurun_out/dump) with TSan and ASan + UBSan; the library's GPU-free self-checks
+# (tools/selftest_check.cpp: parallel walk, the sharded walk's protocol, the block-wise double sum) with both as well.
 #   usage: tools/sanitize_host.sh [dump_dir]
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
@@ -26,4 +27,11 @@ if [ -f "$D/walk_recs.bin" ]; then
 else
   echo "no dumped chunk under $D: walk replay skipped"
 fi
+C=$R/readsb_amd/csrc
+CXXS="-std=c++17 -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -pthread $R/tools/selftest_check.cpp $C/selftest.cpp $C/resolve.cpp $C/seqsum.cpp"
+g++ -O1 $SAN $CXXS -o selftest_asan
+./selftest_asan | tail -3
+g++ -O1 -g -fsanitize=thread $CXXS -o selftest_tsan          # minutes: the walk's spinning workers under TSan
+./selftest_tsan 2> tsan.log | tail -3
+if grep -q "WARNING: ThreadSanitizer" tsan.log; then head -40 tsan.log; exit 1; fi
 echo "sanitizers: clean"

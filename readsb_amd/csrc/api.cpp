@@ -290,6 +290,7 @@ struct mgpu_ctx {
     // SC16 formats: the float sums of the chunks in flight — a ring, not the slots' own buffers, so that nobody has to wait for a chunk's
     // sums before the chunk's slot goes back to the GPU (chunk seq uses entry seq % kFsumRing)
     struct FsumRing { double *d = nullptr, *h = nullptr; void *scratch = nullptr; hipEvent_t ev = nullptr; } fsum_ring[kFsumRing];
+    uint32_t prescreen_variant = 3;                                        // PostSweepParams::variant (the experiments build can ask for the older passes)
     hipStream_t stream_f = nullptr;                                        // SC16 formats: the float sums' chains (k_fsum_sc16), so that what follows a walk does not queue behind them
     hipStream_t s_post = nullptr;                                          // what follows the walk (window statistics, messages on the device): stream2, or stream_wk
     hipStream_t stream_wk = nullptr;                                       // the walk on the device: highest priority, its small kernels must not queue behind the main stream's
@@ -934,7 +935,8 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     if (const char *e = getenv("MGPU_DEBUG_STAGE")) c->dbg_stage = atoi(e);   // (generation 3 only)
     if (const char *e = getenv("MGPU_TIMING_EVERY")) { const int v = atoi(e); if (v >= 1) c->timing_every = v; }
     if (const char *e = getenv("MGPU_DUMP_DIR")) { c->dump_dir = e; c->sig_late = false; }   // (the dump holds per-record signal powers)
-    c->fsum_wide = getenv("MGPU_FSUM_WIDE") != nullptr;   // (measured, r04k: no faster than the chain per buffer, twice its HBM traffic)
+    c->fsum_wide = getenv("MGPU_FSUM_WIDE") != nullptr;
+    if (const char *e = getenv("MGPU_PRESCREEN_VARIANT")) c->prescreen_variant = (uint32_t) atoi(e);   // (measured, r04k: no faster than the chain per buffer, twice its HBM traffic)
 #endif
     c->device_slot = take_device_slot(cfg->device);
     // the first context of a device has two L3 groups to itself (bind_near_device): a walk team of 8 and a builder team of 6;
@@ -1177,7 +1179,7 @@ static int enqueue_post(mgpu_ctx *c, Slot &sl) {
     hipStream_t s = c->stream;
     // class planes -> class bitmap, pre-screen (the surviving records stay in HBM: d_live), counters and per-buffer sums to the host
     PostSweepParams q{};
-    q.pool = sl.d_pool; q.unit_first = sl.d_unit_first; q.nunits = nunits; q.chains_per_unit = c->sweep_version == 3 ? 1u : (uint32_t) (kUnit / 2048); q.adder_bitmap = c->d_adder_bitmap;
+    q.pool = sl.d_pool; q.pool_cap = (uint32_t) c->cap_pool; q.variant = c->prescreen_variant; q.unit_first = sl.d_unit_first; q.nunits = nunits; q.chains_per_unit = c->sweep_version == 3 ? 1u : (uint32_t) (kUnit / 2048); q.adder_bitmap = c->d_adder_bitmap;
     q.unit_live = sl.d_unit_live; q.block_live = sl.d_unit_live + c->cap_units + 2; q.live = sl.d_live; q.live_sig = sl.d_live_sig; q.counters = sl.d_counters;
     // a shard pass hands its records to another rank, which has no samples: their signal powers go with them.  Otherwise they are
     // computed after the walk, for the accepted frames only (k_msg_sig): 40 % of the work, off the main stream

@@ -153,7 +153,9 @@ void launch_sweep_slice(const SweepParams &p, hipStream_t s);      // generation
 // everything between the sweep and the host: class planes -> class bitmap (+ counters, planes zeroed again),
 // pre-screen count / scan / write, scratch block to the host (and zeroed again)
 struct PostSweepParams {
-    PhaseRec *pool;                       // (the count pass may leave live masks in the segment headers)
+    PhaseRec *pool;                       // (the count pass leaves live masks and output offsets in the segment headers)
+    uint32_t pool_cap;                    // records the pool holds
+    uint32_t variant;                     // bit 0: the count pass by chains (count_unit_chains), bit 1: the write pass too; 3 = the product
     const uint32_t *unit_first;           // first segment header of every chain, chains_per_unit consecutive chains per unit
     uint32_t chains_per_unit;             // 4: one chain per k_slice tile of 2048 positions; 1: generation 3
     uint32_t nunits;

@@ -141,8 +141,8 @@ struct Slot {
     uint16_t *d_mag = nullptr;
     PhaseRec *d_pool = nullptr;
     uint32_t *d_dealer = nullptr;         // k_slice's tile dealer: 64 counters, one per 256 bytes (handed back zeroed by k_publish)
-    uint32_t *d_pool_used = nullptr, *d_unit_first = nullptr, *d_unit_count = nullptr, *d_unit_live = nullptr, *d_class_bitmap = nullptr;
-    uint32_t *d_class_uncond = nullptr, *d_class_final = nullptr, *d_cand_count = nullptr, *d_sweep_part = nullptr;
+    uint32_t *d_pool_used = nullptr, *d_unit_first = nullptr, *d_unit_count = nullptr, *d_unit_live = nullptr;
+    uint32_t *d_class_final = nullptr, *d_cand_count = nullptr, *d_sweep_part = nullptr;
     uint16_t *d_cand = nullptr;
     size_t class_bytes = 0;
     // one zero-initialised scratch block per chunk: counters | pool_used | per-buffer sums (1 memset, 1 copy back)
@@ -660,19 +660,15 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
     HIPCHK(c, hipMalloc(&sl.d_pool, c->cap_pool * sizeof(PhaseRec)));
     HIPCHK(c, hipMalloc(&sl.d_unit_first, (c->cap_units * (size_t) (kUnit / 2048) + 1) * sizeof(uint32_t)));   // one record chain per k_slice tile
     HIPCHK(c, hipMalloc(&sl.d_unit_count, (c->cap_units + 1) * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc(&sl.d_unit_live, (c->cap_units + 2 + c->cap_units / 4 + 2) * sizeof(uint32_t)));   // per unit, then per count-pass workgroup
-    sl.class_bytes = (mag_len / 32 + 64) * sizeof(uint32_t);
-    HIPCHK(c, hipMalloc(&sl.d_class_bitmap, sl.class_bytes));
-    HIPCHK(c, hipMalloc(&sl.d_class_uncond, sl.class_bytes));
+    HIPCHK(c, hipMalloc(&sl.d_unit_live, (c->cap_units + 2 + 3 * (c->cap_units / 4 + 2)) * sizeof(uint32_t)));   // per unit, then per count-pass workgroup: live records, the two class counts
+    sl.class_bytes = (mag_len / 32 + 64 + kUnit / 32) * sizeof(uint32_t);      // (the count pass writes whole units: kUnit / 32 words each)
     HIPCHK(c, hipMalloc(&sl.d_class_final, sl.class_bytes));
     // the class planes and the scratch block are handed back zeroed by the kernels that consume them
-    HIPCHK(c, hipMemsetAsync(sl.d_class_bitmap, 0, sl.class_bytes, c->stream));
-    HIPCHK(c, hipMemsetAsync(sl.d_class_uncond, 0, sl.class_bytes, c->stream));
     HIPCHK(c, hipMalloc(&sl.d_cand, (c->cap_units * (size_t) kUnit + 64) * sizeof(uint16_t)));
     HIPCHK(c, hipMalloc(&sl.d_cand_count, (c->cap_units * (size_t) (kUnit / kSweepTile) + 1) * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc(&sl.d_dealer, (size_t) kDealerCounters * kDealerStride * sizeof(uint32_t)));   // (k_publish hands it back zeroed)
     HIPCHK(c, hipMemsetAsync(sl.d_dealer, 0, (size_t) kDealerCounters * kDealerStride * sizeof(uint32_t), c->stream));
-    HIPCHK(c, hipMalloc(&sl.d_sweep_part, ((size_t) kSweepGridMax * 4 + (size_t) kFinMaxBlocks * 2) * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(&sl.d_sweep_part, ((size_t) kSweepGridMax * 4) * sizeof(uint32_t)));
     {
         const size_t nb = c->cap_buffers, words = CNT_NUM + 1 + 4 * nb + kAcLists;   // ... + Mode A/C list counters
         sl.scratch_bytes = words * sizeof(unsigned long long);
@@ -737,8 +733,8 @@ static void free_slot(Slot &sl) {
     if (sl.h_live_win) (void) hipHostFree(sl.h_live_win);
     if (sl.h_fsx) (void) hipHostFree(sl.h_fsx);
     if (sl.d_fsx) (void) hipFree(sl.d_fsx);
-    void *dev[] = {sl.d_live_win, sl.d_dealer, sl.d_blob, sl.d_live, sl.d_live_sig, sl.d_mag, sl.d_pool, sl.d_scratch, sl.d_unit_first, sl.d_unit_count, sl.d_unit_live, sl.d_class_bitmap,
-                   sl.d_class_uncond, sl.d_class_final, sl.d_cand, sl.d_cand_count, sl.d_sweep_part,
+    void *dev[] = {sl.d_live_win, sl.d_dealer, sl.d_blob, sl.d_live, sl.d_live_sig, sl.d_mag, sl.d_pool, sl.d_scratch, sl.d_unit_first, sl.d_unit_count, sl.d_unit_live,
+                   sl.d_class_final, sl.d_cand, sl.d_cand_count, sl.d_sweep_part,
                    sl.d_win, sl.d_win_part, sl.d_msg_pos,
                    sl.d_msg_limit, sl.d_msg_len, sl.d_msg_skip, sl.d_msg_sig, sl.d_wk_in, sl.d_wk_acc, sl.d_wk_sig};
     for (void *p : dev)
@@ -1091,7 +1087,7 @@ static int enqueue_convert(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
     // the slot's magnitudes / class bitmap / message lists are still read by the window-statistics
     // kernel of its previous use (stream2)
     if (sl.window_pending) { HIPCHK(c, hipStreamWaitEvent(s, sl.ev_window, 0)); sl.window_pending = false; }
-    // (scratch block and class planes are zero: k_publish / k_count_finalize of the slot's previous chunk left them so)
+    // (the scratch block is zero: k_publish of the slot's previous chunk left it so)
     if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[0], s));
     if (!sl.have_mag) {
         ConvertParams cp{};
@@ -1142,8 +1138,8 @@ static int enqueue_sweep(mgpu_ctx *c, Slot &sl) {
     sp.tab_long = c->d_tab_long; sp.tab_short = c->d_tab_short; sp.n_long = c->n_long; sp.n_short = c->n_short;
     sp.pool = sl.d_pool; sp.pool_cap = (uint32_t) c->cap_pool; sp.pool_used = sl.d_pool_used;
     sp.unit_first = sl.d_unit_first; sp.unit_count = sl.d_unit_count; sp.nunits = nunits; sp.dealer = sl.d_dealer;
-    sp.adder_bitmap = c->d_adder_bitmap; sp.class_bitmap = sl.d_class_bitmap; sp.counters = sl.d_counters;
-    sp.cand = sl.d_cand; sp.cand_count = sl.d_cand_count; sp.class_uncond = sl.d_class_uncond; sp.sweep_part = sl.d_sweep_part;
+    sp.adder_bitmap = c->d_adder_bitmap; sp.counters = sl.d_counters;
+    sp.cand = sl.d_cand; sp.cand_count = sl.d_cand_count; sp.sweep_part = sl.d_sweep_part;
     // ev[5] .. ev[4] bracket exactly one kernel: k_sweep (bench.py's roofline); ev[4] .. ev[2]: k_slice
     if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[5], s));
 #if MGPU_EXPERIMENTS
@@ -1185,7 +1181,6 @@ static int enqueue_post(mgpu_ctx *c, Slot &sl) {
     // computed after the walk, for the accepted frames only (k_msg_sig): 40 % of the work, off the main stream
     sl.sig_late = c->sig_late && c->shard_mode == 0;
     q.mag = sl.sig_late ? nullptr : sl.d_mag;
-    q.class_cond = sl.d_class_bitmap; q.class_uncond = sl.d_class_uncond;
     q.class_final = sl.d_class_final;
     q.class_words = (n + 31) / 32;
     q.dealer = sl.d_dealer;
@@ -1193,8 +1188,7 @@ static int enqueue_post(mgpu_ctx *c, Slot &sl) {
     q.d_scratch = sl.d_scratch; q.h_scratch = sl.h_scratch; q.scratch_words = (uint32_t) (sl.scratch_bytes / sizeof(unsigned long long));
     // the count pass leaves its decisions as masks in the segment headers (one scoring pass = one segment of at most 64
     // records), so the write pass does not look at the adder bitmap again
-    q.keep_masks = true;
-    q.fin_part = sl.d_sweep_part + (size_t) kSweepGridMax * 4;
+    q.fin_part = q.block_live + c->cap_units / 4 + 2;
     q.slice_part = sl.d_sweep_part; q.slice_blocks = sl.slice_blocks;       // k_slice's rows of counts (0 rows: the experiments build's fused kernel counts for itself)
     if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[6], s));
     if (launch_prescreen(q, s, s, sl.ev_scan) != 0) { c->err = "event ordering of the pre-screen passes failed"; return MGPU_E_HIP; }

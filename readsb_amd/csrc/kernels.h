@@ -36,7 +36,6 @@ constexpr int kSweepMaxBlocks = 256 * 4;  // resident workgroups of k_slice (at 
 constexpr int kSweepGridMax = 256 * 8;    // resident workgroups of k_sweep (at most 8 per CU) = rows of sweep_part
 constexpr int kDealerCounters = 64;       // k_slice's tile dealer: pools of workgroups, one counter each ...
 constexpr int kDealerStride = 64;         // ... 256 bytes apart: device atomics on words of one 64-byte line serialise with each other (tools/micro/atomic_cost.hip)
-constexpr int kFinMaxBlocks = 1024;       // class-plane finalize workgroups (k_count_finalize)
 constexpr int kPoolChunkRecords = 256;    // pool records a wave reserves per returning atomic
 constexpr int kSweepMaxWaves = kSweepMaxBlocks * (kBlock / 64);
 constexpr int kBatch = 64;              // candidates sliced per batch (4 waves x 16)
@@ -108,8 +107,6 @@ struct SweepParams {
     uint32_t pace_recip;      // k_sweep: 2^32 / reference step time in 10 ns ticks (set by launch_sweep; 0 = no pacing)
     uint32_t *sweep_part;     // [k_slice workgroups][8] partial counters (records, candidates, phases 4/5, 6/7, 8), summed by the pre-screen write pass
     uint32_t *adder_bitmap;   // 2^24 bits: addresses some clean DF17 / DF11 IID 0 frame carries
-    uint32_t *class_bitmap;   // 1 bit per scan position: candidate whose records are all conditional
-    uint32_t *class_uncond;   // scratch plane: candidate with >= 1 unconditional record (both planes zeroed per chunk)
     unsigned long long *counters;   // [CNT_NUM]
 #if MGPU_EXPERIMENTS
     int32_t debug_stage;      // generation 3 only: disables kernel stages (timing experiments, MGPU_DEBUG_STAGE)
@@ -155,7 +152,7 @@ void launch_sweep_slice(const SweepParams &p, hipStream_t s);      // generation
 struct PostSweepParams {
     PhaseRec *pool;                       // (the count pass leaves live masks and output offsets in the segment headers)
     uint32_t pool_cap;                    // records the pool holds
-    uint32_t variant;                     // bit 0: the count pass by chains (count_unit_chains), bit 1: the write pass too; 3 = the product
+    uint32_t variant;                     // bit 1: the write pass by chains (write_unit_chains; else the older one, one chain after the other); bit 2 (experiments build): checking kernels; 3 = the product
     const uint32_t *unit_first;           // first segment header of every chain, chains_per_unit consecutive chains per unit
     uint32_t chains_per_unit;             // 4: one chain per k_slice tile of 2048 positions; 1: generation 3
     uint32_t nunits;
@@ -166,15 +163,14 @@ struct PostSweepParams {
     const uint16_t *mag;
     unsigned long long *live_sig;         // pinned host memory
     unsigned long long *counters;
-    uint32_t *class_cond, *class_uncond, *class_final;   // class_final == nullptr: generations 1/2 (bitmap written by the sweep)
+    uint32_t *class_final;                // the class bitmap (1 bit per scan position: records, all of them conditional), written by the count pass: kUnit / 32 words per unit
     uint64_t class_words;
     uint32_t *dealer;                     // k_slice's dealer counters: zeroed again by k_publish
     unsigned long long *live_win;         // shard passes: per live record the packed counts of its would-be skip window (null: not wanted)
     uint64_t n; int32_t thr; uint32_t buf_len;   // ... and what that kernel needs: the chunk's positions, the threshold, the buffer length
     unsigned long long *d_scratch, *h_scratch;
     uint32_t scratch_words;
-    bool keep_masks;                      // segments of <= 64 records: the count pass leaves its decisions in the headers
-    uint32_t *fin_part;                   // [kFinMaxBlocks][2] class counts per finalize workgroup, summed by the write pass
+    uint32_t *fin_part;                   // [count-pass workgroups][2] class counts, summed by the write pass
     const uint32_t *slice_part;           // k_slice's rows of counts (SweepParams::sweep_part), summed by the write pass; slice_blocks = 0: none
     uint32_t slice_blocks;
 };

@@ -107,7 +107,6 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 #if MGPU_EXPERIMENTS
 #include "kernels/sweep_slice.inc"
 #endif
-#include "kernels/class_finalize.inc"
 #include "kernels/prescreen.inc"
 #include "kernels/modeac.inc"
 #include "kernels/window_stats.inc"

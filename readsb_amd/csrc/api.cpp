@@ -659,7 +659,7 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
     HIPCHK(c, hipMemsetAsync(sl.d_mag, 0, mag_len * sizeof(uint16_t), c->stream));
     HIPCHK(c, hipMalloc(&sl.d_pool, c->cap_pool * sizeof(PhaseRec)));
     HIPCHK(c, hipMalloc(&sl.d_unit_first, (c->cap_units * (size_t) (kUnit / 2048) + 1) * sizeof(uint32_t)));   // one record chain per k_slice tile
-    HIPCHK(c, hipMalloc(&sl.d_unit_count, (c->cap_units + 1) * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(&sl.d_unit_count, (c->cap_units * (size_t) (kUnit / 2048) + 1) * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc(&sl.d_unit_live, (c->cap_units + 2 + 3 * (c->cap_units / 4 + 2)) * sizeof(uint32_t)));   // per unit, then per count-pass workgroup: live records, the two class counts
     sl.class_bytes = (mag_len / 32 + 64 + kUnit / 32) * sizeof(uint32_t);      // (the count pass writes whole units: kUnit / 32 words each)
     HIPCHK(c, hipMalloc(&sl.d_class_final, sl.class_bytes));
@@ -1175,7 +1175,7 @@ static int enqueue_post(mgpu_ctx *c, Slot &sl) {
     hipStream_t s = c->stream;
     // class planes -> class bitmap, pre-screen (the surviving records stay in HBM: d_live), counters and per-buffer sums to the host
     PostSweepParams q{};
-    q.pool = sl.d_pool; q.pool_cap = (uint32_t) c->cap_pool; q.variant = c->prescreen_variant; q.unit_first = sl.d_unit_first; q.nunits = nunits; q.chains_per_unit = c->sweep_version == 3 ? 1u : (uint32_t) (kUnit / 2048); q.adder_bitmap = c->d_adder_bitmap;
+    q.pool = sl.d_pool; q.pool_cap = (uint32_t) c->cap_pool; q.variant = c->prescreen_variant; q.unit_first = sl.d_unit_first; q.first_count = sl.d_unit_count; q.nunits = nunits; q.chains_per_unit = c->sweep_version == 3 ? 1u : (uint32_t) (kUnit / 2048); q.adder_bitmap = c->d_adder_bitmap;
     q.unit_live = sl.d_unit_live; q.block_live = sl.d_unit_live + c->cap_units + 2; q.live = sl.d_live; q.live_sig = sl.d_live_sig; q.counters = sl.d_counters;
     // a shard pass hands its records to another rank, which has no samples: their signal powers go with them.  Otherwise they are
     // computed after the walk, for the accepted frames only (k_msg_sig): 40 % of the work, off the main stream

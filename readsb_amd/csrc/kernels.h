@@ -99,7 +99,7 @@ struct SweepParams {
     uint32_t pool_cap;
     uint32_t *pool_used;      // device counter (records incl. headers)
     uint32_t *unit_first;     // k_slice: [tiles of 2048 positions] index of the tile's first segment header, kNone if empty (generation 3: per unit)
-    uint32_t *unit_count;     // generation 3 only: [nunits] records of the unit (without headers)
+    uint32_t *unit_count;     // k_slice: [tiles] records in the tile's first segment; generation 3: [nunits] records of the unit (without headers)
     uint32_t *dealer;         // k_slice: [kDealerCounters] tiles dealt from each pool so far, kDealerStride words apart (zero at launch)
     uint32_t nunits;
     uint16_t *cand;           // candidate codes (position in the unit << 3 | phase mask), one list per step of kSweepTile positions, kSweepTile slots each
@@ -154,6 +154,7 @@ struct PostSweepParams {
     uint32_t pool_cap;                    // records the pool holds
     uint32_t variant;                     // bit 1: the write pass by chains (write_unit_chains; else the older one, one chain after the other); bit 2 (experiments build): checking kernels; 3 = the product
     const uint32_t *unit_first;           // first segment header of every chain, chains_per_unit consecutive chains per unit
+    const uint32_t *first_count;          // four chains per unit: the records in every chain's first segment (SweepParams::unit_count)
     uint32_t chains_per_unit;             // 4: one chain per k_slice tile of 2048 positions; 1: generation 3
     uint32_t nunits;
     const uint32_t *adder_bitmap;

@@ -10,6 +10,9 @@ for l in open(sys.argv[1]):
         print(sys.argv[1], round(d['value']), d['ms_per_step'], 'sweep', round(r.get('avg_launch_ms',0),4), round(r['frac'],4), 'stage', d.get('stage_ms'))
 PY
 }
-timeout 900 python -m pytest tests/test_gpu_prescreen_chains.py tests/test_gpu_parity.py tests/test_gpu_golden.py tests/test_gpu_kernel_generations.py -m gpu -x -q 2>&1 | tail -5
-timeout 300 $B > gpurun_out/p1.log 2>&1; show gpurun_out/p1.log
-timeout 300 $B > gpurun_out/p2.log 2>&1; show gpurun_out/p2.log
+export MGPU_LIBRARY=libmodes_gpu_exp.so
+for i in 1 2; do
+MGPU_CONV_AHEAD=0 timeout 300 $B > gpurun_out/c0_$i.log 2>&1; show gpurun_out/c0_$i.log
+MGPU_CONV_AHEAD=1 timeout 300 $B > gpurun_out/c1_$i.log 2>&1; show gpurun_out/c1_$i.log
+done
+MGPU_CONV_AHEAD=1 timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_deferred.py -m gpu -x -q 2>&1 | tail -3

@@ -1,7 +1,7 @@
 #!/bin/bash
 cd /root/repo
 mkdir -p gpurun_out
-B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-configs"
+B="python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra-configs"
 show() { python - "$1" <<'PY'
 import json,sys
 for l in open(sys.argv[1]):
@@ -11,8 +11,7 @@ for l in open(sys.argv[1]):
 PY
 }
 export MGPU_LIBRARY=libmodes_gpu_exp.so
-for i in 1 2; do
-MGPU_CONV_AHEAD=0 timeout 300 $B > gpurun_out/c0_$i.log 2>&1; show gpurun_out/c0_$i.log
-MGPU_CONV_AHEAD=1 timeout 300 $B > gpurun_out/c1_$i.log 2>&1; show gpurun_out/c1_$i.log
+for i in 1 2 3; do
+MGPU_SIG_EARLY=0 timeout 300 $B > gpurun_out/s0_$i.log 2>&1; show gpurun_out/s0_$i.log
+MGPU_SIG_EARLY=1 timeout 300 $B > gpurun_out/s1_$i.log 2>&1; show gpurun_out/s1_$i.log
 done
-MGPU_CONV_AHEAD=1 timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_deferred.py -m gpu -x -q 2>&1 | tail -3

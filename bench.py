@@ -493,8 +493,8 @@ def bench_config5(args, rank, local_rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--samples", type=int, default=4096 * BUF, help="samples per stream per step (multiple of 131072)")
     ap.add_argument("--msgs-per-sec", type=float, default=2000.0)
     ap.add_argument("--config", type=int, default=1, help="1 (default): one stream per GPU (BASELINE configs[1] / configs[3]); 5: one dense-burst "

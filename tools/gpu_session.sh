@@ -1,5 +1,5 @@
 #!/bin/bash
 # scratch: what the last GPU session of the round ran (gpurun -- 'bash tools/gpu_session.sh')
 cd /root/repo
-timeout 500 python bench.py --config 5 --emulate-ranks 8 --samples 8640000000 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/c5_hour.log 2>&1
-tail -1 gpurun_out/c5_hour.log | cut -c1-600
+timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_golden.py tests/test_gpu_kernel_generations.py tests/test_gpu_prescreen_chains.py -m gpu -x -q 2>&1 | tail -3
+timeout 600 python bench.py --steps 20 --warmup 3 > gpurun_out/bench_keys.log 2>&1; tail -1 gpurun_out/bench_keys.log | cut -c1-120

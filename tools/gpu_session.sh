@@ -1,4 +1,4 @@
 #!/bin/bash
-# scratch: what the last GPU session of the round ran (gpurun -- 'bash tools/gpu_session.sh')
+# scratch: the command of one GPU session (gpurun -- 'bash tools/gpu_session.sh'); edit, run, read gpurun_out/
 cd /root/repo
-timeout 600 python bench.py > gpurun_out/bench_final.log 2>&1; tail -1 gpurun_out/bench_final.log | cut -c1-120
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -4

@@ -140,7 +140,7 @@ struct Slot {
     // device
     uint16_t *d_mag = nullptr;
     PhaseRec *d_pool = nullptr;
-    uint32_t *d_dealer = nullptr;         // k_slice's tile dealer: 64 counters, one per 256 bytes (handed back zeroed by k_publish)
+    uint32_t *d_dealer = nullptr;         // k_slice's tile dealer and, behind it, k_sweep's step dealer: 2 x 64 counters, one per 256 bytes (handed back zeroed by k_publish)
     uint32_t *d_pool_used = nullptr, *d_unit_first = nullptr, *d_unit_count = nullptr, *d_unit_live = nullptr;
     uint32_t *d_class_final = nullptr, *d_cand_count = nullptr, *d_sweep_part = nullptr;
     uint16_t *d_cand = nullptr;
@@ -666,8 +666,8 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
     // the class planes and the scratch block are handed back zeroed by the kernels that consume them
     HIPCHK(c, hipMalloc(&sl.d_cand, (c->cap_units * (size_t) kUnit + 64) * sizeof(uint16_t)));
     HIPCHK(c, hipMalloc(&sl.d_cand_count, (c->cap_units * (size_t) (kUnit / kSweepTile) + 1) * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc(&sl.d_dealer, (size_t) kDealerCounters * kDealerStride * sizeof(uint32_t)));   // (k_publish hands it back zeroed)
-    HIPCHK(c, hipMemsetAsync(sl.d_dealer, 0, (size_t) kDealerCounters * kDealerStride * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMalloc(&sl.d_dealer, (size_t) 2 * kDealerCounters * kDealerStride * sizeof(uint32_t)));   // (k_publish hands it back zeroed)
+    HIPCHK(c, hipMemsetAsync(sl.d_dealer, 0, (size_t) 2 * kDealerCounters * kDealerStride * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMalloc(&sl.d_sweep_part, ((size_t) kSweepGridMax * 4) * sizeof(uint32_t)));
     {
         const size_t nb = c->cap_buffers, words = CNT_NUM + 1 + 4 * nb + kAcLists;   // ... + Mode A/C list counters

@@ -100,7 +100,7 @@ struct SweepParams {
     uint32_t *pool_used;      // device counter (records incl. headers)
     uint32_t *unit_first;     // k_slice: [tiles of 2048 positions] index of the tile's first segment header, kNone if empty (generation 3: per unit)
     uint32_t *unit_count;     // k_slice: [tiles] records in the tile's first segment; generation 3: [nunits] records of the unit (without headers)
-    uint32_t *dealer;         // k_slice: [kDealerCounters] tiles dealt from each pool so far, kDealerStride words apart (zero at launch)
+    uint32_t *dealer;         // k_slice: [kDealerCounters] tiles dealt from each pool so far, kDealerStride words apart (zero at launch); behind them k_sweep: [kDealerCounters] blocks of steps dealt
     uint32_t nunits;
     uint16_t *cand;           // candidate codes (position in the unit << 3 | phase mask), one list per step of kSweepTile positions, kSweepTile slots each
     uint32_t *cand_count;     // [steps], + one empty list behind an odd number of steps

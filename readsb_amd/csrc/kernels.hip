@@ -94,6 +94,23 @@ __device__ __forceinline__ int wave_excl_scan_small(uint32_t v, int &total) {
     return ex;
 }
 
+// The dealers' request (k_sweep's steps, k_slice's tiles): one returning device atomic from lane 0 whose answer is read later in the
+// SAME iteration of the caller's loop, into a variable declared inside that iteration.  Two things the compiler otherwise does to
+// such a request, both of which put an s_waitcnt vmcnt(0) right behind the atomic (rounds 3-4 shipped k_slice that way: every
+// request waited for at once, and the tile's prefetched samples with it): on a uniform address LLVM's atomic optimizer rewrites it
+// into ballot + atomic + v_readfirstlane of the result — hence the offset through a VGPR it cannot see through; and a result
+// variable that lives across iterations is redefined conditionally, which costs a v_mov of the in-flight register at the merge.
+// (`opaque_zero`: made once per kernel by deal_opaque_zero() — made at every request, its register is the ticket's of the request
+// before, and the compiler waits for that one first.)
+__device__ __forceinline__ uint32_t deal_opaque_zero() {
+    uint32_t off = 0;
+    asm volatile("" : "+v"(off));
+    return off;
+}
+__device__ __forceinline__ uint32_t deal_ask(uint32_t *counter, uint32_t opaque_zero) {   // call from ONE lane
+    return __hip_atomic_fetch_add(counter + opaque_zero, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);

@@ -8,7 +8,7 @@ import sys
 name = sys.argv[1]
 lines = open("readsb_amd/csrc/kernels.s").read().split("\n")
 start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\S*" + re.escape(name) + r"\S*:", l))
-end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))   # (a kernel may hold several s_endpgm)
 body = lines[start:end + 1]
 if "--dump" in sys.argv:
     lab = sys.argv[sys.argv.index("--dump") + 1]

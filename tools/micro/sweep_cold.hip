@@ -68,7 +68,7 @@ int main(int argc, char **argv) {
 
     uint8_t *d_iq;
     uint16_t *d_mag, *d_cand, *d_lut;
-    uint32_t *d_count, *d_part;
+    uint32_t *d_count, *d_part, *d_dealer;
     unsigned long long *d_sums, *d_waves;
     const uint32_t nsteps = (uint32_t) ((n + kSwStep - 1) / kSwStep);
     CK(hipMalloc(&d_iq, n * 2));
@@ -76,6 +76,7 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&d_cand, (size_t) (nsteps + 2) * kSwStep * 2));
     CK(hipMalloc(&d_count, (size_t) (nsteps + 2) * 4));
     CK(hipMalloc(&d_part, 65536 * 8 * 4));
+    CK(hipMalloc(&d_dealer, (size_t) 2 * kDealerCounters * kDealerStride * 4));
     CK(hipMalloc(&d_sums, (size_t) (buffers + 3) * 2 * 8));
     CK(hipMalloc(&d_waves, 65536 * 4 * 2 * 8));
     const std::vector<uint16_t> lut = uc8_folded_table();
@@ -100,13 +101,14 @@ int main(int argc, char **argv) {
     if (blocks > want_blocks) blocks = want_blocks;
     if (blocks > 65536) blocks = 65536;
     SweepParams p{};
-    p.n = n; p.thr = thr; p.cand = d_cand; p.cand_count = d_count; p.sweep_part = d_part; p.dbg_waves = d_waves;
+    p.n = n; p.thr = thr; p.cand = d_cand; p.cand_count = d_count; p.sweep_part = d_part; p.dbg_waves = d_waves; p.dealer = d_dealer;
 
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     auto run = [&](int r, float &us) -> int {
         p.mag = d_mag + (size_t) r * stride;
+        CK(hipMemsetAsync(d_dealer, 0, (size_t) 2 * kDealerCounters * kDealerStride * 4, nullptr));   // (the pipeline's k_publish hands the counters back zeroed)
         CK(hipEventRecord(e0, nullptr));
         p.pace_recip = pace_ticks > 0.0f ? (uint32_t) (4294967296.0 / pace_ticks) : 0u;
         hipLaunchKernelGGL(k_sweep, dim3(blocks), dim3(kBlock), 0, nullptr, p);
@@ -177,14 +179,14 @@ int main(int argc, char **argv) {
     stat(cold, cmin, cmed, cmax, cavg);
     stat(warm, wmin, wmed, wmax, wavg);
     const double bytes = (double) n * 2.0;
-    printf("{\"kernel\": \"k_sweep\", \"variant\": \"exp %d nbuf %d\", \"stage\": %d, \"samples_per_launch\": %llu, \"algorithmic_bytes_per_launch\": %.0f, \"replicas\": %d, "
+    printf("{\"kernel\": \"k_sweep\", \"variant\": \"exp %d nbuf %d deal %d touch %d\", \"stage\": %d, \"samples_per_launch\": %llu, \"algorithmic_bytes_per_launch\": %.0f, \"replicas\": %d, "
            "\"cold_array_bytes\": %.0f, \"pace_ticks\": %.0f, \"blocks\": %u, \"waves\": %u, \"dense\": %d, \"rate\": %.0f, \"candidates\": %llu, \"candidates_cpu\": %zu, "
            "\"mismatches_vs_cpu_scan\": %llu, "
            "\"cold_us\": {\"min\": %.2f, \"median\": %.2f, \"mean\": %.2f, \"max\": %.2f, \"launches\": %zu}, "
            "\"cold_GBs\": %.1f, \"cold_frac_of_8TBs\": %.4f, "
            "\"warm_us\": {\"min\": %.2f, \"median\": %.2f, \"mean\": %.2f, \"max\": %.2f, \"launches\": %zu}, \"warm_GBs\": %.1f, \"warm_frac_of_8TBs\": %.4f, "
            "\"waves_alive_frac\": %.3f, \"wave_life_mean_us\": %.2f, \"last_start_us\": %.2f, \"end_us\": {\"p10\": %.2f, \"p50\": %.2f, \"p90\": %.2f, \"max\": %.2f}}\n",
-           (int) MGPU_SW_EXP, (int) MGPU_SW_NBUF, (int) MGPU_SW_STAGE, (unsigned long long) n, bytes, replicas, (double) replicas * stride * 2, (double) pace_ticks, blocks, nwaves, dense, rate,
+           (int) MGPU_SW_EXP, (int) MGPU_SW_NBUF, (int) MGPU_SW_DEAL, (int) MGPU_SW_TOUCH, (int) MGPU_SW_STAGE, (unsigned long long) n, bytes, replicas, (double) replicas * stride * 2, (double) pace_ticks, blocks, nwaves, dense, rate,
            (unsigned long long) ncand, want.size(), (unsigned long long) mismatches,
            cmin, cmed, cavg, cmax, cold.size(), bytes / (cavg * 1e-6) / 1e9, bytes / (cavg * 1e-6) / 1e9 / 8000.0,
            wmin, wmed, wavg, wmax, warm.size(), bytes / (wavg * 1e-6) / 1e9, bytes / (wavg * 1e-6) / 1e9 / 8000.0,

@@ -39,9 +39,12 @@ extern "C" {
 #define MGPU_E_CAPACITY     -6   /* more samples than cfg.max_samples in one call */
 #define MGPU_E_EOF          -7   /* stream already ended on a short buffer (sdr_ifile.c:223-237) */
 
-/* Bumped whenever a struct of this header grows or an entry point changes meaning.  4 (round 4): mgpu_config.chunk_buffers;
- * with MGPU_FILTER_CLOCK_EXTERNAL the filter starts EMPTY since 3 (the host mirrors modesInit's icaoFilterAdd(Modes.show_only)). */
-#define MGPU_ABI_VERSION 4
+/* Bumped whenever a struct of this header grows or an entry point changes meaning.  5 (round 5): mgpu_config.abi_version is checked
+ * by mgpu_create, mgpu_abi_version() exported; 4 (round 4): mgpu_config.chunk_buffers; with MGPU_FILTER_CLOCK_EXTERNAL the filter
+ * starts EMPTY since 3 (the host mirrors modesInit's icaoFilterAdd(Modes.show_only)). */
+#define MGPU_ABI_VERSION 5
+/* The version the loaded library was built with: a host compares it with the MGPU_ABI_VERSION of the header it was compiled against. */
+uint32_t mgpu_abi_version(void);
 
 typedef struct mgpu_ctx mgpu_ctx;
 
@@ -69,7 +72,10 @@ struct mgpu_config {
     uint32_t chunk_buffers;       /* buffers per pipeline chunk (one launch of every kernel); 0 = 1024 (half as many kernel boundaries and tails
                                    * as 512: 325 against 300 Gsamples/s, profiles/r04_chunk_buffers.txt); a host that wants its messages sooner
                                    * takes fewer (latency = three chunks) */
-    uint32_t reserved;
+    uint32_t abi_version;         /* MGPU_ABI_VERSION of the header the HOST was compiled against (mgpu_config_defaults below passes it);
+                                   * mgpu_create() refuses another (MGPU_E_INVAL) — a host built against an older, shorter struct would
+                                   * otherwise have the bytes behind its struct read as chunk_buffers.  (The last field: it sits where such a
+                                   * host's struct has ended.) */
 };
 
 /* The ICAO filter's 60 s expiry (backgroundTasks, readsb.c:1227-1231: `static next_flip = 0`, so the first
@@ -93,7 +99,15 @@ struct mgpu_config {
 #define MGPU_FILTER_CLOCK_EXTERNAL     2
 
 /* Fills cfg with the reference defaults (configSetDefaults, readsb.c:150-228). */
+/* Defaults of every field.  C / C++ hosts get the macro: it hands the library the size and the version of the struct THEY were compiled
+ * with, the library writes no byte beyond that size and records the version for mgpu_create's check.  The plain entry point (what
+ * a binding that looks symbols up at run time calls, e.g. readsb_amd/binding.py, whose struct is generated from this header's
+ * revision) fills in the library's own. */
+void mgpu_config_defaults_abi(struct mgpu_config *cfg, uint32_t struct_bytes, uint32_t abi_version);
 void mgpu_config_defaults(struct mgpu_config *cfg);
+#ifndef MGPU_NO_DEFAULTS_MACRO
+#define mgpu_config_defaults(cfg) mgpu_config_defaults_abi((cfg), (uint32_t) sizeof(struct mgpu_config), MGPU_ABI_VERSION)
+#endif
 
 /* One accepted message, in stream order: everything demodulate2400 hands to
  * decodeModesMessage()/netUseMessage() (demod_2400.c:401-471).  64 bytes. */
@@ -138,25 +152,28 @@ struct mgpu_counters {
     uint64_t demod_modeac;       /* Mode A/C replies accepted (stats.h:72), only with cfg.mode_ac */
 };
 
-/* Device time of the last feed, from HIP events on the context's stream (ms). */
+/* Where the last feed's time went (ms).  The four kernel figures are pairs of HIP events on the context's main stream around ONE
+ * kernel / one group of kernels, on every fourth chunk only (n_timed_chunks: a timing event costs ~5 us of idle stream); a pair adds
+ * a constant ~4 us to what it brackets (mgpu_event_bracket_us measures it).  The host figures are wall-clock sums of stage threads
+ * that run beside each other and beside the GPU: they overlap, they do not add up to total_ms. */
 struct mgpu_timing {
-    float h2d_ms;        /* host->device copy of the IQ block (0 for resident input) */
-    float convert_ms;    /* k_convert_* */
-    float sweep_ms;      /* the sweep kernel alone (k_sweep_slice: sweep + slicer + scoring), HIP events around its launches */
-    float prescreen_ms;  /* class-plane finalize + record pre-screen + compaction + scratch copy-back */
-    float resolve_ms;    /* ordered accept / skip-ahead / ICAO filter walk (host wall time) */
-    float sigpower_ms;   /* host time spent launching the skip-window statistics kernel */
-    float d2h_ms;        /* fetcher thread: live records out of the pinned buffer the pre-screen kernel wrote (host) */
-    float total_ms;      /* wall time of the whole call */
+    float h2d_ms;        /* host time spent issuing the IQ block's host->device copies (0 for resident input) */
+    float convert_ms;    /* k_convert_* (UC8 / SC16 / SC16Q11 -> magnitudes, per-buffer sums) */
+    float sweep_ms;      /* k_sweep alone: the preamble sweep, the kernel the HBM roofline applies to (experiments build, MGPU_SWEEP_VERSION=3: the fused k_sweep_slice) */
+    float prescreen_ms;  /* the post-sweep passes: k_count (+ class bitmap) + k_prescreen_write + k_publish */
+    float resolve_ms;    /* walker team: the ordered accept / skip-ahead / ICAO filter walk (host wall time) */
+    float sigpower_ms;   /* walker thread: launching what follows the walk on the second stream (k_stage_in, k_msg_sig, k_window_stats, k_build_messages) */
+    float d2h_ms;        /* fetcher thread: waiting for the chunk, the live records HBM -> page-locked memory -> the walk's memory (host wall time) */
+    float total_ms;      /* wall time of the whole call (deferred feeds: since the accounting was opened) */
     uint64_t n_candidates;   /* positions that passed a preamble threshold */
     uint64_t n_records;      /* per-phase records the slicer emitted */
     uint64_t n_live_records; /* records that survived the pre-screen (reach the ordered walk) */
     uint64_t n_messages;     /* accepted messages */
-    uint64_t n_chunks;       /* pipeline chunks = launches of each kernel; the *_ms fields above are sums over them */
-    float slice_ms;          /* generation 4 only: k_slice (bit slicer + CRC + score); sweep_ms is then k_sweep alone */
-    float build_ms;          /* builder thread: struct modesMessage fields + signal / noise statistics (host) */
+    uint64_t n_chunks;       /* pipeline chunks = launches of each kernel */
+    float slice_ms;          /* k_slice: bit slicer + CRC-24 + the filter-independent half of the scoring */
+    float build_ms;          /* builder team: struct modesMessage fields + signal / noise statistics, including its wait for the chunk's signal powers (host wall time) */
     uint64_t n_timed_chunks; /* chunks that carried the stage timing events: convert_ms, sweep_ms, slice_ms and prescreen_ms are sums
-                              * over THESE (every 4th chunk by default, MGPU_TIMING_EVERY=1: all; an event costs ~5 us of idle stream) */
+                              * over THESE (every 4th chunk; experiments build: MGPU_TIMING_EVERY) */
 };
 
 /* ---- lifecycle -------------------------------------------------------------------- */

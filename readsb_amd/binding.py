@@ -56,7 +56,7 @@ class Config(C.Structure):
         ("preamble_threshold", C.c_int32), ("buf_samples", C.c_uint32), ("trailing_samples", C.c_uint32),
         ("mode_ac", C.c_uint32), ("max_samples", C.c_uint64), ("startup_time_ms", C.c_int64),
         ("record_pool_records", C.c_uint64), ("max_messages", C.c_uint64),
-        ("filter_clock", C.c_uint32), ("streams_on_device", C.c_uint32), ("chunk_buffers", C.c_uint32), ("reserved", C.c_uint32),
+        ("filter_clock", C.c_uint32), ("streams_on_device", C.c_uint32), ("chunk_buffers", C.c_uint32), ("abi_version", C.c_uint32),
     ]
 
 
@@ -77,6 +77,19 @@ class Counters(C.Structure):
             v = getattr(self, name)
             out[name] = list(v) if hasattr(v, "__len__") else v
         return out
+
+    @classmethod
+    def from_dict(cls, d):
+        """The struct of an as_dict() result (the wire form of the counters between ranks is the struct's bytes, as in the C host)."""
+        k = cls()
+        for name, ctype in cls._fields_:
+            v = d[name]
+            if hasattr(ctype, "_length_"):
+                for i in range(ctype._length_):
+                    getattr(k, name)[i] = v[i]
+            else:
+                setattr(k, name, v)
+        return k
 
 
 class Timing(C.Structure):

@@ -617,7 +617,17 @@ static void bind_near_device(std::thread *const *walk, int nwalk, std::thread *c
 
 extern "C" {
 
-void mgpu_config_defaults(struct mgpu_config *cfg) {
+#undef mgpu_config_defaults
+static void config_defaults(struct mgpu_config *cfg);
+void mgpu_config_defaults(struct mgpu_config *cfg) { config_defaults(cfg); }
+// the host's struct may be an older, shorter one: nothing is written behind it, and the version it names is what mgpu_create checks
+void mgpu_config_defaults_abi(struct mgpu_config *cfg, uint32_t struct_bytes, uint32_t abi_version) {
+    struct mgpu_config full;
+    config_defaults(&full);
+    full.abi_version = abi_version;
+    std::memcpy(cfg, &full, struct_bytes < sizeof(full) ? struct_bytes : sizeof(full));
+}
+static void config_defaults(struct mgpu_config *cfg) {
     std::memset(cfg, 0, sizeof(*cfg));
     cfg->device = 0;
     cfg->format = MGPU_FMT_UC8;
@@ -628,7 +638,10 @@ void mgpu_config_defaults(struct mgpu_config *cfg) {
     cfg->trailing_samples = kTrailing; // readsb.c:288
     cfg->max_samples = 64ull * 131072;
     cfg->startup_time_ms = 0;
+    cfg->abi_version = MGPU_ABI_VERSION;
 }
+
+uint32_t mgpu_abi_version(void) { return MGPU_ABI_VERSION; }
 
 const char *mgpu_strerror(int code) {
     switch (code) {
@@ -880,7 +893,9 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     *out = nullptr;
     if (cfg->trailing_samples != (uint32_t) kTrailing || cfg->buf_samples == 0 || cfg->buf_samples % kTile != 0 ||
         cfg->max_samples == 0 || cfg->format < 0 || cfg->format > 2 || cfg->nfix_crc < 0 || cfg->nfix_crc > 2 ||
-        cfg->filter_clock > MGPU_FILTER_CLOCK_EXTERNAL)
+        cfg->filter_clock > MGPU_FILTER_CLOCK_EXTERNAL ||
+        cfg->abi_version != MGPU_ABI_VERSION ||           // the host's header is another version's (or it did not call mgpu_config_defaults)
+        cfg->chunk_buffers > 16384u)                      // (0 = the default; 16384 buffers = 2^31 samples: positions are 32 bits)
         return MGPU_E_INVAL;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device >= ndev) return MGPU_E_NODEVICE;

@@ -23,6 +23,7 @@
 #define __HIP_PLATFORM_AMD__ 1
 #include <fcntl.h>
 #include <inttypes.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -48,23 +49,39 @@ enum { BUF = 131072, TRAILING = 326, SUM_BLOCK = 1024 };
 struct transport {
     int rank, world, use_files, seq;
     char dir[3072];
+    char run[64];                 /* --run-id: part of every file name, so that a directory (or id-file) left over from another run is never read */
     ncclComm_t comm;
     hipStream_t s;
 };
 
+static void file_name(const struct transport *t, int seq, int rank, char *out, size_t cap) {
+    snprintf(out, cap, "%s/x%s.%d.%d", t->dir, t->run, seq, rank);
+}
+
 static int file_put(const struct transport *t, int seq, const void *p, uint64_t bytes) {
-    char tmp[4200], fin[4096];
-    snprintf(fin, sizeof(fin), "%s/x%d.%d", t->dir, seq, t->rank);
+    char tmp[4300], fin[4200];
+    file_name(t, seq, t->rank, fin, sizeof(fin));
     snprintf(tmp, sizeof(tmp), "%s.tmp", fin);
     FILE *f = fopen(tmp, "wb");
-    if (!f || (bytes && fwrite(p, 1, bytes, f) != bytes)) { perror(tmp); return -1; }
-    fclose(f);
+    if (!f) { perror(tmp); return -1; }
+    const int bad = bytes && fwrite(p, 1, bytes, f) != bytes;
+    if (fclose(f) != 0 || bad) { perror(tmp); unlink(tmp); return -1; }
     return rename(tmp, fin);
 }
 
+/* at exit: a rank removes the files it wrote, except the last exchange's (a peer may still be reading that one; it is empty) */
+static void file_cleanup(const struct transport *t) {
+    if (!t->use_files) return;
+    for (int seq = 0; seq + 1 < t->seq; ++seq) {
+        char fin[4200];
+        file_name(t, seq, t->rank, fin, sizeof(fin));
+        unlink(fin);
+    }
+}
+
 static int file_get(const struct transport *t, int seq, int from, void **p, uint64_t *bytes) {
-    char fin[4096];
-    snprintf(fin, sizeof(fin), "%s/x%d.%d", t->dir, seq, from);
+    char fin[4200];
+    file_name(t, seq, from, fin, sizeof(fin));
     for (int tries = 0; tries < 600000; ++tries) {                     /* up to ten minutes */
         struct stat st;
         if (stat(fin, &st) == 0) {
@@ -146,14 +163,18 @@ static int t_gather_root(struct transport *t, const void *mine, uint64_t bytes, 
     return 0;
 }
 
-static int exchange_id(const char *path, int rank, ncclUniqueId *id) {
+static int exchange_id(const char *path0, const char *run, int rank, ncclUniqueId *id) {
+    char path[4200];
+    snprintf(path, sizeof(path), "%s%s%s", path0, run[0] ? "." : "", run);   /* (the run id: an id-file of an earlier run is another file) */
     if (rank == 0) {
         if (ncclGetUniqueId(id) != ncclSuccess) return -1;
-        char tmp[4096];
+        char tmp[4300];
         snprintf(tmp, sizeof(tmp), "%s.tmp", path);
+        unlink(path);                                                          /* (same run id twice: the old id goes before the new one is written) */
         FILE *f = fopen(tmp, "wb");
-        if (!f || fwrite(id, sizeof(*id), 1, f) != 1) { perror(tmp); return -1; }
-        fclose(f);
+        if (!f) { perror(tmp); return -1; }
+        const int bad = fwrite(id, sizeof(*id), 1, f) != 1;
+        if (fclose(f) != 0 || bad) { perror(tmp); unlink(tmp); return -1; }
         return rename(tmp, path);
     }
     for (int tries = 0; tries < 60000; ++tries) {
@@ -179,7 +200,7 @@ static int feed(mgpu_ctx *ctx, const uint8_t *d_iq, uint64_t lo, size_t bps, uin
 int main(int argc, char **argv) {
     struct mgpu_config cfg;
     mgpu_config_defaults(&cfg);
-    const char *ifile = NULL, *idfile = NULL, *outpath = NULL, *tdir = NULL;
+    const char *ifile = NULL, *idfile = NULL, *outpath = NULL, *tdir = NULL, *runid = "";
     int rank = 0, world = 1, device = -1;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--ifile") && i + 1 < argc) ifile = argv[++i];
@@ -197,20 +218,22 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--world") && i + 1 < argc) world = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--id-file") && i + 1 < argc) idfile = argv[++i];
         else if (!strcmp(argv[i], "--file-transport") && i + 1 < argc) tdir = argv[++i];
+        else if (!strcmp(argv[i], "--run-id") && i + 1 < argc) runid = argv[++i];
         else if (!strcmp(argv[i], "--out") && i + 1 < argc) outpath = argv[++i];
         else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
     }
     if (!ifile || (!idfile && !tdir) || world < 1 || rank < 0 || rank >= world) {
-        fprintf(stderr, "usage: %s --rank R --world N (--id-file PATH | --file-transport DIR) --ifile FILE [--iformat F] [--fix|--no-fix|--aggressive] [--out beast.bin]\n", argv[0]);
+        fprintf(stderr, "usage: %s --rank R --world N (--id-file PATH | --file-transport DIR) [--run-id ID (the same on every rank, new for every run)] --ifile FILE [--iformat F] [--fix|--no-fix|--aggressive] [--out beast.bin]\n", argv[0]);
         return 2;
     }
     cfg.device = device >= 0 ? device : (tdir ? 0 : rank);
     CHK_HIP(hipSetDevice(cfg.device));
-    struct transport T = {rank, world, tdir != NULL, 0, {0}, NULL, NULL};
+    struct transport T = {rank, world, tdir != NULL, 0, {0}, {0}, NULL, NULL};
+    snprintf(T.run, sizeof(T.run), "%s", runid);
     if (tdir) snprintf(T.dir, sizeof(T.dir), "%s", tdir);
     else {
         ncclUniqueId id;
-        if (exchange_id(idfile, rank, &id) != 0) { fprintf(stderr, "rank %d: no ncclUniqueId\n", rank); return 1; }
+        if (exchange_id(idfile, T.run, rank, &id) != 0) { fprintf(stderr, "rank %d: no ncclUniqueId\n", rank); return 1; }
         CHK_NCCL(ncclCommInitRank(&T.comm, world, id, rank));
     }
     CHK_HIP(hipStreamCreate(&T.s));
@@ -340,8 +363,9 @@ int main(int argc, char **argv) {
                 nmsg += got;
             }
             CHK_MGPU(mgpu_shard_stream_end(ctx, clocks, nbuf_own + 1, &nclocks), ctx);
-            uint64_t zero = 0;
-            CHK_MGPU(mgpu_collect(ctx, msgs + nmsg, msg_cap - nmsg, &zero, &counters), ctx);
+            uint64_t late = 0;                                              /* (the feeds above are synchronous: nothing is left — but if something were, it counts) */
+            CHK_MGPU(mgpu_collect(ctx, msgs + nmsg, msg_cap - nmsg, &late, &counters), ctx);
+            nmsg += late;
             const void *p0, *p1;
             const double *tp;
             CHK_MGPU(mgpu_shard_state(ctx, 0, &p0, &sfb), ctx);
@@ -479,6 +503,7 @@ int main(int argc, char **argv) {
             rank, world, b0, b0 + nbuf_own, nwin, rounds, passes, import ? " (imported state)" : "", nmsg);
     mgpu_destroy(ctx);
     (void) hipFree(d_iq);
+    file_cleanup(&T);
     if (!T.use_files) ncclCommDestroy(T.comm);
     (void) hipStreamDestroy(T.s);
     if (n) munmap((void *) iq, (size_t) st.st_size);

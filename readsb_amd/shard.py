@@ -1,28 +1,29 @@
 """One capture sharded by buffer ranges over several GPUs (BASELINE config 5).
 
-Buffers of 131072 samples are independent except for the ICAO filter: the ordered walk needs the filter's
-state, and the GPU pre-screen needs to know which addresses could be in the filter at all — every address some clean
-DF17 / DF11-IID0 frame carried ("adder", mode_s.c:766-779) in the last TWO filter generations: an address is dropped by the
-second expiry after its last add, at most 120 s of sample time later (icao_filter.c:96-130, readsb.c:1227-1231).
+Buffers of 131072 samples are independent except for the ICAO filter: scoring reads it, accepted clean DF17 /
+DF11-IID0 frames write it, and it expires on the stream's 60 s clock (icao_filter.c:96-130, readsb.c:1227-1231).
 
-  rank 0    owns the first range and puts it through the ordinary pipeline (nothing precedes it): messages straight away;
-  rank r>0  sweeps the WARMUP (120 s + one buffer) of samples before its range for their adders only (pass "1": convert, sweep,
-            slice, no records kept), then its own range against that bitmap plus its own adders as it goes (pass "2"), and
-            ships the surviving records of every chunk as a packet (~45 bytes per 1000 samples, all the sweep-side statistics
-            included) to rank 0;
-  rank 0    continues its stream with the packets in range order (mgpu_walk_packets: the ordered walk and the message build
-            exactly as for its own chunks).
+**The form that ships (round 4; `ShardStreamRank`, `run_stream_protocol`, `demodulate_sharded_stream*`): every rank walks and
+builds its OWN range.**
+  1. the expiry schedule of the whole capture is derived up front: a pre-pass over the ~6 % of buffers an expiry can follow gives
+     every rank the clocks its share of the schedule needs (`expiry_windows`, `schedule_from_window_estimates`);
+  2. every rank puts two filter generations of warm-up + its range through the ordinary pipeline with that schedule IMPOSED
+     (`mgpu_shard_stream_begin / _mark / _end`): its messages and counters are final if the schedule and the filter state at its
+     seam were right;
+  3. rounds over (schedule, seam states) confirm or repair both (`protocol_round` = `mgpu_shard_round`, a fixed point: in practice
+     one round);
+  4. the ranges' messages are gathered on rank 0 as in config 4, the integer counters add up, and the two order-dependent double
+     sums (demod_2400.c:445-447, 474-479) are re-added exactly from per-block partial sums (`prepare_sum_blocks`,
+     `combine_ranges`, seqsum.cpp) — O(blocks) on the combining rank, 1.5 % of the unsharded time on the one-hour capture.
+The result is the unsharded message list and every counter, bit for bit (tests/test_gpu_shard.py, tests/test_shard_walk.py;
+the same protocol in C over RCCL: readsb_amd/host/readsb_gpu_shard.c).  With one rank this IS the unsharded pipeline.
 
-No collective but the gather of the packets.  The result is the unsharded message list and every counter, bit for bit.  With
-one rank this IS the unsharded pipeline.  With N ranks the GPU phase takes (1 + 120 s / range) / N of the unsharded time, and the
-walk + build of the other ranks' packets on rank 0 does not shrink (Amdahl: on dense bursts it is ~1.5x what the whole
-unsharded pipeline takes per sample, because there it hides behind the GPU) — sharding that walk across the ranks
-(`Resolver::parallel_walk` with ranks in place of threads) is what would make this scale.  (Round 2 swept every range twice and
-OR-ed the adder bitmaps of the whole capture over the ranks: twice the GPU work, and nothing overlapped.)
+The older forms: rounds 2-3 (the first part of this file: `run_shard_pass` / `rank_packets` / `demodulate_sharded[_local]`): ranks r > 0 sweep a 120 s warm-up for its adder addresses, then their range, and ship the surviving
+records as packets; rank 0 walks every range's packets in order (`mgpu_walk_packets`).  Exact as well, but the walk does not shrink
+with the number of ranks; and round 4's first cut (`ShardWalkRank`, `demodulate_sharded_walk*`: every rank walks its own range's
+PACKETS).  Both kept because bench.py --config5-form packets and the tests compare the forms with each other.
 
-`shard_ranges` / `run_shard_pass*` / `rank_packets` are the pieces; `demodulate_sharded_local` runs all shards in one process
-(tests, single GPU); `demodulate_sharded` is the torch.distributed version (one rank = one shard; `gloo` with host tensors or
-`nccl` with device tensors)."""
+`gloo` with host tensors or `nccl` (= RCCL) with device tensors for both."""
 import numpy as np
 
 from .binding import _FMT_BYTES, MSG_DTYPE
@@ -475,14 +476,23 @@ def _gather_and_combine(me, sched, n, fc, device, phases, stats, t0, concat=True
     world, rank = dist.get_world_size(), dist.get_rank()
     t1 = time.perf_counter()
     # ---- the ranges' results to rank 0 ----
-    import pickle
+    # wire form of a rank's small part: [messages: i64][struct mgpu_counters][noise terms: f64 ...] — fixed layouts, as in the C host
+    # (readsb_gpu_shard.c); a rank without a range sends the count alone
+    import ctypes as C
+    from .binding import Counters
+    ksz = C.sizeof(Counters)
+
+    def unpack_meta(m):
+        if len(m) <= 8:
+            return None, np.zeros(0)
+        return Counters.from_buffer_copy(m[8:8 + ksz]).as_dict(), np.frombuffer(m[8 + ksz:], dtype=np.float64)
     cnt = me.counters
     blob = b""
     if cnt is not None:
-        blob = pickle.dumps((cnt, me.noise.tobytes()))
+        blob = bytes(Counters.from_dict(cnt)) + np.ascontiguousarray(me.noise, dtype=np.float64).tobytes()
     metas = _all_gather_bytes(np.array([me.msgs.size], dtype=np.int64).tobytes() + blob, device)
     counts = [int(np.frombuffer(m[:8], dtype=np.int64)[0]) for m in metas]
-    earlier = [pickle.loads(m[8:])[0] if len(m) > 8 else None for m in metas[:rank]]
+    earlier = [unpack_meta(m)[0] for m in metas[:rank]]
     from .binding import SUM_BLOCK, SUM_BLOCK_DTYPE
     blocks = prepare_sum_blocks(me.msgs, earlier)                 # (every rank at once: its part of the sequential signal-power sum)
     rec, brec = MSG_DTYPE.itemsize, SUM_BLOCK_DTYPE.itemsize
@@ -507,8 +517,8 @@ def _gather_and_combine(me, sched, n, fc, device, phases, stats, t0, concat=True
         raw = raw.numpy() if raw.device.type == "cpu" else raw.cpu().numpy()      # (gloo: a view; RCCL: the D2H copy a host-side consumer needs anyway)
         msgs = raw[:counts[r] * rec].view(MSG_DTYPE)
         if len(metas[r]) > 8:
-            c, terms = pickle.loads(metas[r][8:])
-            parts.append((msgs, c, np.frombuffer(terms, dtype=np.float64), raw[counts[r] * rec:].view(SUM_BLOCK_DTYPE)))
+            c, terms = unpack_meta(metas[r])
+            parts.append((msgs, c, terms, raw[counts[r] * rec:].view(SUM_BLOCK_DTYPE)))
         else:
             parts.append((msgs, None, np.zeros(0)))
     res = combine_ranges(parts, n, len(sched) + (1 if fc == 1 else 0), stats, concat=concat)

@@ -14,7 +14,10 @@ static const char *g_prefix;
 static int g_nctx, g_finish;
 static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
 
-void mgpu_config_defaults(struct mgpu_config *cfg) { memset(cfg, 0, sizeof(*cfg)); cfg->nfix_crc = 1; cfg->fixDF = 1; cfg->preamble_threshold = 58; }
+#undef mgpu_config_defaults   /* (the header's macro: hosts call mgpu_config_defaults_abi) */
+static void config_defaults_(struct mgpu_config *cfg) { memset(cfg, 0, sizeof(*cfg)); cfg->abi_version = MGPU_ABI_VERSION; cfg->nfix_crc = 1; cfg->fixDF = 1; cfg->preamble_threshold = 58; }
+void mgpu_config_defaults(struct mgpu_config *cfg) { config_defaults_(cfg); }
+void mgpu_config_defaults_abi(struct mgpu_config *cfg, uint32_t struct_bytes, uint32_t abi_version) { (void) struct_bytes; config_defaults_(cfg); cfg->abi_version = abi_version; }
 int mgpu_device_count(void) { return 3; }
 int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     mgpu_ctx *c = calloc(1, sizeof(*c));

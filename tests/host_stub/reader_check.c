@@ -18,7 +18,10 @@ static FILE *g_out;
 static uint64_t g_feeds, g_samples, g_finish, g_reg, g_unreg, g_bad;
 static void *g_regptr[8];
 
-void mgpu_config_defaults(struct mgpu_config *cfg) { memset(cfg, 0, sizeof(*cfg)); cfg->buf_samples = 131072; cfg->trailing_samples = 326; }
+#undef mgpu_config_defaults   /* (the header's macro: hosts call mgpu_config_defaults_abi) */
+static void config_defaults_(struct mgpu_config *cfg) { memset(cfg, 0, sizeof(*cfg)); cfg->abi_version = MGPU_ABI_VERSION; cfg->buf_samples = 131072; cfg->trailing_samples = 326; }
+void mgpu_config_defaults(struct mgpu_config *cfg) { config_defaults_(cfg); }
+void mgpu_config_defaults_abi(struct mgpu_config *cfg, uint32_t struct_bytes, uint32_t abi_version) { (void) struct_bytes; config_defaults_(cfg); cfg->abi_version = abi_version; }
 int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     *out = calloc(1, sizeof(**out)); (*out)->format = cfg->format; (*out)->max_samples = cfg->max_samples; return MGPU_OK;
 }

@@ -45,6 +45,46 @@ def test_struct_sizes_match_the_c_header(built, tmp_path):
     assert sizes[1] == 64
 
 
+def test_abi_version_is_checked(built, tmp_path):
+    """mgpu_create refuses a config that names another header version (a host compiled against an older, shorter struct), and the
+    defaults macro a C host gets writes nothing behind the struct size it passes."""
+    import subprocess
+    import readsb_amd
+    from readsb_amd import binding
+    lib = readsb_amd.load_library()
+    lib.mgpu_abi_version.restype = C.c_uint32
+    header = open(os.path.join(helpers.ROOT, "include", "modes_gpu.h")).read()
+    version = int(re.search(r"#define MGPU_ABI_VERSION (\d+)", header).group(1))
+    assert lib.mgpu_abi_version() == version
+    cfg = binding.Config()
+    lib.mgpu_config_defaults(C.byref(cfg))
+    assert cfg.abi_version == version
+    cfg.abi_version = version - 1
+    ctx = C.c_void_p()
+    lib.mgpu_create.argtypes = [C.POINTER(binding.Config), C.POINTER(C.c_void_p)]
+    lib.mgpu_create.restype = C.c_int
+    assert lib.mgpu_create(C.byref(cfg), C.byref(ctx)) == -1 and not ctx.value            # MGPU_E_INVAL, before any device is looked for
+    cfg.abi_version = version
+    cfg.chunk_buffers = 1 << 20
+    assert lib.mgpu_create(C.byref(cfg), C.byref(ctx)) == -1 and not ctx.value
+    # a host whose struct ends 8 bytes earlier (round 3's): the bytes behind it stay untouched
+    lib.mgpu_config_defaults_abi.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    lib.mgpu_config_defaults_abi.restype = None
+    buf = (C.c_uint8 * (C.sizeof(binding.Config) + 8))(*([0xA5] * (C.sizeof(binding.Config) + 8)))
+    lib.mgpu_config_defaults_abi(buf, C.sizeof(binding.Config) - 8, 3)
+    assert bytes(buf[C.sizeof(binding.Config) - 8:]) == b"\xa5" * 16
+    # and the C form: the macro passes the compiling host's own size and version
+    src = tmp_path / "d.c"
+    src.write_text('#include <stdio.h>\n#include "modes_gpu.h"\nint main(void){struct mgpu_config c; mgpu_config_defaults(&c);'
+                   'printf("%u %u %u\\n", c.abi_version, (unsigned) MGPU_ABI_VERSION, mgpu_abi_version()); return 0;}\n')
+    exe = tmp_path / "d"
+    libdir = os.path.dirname(readsb_amd.lib_path())
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(helpers.ROOT, "include"), str(src), "-o", str(exe),
+                    "-L", libdir, "-l:" + os.path.basename(readsb_amd.lib_path()), "-Wl,-rpath," + libdir], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert out == [str(version)] * 3
+
+
 def test_no_cpu_fallback(built):
     """Without a GPU the product must fail loudly, never compute on the CPU."""
     import readsb_amd

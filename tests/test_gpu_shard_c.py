@@ -8,6 +8,7 @@ import ctypes as C
 import json
 import os
 import subprocess
+import uuid
 
 import numpy as np
 import pytest
@@ -55,13 +56,14 @@ def test_c_shard_gives_the_reference_stream_and_counters(built, tmp_path, world,
     base = [EXE, "--world", str(world), "--ifile", str(path), "--startup-time-ms", str(helpers.STARTUP_MS)] + opts
     out = tmp_path / "beast.bin"
     if world == 1:
-        r = subprocess.run(base + ["--rank", "0", "--id-file", str(tmp_path / "nccl.id"), "--out", str(out)], capture_output=True, text=True, timeout=600)
+        r = subprocess.run(base + ["--rank", "0", "--id-file", str(tmp_path / "nccl.id"), "--run-id", uuid.uuid4().hex[:12], "--out", str(out)], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
         line = r.stdout.strip().splitlines()[-1]
     else:
         tdir = tmp_path / "xfer"
         tdir.mkdir()
-        procs = [subprocess.Popen(base + ["--rank", str(k), "--file-transport", str(tdir)] + (["--out", str(out)] if k == 0 else []),
+        run_id = uuid.uuid4().hex[:12]                       # (the same on every rank, new for every run: stale files of another run are never read)
+        procs = [subprocess.Popen(base + ["--rank", str(k), "--file-transport", str(tdir), "--run-id", run_id] + (["--out", str(out)] if k == 0 else []),
                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for k in range(world)]
         outs = [p.communicate(timeout=900) for p in procs]
         for k, p in enumerate(procs):

@@ -1607,14 +1607,14 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
     if (nmsg) { const int rc = hold_behind_sweep(c, sl, job.slot, s2); if (rc != MGPU_OK) return rc; }
     if (nmsg)
         launch_stage_in(sl.h_msg_pos, sl.h_msg_limit, sl.h_msg_skip, sl.d_msg_pos, sl.d_msg_limit, sl.d_msg_skip, nmsg, s2);
-    if (nmsg && job.sig_late) {    // the accepted frames' signal powers, now that it is known which frames they are: first, the builder waits for them
-        // (the kernel stores the builder's copy itself: a hipMemcpyAsync from this thread contends with the fetcher's inside the runtime)
-        launch_msg_sig(sl.d_mag, sl.d_msg_pos, sl.d_msg_skip, nmsg, sl.d_msg_sig, job.h_msig, s2);
-        HIPCHK(c, hipEventRecord(job.ev_copied, s2));
-    }
-    if (nmsg)
+    // what the skip windows hid from the counters and — first, the builder waits for them — the accepted frames' signal powers, now
+    // that it is known which frames they are: one kernel since round 5 (the window's samples are the frame's).  The kernel stores the
+    // builder's copy itself: a hipMemcpyAsync from this thread contends with the fetcher's inside the runtime.
+    if (nmsg) {
         launch_window_stats(sl.d_mag, n, sl.thr, sl.d_class_final, sl.d_msg_pos, sl.d_msg_skip,
-                            sl.d_msg_limit, nmsg, sl.d_win_part, c->d_win, s2);
+                            sl.d_msg_limit, nmsg, sl.d_win_part, c->d_win, s2, job.sig_late ? sl.d_msg_sig : nullptr, job.sig_late ? job.h_msig : nullptr,
+                            job.sig_late ? job.ev_copied : nullptr);
+    }
     if (nmsg && c->device_msgs && job.feed >= 0) {
         // the accepted frames become message records on the device (kernels/build.inc), appended to the feed's device list
         FeedSlot &fs = c->feed[job.feed];

@@ -255,6 +255,7 @@ void launch_live_windows(const uint16_t *mag, uint64_t n, int thr, const uint32_
                          uint32_t buf_len, unsigned long long *out, hipStream_t s);
 void launch_window_stats(const uint16_t *mag, uint64_t n, int thr, const uint32_t *class_bitmap, const uint32_t *pos,
                          const uint16_t *skip, const uint32_t *limit, uint32_t nmsg, unsigned long long *part, unsigned long long *out,
-                         hipStream_t s);
+                         hipStream_t s, unsigned long long *sig_out = nullptr, unsigned long long *sig_host = nullptr,
+                         hipEvent_t ev_sig = nullptr);   // sig_out: also the frames' signal powers (k_msg_sig's form), sig_host: a second copy in page-locked host memory, ev_sig: recorded behind them
 
 }  // namespace mgpu

@@ -554,6 +554,34 @@ struct mgpu_fields {
 int mgpu_decode_fields(mgpu_ctx *ctx, const struct mgpu_msg *msgs, uint64_t n, struct mgpu_fields *out);
 int mgpu_decode_fields_device(mgpu_ctx *ctx, const struct mgpu_msg *d_msgs, uint64_t n, struct mgpu_fields *d_out);
 
+/* ---- first stage of the tracker + the forwarding rule --------------------------------------------------------
+ * What the reference decides about an accepted message before and around its position tracker, on the device, over the message
+ * list: address_reliable (track.c:1688-1693); whether trackUpdateFromMessage finds or creates the message's aircraft and counts it
+ * (track.c:1905-1966: aircraftGet / aircraftCreate for reliable addresses only, a->seen, the 45 s rule for the formats whose
+ * address is the CRC residue, a->messages++); and outputMessage's rule (net_io.c:5846-5849) over the batch drainMessageBuffer
+ * hands it (net_io.c:5924-5940: one sample buffer's messages, cut every 256, all updates before all outputs):
+ *     forwarded  <=>  (crc == 0 && correctedbits == 0)  ||  (mm->aircraft && mm->aircraft->messages > 1)  ||  Mode A/C
+ * (the beast and raw outputs additionally want correctedbits < 2, net_io.c:5863-5872: the caller's test, it needs nothing from here).
+ * The position tracker itself (cpr.c, the speed / range checks, track.c:423-745) stays on the host: when it judges a position
+ * message bad or duplicate it puts the aircraft's copy back, a->messages and a->seen with it (track.c:2625-2627), and it deletes
+ * aircraft without a reliable position after 5 silent minutes (track.c:2856-2880).  The gate carries both as BOUNDS per aircraft
+ * and answers "deferred" exactly where the bounds disagree — in practice inside an aircraft's first two messages only: 0.2 % of a
+ * 200-aircraft minute (tests/golden/gate_*.npz: every other verdict equals what the whole reference program forwarded).
+ *   verdict[i]: bits 0-1  MGPU_GATE_DROP / _FORWARD / _DEFER;  bit 2  address_reliable;  bit 3  mm->aircraft may be set;
+ *               bit 4  mm->aircraft is set for certain.
+ * msgs: the accepted messages in netUseMessage order (what mgpu_collect returns), WHOLE sample buffers per call, timestamps on the
+ * ifile grid (buffer = (timestamp - 772) / 5 / cfg.buf_samples).  The aircraft table (device memory, 1 GiB, allocated by the first
+ * call) lives from call to call until mgpu_track_gate_reset / mgpu_destroy. */
+#define MGPU_GATE_DROP     0
+#define MGPU_GATE_FORWARD  1
+#define MGPU_GATE_DEFER    2
+#define MGPU_GATE_ADDRESS_RELIABLE  4
+#define MGPU_GATE_AIRCRAFT_POSSIBLE 8
+#define MGPU_GATE_AIRCRAFT_CERTAIN  16
+int mgpu_track_gate(mgpu_ctx *ctx, const struct mgpu_msg *msgs, uint64_t n, uint8_t *verdict);                 /* host arrays; decodes the fields it needs itself */
+int mgpu_track_gate_device(mgpu_ctx *ctx, const struct mgpu_msg *d_msgs, const struct mgpu_fields *d_fields, uint64_t n, uint8_t *d_verdict);   /* everything in device memory */
+int mgpu_track_gate_reset(mgpu_ctx *ctx);
+
 /* ---- tables, for known-answer tests against crc.c --------------------------------- */
 
 /* These run on the host (they are how the device tables are built) and need no context. */

@@ -261,6 +261,9 @@ def load_library():
     lib.mgpu_set_message_buffer.argtypes = [vp, vp, u64]
     lib.mgpu_decode_fields.argtypes = [vp, vp, u64, vp]
     lib.mgpu_decode_fields_device.argtypes = [vp, vp, u64, vp]
+    lib.mgpu_track_gate.argtypes = [vp, vp, u64, vp]
+    lib.mgpu_track_gate_device.argtypes = [vp, vp, vp, u64, vp]
+    lib.mgpu_track_gate_reset.argtypes = [vp]
     lib.mgpu_beast_encode.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64)]
     lib.mgpu_beast_encode_device.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64)]
     lib.mgpu_shard_begin.argtypes = [vp, u64, vp, i32]
@@ -510,6 +513,22 @@ class Demodulator:
 
     def decode_fields_device(self, d_msgs_ptr, n, d_out_ptr):
         self._chk(self.lib.mgpu_decode_fields_device(self.ctx, C.c_void_p(d_msgs_ptr), n, C.c_void_p(d_out_ptr)), "mgpu_decode_fields_device")
+
+    def track_gate(self, msgs):
+        """First stage of the tracker + the forwarding rule on the GPU (include/modes_gpu.h): one verdict byte per message — bits 0-1
+        0 not forwarded / 1 forwarded / 2 deferred to the host's tracker.  msgs: accepted messages in order, whole sample buffers
+        per call; the aircraft table lives on the device from call to call (track_gate_reset)."""
+        msgs = np.ascontiguousarray(msgs)
+        assert msgs.dtype == MSG_DTYPE
+        out = np.empty(len(msgs), dtype=np.uint8)
+        self._chk(self.lib.mgpu_track_gate(self.ctx, C.c_void_p(msgs.ctypes.data), len(msgs), C.c_void_p(out.ctypes.data)), "mgpu_track_gate")
+        return out
+
+    def track_gate_device(self, d_msgs_ptr, d_fields_ptr, n, d_verdict_ptr):
+        self._chk(self.lib.mgpu_track_gate_device(self.ctx, C.c_void_p(d_msgs_ptr), C.c_void_p(d_fields_ptr), n, C.c_void_p(d_verdict_ptr)), "mgpu_track_gate_device")
+
+    def track_gate_reset(self):
+        self._chk(self.lib.mgpu_track_gate_reset(self.ctx), "mgpu_track_gate_reset")
 
     def beast_encode(self, msgs):
         """Beast wire stream (bytes) of a record array (host memory in, host memory out, encoded on the GPU)."""

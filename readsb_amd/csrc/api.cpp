@@ -389,6 +389,10 @@ struct mgpu_ctx {
     mgpu_fields *d_fields = nullptr;
     uint64_t fields_cap = 0;
     double *d_roll_tan = nullptr;                             // tables.h build_roll_tangent_table(), uploaded on first use
+    // the first-stage tracking gate (kernels/gate.inc): the aircraft table (1 GiB, allocated and zeroed by the first call), its scratch
+    void *d_gate_table = nullptr, *d_gate_scratch = nullptr;
+    uint8_t *d_gate_verdict = nullptr;
+    uint64_t gate_cap = 0;
     uint32_t *d_beast_blocks = nullptr;
     unsigned long long *d_beast_total = nullptr;
     uint64_t beast_cap_msgs = 0, beast_cap_in = 0, beast_cap_out = 0;
@@ -1021,7 +1025,7 @@ void mgpu_destroy(mgpu_ctx *c) {
     }
     for (hipEvent_t e : c->ev_iq_read)
         if (e) (void) hipEventDestroy(e);
-    void *dev[] = {c->d_roll_tan, c->d_fields, c->d_beast_off, c->d_beast_len, c->d_beast_in, c->d_beast_out, c->d_beast_blocks, c->d_beast_total, c->d_hist, c->d_hist_iq, c->d_hist_sums, c->d_iq, c->d_win, c->d_adder_bitmap, c->d_bit_syndrome, c->d_group_syndrome, c->d_parity,
+    void *dev[] = {c->d_gate_table, c->d_gate_scratch, c->d_gate_verdict, c->d_roll_tan, c->d_fields, c->d_beast_off, c->d_beast_len, c->d_beast_in, c->d_beast_out, c->d_beast_blocks, c->d_beast_total, c->d_hist, c->d_hist_iq, c->d_hist_sums, c->d_iq, c->d_win, c->d_adder_bitmap, c->d_bit_syndrome, c->d_group_syndrome, c->d_parity,
                    c->d_tab_long, c->d_tab_short, c->d_uc8_folded};
     for (void *p : dev)
         if (p) (void) hipFree(p);
@@ -3051,6 +3055,75 @@ int mgpu_decode_fields(mgpu_ctx *c, const struct mgpu_msg *msgs, uint64_t n, str
     launch_decode_fields((const mgpu_msg *) c->d_beast_in, n, c->d_fields, c->d_roll_tan, c->stream);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(out, c->d_fields, n * sizeof(mgpu_fields), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MGPU_OK;
+}
+
+// ---- first stage of the tracker + forwarding rule (track.c:1688-1693, 1905-1966; net_io.c:5846-5849, 5924-5940), kernels/gate.inc ----
+
+static int gate_reserve(mgpu_ctx *c, uint64_t n) {
+    if (!c->d_gate_table) {
+        HIPCHK(c, hipMalloc(&c->d_gate_table, gate_table_bytes()));
+        HIPCHK(c, hipMemsetAsync(c->d_gate_table, 0, gate_table_bytes(), c->stream));
+    }
+    if (n > c->gate_cap) {
+        if (c->d_gate_scratch) (void) hipFree(c->d_gate_scratch);
+        if (c->d_gate_verdict) (void) hipFree(c->d_gate_verdict);
+        c->d_gate_scratch = nullptr; c->d_gate_verdict = nullptr; c->gate_cap = 0;
+        const uint64_t want = n + n / 4 + 1024;
+        HIPCHK(c, hipMalloc(&c->d_gate_scratch, gate_scratch_bytes(want)));
+        HIPCHK(c, hipMalloc(&c->d_gate_verdict, want));
+        c->gate_cap = want;
+    }
+    return MGPU_OK;
+}
+
+int mgpu_track_gate_reset(mgpu_ctx *c) {
+    if (!c) return MGPU_E_INVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (c->d_gate_table) {
+        HIPCHK(c, hipMemsetAsync(c->d_gate_table, 0, gate_table_bytes(), c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return MGPU_OK;
+}
+
+int mgpu_track_gate_device(mgpu_ctx *c, const struct mgpu_msg *d_msgs, const struct mgpu_fields *d_fields, uint64_t n, uint8_t *d_verdict) {
+    if (!c || (n && (!d_msgs || !d_fields || !d_verdict)) || n > 0xffffffffull) return MGPU_E_INVAL;
+    if (n == 0) return MGPU_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (int rc = gate_reserve(c, n)) return rc;
+    launch_track_gate(d_msgs, d_fields, n, c->cfg.buf_samples, c->d_gate_table, c->d_gate_scratch, d_verdict, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MGPU_OK;
+}
+
+int mgpu_track_gate(mgpu_ctx *c, const struct mgpu_msg *msgs, uint64_t n, uint8_t *verdict) {
+    if (!c || (n && (!msgs || !verdict)) || n > 0xffffffffull) return MGPU_E_INVAL;
+    if (n == 0) return MGPU_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (n * sizeof(mgpu_msg) > c->beast_cap_in) {
+        if (c->d_beast_in) (void) hipFree(c->d_beast_in);
+        c->d_beast_in = nullptr; c->beast_cap_in = 0;
+        const uint64_t want = (n + n / 4 + 1024) * sizeof(mgpu_msg);
+        HIPCHK(c, hipMalloc(&c->d_beast_in, want));
+        c->beast_cap_in = want;
+    }
+    if (n > c->fields_cap) {
+        if (c->d_fields) (void) hipFree(c->d_fields);
+        c->d_fields = nullptr; c->fields_cap = 0;
+        const uint64_t want = n + n / 4 + 1024;
+        HIPCHK(c, hipMalloc(&c->d_fields, want * sizeof(mgpu_fields)));
+        c->fields_cap = want;
+    }
+    if (int rc = fields_tables(c)) return rc;
+    if (int rc = gate_reserve(c, n)) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_beast_in, msgs, n * sizeof(mgpu_msg), hipMemcpyHostToDevice, c->stream));
+    launch_decode_fields((const mgpu_msg *) c->d_beast_in, n, c->d_fields, c->d_roll_tan, c->stream);
+    launch_track_gate((const mgpu_msg *) c->d_beast_in, c->d_fields, n, c->cfg.buf_samples, c->d_gate_table, c->d_gate_scratch, c->d_gate_verdict, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(verdict, c->d_gate_verdict, n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MGPU_OK;
 }

@@ -196,6 +196,12 @@ void launch_modeac_scan(const uint16_t *mag, uint64_t n, uint32_t buf_samples, c
 void launch_decode_fields(const mgpu_msg *msgs, uint64_t n, mgpu_fields *out, const double *roll_tan, hipStream_t s);
 void launch_beast_encode(const mgpu_msg *msgs, uint64_t n, uint16_t *meta, uint32_t *block_bytes, unsigned long long *block_off, uint8_t *out,
                          uint64_t cap, unsigned long long *total, hipStream_t s);
+// first stage of the tracker + the forwarding rule over a message list in device memory (kernels/gate.inc): table = gate_table_bytes()
+// bytes, zeroed once and kept from call to call; scratch = gate_scratch_bytes(n); verdict: one byte per message (include/modes_gpu.h)
+size_t gate_table_bytes();
+size_t gate_scratch_bytes(uint64_t n);
+void launch_track_gate(const mgpu_msg *msgs, const mgpu_fields *fields, uint64_t n, uint32_t buf_samples, void *table, void *scratch,
+                       uint8_t *verdict, hipStream_t s);
 // signal power of accepted messages: sum of mag^2 over d_mag[pos+19 .. pos+19+len)
 void launch_signal_power(const uint16_t *mag, const uint32_t *pos, const uint16_t *len, uint32_t nmsg,
                          unsigned long long *out, hipStream_t s);

@@ -133,5 +133,6 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 #endif
 #include "kernels/beast.inc"
 #include "kernels/fields.inc"
+#include "kernels/gate.inc"
 
 }  // namespace mgpu

@@ -42,8 +42,8 @@ SWEEP_BYTES_PER_SAMPLE = 2.0   # k_preamble_sweep reads one u16 m
 # VALU issue rate measured on this chip (tools/micro/valu_issue.hip, profiles/r02_valu_issue.txt): three-operand / packed /
 # dot2 instructions — what these kernels are made of — sustain 36 T lane-ops/s chip-wide (v_add/v_xor: ~60)
 VALU_PEAK_TLANEOPS = 37.3
-PMC_SQ_SUMMARY = os.path.join(ROOT, "profiles", "r04_pmc_sq_summary.txt")
-PMC_HBM = os.path.join(ROOT, "profiles", "r04_pmc_hbm.json")
+PMC_SQ_SUMMARY = os.path.join(ROOT, "profiles", "r05_pmc_sq_summary.txt")
+PMC_HBM = os.path.join(ROOT, "profiles", "r05_pmc_hbm.json")
 
 
 # the launch the committed PMC / SQ summaries were collected on: one default chunk (1024 buffers = 134 217 728 samples) of UC8 magnitudes

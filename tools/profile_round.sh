@@ -5,7 +5,7 @@
 #   usage: tools/profile_round.sh <tag>
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-tag=${1:-r04}
+tag=${1:-r05}
 out=$R/gpurun_out/$tag
 mkdir -p $out
 cd /tmp
@@ -23,7 +23,7 @@ sha=$(python -c "import bench; print(bench.kernel_source_sha())")
 python tools/pmc_summary.py $(find $out/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $out/pmc_write -name "*counter_collection.csv" | head -1) $out/pmc_hbm.json $sha > /dev/null 2> $out/pmc_hbm.err
 timeout 400 python bench.py --steps 20 --warmup 3 > $out/bench_plain.log 2>&1
 # the micro harnesses (make -C tools micro): k_sweep alone over a cold > 1 GiB array (and its stages), instruction issue rates, atomics; k_slice's parts
-for v in "" _s1 _s2 _s3; do timeout 120 tools/micro/sweep_cold$v 1024 5 4 > $out/sweep_cold$v.json 2> $out/sweep_cold$v.err; done
+for v in "" _s1 _s2 _s3 _d0 _b1 _b4; do timeout 120 tools/micro/sweep_cold$v 1024 5 4 > $out/sweep_cold$v.json 2> $out/sweep_cold$v.err; done   # _d0: generation 6 (contiguous ranges, no dealer); _b1 / _b4: dealt blocks of 1 / 4 steps
 timeout 120 tools/micro/sweep_cold 1024 5 4 0 2000 0 0 0 > $out/sweep_cold_unpaced.json 2>/dev/null
 timeout 120 tools/micro/valu_issue $out/valu_issue.json > $out/valu_issue.txt 2>&1
 timeout 120 tools/micro/atomic_cost > $out/atomic_cost.txt 2>&1
@@ -32,5 +32,7 @@ tail -1 $out/bench_plain.log | cut -c1-3000
 cat $out/stats/bench_kernel_stats.csv | cut -c1-120
 cat $out/pmc_hbm.json | head -40
 for i in 0 1; do tail -1 $out/extra$i.log | cut -c1-600; cut -c1-110 $out/stats_extra$i/extra_kernel_stats.csv | head -8; done
-for v in "" _s1 _s2 _s3 _unpaced; do echo "sweep_cold$v: $(cut -c1-400 $out/sweep_cold$v.json)"; done
+for v in "" _s1 _s2 _s3 _d0 _b1 _b4 _unpaced; do echo "sweep_cold$v: $(cut -c1-400 $out/sweep_cold$v.json)"; done
 tail -12 $out/valu_issue.txt; tail -8 $out/atomic_cost.txt; cat $out/slice_stages.txt
+# the whole GPU suite on the code that was profiled
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -5 > $out/gpu_suite_tail.txt; cat $out/gpu_suite_tail.txt

@@ -382,9 +382,13 @@ int mgpu_shard_noise_terms(mgpu_ctx *ctx, const double **terms, uint64_t *n);   
 /* The same rank with its pass through the ORDINARY pipeline — ordered walk and message build overlapped with the kernels, as for any
  * stream — for when the schedule is known before the pass (shard.py derives it from a pre-pass over the few buffers around every
  * expiry's possible positions):  mgpu_shard_stream_begin (resets the context; first_sample = the warm-up's first sample, or own_first
- * with start_state) | mgpu_feed_iq*(warm-up), synchronous | mgpu_shard_stream_mark (the warm-up's messages and statistics are dropped,
- * the state at own_first kept, clocks logged from here) | mgpu_feed_iq*(range) with mgpu_collect as for any stream, deferred feeds
- * allowed | mgpu_shard_stream_end -> the range's true end clocks; states by mgpu_shard_state, noise terms by mgpu_shard_noise_terms.
+ * with start_state) | mgpu_feed_iq*(warm-up) | mgpu_shard_stream_mark (the state at own_first is kept, clocks are logged from
+ * there; the warm-up leaves no messages and no statistics) | mgpu_feed_iq*(range) with mgpu_collect as for any stream |
+ * mgpu_shard_stream_end -> the range's true end clocks; states by mgpu_shard_state, noise terms by mgpu_shard_noise_terms.
+ * Synchronous or DEFERRED feeds (mgpu_set_deferred before _begin): with deferred feeds nothing waits at the mark — the walker marks
+ * the range's begin itself when it reaches the range's first chunk, and the range's kernels run while the warm-up is still being
+ * walked (one pipeline fill and drain per pass instead of two); every feed call still has its own message list to be collected,
+ * the warm-up's are empty.
  * The rounds that follow are those of mgpu_shard_walk; a rank whose premise failed runs its pass again. */
 struct mgpu_shard_stream_args {
     uint64_t first_sample;       /* where the pass starts (a multiple of buf_samples) */

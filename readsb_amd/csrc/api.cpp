@@ -369,6 +369,7 @@ struct mgpu_ctx {
     bool shard_noise_on = false;                              // a rank's pass through the ordinary pipeline (mgpu_shard_stream_*): the builder logs every buffer's noise term
     uint64_t shard_stream_own_first = 0;
     bool shard_stream = false, shard_stream_cold = false;
+    bool shard_marked = false;                                // ... the range has begun for the walker (shard_mark_now): with deferred feeds the walker gets there on its own
     // beast encoder scratch (mgpu_beast_encode*): grown on demand
     uint16_t *d_beast_len = nullptr;        // per message: frame length | signal byte << 8
     uint8_t *d_beast_in = nullptr, *d_beast_out = nullptr;
@@ -1346,10 +1347,12 @@ static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
     if (job.fsum_idx < 0) job.fsums.assign(sl.h_fsums, sl.h_fsums + 2 * c->cap_buffers);
     // ---- counters that do not depend on the skip windows ----
     const unsigned long long *hc = sl.h_counters;
-    c->feed_cand[0] += hc[CNT_CANDIDATES];
-    for (int i = 0; i < 5; ++i) c->feed_cand[1 + i] += hc[CNT_PHASE0 + i];
-    c->feed_cand[6] += hc[CNT_CLASS_COND];
-    c->feed_cand[7] += hc[CNT_CLASS_UNCOND];
+    if (!(c->shard_stream && job.stream_pos < c->shard_stream_own_first)) {   // (a rank's warm-up is walked for the filter's state only: its statistics are nobody's)
+        c->feed_cand[0] += hc[CNT_CANDIDATES];
+        for (int i = 0; i < 5; ++i) c->feed_cand[1 + i] += hc[CNT_PHASE0 + i];
+        c->feed_cand[6] += hc[CNT_CLASS_COND];
+        c->feed_cand[7] += hc[CNT_CLASS_UNCOND];
+    }
     c->acc.n_candidates += hc[CNT_CANDIDATES];
     c->acc.n_records += hc[CNT_RECORDS];
     c->acc.n_live_records += nlive;
@@ -1568,9 +1571,14 @@ static int hold_behind_sweep(mgpu_ctx *c, const Slot &sl, int slot_idx, hipStrea
 }
 
 // ---- part 2 (walker thread): the ordered accept walk, then the window statistics of what it hid ----
+static void shard_mark_now(mgpu_ctx *c);
 static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
     const uint64_t n = sl.n;
     const uint64_t nlive = job.nlive;
+    // a rank's pass through the pipeline (mgpu_shard_stream_*): the range begins with this chunk — or this chunk is still warm-up,
+    // walked for the filter's state only: no statistics, nothing behind the walk
+    if (c->shard_stream && !c->shard_marked && job.stream_pos >= c->shard_stream_own_first) shard_mark_now(c);
+    const bool warmup = c->shard_stream && job.stream_pos < c->shard_stream_own_first;
     const double t_res0 = wall_ms();
     const uint64_t aux_cap = nlive + 1 < c->cap_msgs ? nlive + 1 : c->cap_msgs;
     job.pos.resize(aux_cap); c->w_limit.resize(aux_cap); c->w_skip.resize(aux_cap);
@@ -1603,8 +1611,8 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
     c->acc.resolve_ms += (float) (wall_ms() - t_res0);
     if (c->dbg_print) fprintf(stderr, "dbg: walk %.3f ms for %llu live records -> %lld msgs\n", wall_ms() - t_res0, (unsigned long long) nlive, (long long) wn);
     if (wn < 0) { c->err = "max_messages exceeded"; return MGPU_E_OVERFLOW; }
-    const uint32_t nmsg = (uint32_t) wn;
-    c->feed_rc.add(job.rc);
+    const uint32_t nmsg = warmup ? 0u : (uint32_t) wn;      // (warm-up: the builder skips the job, nobody wants its windows or signal powers)
+    if (!warmup) c->feed_rc.add(job.rc);
 #if MGPU_EXPERIMENTS
     if (wk_running) { const int rc = device_walk_compare(c, sl, job, nmsg); if (rc != MGPU_OK) return rc; }
 #endif
@@ -2912,18 +2920,16 @@ int mgpu_shard_stream_begin(mgpu_ctx *c, const struct mgpu_shard_stream_args *a)
     else { res.reset_empty(c->cfg.startup_time_ms); c->shard_stream_cold = true; }
     res.set_schedule(c->shard_sched.data(), c->shard_sched.size());
     c->shard_stream = true;
+    c->shard_marked = false;
+    c->shard_noise_on = true;                                  // (the builder skips the warm-up's chunks altogether: only the range's buffers log a term)
     c->shard_stream_own_first = a->own_first;
     c->shard_out.clocks.clear(); c->shard_out.state_first.clear(); c->shard_out.state_end.clear();
     c->shard_noise.clear();
     return MGPU_OK;
 }
 
-int mgpu_shard_stream_mark(mgpu_ctx *c) {
-    if (!c || !c->shard_stream) return MGPU_E_INVAL;
-    { const int rc = drain(c); if (rc != MGPU_OK) return rc; }
-    if (c->deferred || c->stream_pos != c->shard_stream_own_first) { c->err = "mgpu_shard_stream_mark: after the warm-up's (synchronous) feeds, at the range's first sample"; return MGPU_E_INVAL; }
-    c->pending.clear();                                        // the warm-up's messages and statistics are nobody's
-    std::memset(&c->counters, 0, sizeof(c->counters));
+// What the walker does when the range begins (in stream order: behind the warm-up's last chunk, ahead of the range's first).
+static void shard_mark_now(mgpu_ctx *c) {
     Resolver &res = c->resolver;
     if (c->shard_stream_cold) {                                // the expiries before the range, counted from the schedule
         const int64_t ts0 = (int64_t) c->shard_stream_own_first * 5;
@@ -2932,7 +2938,22 @@ int mgpu_shard_stream_mark(mgpu_ctx *c) {
     }
     res.export_state(c->shard_out.state_first);
     res.log_end_clocks(&c->shard_out.clocks);
-    c->shard_noise_on = true;
+    c->shard_marked = true;
+}
+
+// Between the warm-up's feeds and the range's.  Synchronous feeds: the warm-up has been walked, the range begins here.  Deferred
+// feeds (round 5): nothing waits — the warm-up's chunks may still be anywhere in the pipeline, the walker marks the range's begin
+// itself when it gets to its first chunk (walk_job), and the range's kernels run while the warm-up is still being walked.  The
+// warm-up's statistics are kept out of every accumulator chunk by chunk (fetch_slot, walk_job, build_job), so one accounting
+// period covers the whole pass.
+int mgpu_shard_stream_mark(mgpu_ctx *c) {
+    if (!c || !c->shard_stream) return MGPU_E_INVAL;
+    if (c->stream_pos != c->shard_stream_own_first) { c->err = "mgpu_shard_stream_mark: behind the warm-up's feeds, at the range's first sample"; return MGPU_E_INVAL; }
+    if (c->deferred) return MGPU_OK;
+    { const int rc = drain(c); if (rc != MGPU_OK) return rc; }
+    c->pending.clear();                                        // (the warm-up leaves no messages and no statistics; nflips is set at the end)
+    std::memset(&c->counters, 0, sizeof(c->counters));
+    if (!c->shard_marked) shard_mark_now(c);
     return MGPU_OK;
 }
 
@@ -2940,6 +2961,7 @@ int mgpu_shard_stream_end(mgpu_ctx *c, int64_t *end_clocks, uint64_t cap, uint64
     if (!c || !c->shard_stream || !end_clocks || !n_out) return MGPU_E_INVAL;
     *n_out = 0;
     { const int rc = drain(c); if (rc != MGPU_OK) return rc; }
+    if (!c->shard_marked) shard_mark_now(c);                   // (an empty range: no chunk of it ever reached the walker)
     c->resolver.log_end_clocks(nullptr);
     c->shard_noise_on = false;
     c->resolver.export_state(c->shard_out.state_end);

@@ -636,18 +636,36 @@ class ShardStreamRank(ShardWalkRank):
         t0 = time.perf_counter()
         d = self.d
         start = self.first if self.import_state is not None else self.ws
-        d.shard_stream_begin(start, self.src.history(start), self.first, sched_ts, self.import_state)
-        self.src.feed(start, self.first)                         # the warm-up (nothing with an imported state)
-        d.shard_stream_mark()
-        d.set_message_buffer(self.out)
-        self.src.feed(self.first, self.last)
-        self.result = d.shard_stream_end(self.nbuf)
-        self.used = key
-        self.walks += 1
-        self._lap("stream_pass", t0)
-        t0 = time.perf_counter()
-        self.msgs, self.counters = d.collect(out=self.out) if self.out is not None else d.collect()
-        self.noise = d.shard_noise_terms()
+        cap = int(d.cfg.max_samples)
+        cap -= cap % BUF
+        # Warm-up and range as DEFERRED feeds when each is one feed call (round 5): the range's kernels run while the warm-up is
+        # still being walked, the walker marks the range's begin itself (mgpu_shard_stream_mark then waits for nothing) — one
+        # pipeline fill and drain per pass instead of two.  Otherwise the synchronous form.
+        deferred = self.out is not None and (self.first - start) <= cap and (self.last - self.first) <= cap
+        if deferred:
+            d.set_deferred(True)
+        try:
+            d.shard_stream_begin(start, self.src.history(start), self.first, sched_ts, self.import_state)
+            self.src.feed(start, self.first)                     # the warm-up (nothing with an imported state)
+            d.shard_stream_mark()
+            d.set_message_buffer(self.out)
+            self.src.feed(self.first, self.last)
+            self.result = d.shard_stream_end(self.nbuf)
+            self.used = key
+            self.walks += 1
+            self._lap("stream_pass", t0)
+            t0 = time.perf_counter()
+            if deferred:
+                if self.first > start:
+                    d.collect_feed(self.out[:0])                 # the warm-up's feed: no messages
+                self.msgs, self.counters = d.collect_feed(self.out, want_counters=True)
+            else:
+                self.msgs, self.counters = d.collect(out=self.out) if self.out is not None else d.collect()
+            self.noise = d.shard_noise_terms()
+        finally:
+            if deferred:
+                d.set_message_buffer(None)
+                d.set_deferred(False)
         self._lap("collect", t0)
         return self.result
 
@@ -694,12 +712,14 @@ def run_stream_protocol(ranks, exchange, nsamples, startup_ms, filter_clock=0, s
                 r.import_state = imports[r.rank]
 
 
-def demodulate_sharded_stream_local(d, iq, nshards, stats=None):
-    """All ranks of the stream form played by ONE Demodulator, one after the other (tests, single GPU)."""
+def demodulate_sharded_stream_local(d, iq, nshards, stats=None, out_capacity=None):
+    """All ranks of the stream form played by ONE Demodulator, one after the other (tests, single GPU).  out_capacity: every rank
+    builds its messages into an array of its own of that many records (what a rank of demodulate_sharded_stream does with `out`) —
+    and, where warm-up and range are one feed call each, passes through the pipeline with deferred feeds."""
     iq = np.ascontiguousarray(iq).view(np.uint8).reshape(-1)
     n = iq.size // _FMT_BYTES[d.fmt]
     src = _Source(d, iq=iq)
-    ranks = [ShardStreamRank(d, r, nshards, n, src) for r in range(nshards)]
+    ranks = [ShardStreamRank(d, r, nshards, n, src, out=None if out_capacity is None else np.empty(int(out_capacity), dtype=MSG_DTYPE)) for r in range(nshards)]
     startup, fc = int(d.cfg.startup_time_ms), int(d.cfg.filter_clock)
     sched = run_stream_protocol(ranks, lambda payloads: payloads, n, startup, fc, stats=stats)
     if stats is not None:

@@ -58,19 +58,23 @@ def test_sharded_walk_equals_unsharded(built, nshards, seconds, dense, rate, nfi
         assert stats["rounds"] == 1 and not any(stats["imported"])  # every warm-up reaches back to the start: one walk per rank
 
 
-@pytest.mark.parametrize("nshards,seconds,dense,rate,nfix,naircraft", [(2, 8.0, 1, 8000.0, 2, 200), (8, 70.0, 1, 6000.0, 1, 200), (2, 290.0, 0, 1500.0, 1, 200),
-                                                                       (3, 400.0, 0, 1200.0, 1, 3000)])
-def test_sharded_stream_equals_unsharded(built, nshards, seconds, dense, rate, nfix, naircraft):
+@pytest.mark.parametrize("nshards,seconds,dense,rate,nfix,naircraft,deferred", [(2, 8.0, 1, 8000.0, 2, 200, False), (8, 70.0, 1, 6000.0, 1, 200, False),
+                                                                                (2, 290.0, 0, 1500.0, 1, 200, False), (3, 400.0, 0, 1200.0, 1, 3000, False),
+                                                                                # round 5: warm-up and range as deferred feeds, the walker marks the range's begin itself
+                                                                                (8, 70.0, 1, 6000.0, 1, 200, True), (2, 290.0, 0, 1500.0, 1, 200, True),
+                                                                                (3, 400.0, 0, 1200.0, 1, 3000, True)])
+def test_sharded_stream_equals_unsharded(built, nshards, seconds, dense, rate, nfix, naircraft, deferred):
     """... and the form whose walk and build overlap the kernels: the schedule from a pre-pass over the buffers an expiry can follow
     (shard.expiry_windows), every rank's warm-up + range through the ordinary pipeline (mgpu_shard_stream_*)."""
     import readsb_amd
     from readsb_amd import shard
     iq = helpers.synth(seconds=seconds, seed=2900 + nshards + int(seconds), rate=rate, dense=dense, naircraft=naircraft, threads=16)
     want, wst = helpers.ref_run(iq, 0, nfix, 1, 58) if helpers.have_ref() else helpers.oracle_run(iq, 0, nfix, 1, 58)
-    d = readsb_amd.Demodulator(nfix_crc=nfix, startup_time_ms=helpers.STARTUP_MS, max_samples=256 * 131072)
+    # (deferred: a feed call must hold a whole warm-up — up to 120 s + a buffer — or a whole range)
+    d = readsb_amd.Demodulator(nfix_crc=nfix, startup_time_ms=helpers.STARTUP_MS, max_samples=(4096 if deferred else 256) * 131072)
     stats = {}
     try:
-        got, cnt = shard.demodulate_sharded_stream_local(d, iq, nshards, stats)
+        got, cnt = shard.demodulate_sharded_stream_local(d, iq, nshards, stats, out_capacity=len(want) + 4096 if deferred else None)
     finally:
         d.close()
     assert len(want) > 5000

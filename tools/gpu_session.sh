@@ -1,13 +1,12 @@
 #!/bin/bash
 cd /root/repo
-out=gpurun_out/r05k; mkdir -p $out
-timeout 900 python bench.py --config 5 --emulate-ranks 8 --samples 8640000000 --steps 3 --warmup 1 > $out/c5_hour_cpu.json 2> $out/c5_hour_cpu.err
-tail -1 $out/c5_hour_cpu.json | python3 -c "
+out=gpurun_out/r05l; mkdir -p $out
+MGPU_LIBRARY=libmodes_gpu_cv2.so timeout 300 python -m pytest tests/test_gpu_convert.py tests/test_gpu_parity.py -x -q 2>&1 | tail -3
+summ() { tail -1 $1 | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.readline())
-e=d['emulated_ranks']
-print('value', d['value'], 'ms/step', d['ms_per_step'])
-print('per rank', e['per_rank_ms'])
-print('critical', e['rank_critical_path_ms'], 'projected', e['projected_ms_without_communication'], e['projected_speedup_without_communication'], 'identical', e['identical_to_unsharded'], 'rank0 serial', e['rank0_serial_total_ms'])
-print(d.get('cpu_baseline'))"
-tail -3 $out/c5_hour_cpu.err
+print('$1', 'value', d['value'], 'ms/step', d['ms_per_step'], d.get('stage_ms'))"; }
+for i in 1 2; do
+timeout 300 python bench.py --steps 20 --warmup 5 --no-extra-configs --no-cpu-baseline > $out/base$i.log 2>/dev/null; summ $out/base$i.log
+MGPU_LIBRARY=libmodes_gpu_cv2.so timeout 300 python bench.py --steps 20 --warmup 5 --no-extra-configs --no-cpu-baseline > $out/cv2_$i.log 2>/dev/null; summ $out/cv2_$i.log
+done

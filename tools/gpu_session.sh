@@ -1,12 +1,11 @@
 #!/bin/bash
 cd /root/repo
-out=gpurun_out/r05l; mkdir -p $out
-MGPU_LIBRARY=libmodes_gpu_cv2.so timeout 300 python -m pytest tests/test_gpu_convert.py tests/test_gpu_parity.py -x -q 2>&1 | tail -3
-summ() { tail -1 $1 | python3 -c "
-import json,sys
-d=json.loads(sys.stdin.readline())
-print('$1', 'value', d['value'], 'ms/step', d['ms_per_step'], d.get('stage_ms'))"; }
-for i in 1 2; do
-timeout 300 python bench.py --steps 20 --warmup 5 --no-extra-configs --no-cpu-baseline > $out/base$i.log 2>/dev/null; summ $out/base$i.log
-MGPU_LIBRARY=libmodes_gpu_cv2.so timeout 300 python bench.py --steps 20 --warmup 5 --no-extra-configs --no-cpu-baseline > $out/cv2_$i.log 2>/dev/null; summ $out/cv2_$i.log
-done
+out=gpurun_out/r05m; mkdir -p $out
+export TMPDIR=/tmp
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/$out/stats -o gate -- python /root/repo/tools/bench_gate.py > /root/repo/$out/bench_gate.txt 2> /root/repo/$out/bench_gate.err )
+cat $out/bench_gate.txt; tail -3 $out/bench_gate.err
+python3 - <<'PY'
+import csv
+for r in csv.DictReader(open('/root/repo/gpurun_out/r05m/stats/gate_kernel_stats.csv')):
+    if 'gate' in r['Name']: print(r['Name'][:50].ljust(50), r['Calls'].rjust(4), ('%.1f'%(float(r['AverageNs'])/1e3)).rjust(9), ('%.1f'%(float(r['MaxNs'])/1e3)).rjust(9))
+PY

@@ -439,6 +439,30 @@ static void stage_wait(mgpu_ctx *c, std::unique_lock<std::mutex> &lk, Pred pred)
     }
 }
 
+// Waiting for the GPU on a stage thread.  hipEventSynchronize / hipStreamSynchronize spin for a short while and then go to sleep on an
+// interrupt; on the pool's (shared, loaded) hosts the wake-up came back ~1.0 ms later, every time — and the pipeline has two steady
+// states: when the builder reaches its wait for a chunk's signal powers a little early it sleeps, is 1 ms late for the next chunk
+// too, and the step takes 3-14 ms instead of 1.5 (3 of 14 back-to-back benchmark runs, gpurun r05o: "build_host" 14 ms per step,
+// every stage and kernel as fast as ever — round 4's unexplained "a single host stage now and then runs 2-4 x slower").  The stage
+// threads poll for their jobs anyway, so they poll for the GPU as well: hipEventQuery / hipStreamQuery read the
+// completion signal in memory, no system call, ~2 us between looks.
+static hipError_t wait_event_spin(hipEvent_t ev) {
+    for (unsigned spin = 0;; ++spin) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        for (int k = 0; k < 128; ++k) __builtin_ia32_pause();
+        if ((spin & 1023) == 1023) sched_yield();
+    }
+}
+static hipError_t wait_stream_spin(hipStream_t s) {
+    for (unsigned spin = 0;; ++spin) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e != hipErrorNotReady) return e;
+        for (int k = 0; k < 128; ++k) __builtin_ia32_pause();
+        if ((spin & 1023) == 1023) sched_yield();
+    }
+}
+
 static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next);
 static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job);
 static int build_job(mgpu_ctx *c, HostJob &job);
@@ -916,6 +940,9 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     // kernels fill what the main stream leaves, they are not to take its slots
     int prio_least = 0, prio_greatest = 0;
     (void) hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+#if MGPU_EXPERIMENTS
+    if (const char *e = getenv("MGPU_S2_PRIORITY")) prio_least = atoi(e) > 0 ? prio_greatest : 0;   // experiment: the second stream at normal (0) / highest (1) priority
+#endif
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream_w, hipStreamNonBlocking) != hipSuccess ||
@@ -1274,7 +1301,7 @@ static int fetch_records(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
         HIPCHK(c, hipMemcpyAsync(sl.h_live, sl.d_live, nlive * sizeof(PhaseRec), hipMemcpyDeviceToHost, c->stream_d2h));
         if (!sl.sig_late) HIPCHK(c, hipMemcpyAsync(sl.h_live_sig, sl.d_live_sig, nlive * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream_d2h));
         if (c->shard_mode == 2) HIPCHK(c, hipMemcpyAsync(sl.h_live_win, sl.d_live_win, nlive * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream_d2h));
-        HIPCHK(c, hipStreamSynchronize(c->stream_d2h));
+        HIPCHK(c, wait_stream_spin(c->stream_d2h));
     }
     if (!c->dump_dir.empty()) {   // replay material for tools/walk_replay.cpp
         const char *dd = c->dump_dir.c_str();
@@ -1295,7 +1322,7 @@ static int fetch_records(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
 }
 
 static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
-    HIPCHK(c, hipEventSynchronize(sl.ev[3]));
+    HIPCHK(c, wait_event_spin(sl.ev[3]));
     const double t_gpu_done = wall_ms();
     if (sl.h_counters[CNT_POOL_OVERFLOW]) {
         c->err = "record pool overflow: recreate the context with a larger record_pool_records";
@@ -1340,7 +1367,7 @@ static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
         sl.fsum_pending = false;
         if (c->shard_mode == 0) job.fsum_idx = sl.fsum_idx;
         else {
-            HIPCHK(c, hipEventSynchronize(c->fsum_ring[sl.fsum_idx].ev));
+            HIPCHK(c, wait_event_spin(c->fsum_ring[sl.fsum_idx].ev));
             std::memcpy(sl.h_fsums, c->fsum_ring[sl.fsum_idx].h, 2 * c->cap_buffers * sizeof(double));
         }
     }
@@ -1697,7 +1724,7 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
     std::vector<mgpu_msg> &stage = c->b_stage;               // with Mode A/C the Mode S messages are built here and merged per buffer
     if (nac) { stage.resize(nmsg); }
     if (job.from_device) {                                   // the walk ran on the device: the messages come from there
-        if (nmsg) HIPCHK(c, hipEventSynchronize(job.ev_copied));
+        if (nmsg) HIPCHK(c, wait_event_spin(job.ev_copied));
         if (!on_device && nmsg) {
             mgpu_msg *dst = nac ? stage.data() : out;
             const int parts = nmsg >= 4096 ? c->build_threads : 1;
@@ -1715,7 +1742,7 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
         mgpu_counters &k = c->counters;
         const double *fsums = job.fsums.data();
         if (job.fsum_idx >= 0) {                                  // SC16 formats: the chunk's float sums arrive here at the latest
-            (void) hipEventSynchronize(c->fsum_ring[job.fsum_idx].ev);
+            (void) wait_event_spin(c->fsum_ring[job.fsum_idx].ev);
             fsums = c->fsum_ring[job.fsum_idx].h;
         }
         for (int i = 0; i < 3; ++i) k.demod_accepted[i] += job.rc.accepted[i];
@@ -1763,7 +1790,7 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
         // (sig_late: the accepted frames' signal powers come over the second stream — k_msg_sig and a copy, ahead of the window
         // statistics.  Building first and filling the field in afterwards was slower: the messages leave with streaming stores,
         // and touching 27 000 of their lines again costs more than the wait.)
-        if (job.sig_late && nmsg) HIPCHK(c, hipEventSynchronize(job.ev_copied));
+        if (job.sig_late && nmsg) HIPCHK(c, wait_event_spin(job.ev_copied));
         // The signal / noise statistics — one chain of dependent double additions over the chunk's messages, a third of this stage's
         // time on one thread — ride beside the message build as one more task of the team (they read the accept list and the signal
         // powers only): with chunks of 1024 buffers the builder was the pipeline's slowest stage (round 4: 1.6-1.77 ms per step
@@ -1777,7 +1804,7 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
                                      job.acc.data() + lo, hi - lo, dst + lo);
         });
         stats_done = split;
-    } else if (!job.from_device && job.sig_late && nmsg) HIPCHK(c, hipEventSynchronize(job.ev_copied));   // (messages on the device: statistics only)
+    } else if (!job.from_device && job.sig_late && nmsg) HIPCHK(c, wait_event_spin(job.ev_copied));   // (messages on the device: statistics only)
     if (nac) {   // netUseMessage order: per buffer the Mode S messages of demodulate2400, then the replies of demodulate2400AC
         size_t si = 0, ai = 0, o = 0;
         for (uint32_t b = 0; b < nbuf; ++b) {
@@ -1828,7 +1855,7 @@ static int feed_end(mgpu_ctx *c) {
     c->accounting_open = false;
     if (c->shard_mode != 0) return MGPU_OK;   // a shard pass produces no messages and no statistics here
     HIPCHK(c, hipMemcpyAsync(c->h_win, c->d_win, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->s_post));
-    HIPCHK(c, hipStreamSynchronize(c->s_post));
+    HIPCHK(c, wait_stream_spin(c->s_post));
     mgpu_counters &k = c->counters;
     k.nflips = c->resolver.nflips();
     const unsigned long long *hw = c->h_win;
@@ -2078,7 +2105,7 @@ static int feed_common(mgpu_ctx *c, const void *src, bool src_is_device, uint64_
         // a deferred feed returns with its kernels still to run, but not with the caller's samples still to be read: the last
         // upload has landed when this returns (from page-locked memory the copies are truly asynchronous), so the caller may
         // reuse its block at once, as after a synchronous feed
-        if (rc == MGPU_OK && last_h2d && hipEventSynchronize(last_h2d) != hipSuccess) { c->err = "H2D of the IQ samples failed"; rc = MGPU_E_HIP; }
+        if (rc == MGPU_OK && last_h2d && wait_event_spin(last_h2d) != hipSuccess) { c->err = "H2D of the IQ samples failed"; rc = MGPU_E_HIP; }
         if (rc != MGPU_OK) return rc;
         c->stream_pos += n;
         if (n % c->cfg.buf_samples) c->eof = true;
@@ -2213,7 +2240,7 @@ int mgpu_collect(mgpu_ctx *c, struct mgpu_msg *out, uint64_t cap, uint64_t *n, s
                 if (fs.d_count > cap) { c->err = "mgpu_collect: the feed's messages do not fit (device-messages mode takes whole feeds)"; return MGPU_E_OVERFLOW; }
                 if (fs.d_count) {
                     HIPCHK(c, hipSetDevice(c->cfg.device));
-                    HIPCHK(c, hipEventSynchronize(fs.ev_built));
+                    HIPCHK(c, wait_event_spin(fs.ev_built));
                     HIPCHK(c, hipMemcpy(out, fs.d_msgs, fs.d_count * sizeof(mgpu_msg), hipMemcpyDeviceToHost));
                 }
                 if (n) *n = fs.d_count;
@@ -2249,7 +2276,7 @@ int mgpu_collect_device(mgpu_ctx *c, const struct mgpu_msg **d_msgs, uint64_t *n
         }
         if (fs.d_count) {
             HIPCHK(c, hipSetDevice(c->cfg.device));
-            HIPCHK(c, hipEventSynchronize(fs.ev_built));
+            HIPCHK(c, wait_event_spin(fs.ev_built));
         }
         *d_msgs = fs.d_msgs; *n = fs.d_count;
         std::lock_guard<std::mutex> lk(c->mu);

@@ -69,3 +69,30 @@ def test_gate_in_device_memory(built):
         d.close()
     assert np.array_equal(v, gu.oracle_gate(want_msgs, want_fields))
     gu.check_against_golden(v, gu.golden_forwarded(name), 0.05)
+
+
+def test_gate_edge_cases(built):
+    """An empty list, a lone message, a list of Mode A/C replies only, and the reset: same answers as the CPU restatement."""
+    import readsb_amd
+    name = "uc8_aggressive_modeac_3s"
+    kw, opt = gu.CASES[name]
+    iq, want_msgs, want_fields = gu.oracle_messages(name)
+    d = readsb_amd.Demodulator(nfix_crc=opt["nfix"], mode_ac=opt["mode_ac"], startup_time_ms=helpers.STARTUP_MS, max_samples=len(iq) // 2)
+    try:
+        msgs, _ = d.demodulate_capture(iq)
+        assert len(d.track_gate(msgs[:0])) == 0
+        first = d.track_gate(msgs[:1])
+        assert np.array_equal(first, gu.oracle_gate(want_msgs[:1], want_fields[:1]))
+        d.track_gate_reset()
+        ac = msgs["msgtype"] == 77
+        assert ac.sum() > 10
+        assert (d.track_gate(msgs[ac]) & 3 == 1).all()                       # Mode A/C replies are always forwarded, no aircraft
+        d.track_gate_reset()
+        a = d.track_gate(msgs)
+        b = d.track_gate(msgs)                                                # the same list again: every aircraft is known by now
+        d.track_gate_reset()
+        c = d.track_gate(msgs)
+        assert np.array_equal(a, c) and not np.array_equal(a, b)
+        assert ((b & 3) == 2).sum() < ((a & 3) == 2).sum()                    # ... so fewer verdicts depend on the tracker
+    finally:
+        d.close()

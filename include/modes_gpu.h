@@ -159,7 +159,7 @@ struct mgpu_counters {
 struct mgpu_timing {
     float h2d_ms;        /* host time spent issuing the IQ block's host->device copies (0 for resident input) */
     float convert_ms;    /* k_convert_* (UC8 / SC16 / SC16Q11 -> magnitudes, per-buffer sums) */
-    float sweep_ms;      /* k_sweep alone: the preamble sweep, the kernel the HBM roofline applies to (experiments build, MGPU_SWEEP_VERSION=3: the fused k_sweep_slice) */
+    float sweep_ms;      /* k_sweep alone: the preamble sweep, the kernel the HBM roofline applies to */
     float prescreen_ms;  /* the post-sweep passes: k_count (+ class bitmap) + k_prescreen_write + k_publish */
     float resolve_ms;    /* walker team: the ordered accept / skip-ahead / ICAO filter walk (host wall time) */
     float sigpower_ms;   /* walker thread: launching what follows the walk on the second stream (k_stage_in, k_msg_sig, k_window_stats, k_build_messages) */

@@ -343,7 +343,6 @@ struct mgpu_ctx {
     mgpu_timing timing{}, acc{};
     uint64_t stream_pos = 0;
     bool eof = false;
-    int sweep_version = 5;     // 5 = k_sweep + k_slice; the experiments build (make exp) also has 3 = the fused k_sweep_slice (MGPU_SWEEP_VERSION=3)
 
     // host pipeline behind the GPU: the walker thread takes the slots in submission order (record copy,
     // ordered accept walk, window-statistics launch) and hands a HostJob to the builder thread
@@ -932,9 +931,6 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     mgpu_ctx *c = new (std::nothrow) mgpu_ctx();
     if (!c) return MGPU_E_NOMEM;
     c->cfg = *cfg;
-#if MGPU_EXPERIMENTS
-    if (const char *e = getenv("MGPU_SWEEP_VERSION")) { const int v = atoi(e); if (v == 3 || v == 5) c->sweep_version = v; }
-#endif
     if (hipSetDevice(cfg->device) != hipSuccess) { delete c; return MGPU_E_NODEVICE; }
     // the second stream (what follows a chunk's walk; the SC16 formats' float sums) at the lowest priority the device offers: its
     // kernels fill what the main stream leaves, they are not to take its slots
@@ -1194,12 +1190,7 @@ static int enqueue_sweep(mgpu_ctx *c, Slot &sl) {
     // ev[5] .. ev[4] bracket exactly one kernel: k_sweep (bench.py's roofline); ev[4] .. ev[2]: k_slice
     if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[5], s));
 #if MGPU_EXPERIMENTS
-    sp.debug_stage = c->dbg_stage;     // (generation 3's stages, or k_slice's leave-out experiments)
-    if (c->sweep_version == 3) {
-        launch_sweep_slice(sp, s);
-        sl.slice_blocks = 0;
-        if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[4], s));
-    } else
+    sp.debug_stage = c->dbg_stage;     // (k_slice's leave-out experiments, tools/slice_stages.sh)
 #endif
     {
         sl.sweep_blocks = launch_sweep(sp, s);
@@ -1226,7 +1217,7 @@ static int enqueue_post(mgpu_ctx *c, Slot &sl) {
     hipStream_t s = c->stream;
     // class planes -> class bitmap, pre-screen (the surviving records stay in HBM: d_live), counters and per-buffer sums to the host
     PostSweepParams q{};
-    q.pool = sl.d_pool; q.pool_cap = (uint32_t) c->cap_pool; q.variant = c->prescreen_variant; q.unit_first = sl.d_unit_first; q.first_count = sl.d_unit_count; q.nunits = nunits; q.chains_per_unit = c->sweep_version == 3 ? 1u : (uint32_t) (kUnit / 2048); q.adder_bitmap = c->d_adder_bitmap;
+    q.pool = sl.d_pool; q.pool_cap = (uint32_t) c->cap_pool; q.variant = c->prescreen_variant; q.unit_first = sl.d_unit_first; q.first_count = sl.d_unit_count; q.nunits = nunits; q.chains_per_unit = (uint32_t) (kUnit / 2048); q.adder_bitmap = c->d_adder_bitmap;
     q.unit_live = sl.d_unit_live; q.block_live = sl.d_unit_live + c->cap_units + 2; q.live = sl.d_live; q.live_sig = sl.d_live_sig; q.counters = sl.d_counters;
     // a shard pass hands its records to another rank, which has no samples: their signal powers go with them.  Otherwise they are
     // computed after the walk, for the accepted frames only (k_msg_sig): 40 % of the work, off the main stream
@@ -1331,7 +1322,7 @@ static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
     float ms;
     if (sl.timed) {
         if (hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]) == hipSuccess) c->acc.convert_ms += ms;
-        if (hipEventElapsedTime(&ms, sl.ev[5], sl.ev[4]) == hipSuccess) { c->acc.sweep_ms += ms; if (c->sweep_version == 5) sweep_pace_feedback(ms * 1e3f, sl.n, sl.sweep_blocks, c->event_bracket_us); }
+        if (hipEventElapsedTime(&ms, sl.ev[5], sl.ev[4]) == hipSuccess) { c->acc.sweep_ms += ms; sweep_pace_feedback(ms * 1e3f, sl.n, sl.sweep_blocks, c->event_bracket_us); }
         if (hipEventElapsedTime(&ms, sl.ev[4], sl.ev[2]) == hipSuccess) c->acc.slice_ms += ms;
         if (hipEventElapsedTime(&ms, sl.ev[6], sl.ev[3]) == hipSuccess) c->acc.prescreen_ms += ms;
         c->acc.n_timed_chunks += 1;

@@ -8,7 +8,7 @@
 //            `pa - m` of demodulate2400 summed over the 131072-sample buffers
 //            (demod_2400.c:287-290, sdr_ifile.c:209-213), so D in [0, n) are the preamble
 //            start positions and a position reads d_mag[D .. D+289].
-//   pool   : PhaseRec[], per-unit chains of segments written by k_sweep_slice
+//   pool   : PhaseRec[], per-tile chains of segments written by k_slice
 //   live   : PhaseRec[], records surviving the pre-screen, globally ordered by (pos, phase)
 #pragma once
 #ifndef MGPU_EXPERIMENTS
@@ -27,8 +27,6 @@ constexpr int kTile = 4096;             // scan positions per LDS tile
 constexpr int kHalo = 304;              // >= 290 samples of look-ahead (demod reads pa[0..289]), multiple of 8
 constexpr int kTilesPerUnit = 2;
 constexpr int kUnit = kTile * kTilesPerUnit;   // positions per unit (one record chain per unit, one wave's share)
-constexpr int kWaveTile = 2048;         // k_sweep_slice: positions per wave-private LDS tile
-constexpr int kTile2 = 4096;            // k_sweep_slice: positions per LDS tile
 constexpr int kBlock = 256;
 // k_sweep: positions per candidate list = one of its pre-check steps (16 positions per lane); k_slice's tiles are 2048 = two lists
 constexpr int kSweepTile = 1024;
@@ -38,7 +36,6 @@ constexpr int kDealerCounters = 64;       // k_slice's tile dealer: pools of wor
 constexpr int kDealerStride = 64;         // ... 256 bytes apart: device atomics on words of one 64-byte line serialise with each other (tools/micro/atomic_cost.hip)
 constexpr int kPoolChunkRecords = 256;    // pool records a wave reserves per returning atomic
 constexpr int kSweepMaxWaves = kSweepMaxBlocks * (kBlock / 64);
-constexpr int kBatch = 64;              // candidates sliced per batch (4 waves x 16)
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 
 // flags of a PhaseRec
@@ -77,7 +74,7 @@ enum {
     CNT_POOL_OVERFLOW = 7,
     CNT_CLASS_COND = 8,      // candidates whose records are all conditional (REC_COND)
     CNT_CLASS_UNCOND = 9,    // candidates with >= 1 unconditional record
-    CNT_DEBUG0 = 16,         // .. 31: cycle counters of k_sweep_slice's stages (thread 0 of every workgroup)
+    CNT_DEBUG0 = 16,         // .. 30: the experiments build's checking kernels count what they print here
     CNT_LIVE_TOTAL = 31,     // records surviving the pre-screen (written by k_scan_units)
     CNT_NUM = 32,
 };
@@ -98,8 +95,8 @@ struct SweepParams {
     PhaseRec *pool;
     uint32_t pool_cap;
     uint32_t *pool_used;      // device counter (records incl. headers)
-    uint32_t *unit_first;     // k_slice: [tiles of 2048 positions] index of the tile's first segment header, kNone if empty (generation 3: per unit)
-    uint32_t *unit_count;     // k_slice: [tiles] records in the tile's first segment; generation 3: [nunits] records of the unit (without headers)
+    uint32_t *unit_first;     // k_slice: [tiles of 2048 positions] index of the tile's first segment header, kNone if empty
+    uint32_t *unit_count;     // k_slice: [tiles] records in the tile's first segment
     uint32_t *dealer;         // k_slice: [kDealerCounters] tiles dealt from each pool so far, kDealerStride words apart (zero at launch); behind them k_sweep: [kDealerCounters] blocks of steps dealt
     uint32_t nunits;
     uint16_t *cand;           // candidate codes (position in the unit << 3 | phase mask), one list per step of kSweepTile positions, kSweepTile slots each
@@ -109,7 +106,7 @@ struct SweepParams {
     uint32_t *adder_bitmap;   // 2^24 bits: addresses some clean DF17 / DF11 IID 0 frame carries
     unsigned long long *counters;   // [CNT_NUM]
 #if MGPU_EXPERIMENTS
-    int32_t debug_stage;      // generation 3 only: disables kernel stages (timing experiments, MGPU_DEBUG_STAGE)
+    int32_t debug_stage;      // k_slice with one part left out (timing experiments, MGPU_DEBUG_STAGE, tools/slice_stages.sh)
     unsigned long long *dbg_waves;   // k_sweep: [waves][2] start / end of every wave, 100 MHz (tools/micro/sweep_cold.hip), or null
 #endif
 };
@@ -142,9 +139,6 @@ void launch_fsum_sc16_wide(int format, const uint8_t *iq, const uint16_t *mag, u
 unsigned launch_sweep(const SweepParams &p, hipStream_t s);        // k_sweep: preamble sweep -> per-step candidate lists; returns its grid size
 void sweep_pace_feedback(float kernel_us, uint64_t n, unsigned blocks, float bracket_us);   // a timed k_sweep launch: feeds the pacing's step-time estimate
 unsigned launch_slice(const SweepParams &p, hipStream_t s);        // k_slice: slicer + CRC + scoring over the candidate lists -> record pool; returns its grid size (rows of sweep_part)
-#if MGPU_EXPERIMENTS
-void launch_sweep_slice(const SweepParams &p, hipStream_t s);      // generation 3: both in one kernel (cross-check build only)
-#endif
 // pre-screen: count / write the records whose address may matter to the ordered walk
 // (the write pass also stores each live record's would-be signal power: sum of mag^2 over its frame)
 // everything between the sweep and the host: class planes -> class bitmap (+ counters, planes zeroed again),
@@ -155,7 +149,7 @@ struct PostSweepParams {
     uint32_t variant;                     // bit 1: the write pass by chains (write_unit_chains; else the older one, one chain after the other); bit 2 (experiments build): checking kernels; 3 = the product
     const uint32_t *unit_first;           // first segment header of every chain, chains_per_unit consecutive chains per unit
     const uint32_t *first_count;          // four chains per unit: the records in every chain's first segment (SweepParams::unit_count)
-    uint32_t chains_per_unit;             // 4: one chain per k_slice tile of 2048 positions; 1: generation 3
+    uint32_t chains_per_unit;             // 4: one chain per k_slice tile of 2048 positions
     uint32_t nunits;
     const uint32_t *adder_bitmap;
     uint32_t *unit_live;                  // live records per unit (count pass)

@@ -14,8 +14,8 @@
 // No MFMA anywhere: this is HBM-bound integer/byte streaming work.  All arithmetic on the
 // message path is integer and bit-exact with the reference; the SC16 converters use IEEE float
 // ops with contraction disabled and a correctly rounded sqrt.
-// One translation unit, in parts (kernels/*.inc, included below in dependency order).  -DMGPU_EXPERIMENTS adds the
-// superseded fused kernel k_sweep_slice (generation 3) as a cross-check (make exp -> libmodes_gpu_exp.so).
+// One translation unit, in parts (kernels/*.inc, included below in dependency order).  -DMGPU_EXPERIMENTS (make exp ->
+// libmodes_gpu_exp.so) adds the ordered walk on the device and the A/B switches of DESIGN.md §7.
 #include "kernels.h"
 #include "tables.h"
 
@@ -25,16 +25,6 @@
 namespace mgpu {
 
 #define WAVE 64
-
-// Per-stage cycle counters of the experiments build's k_sweep_slice (make exp TIMERS=1).
-#ifndef MGPU_KERNEL_TIMERS
-#define MGPU_KERNEL_TIMERS 0
-#endif
-#if MGPU_KERNEL_TIMERS
-#define DBG_CLOCK() clock64()
-#else
-#define DBG_CLOCK() 0ll
-#endif
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
@@ -121,9 +111,6 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 #include "kernels/slicer.inc"
 #include "kernels/sweep.inc"
 #include "kernels/slice.inc"
-#if MGPU_EXPERIMENTS
-#include "kernels/sweep_slice.inc"
-#endif
 #include "kernels/prescreen.inc"
 #include "kernels/modeac.inc"
 #include "kernels/window_stats.inc"

@@ -6,7 +6,7 @@ name=$1; rev=${2:-HEAD}; shift; shift || true
 root=$(cd "$(dirname "$0")/.." && pwd)
 tmp=$(mktemp -d)
 git -C "$root" archive "$rev" readsb_amd/csrc include | tar -x -C "$tmp"
-make -s -C "$tmp/readsb_amd/csrc" libmodes_gpu.so CXXFLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -DMGPU_KERNEL_TIMERS=0 $*"
+make -s -C "$tmp/readsb_amd/csrc" libmodes_gpu.so CXXFLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function $*"
 cp "$tmp/readsb_amd/csrc/libmodes_gpu.so" "$root/readsb_amd/csrc/libmodes_gpu_$name.so"
 rm -rf "$tmp"
 echo "built readsb_amd/csrc/libmodes_gpu_$name.so from $rev"

@@ -1,6 +1,5 @@
 #!/usr/bin/env python3
-"""Development aid (GPU box): several captures through the library (MGPU_LIBRARY / MGPU_SWEEP_VERSION select the build and,
-in the experiments build, the kernel generation), compared with the CPU oracle WITHOUT stopping at the first difference:
+"""Development aid (GPU box): several captures through the library (MGPU_LIBRARY selects the build), compared with the CPU oracle WITHOUT stopping at the first difference:
 prints which counters differ and where the message lists part, then the device timing.  Exit code = number of failing cases."""
 import os
 import sys

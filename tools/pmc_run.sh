@@ -9,6 +9,6 @@ python - "$R/gpurun_out/pmc_$tag" <<'PY'
 import csv, glob, sys
 for f in sorted(glob.glob(sys.argv[1] + '/pmc_*/bench_counter_collection.csv')):
     for r in csv.DictReader(open(f)):
-        if 'k_sweep_slice' in r['Kernel_Name']:
+        if r['Kernel_Name'].startswith(('k_sweep', 'k_slice')):
             print(sys.argv[1].split('/')[-1], r['Counter_Name'], float(r['Counter_Value']))
 PY

@@ -1,8 +1,17 @@
 #!/bin/bash
-# scratch: the command of one GPU session (gpurun -- 'bash tools/gpu_session.sh'); edit, run, read gpurun_out/
-cd /root/repo
-out=gpurun_out/r05s; mkdir -p $out
-uptime > $out/uptime.txt
-timeout 600 python bench.py > $out/bench_default.log 2> $out/bench_default.err
-tail -1 $out/bench_default.log | cut -c1-2500
-cat $out/uptime.txt
+# scratch: one GPU session
+cd $GRAFT_REPO_ROOT
+tag=${1:-sess}
+mkdir -p gpurun_out/$tag
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_golden.py tests/test_gpu_formats.py -x -q -m gpu 2>&1 | tail -5 > gpurun_out/$tag/tests.txt
+for i in 1 2; do timeout 300 python bench.py --no-cpu-baseline --no-extra-configs 2>/dev/null | tail -1 > gpurun_out/$tag/bench$i.json; done
+STAGES="0" bash tools/slice_stage_pmc.sh $tag
+python - <<'PY' $tag
+import json,sys
+for i in (1,2):
+    try:
+        d=json.load(open('gpurun_out/%s/bench%d.json'%(sys.argv[1],i)))
+        print('bench',i,d['value'],d['stage_ms'],d['kernels']['k_slice']['avg_launch_ms'],d['roofline']['avg_launch_ms'])
+    except Exception as e: print('bench',i,'failed',e)
+PY
+cat gpurun_out/$tag/tests.txt

@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 tag=${1:-sess}
 mkdir -p gpurun_out/$tag
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_golden.py tests/test_gpu_formats.py -x -q -m gpu 2>&1 | tail -5 > gpurun_out/$tag/tests.txt
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_golden.py tests/test_gpu_formats.py tests/test_gpu_kernel_generations.py -x -q -m gpu 2>&1 | tail -5 > gpurun_out/$tag/tests.txt
 for i in 1 2; do timeout 300 python bench.py --no-cpu-baseline --no-extra-configs 2>/dev/null | tail -1 > gpurun_out/$tag/bench$i.json; done
 STAGES="0" bash tools/slice_stage_pmc.sh $tag
 python - <<'PY' $tag

@@ -972,7 +972,7 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     c->resolver.reset(cfg->startup_time_ms, (int) cfg->filter_clock);
 #if MGPU_EXPERIMENTS   // debug / experiment switches: the experiments build only; the product reads MGPU_NO_AFFINITY and nothing else
     c->dbg_print = getenv("MGPU_DEBUG_PRINT") != nullptr;
-    if (const char *e = getenv("MGPU_DEBUG_STAGE")) c->dbg_stage = atoi(e);   // (generation 3 only)
+    if (const char *e = getenv("MGPU_DEBUG_STAGE")) c->dbg_stage = atoi(e);   // (k_slice with one part left out: tools/slice_stages.sh)
     if (const char *e = getenv("MGPU_TIMING_EVERY")) { const int v = atoi(e); if (v >= 1) c->timing_every = v; }
     if (const char *e = getenv("MGPU_DUMP_DIR")) { c->dump_dir = e; c->sig_late = false; }   // (the dump holds per-record signal powers)
     c->fsum_wide = getenv("MGPU_FSUM_WIDE") != nullptr;
@@ -1099,6 +1099,10 @@ int mgpu_reset(mgpu_ctx *c) {
 // (Measured and dropped: the NEXT chunk's converter enqueued between a chunk's slicer and its post-sweep kernels, so that the
 // fetcher's record copies — which start when k_publish has run and slow whatever streams memory at that moment by 30-50 us —
 // would meet k_sweep instead of the converter: k_sweep then took 68 us instead of 37 and the step 2.85 ms instead of 2.52.)
+// (Measured and dropped, round 5: the converters on a stream of their own, chunk N + 1's held behind chunk N's k_sweep so that it runs
+// beside k_slice — issue-bound — and the post-sweep kernels: 305-325 against 363-367 Gsamples/s (gpurun r05z).  k_slice's persistent
+// grid holds every CU's registers and LDS until it ends, so the converter really runs beside the post-sweep kernels, whose dependent
+// round trips stretch from 0.25 to 0.5 ms per step next to a kernel that saturates the memory system, as with MGPU_WRITE_BESIDE.)
 // HIP events with timing cost ~5 us of idle stream each (the next kernel waits for the marker): only every
 // `timing_every`-th chunk carries the stage events (sl.timed); the others record the completion event alone.
 // k_fsum_sc16 of the slot's chunk on the second stream, behind `after` (an event of the main stream)

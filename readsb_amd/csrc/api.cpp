@@ -1230,6 +1230,7 @@ static int enqueue_post(mgpu_ctx *c, Slot &sl) {
     q.class_final = sl.d_class_final;
     q.class_words = (n + 31) / 32;
     q.dealer = sl.d_dealer;
+    q.cand = sl.d_cand; q.cand_count = sl.d_cand_count;
     q.live_win = c->shard_mode == 2 ? sl.d_live_win : nullptr; q.n = n; q.thr = sl.thr; q.buf_len = c->cfg.buf_samples;
     q.d_scratch = sl.d_scratch; q.h_scratch = sl.h_scratch; q.scratch_words = (uint32_t) (sl.scratch_bytes / sizeof(unsigned long long));
     // the count pass leaves its decisions as masks in the segment headers (one scoring pass = one segment of at most 64
@@ -1491,7 +1492,7 @@ static int walk_job_device(mgpu_ctx *c, Slot &sl, HostJob &job) {
 
     const double t_sig0 = wall_ms();
     if (nmsg)
-        launch_window_stats(sl.d_mag, sl.n, sl.thr, sl.d_class_final, sl.d_msg_pos, sl.d_msg_skip, sl.d_msg_limit, nmsg, sl.d_win_part, c->d_win, s2);
+        launch_window_stats(sl.d_mag, sl.n, sl.d_cand, sl.d_cand_count, sl.d_class_final, sl.d_msg_pos, sl.d_msg_skip, sl.d_msg_limit, nmsg, sl.d_win_part, c->d_win, s2);
     const bool to_device_list = c->device_msgs && job.feed >= 0;
     if (nmsg) {
         const void *d_bufs = sl.d_wk_in + kWkInHead;           // the buffer clocks went over with the walk's input
@@ -1650,7 +1651,7 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
     // that it is known which frames they are: one kernel since round 5 (the window's samples are the frame's).  The kernel stores the
     // builder's copy itself: a hipMemcpyAsync from this thread contends with the fetcher's inside the runtime.
     if (nmsg) {
-        launch_window_stats(sl.d_mag, n, sl.thr, sl.d_class_final, sl.d_msg_pos, sl.d_msg_skip,
+        launch_window_stats(sl.d_mag, n, sl.d_cand, sl.d_cand_count, sl.d_class_final, sl.d_msg_pos, sl.d_msg_skip,
                             sl.d_msg_limit, nmsg, sl.d_win_part, c->d_win, s2, job.sig_late ? sl.d_msg_sig : nullptr, job.sig_late ? job.h_msig : nullptr,
                             job.sig_late ? job.ev_copied : nullptr);
     }

@@ -161,6 +161,7 @@ struct PostSweepParams {
     uint32_t *class_final;                // the class bitmap (1 bit per scan position: records, all of them conditional), written by the count pass: kUnit / 32 words per unit
     uint64_t class_words;
     uint32_t *dealer;                     // k_slice's dealer counters: zeroed again by k_publish
+    const uint16_t *cand; const uint32_t *cand_count;   // k_sweep's candidate lists of the chunk (the live records' windows are counted from them)
     unsigned long long *live_win;         // shard passes: per live record the packed counts of its would-be skip window (null: not wanted)
     uint64_t n; int32_t thr; uint32_t buf_len;   // ... and what that kernel needs: the chunk's positions, the threshold, the buffer length
     unsigned long long *d_scratch, *h_scratch;
@@ -251,9 +252,9 @@ void launch_msg_sig(const uint16_t *mag, const uint32_t *d_pos, const uint16_t *
 void launch_stage_in(const uint32_t *h_pos, const uint32_t *h_limit, const uint16_t *h_skip, uint32_t *d_pos, uint32_t *d_limit,
                      uint16_t *d_skip, uint32_t n, hipStream_t s);   // page-locked host arrays -> device, small grid
 // shard passes: the same numbers for every live record's would-be window, packed into out[record] (kernels/window_stats.inc)
-void launch_live_windows(const uint16_t *mag, uint64_t n, int thr, const uint32_t *class_bitmap, const PhaseRec *live, const unsigned long long *nlive_dev,
+void launch_live_windows(const uint16_t *mag, uint64_t n, const uint16_t *cand, const uint32_t *cand_count, const uint32_t *class_bitmap, const PhaseRec *live, const unsigned long long *nlive_dev,
                          uint32_t buf_len, unsigned long long *out, hipStream_t s);
-void launch_window_stats(const uint16_t *mag, uint64_t n, int thr, const uint32_t *class_bitmap, const uint32_t *pos,
+void launch_window_stats(const uint16_t *mag, uint64_t n, const uint16_t *cand, const uint32_t *cand_count, const uint32_t *class_bitmap, const uint32_t *pos,   // cand / cand_count: k_sweep's lists of the chunk
                          const uint16_t *skip, const uint32_t *limit, uint32_t nmsg, unsigned long long *part, unsigned long long *out,
                          hipStream_t s, unsigned long long *sig_out = nullptr, unsigned long long *sig_host = nullptr,
                          hipEvent_t ev_sig = nullptr);   // sig_out: also the frames' signal powers (k_msg_sig's form), sig_host: a second copy in page-locked host memory, ev_sig: recorded behind them

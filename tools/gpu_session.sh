@@ -1,17 +1,14 @@
 #!/bin/bash
-# scratch: one GPU session
 cd $GRAFT_REPO_ROOT
 tag=${1:-sess}
 mkdir -p gpurun_out/$tag
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -5 > gpurun_out/$tag/tests.txt
-for i in 1 2; do timeout 300 python bench.py --no-cpu-baseline --no-extra-configs 2>/dev/null | tail -1 > gpurun_out/$tag/bench$i.json; done
-KERNEL="void mgpu::k_window_stats" STAGES="0" bash tools/slice_stage_pmc.sh ${tag}_ws
-python - <<'PY' $tag
+for rep in 1 2; do
+for lib in libmodes_gpu.so libmodes_gpu_prews.so libmodes_gpu_r4end.so; do
+  for i in 2 1; do
+    MGPU_LIBRARY=$lib timeout 300 python tools/profile_extra.py $i 2>/dev/null | tail -1 | python -c "
 import json,sys
-for i in (1,2):
-    try:
-        d=json.load(open('gpurun_out/%s/bench%d.json'%(sys.argv[1],i)))
-        print('bench',i,d['value'],d['stage_ms'],d['kernels']['k_slice']['avg_launch_ms'],d['roofline']['avg_launch_ms'])
-    except Exception as e: print('bench',i,'failed',e)
-PY
-cat gpurun_out/$tag/tests.txt
+d=json.loads(sys.stdin.readline()); k=list(d)[0]; v=d[k]
+print('$lib', k[:20], v.get('msamples_s_both_repetitions'), v.get('us_per_launch'), v.get('host_stage_ms_both_repetitions')[1])"
+  done
+done
+done 2>&1 | tee gpurun_out/$tag/ab.txt

@@ -30,7 +30,10 @@ constexpr int kUnit = kTile * kTilesPerUnit;   // positions per unit (one record
 constexpr int kBlock = 256;
 // k_sweep: positions per candidate list = one of its pre-check steps (16 positions per lane); k_slice's tiles are 2048 = two lists
 constexpr int kSweepTile = 1024;
-constexpr int kSweepMaxBlocks = 256 * 4;  // resident workgroups of k_slice (at most 4 per CU)
+#ifndef MGPU_SL_WGS_PER_CU
+#define MGPU_SL_WGS_PER_CU 4
+#endif
+constexpr int kSweepMaxBlocks = 256 * MGPU_SL_WGS_PER_CU;  // resident workgroups of k_slice (at most 4 per CU)
 constexpr int kSweepGridMax = 256 * 8;    // resident workgroups of k_sweep (at most 8 per CU) = rows of sweep_part
 constexpr int kDealerCounters = 64;       // k_slice's tile dealer: pools of workgroups, one counter each ...
 constexpr int kDealerStride = 64;         // ... 256 bytes apart: device atomics on words of one 64-byte line serialise with each other (tools/micro/atomic_cost.hip)

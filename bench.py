@@ -42,6 +42,7 @@ SWEEP_BYTES_PER_SAMPLE = 2.0   # k_preamble_sweep reads one u16 m
 # VALU issue rate measured on this chip (tools/micro/valu_issue.hip, profiles/r02_valu_issue.txt): three-operand / packed /
 # dot2 instructions — what these kernels are made of — sustain 36 T lane-ops/s chip-wide (v_add/v_xor: ~60)
 VALU_PEAK_TLANEOPS = 37.3
+N_SIMDS = 1024                 # 256 CUs x 4
 PMC_SQ_SUMMARY = os.path.join(ROOT, "profiles", "r05_pmc_sq_summary.txt")
 PMC_HBM = os.path.join(ROOT, "profiles", "r05_pmc_hbm.json")
 
@@ -69,7 +70,7 @@ def valu_issue(kernel, avg_launch_ms, samples_per_launch, path=PMC_SQ_SUMMARY):
     from the committed SQ counter pass of this same command (SQ_INSTS_VALU) over the launch time measured live.
     Informative; None if the summary is missing or does not parse."""
     try:
-        insts, inside, sha_ok = None, False, False
+        insts, others, inside, sha_ok = None, 0, False, False
         for ln in open(path):
             if ln.startswith("# kernel_source_sha:"):
                 sha_ok = ln.split(":")[1].strip() == kernel_source_sha()
@@ -78,12 +79,22 @@ def valu_issue(kernel, avg_launch_ms, samples_per_launch, path=PMC_SQ_SUMMARY):
                 inside = ln.strip().split("<")[0] in (kernel, kernel + "_t")      # k_sweep is the template k_sweep_t<fused?>
             elif inside and ln.split()[0] == "SQ_INSTS_VALU":
                 insts = int(ln.split()[1])
+            elif inside and ln.split()[0] in ("SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM"):
+                others += int(ln.split()[1])
         if not insts or avg_launch_ms <= 0 or not sha_ok:
             return None
         tl = insts * 64 / (avg_launch_ms * 1e-3) / 1e12
+        # Round 5: what bounds these kernels is instruction ISSUE, whatever the instruction — a SIMD issues one long-encoded vector
+        # (VOP3 / VOP3P / DPP), scalar or LDS instruction per ~1.8 ns from two resident waves on, a short-encoded VOP2 per ~1.0 ns,
+        # and with six waves a vector and a scalar instruction beside each other (profiles/r05_valu_issue.txt): the launch time per
+        # wave-instruction of ANY kind and SIMD is the number to hold against those (branches and waits are not counted)
+        all_insts = insts + others
         return {"wave_insts_per_launch": insts, "lane_ops_per_sample": round(insts * 64 / samples_per_launch, 1),
                 "achieved_Tlaneops_s": round(tl, 2), "peak_Tlaneops_s": VALU_PEAK_TLANEOPS,
-                "frac": round(tl / VALU_PEAK_TLANEOPS, 3), "source": "SQ_INSTS_VALU, " + os.path.relpath(path, ROOT)}
+                "frac": round(tl / VALU_PEAK_TLANEOPS, 3),
+                "all_wave_insts_per_launch": all_insts, "ns_per_inst_per_simd": round(avg_launch_ms * 1e6 * N_SIMDS / all_insts, 2),
+                "ns_per_inst_reference": "1.8 long-encoded vector / scalar / LDS alone, 1.0 VOP2 alone, 0.95 a vector + scalar pair at six waves",
+                "source": "SQ_INSTS_VALU / SALU / LDS / VMEM / SMEM, " + os.path.relpath(path, ROOT)}
     except Exception:
         return None
 

@@ -28,11 +28,12 @@ timeout 120 tools/micro/sweep_cold 1024 5 4 0 2000 0 0 0 > $out/sweep_cold_unpac
 timeout 120 tools/micro/valu_issue $out/valu_issue.json > $out/valu_issue.txt 2>&1
 timeout 120 tools/micro/atomic_cost > $out/atomic_cost.txt 2>&1
 timeout 300 bash tools/slice_stages.sh > $out/slice_stages.txt 2>&1
+timeout 400 bash tools/slice_stage_pmc.sh $tag/stage_pmc > /dev/null 2>&1; cp $out/stage_pmc/stage_pmc.txt $out/slice_stage_pmc.txt 2>/dev/null   # k_slice's instruction counters per left-out stage
 tail -1 $out/bench_plain.log | cut -c1-3000
 cat $out/stats/bench_kernel_stats.csv | cut -c1-120
 cat $out/pmc_hbm.json | head -40
 for i in 0 1; do tail -1 $out/extra$i.log | cut -c1-600; cut -c1-110 $out/stats_extra$i/extra_kernel_stats.csv | head -8; done
 for v in "" _s1 _s2 _s3 _d0 _b1 _b4 _unpaced; do echo "sweep_cold$v: $(cut -c1-400 $out/sweep_cold$v.json)"; done
-tail -12 $out/valu_issue.txt; tail -8 $out/atomic_cost.txt; cat $out/slice_stages.txt
+tail -12 $out/valu_issue.txt; tail -8 $out/atomic_cost.txt; cat $out/slice_stages.txt; cut -c1-200 $out/slice_stage_pmc.txt
 # the whole GPU suite on the code that was profiled
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -5 > $out/gpu_suite_tail.txt; cat $out/gpu_suite_tail.txt

@@ -153,7 +153,7 @@ struct mgpu_counters {
 };
 
 /* Where the last feed's time went (ms).  The four kernel figures are pairs of HIP events on the context's main stream around ONE
- * kernel / one group of kernels, on every fourth chunk only (n_timed_chunks: a timing event costs ~5 us of idle stream); a pair adds
+ * kernel / one group of kernels, on every seventh chunk only (n_timed_chunks: a timing event costs ~5 us of idle stream; neighbouring figures share an event); a pair adds
  * a constant ~4 us to what it brackets (mgpu_event_bracket_us measures it).  The host figures are wall-clock sums of stage threads
  * that run beside each other and beside the GPU: they overlap, they do not add up to total_ms. */
 struct mgpu_timing {
@@ -173,7 +173,7 @@ struct mgpu_timing {
     float slice_ms;          /* k_slice: bit slicer + CRC-24 + the filter-independent half of the scoring */
     float build_ms;          /* builder team: struct modesMessage fields + signal / noise statistics, including its wait for the chunk's signal powers (host wall time) */
     uint64_t n_timed_chunks; /* chunks that carried the stage timing events: convert_ms, sweep_ms, slice_ms and prescreen_ms are sums
-                              * over THESE (every 4th chunk; experiments build: MGPU_TIMING_EVERY) */
+                              * over THESE (every 7th chunk; experiments build: MGPU_TIMING_EVERY) */
 };
 
 /* ---- lifecycle -------------------------------------------------------------------- */

@@ -166,7 +166,7 @@ struct Slot {
     double *d_fsx = nullptr, *h_fsx = nullptr;   // SC16 formats: the float sums' own device / page-locked buffers (k_fsum_sc16 runs beside the chunk and ends on its own)
     uint32_t *h_msg_pos = nullptr, *h_msg_limit = nullptr;
     uint16_t *h_msg_len = nullptr, *h_msg_skip = nullptr;
-    hipEvent_t ev[7] = {};               // 3: the chunk is complete (always recorded) | stage timing, sampled chunks only (timed): 0 1 convert, 5 4 k_sweep, 4 2 k_slice, 6 3 post-sweep
+    hipEvent_t ev[5] = {};               // 3: the chunk is complete (always recorded) | stage timing, sampled chunks only (timed): 0 1 convert, 1 4 k_sweep, 4 2 k_slice, 2 3 post-sweep (a timing event costs ~4.5 us of idle stream: neighbouring brackets share theirs)
     bool timed = false;
     uint32_t slice_blocks = 0;            // rows of d_sweep_part the chunk's k_slice wrote
     uint32_t sweep_blocks = 0;            // grid of the chunk's k_sweep
@@ -333,7 +333,7 @@ struct mgpu_ctx {
     bool deferred = false;
     bool device_msgs = false;                                 // mgpu_set_device_messages
     bool sig_late = true;                                     // MGPU_SIG_LATE=0: signal power of every live record in the pre-screen write pass (as in shard passes) instead of the accepted frames' after the walk
-    int timing_every = 4;                                     // MGPU_TIMING_EVERY: chunks per set of stage timing events (1 = every chunk)
+    int timing_every = 7;                                     // chunks per set of stage timing events (1 = every chunk; MGPU_TIMING_EVERY in the experiments build).  Odd: with feeds of four chunks the sampled chunk is not always a feed's first
     bool fsum_wide = false;                                   // (experiments build: MGPU_FSUM_WIDE=1) the float sums as three wide kernels instead of one chain per buffer
     float event_bracket_us = 4.5f;                            // what a pair of timing events adds to the kernel it brackets (mgpu_event_bracket_us measures it)
     uint64_t timing_seq = 0;
@@ -1191,8 +1191,7 @@ static int enqueue_sweep(mgpu_ctx *c, Slot &sl) {
     sp.unit_first = sl.d_unit_first; sp.unit_count = sl.d_unit_count; sp.nunits = nunits; sp.dealer = sl.d_dealer;
     sp.adder_bitmap = c->d_adder_bitmap; sp.counters = sl.d_counters;
     sp.cand = sl.d_cand; sp.cand_count = sl.d_cand_count; sp.sweep_part = sl.d_sweep_part;
-    // ev[5] .. ev[4] bracket exactly one kernel: k_sweep (bench.py's roofline); ev[4] .. ev[2]: k_slice
-    if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[5], s));
+    // ev[1] (recorded behind the converter, enqueue_convert) .. ev[4] bracket exactly one kernel: k_sweep (bench.py's roofline); ev[4] .. ev[2]: k_slice
 #if MGPU_EXPERIMENTS
     sp.debug_stage = c->dbg_stage;     // (k_slice's leave-out experiments, tools/slice_stages.sh)
 #endif
@@ -1237,7 +1236,6 @@ static int enqueue_post(mgpu_ctx *c, Slot &sl) {
     // records), so the write pass does not look at the adder bitmap again
     q.fin_part = q.block_live + c->cap_units / 4 + 2;
     q.slice_part = sl.d_sweep_part; q.slice_blocks = sl.slice_blocks;       // k_slice's rows of counts (0 rows: the experiments build's fused kernel counts for itself)
-    if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[6], s));
     hipStream_t s_write = c->stream_pw ? c->stream_pw : s;
     if (launch_prescreen(q, s, s_write, sl.ev_scan) != 0) { c->err = "event ordering of the pre-screen passes failed"; return MGPU_E_HIP; }
     HIPCHK(c, hipEventRecord(sl.ev[3], s_write));
@@ -1327,9 +1325,9 @@ static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
     float ms;
     if (sl.timed) {
         if (hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]) == hipSuccess) c->acc.convert_ms += ms;
-        if (hipEventElapsedTime(&ms, sl.ev[5], sl.ev[4]) == hipSuccess) { c->acc.sweep_ms += ms; sweep_pace_feedback(ms * 1e3f, sl.n, sl.sweep_blocks, c->event_bracket_us); }
+        if (hipEventElapsedTime(&ms, sl.ev[1], sl.ev[4]) == hipSuccess) { c->acc.sweep_ms += ms; sweep_pace_feedback(ms * 1e3f, sl.n, sl.sweep_blocks, c->event_bracket_us); }
         if (hipEventElapsedTime(&ms, sl.ev[4], sl.ev[2]) == hipSuccess) c->acc.slice_ms += ms;
-        if (hipEventElapsedTime(&ms, sl.ev[6], sl.ev[3]) == hipSuccess) c->acc.prescreen_ms += ms;
+        if (hipEventElapsedTime(&ms, sl.ev[2], sl.ev[3]) == hipSuccess) c->acc.prescreen_ms += ms;
         c->acc.n_timed_chunks += 1;
     }
     const uint64_t nlive = sl.h_counters[CNT_LIVE_TOTAL];

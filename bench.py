@@ -749,6 +749,8 @@ def main():
         slice_ = max(slice_raw - nlaunch * bracket_us * 1e-3, 1e-6)
         # `achieved` / `frac`: from the RAW interval between the two events around the kernel (what rocprofv3's average duration of the
         # same kernel agrees with); the figure with the events' own constant taken off stands beside it (`frac_bracket_corrected`)
+        if sweep_raw <= 0 or slice_raw <= 0:     # (cannot happen: the first chunk of every accounting period is a sampled one)
+            raise SystemExit("bench.py: no chunk of the timed region carried the stage timing events")
         achieved = n * SWEEP_BYTES_PER_SAMPLE / (sweep_raw * 1e-3) / 1e9
         achieved_corrected = n * SWEEP_BYTES_PER_SAMPLE / (sweep * 1e-3) / 1e9
         per_launch = int(n * SWEEP_BYTES_PER_SAMPLE / nlaunch)

@@ -153,7 +153,7 @@ struct mgpu_counters {
 };
 
 /* Where the last feed's time went (ms).  The four kernel figures are pairs of HIP events on the context's main stream around ONE
- * kernel / one group of kernels, on every seventh chunk only (n_timed_chunks: a timing event costs ~5 us of idle stream; neighbouring figures share an event); a pair adds
+ * kernel / one group of kernels, on the first chunk since the figures were last reset and every seventh after it (n_timed_chunks: a timing event costs ~5 us of idle stream; neighbouring figures share an event); a pair adds
  * a constant ~4 us to what it brackets (mgpu_event_bracket_us measures it).  The host figures are wall-clock sums of stage threads
  * that run beside each other and beside the GPU: they overlap, they do not add up to total_ms. */
 struct mgpu_timing {

@@ -1837,6 +1837,7 @@ static int feed_begin(mgpu_ctx *c) {
     { std::lock_guard<std::mutex> lk(c->mu); c->hot.store(true, std::memory_order_relaxed); }
     c->cv.notify_all();                      // the stage threads switch from sleeping to polling
     c->accounting_open = true;
+    c->timing_seq = 0;                       // the first chunk of an accounting period carries the stage events: mgpu_timing has kernel figures however short the period
     c->acct_t0 = wall_ms();
     std::memset(&c->acc, 0, sizeof(c->acc));
     std::memset(c->feed_cand, 0, sizeof(c->feed_cand));

@@ -213,7 +213,10 @@ int mgpu_feed_iq(mgpu_ctx *ctx, const void *iq_host, uint64_t nsamples);
  * synchronously.  The struct mag_buf entries and the shard calls are refused (MGPU_E_INVAL) while deferred mode is on.
  * Lifetime of the caller's block: a deferred mgpu_feed_iq returns when the last byte of `iq_host` has been copied to the device
  * (the kernels are still to run), so the block may be reused at once, exactly as after a synchronous feed; a device block
- * (mgpu_feed_iq_device) is read by kernels that are still to run and must stay untouched until that feed has been collected. */
+ * (mgpu_feed_iq_device) is read by kernels that are still to run and must stay untouched until that feed has been collected.
+ * While feeds are in flight the CALLING thread's waits (for a free slot in a feed call, for the oldest feed in mgpu_collect) poll —
+ * pauses and sched_yield, as the stage threads' do — instead of sleeping on a condition variable: a wake-up that comes a
+ * millisecond late on a loaded host is as long as the work the GPU still has queued. */
 int mgpu_set_deferred(mgpu_ctx *ctx, int on);
 
 /* Device-resident messages (deferred mode only, no Mode A/C): the accepted frames' records are built on the GPU

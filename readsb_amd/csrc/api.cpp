@@ -6,6 +6,7 @@
 // MGPU_E_NODEVICE.
 #include <hip/hip_runtime.h>
 #include <pthread.h>
+#include <dirent.h>
 #include <sched.h>
 
 #include <cctype>
@@ -556,6 +557,37 @@ struct NearDevice {
     ~NearDevice() { if (moved) (void) pthread_setaffinity_np(pthread_self(), sizeof(saved), &saved); }
 };
 
+static std::string sysfs_line(const std::string &path) {
+    char line[4096] = {0};
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f) return std::string();
+    const bool ok = fgets(line, sizeof(line), f) != nullptr;
+    fclose(f);
+    std::string v = ok ? line : "";
+    while (!v.empty() && (v.back() == '\n' || v.back() == ' ')) v.pop_back();
+    return v;
+}
+
+// index of the PCI function `id` ("0000:c1:00.0") among the functions with its vendor, device id and local CPU list, ordered by address; -1: unknown
+static int device_index_on_node(const std::string &id) {
+    const std::string base = "/sys/bus/pci/devices/";
+    const std::string vendor = sysfs_line(base + id + "/vendor"), dev = sysfs_line(base + id + "/device"), cpus = sysfs_line(base + id + "/local_cpulist");
+    if (vendor.empty() || dev.empty() || cpus.empty()) return -1;
+    DIR *d = opendir(base.c_str());
+    if (!d) return -1;
+    std::vector<std::string> same;
+    while (const dirent *e = readdir(d)) {
+        const std::string name = e->d_name;
+        if (name.empty() || name[0] == '.') continue;
+        if (sysfs_line(base + name + "/vendor") == vendor && sysfs_line(base + name + "/device") == dev && sysfs_line(base + name + "/local_cpulist") == cpus)
+            same.push_back(name);
+    }
+    closedir(d);
+    std::sort(same.begin(), same.end());
+    const auto it = std::find(same.begin(), same.end(), id);
+    return it == same.end() ? -1 : (int) (it - same.begin());
+}
+
 // Two groups of threads, two L3 groups: `walk` (the walker and its helpers: they pass cache lines of the filter state and of
 // the record list among themselves all the time) and `rest` (fetcher, builder and its helpers).  The hand-off between the
 // two — one job per chunk — crosses CCDs once.  An 8-GPU node has two CCDs per GPU on the GPU's own NUMA node (EPYC 9575F:
@@ -592,8 +624,13 @@ static void bind_near_device(std::thread *const *walk, int nwalk, std::thread *c
         l3_of[i] = sysfs_int("/sys/devices/system/cpu/cpu" + std::to_string(cpus[i]) + "/cache/index3/id", -1);
         if (std::find(l3_ids.begin(), l3_ids.end(), l3_of[i]) == l3_ids.end()) l3_ids.push_back(l3_of[i]);
     }
-    // ranks that each see one device as ordinal 0 (per-rank HIP_VISIBLE_DEVICES) still spread out by LOCAL_RANK
-    int ordinal = device;
+    // Which of the node's GPUs this is: its place among the PCI functions of the same vendor / device id on the same NUMA node, by bus
+    // address (sysfs is not namespaced: a container that was handed ONE of a node's eight GPUs still sees the others there).  The HIP
+    // ordinal is 0 in every such container — four of them on one socket picked the same two L3 groups and the same cores (round 5:
+    // now and then a benchmark process ran at 0.6 of the rate with one host stage slow and nothing else changed).  Ranks that
+    // share one device (tests) or see one device each (per-rank HIP_VISIBLE_DEVICES) still spread out by LOCAL_RANK.
+    int ordinal = device_index_on_node(id);
+    if (ordinal < 0) ordinal = device;
     if (const char *lr = getenv("LOCAL_RANK")) { const int v = atoi(lr); if (v >= 0) ordinal = v; }
     const size_t ng = l3_ids.size();
     int want_walk, want_rest;

@@ -162,7 +162,7 @@ struct mgpu_timing {
     float sweep_ms;      /* k_sweep alone: the preamble sweep, the kernel the HBM roofline applies to */
     float prescreen_ms;  /* the post-sweep passes: k_count (+ class bitmap) + k_prescreen_write + k_publish */
     float resolve_ms;    /* walker team: the ordered accept / skip-ahead / ICAO filter walk (host wall time) */
-    float sigpower_ms;   /* walker thread: launching what follows the walk on the second stream (k_stage_in, k_msg_sig, k_window_stats, k_build_messages) */
+    float sigpower_ms;   /* walker thread: launching what follows the walk on the second stream (k_stage_in, k_window_stats incl. the signal powers, k_build_messages) */
     float d2h_ms;        /* fetcher thread: waiting for the chunk, the live records HBM -> page-locked memory -> the walk's memory (host wall time) */
     float total_ms;      /* wall time of the whole call (deferred feeds: since the accounting was opened) */
     uint64_t n_candidates;   /* positions that passed a preamble threshold */

@@ -609,6 +609,11 @@ const uint16_t *mgpu_uc8_table(void);
 int mgpu_selftest_walk(uint64_t seed, uint32_t nchunks, uint32_t buffers_per_chunk, uint32_t nsegments,
                        uint32_t naircraft, uint32_t *speculated_permille);
 
+/* Which of a node's GPUs a PCI function is — its place among the functions with the same vendor, device id and local CPU list
+ * under `pci_devices_dir` (the library reads /sys/bus/pci/devices), by bus address; what the pipeline's threads choose their L3
+ * groups by (a container that holds ONE of a node's GPUs sees HIP ordinal 0 whichever it is).  -1 = not found, -2 = bad arguments. */
+int mgpu_selftest_device_index(const char *pci_devices_dir, const char *bus_id);
+
 /* Same idea for the walk on the device (below), needs no GPU either: its algorithm restated on the host — every buffer walked on
  * its own against the filter at the start of the chunk plus a table of first adds, iterated (at most max_walks times) until the
  * table reproduces itself, then the premise check — against the serial walk on the same seeded streams.  Chunks that do not

@@ -569,8 +569,7 @@ static std::string sysfs_line(const std::string &path) {
 }
 
 // index of the PCI function `id` ("0000:c1:00.0") among the functions with its vendor, device id and local CPU list, ordered by address; -1: unknown
-static int device_index_on_node(const std::string &id) {
-    const std::string base = "/sys/bus/pci/devices/";
+static int device_index_on_node(const std::string &id, const std::string &base = "/sys/bus/pci/devices/") {
     const std::string vendor = sysfs_line(base + id + "/vendor"), dev = sysfs_line(base + id + "/device"), cpus = sysfs_line(base + id + "/local_cpulist");
     if (vendor.empty() || dev.empty() || cpus.empty()) return -1;
     DIR *d = opendir(base.c_str());
@@ -2187,6 +2186,13 @@ int mgpu_set_deferred(mgpu_ctx *c, int on) {
 }
 
 int mgpu_feed_iq(mgpu_ctx *c, const void *iq_host, uint64_t nsamples) { return feed_common(c, iq_host, false, nsamples); }
+
+int mgpu_selftest_device_index(const char *pci_devices_dir, const char *bus_id) {
+    if (!pci_devices_dir || !bus_id) return -2;
+    std::string base(pci_devices_dir);
+    if (base.empty() || base.back() != '/') base += '/';
+    return device_index_on_node(bus_id, base);
+}
 
 int mgpu_host_cpus(mgpu_ctx *c, int32_t *cpus, int32_t cap) {
     if (!c || (!cpus && cap)) return MGPU_E_INVAL;

@@ -199,3 +199,31 @@ def test_bench_roofline_helpers(tmp_path):
     stale.write_text(good.read_text().replace(bench.kernel_source_sha(), "0123456789abcdef"))
     assert bench.valu_issue("k_sweep", 0.040, 67108864, str(stale)) is None            # counters of other code are not this run's
     assert bench.valu_issue("k_sweep", 0.040, 67108864, "/nonexistent/file") is None and bench.valu_issue("k_sweep", 0.0, 1, str(good)) is None
+
+
+def test_device_index_on_its_numa_node(built, tmp_path):
+    """Host logic, no GPU: the pipeline's threads pick their L3 groups by the device's place among the node's GPUs of its NUMA node
+    (sysfs), not by the HIP ordinal — a fake /sys/bus/pci/devices with eight accelerators on two nodes and a few other functions."""
+    import readsb_amd
+    lib = C.CDLL(readsb_amd.lib_path())
+    f = lib.mgpu_selftest_device_index
+    f.argtypes = [C.c_char_p, C.c_char_p]
+    f.restype = C.c_int
+    gpus = ["0000:0a:00.0", "0000:23:00.0", "0000:5a:00.0", "0000:72:00.0", "0000:8b:00.0", "0000:a4:00.0", "0000:d9:00.0", "0000:f1:00.0"]
+
+    def put(name, vendor, device, cpus):
+        d = tmp_path / name
+        d.mkdir()
+        (d / "vendor").write_text(vendor + "\n")
+        (d / "device").write_text(device + "\n")
+        (d / "local_cpulist").write_text(cpus + "\n")
+
+    for k, g in enumerate(gpus):
+        put(g, "0x1002", "0x75a3", "0-63,128-191" if k < 4 else "64-127,192-255")
+    put("0000:00:00.0", "0x1022", "0x14a4", "0-63,128-191")          # a host bridge
+    put("0000:0b:00.0", "0x1002", "0x1234", "0-63,128-191")          # another function of the same vendor
+    put("0000:24:00.0", "0x15b3", "0x1021", "0-63,128-191")          # a NIC
+    for k, g in enumerate(gpus):
+        assert f(str(tmp_path).encode(), g.encode()) == k % 4, g
+    assert f(str(tmp_path).encode(), b"0000:ff:00.0") == -1
+    assert f(None, b"x") == -2

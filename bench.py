@@ -502,6 +502,58 @@ def bench_config5(args, rank, local_rank, world):
         dist.destroy_process_group()
 
 
+def relaunch_or_check_world(args):
+    """`--gpus N` means N ranks, one per GPU.  Under torchrun (WORLD_SIZE set) the flag and the environment must agree.  Without
+    torchrun and N > 1 this process becomes the launcher: it runs itself under `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1` with the same arguments and exits with the launcher's status — so
+    `python bench.py --gpus 8` and the driver's explicit torchrun command are the same job.  More ranks than GPUs is an error,
+    never a silent one-GPU run (round 5: the flag was parsed and ignored)."""
+    import subprocess
+    if args.gpus < 1:
+        raise SystemExit(f"bench.py: --gpus {args.gpus}: at least one")
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher's WORLD_SIZE is {env_world}: pass --gpus {env_world} "
+                         f"(or start bench.py without torchrun and let --gpus launch the ranks)")
+    if args.gpus > 1 and not args.dryrun_gloo:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but this node shows {have} GPU(s): one rank per GPU "
+                             f"(--dryrun-gloo runs the N-rank code path on one device)")
+    if env_world is None and args.gpus > 1:
+        import socket
+        with socket.socket() as s:                              # a free rendezvous port on the loopback interface
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        raise SystemExit(subprocess.call(cmd))
+
+
+def launch_check(args):
+    """--launch-check: the ranks find each other and agree on the world size; rank 0 prints it.  With --dryrun-gloo no GPU is touched."""
+    import torch
+    import torch.distributed as dist
+    world, local_rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    seen = 1
+    if world > 1:
+        if args.dryrun_gloo:
+            dist.init_process_group("gloo")
+            t = torch.ones(1, dtype=torch.int64)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            t = torch.ones(1, dtype=torch.int64, device=torch.device("cuda", local_rank))
+        dist.all_reduce(t)
+        seen = int(t.item())
+        dist.destroy_process_group()
+    if int(os.environ.get("RANK", "0")) == 0:
+        emit({"launch_check": True, "n_gpus": world, "ranks_seen": seen, "gpus_flag": args.gpus,
+              "launched_by": "torchrun" if os.environ.get("TORCHELASTIC_RUN_ID") else "direct"})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -528,8 +580,14 @@ def main():
     ap.add_argument("--dryrun-gloo", action="store_true",
                     help="dry run of the N>1 code path on ONE GPU: gloo backend, collectives on CPU tensors, every rank on device 0 "
                          "(torchrun --nproc-per-node 2 bench.py --gpus 2 --dryrun-gloo ...); the numbers mean nothing")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="the N-rank launch alone (no GPU needed with --dryrun-gloo): every rank joins the process group, rank 0 prints a line "
+                         "with the world size it found — tests/test_bench_launch.py")
     args = ap.parse_args()
 
+    relaunch_or_check_world(args)
+    if args.launch_check:
+        return launch_check(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

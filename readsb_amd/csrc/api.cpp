@@ -184,6 +184,9 @@ struct Slot {
     // the second stream keeps out of k_sweep's way (walk_job: hold_behind_sweep): the chunk's k_sweep has run | which chunk that was
     hipEvent_t ev_swept = nullptr;
     std::atomic<uint64_t> swept_seq{~0ull};
+    // the converter beside the previous chunk's k_slice (mgpu_ctx::conv_side): its own stream -> the chunk's magnitudes are there
+    // (the main stream waits for it) | start of the chunk's k_sweep on the main stream (stage timing: ev[1] is on the converter's stream then)
+    hipEvent_t ev_conv = nullptr, ev_sweep0 = nullptr;
     uint64_t seq = 0;                     // the chunk's number in the context's life (slot = seq % kSlots)
     // the job
     uint64_t n = 0, stream_pos = 0;
@@ -294,6 +297,13 @@ struct mgpu_ctx {
     uint32_t prescreen_variant = 3;                                        // PostSweepParams::variant (the experiments build can ask for the older passes)
     hipStream_t stream_pw = nullptr;                                       // experiment (MGPU_WRITE_BESIDE=1, experiments build): the pre-screen's write pass + k_publish on a stream of their own, beside the next chunk's converter — measured 297 against 357 Gsamples/s (gpurun r05i): beside a kernel that saturates the memory system the write pass's dependent round trips stretch the post-sweep stage from 0.25 to 0.73 ms per step
     hipStream_t stream_f = nullptr;                                        // SC16 formats: the float sums' chains (k_fsum_sc16), so that what follows a walk does not queue behind them
+    // The UC8 converter of chunk N + 1 beside chunk N's k_slice (round 6): the converter is the pipeline's one HBM-bound
+    // kernel, k_slice its largest issue-bound one.  stream_c carries the converters, each held behind the k_sweep of the chunk before;
+    // k_slice's grid is capped at three workgroups per CU (slice_blocks_cap) so that a converter workgroup (32 KB of LDS) fits beside them.
+    hipStream_t stream_c = nullptr;
+    int conv_side = 0;                                                     // 1: on (UC8 without Mode A/C, 1-bit repair tables: with the 2-bit tables k_slice's three workgroups leave no LDS)
+    int convert_variant = 0;                                               // launch_convert's variant (1: the round-1..5 converter; experiments build)
+    unsigned conv_side_blocks = 2048, slice_blocks_cap = 0;                // grid of the side converter | of k_slice beside it (0: whatever is resident)
     hipStream_t s_post = nullptr;                                          // what follows the walk (window statistics, messages on the device): stream2, or stream_wk
     hipStream_t stream_wk = nullptr;                                       // the walk on the device: highest priority, its small kernels must not queue behind the main stream's
     std::string err;
@@ -788,6 +798,8 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
     HIPCHK(c, hipEventCreateWithFlags(&sl.ev_window, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&sl.ev_scan, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&sl.ev_swept, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&sl.ev_conv, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreate(&sl.ev_sweep0));
     HIPCHK(c, hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&sl.ev_pre, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&sl.ev_fsum, hipEventDisableTiming));
@@ -820,6 +832,8 @@ static void free_slot(Slot &sl) {
     if (sl.ev_window) (void) hipEventDestroy(sl.ev_window);
     if (sl.ev_scan) (void) hipEventDestroy(sl.ev_scan);
     if (sl.ev_swept) (void) hipEventDestroy(sl.ev_swept);
+    if (sl.ev_conv) (void) hipEventDestroy(sl.ev_conv);
+    if (sl.ev_sweep0) (void) hipEventDestroy(sl.ev_sweep0);
     if (sl.d_ac_noise) (void) hipFree(sl.d_ac_noise);
     if (sl.h_ac) (void) hipHostFree(sl.h_ac);
     if (sl.ev_h2d) (void) hipEventDestroy(sl.ev_h2d);
@@ -979,6 +993,7 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
         hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream_w, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream_d2h, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream_c, hipStreamNonBlocking) != hipSuccess ||
         (cfg->format != MGPU_FMT_UC8 && hipStreamCreateWithPriority(&c->stream_f, hipStreamNonBlocking, prio_least) != hipSuccess)) { mgpu_destroy(c); return MGPU_E_HIP; }
     // valid_df_*_bitset, init_bitsets() demod_2400.c:112-128 (ENABLE_DF24 off, readsb.h:303)
     c->valid_short = (1u << 0) | (1u << 4) | (1u << 5) | (1u << 11);
@@ -1013,6 +1028,10 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     if (const char *e = getenv("MGPU_DUMP_DIR")) { c->dump_dir = e; c->sig_late = false; }   // (the dump holds per-record signal powers)
     c->fsum_wide = getenv("MGPU_FSUM_WIDE") != nullptr;
     if (const char *e = getenv("MGPU_WRITE_BESIDE")) { if (atoi(e) && hipStreamCreateWithFlags(&c->stream_pw, hipStreamNonBlocking) != hipSuccess) { mgpu_destroy(c); return MGPU_E_HIP; } }
+    if (const char *e = getenv("MGPU_CONVERT_OLD")) c->convert_variant = atoi(e) ? 1 : 0;          // A/B: the round-1..5 UC8 converter
+    if (const char *e = getenv("MGPU_CONV_SIDE")) c->conv_side = atoi(e);                          // A/B: the converter beside k_slice
+    if (const char *e = getenv("MGPU_CONV_SIDE_BLOCKS")) c->conv_side_blocks = (unsigned) atoi(e);
+    if (const char *e = getenv("MGPU_SLICE_BLOCKS")) c->slice_blocks_cap = (unsigned) atoi(e);
     if (const char *e = getenv("MGPU_PRESCREEN_VARIANT")) c->prescreen_variant = (uint32_t) atoi(e);   // (measured, r04k: no faster than the chain per buffer, twice its HBM traffic)
 #endif
     c->device_slot = take_device_slot(cfg->device);
@@ -1058,6 +1077,7 @@ void mgpu_destroy(mgpu_ctx *c) {
     if (c->stream_w) (void) hipStreamSynchronize(c->stream_w);
     if (c->stream_pw) (void) hipStreamSynchronize(c->stream_pw);
     if (c->stream_f) (void) hipStreamSynchronize(c->stream_f);
+    if (c->stream_c) (void) hipStreamSynchronize(c->stream_c);
     if (c->stream_wk) (void) hipStreamSynchronize(c->stream_wk);
     for (auto &sl : c->slot) free_slot(sl);
     for (auto &f : c->feed) {
@@ -1098,6 +1118,7 @@ void mgpu_destroy(mgpu_ctx *c) {
     if (c->stream_pw) (void) hipStreamDestroy(c->stream_pw);
     if (c->stream_d2h) (void) hipStreamDestroy(c->stream_d2h);
     if (c->stream_f) (void) hipStreamDestroy(c->stream_f);
+    if (c->stream_c) (void) hipStreamDestroy(c->stream_c);
     if (c->stream_wk) (void) hipStreamDestroy(c->stream_wk);
     delete c;
 }
@@ -1165,15 +1186,28 @@ static int enqueue_fsum(mgpu_ctx *c, Slot &sl, const uint8_t *iq, hipEvent_t aft
     return MGPU_OK;
 }
 
+// The converter of this chunk on stream_c, beside the k_slice of the chunk before?  UC8 without Mode A/C (its scan wants the sums at
+// once) and not a shard pass (their chunks come one at a time).
+static bool convert_on_side(const mgpu_ctx *c, const Slot &sl) {
+    return c->conv_side && c->cfg.format == MGPU_FMT_UC8 && !c->cfg.mode_ac && !sl.have_mag && c->shard_mode == 0;
+}
+
 static int enqueue_convert(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
     const mgpu_config &cfg = c->cfg;
     const uint64_t n = sl.n;
-    hipStream_t s = c->stream;
+    const bool side = convert_on_side(c, sl);
+    hipStream_t s = side ? c->stream_c : c->stream;
     sl.timed = c->timing_every <= 1 || (c->timing_seq++ % (uint64_t) c->timing_every) == 0;
     sl.fsum_pending = false;
     // the slot's magnitudes / class bitmap / message lists are still read by the window-statistics
     // kernel of its previous use (stream2)
-    if (sl.window_pending) { HIPCHK(c, hipStreamWaitEvent(s, sl.ev_window, 0)); sl.window_pending = false; }
+    if (sl.window_pending) { HIPCHK(c, hipStreamWaitEvent(s, sl.ev_window, 0)); if (side) HIPCHK(c, hipStreamWaitEvent(c->stream, sl.ev_window, 0)); sl.window_pending = false; }
+    if (side) {
+        // behind the k_sweep of the chunk before: everything the main stream ran with this slot's buffers (its chunk of kSlots ago) is
+        // through by then, and so is the converter that wrote the 326-sample tail (this stream).  Then beside that chunk's k_slice.
+        const Slot &prev = c->slot[(sl.seq + mgpu_ctx::kSlots - 1) % mgpu_ctx::kSlots];
+        if (sl.seq > 0 && prev.swept_seq.load(std::memory_order_acquire) == sl.seq - 1) HIPCHK(c, hipStreamWaitEvent(s, prev.ev_swept, 0));
+    }
     // (the scratch block is zero: k_publish of the slot's previous chunk left it so)
     if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[0], s));
     if (!sl.have_mag) {
@@ -1183,7 +1217,7 @@ static int enqueue_convert(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
         cp.uc8_folded = c->d_uc8_folded;
         cp.sum_level = sl.d_sum_level; cp.sum_power = sl.d_sum_power;
         cp.fsum_level = sl.d_fsum_level; cp.fsum_power = sl.d_fsum_power;
-        launch_convert(cfg.format, cp, s);
+        launch_convert(cfg.format, cp, s, side ? c->conv_side_blocks : 0u, c->convert_variant);
         if (cfg.format != MGPU_FMT_UC8 && cfg.mode_ac) {
             // mean level / power of the SC16 formats = the reference's sequential float sums (k_fsum_*, kernels/convert.inc), on a stream
             // of their own, into buffers of their own.  Mode A/C needs them before its scan (the noise floor): behind the converter
@@ -1209,6 +1243,11 @@ static int enqueue_convert(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
                       sl.fsum_pending ? c->fsum_ring[sl.fsum_idx].h : sl.d_fsum_level, sl.fsum_pending ? c->fsum_ring[sl.fsum_idx].h + c->cap_buffers : sl.d_fsum_power,
                       sl.d_ac_noise, sl.h_ac, (uint32_t) c->cap_ac, sl.d_scratch + CNT_NUM + 1 + 4 * c->cap_buffers, sl.d_counters, s);
     if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[1], s));
+    if (side) {                                              // the main stream goes on when the magnitudes are there
+        HIPCHK(c, hipEventRecord(sl.ev_conv, s));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, sl.ev_conv, 0));
+        if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev_sweep0, c->stream));
+    }
     return MGPU_OK;
 }
 
@@ -1244,7 +1283,7 @@ static int enqueue_sweep(mgpu_ctx *c, Slot &sl) {
             const int rc = enqueue_fsum(c, sl, sl.fsum_iq, sl.ev_swept);
             if (rc != MGPU_OK) return rc;
         }
-        sl.slice_blocks = launch_slice(sp, s);
+        sl.slice_blocks = launch_slice(sp, s, c->conv_side ? c->slice_blocks_cap : 0u);
     }
     if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[2], s));
     return MGPU_OK;
@@ -1289,7 +1328,7 @@ static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq, hipEvent_t aft
             HIPCHK(c, hipEventRecord(sl.ev_convdone, c->stream));
             HIPCHK(c, hipStreamWaitEvent(c->stream_f, sl.ev_convdone, 0));
             HIPCHK(c, hipEventRecord(after_convert, c->stream_f));
-        } else HIPCHK(c, hipEventRecord(after_convert, c->stream));
+        } else HIPCHK(c, hipEventRecord(after_convert, convert_on_side(c, sl) ? c->stream_c : c->stream));
         return MGPU_OK;
     };
     if (rc == MGPU_OK && after_convert && !fsum_late) rc = mark_read();
@@ -1361,7 +1400,7 @@ static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
     float ms;
     if (sl.timed) {
         if (hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]) == hipSuccess) c->acc.convert_ms += ms;
-        if (hipEventElapsedTime(&ms, sl.ev[1], sl.ev[4]) == hipSuccess) { c->acc.sweep_ms += ms; sweep_pace_feedback(ms * 1e3f, sl.n, sl.sweep_blocks, c->event_bracket_us); }
+        if (hipEventElapsedTime(&ms, convert_on_side(c, sl) ? sl.ev_sweep0 : sl.ev[1], sl.ev[4]) == hipSuccess) { c->acc.sweep_ms += ms; sweep_pace_feedback(ms * 1e3f, sl.n, sl.sweep_blocks, c->event_bracket_us); }
         if (hipEventElapsedTime(&ms, sl.ev[4], sl.ev[2]) == hipSuccess) c->acc.slice_ms += ms;
         if (hipEventElapsedTime(&ms, sl.ev[2], sl.ev[3]) == hipSuccess) c->acc.prescreen_ms += ms;
         c->acc.n_timed_chunks += 1;
@@ -2125,6 +2164,7 @@ static int feed_common(mgpu_ctx *c, const void *src, bool src_is_device, uint64_
             if (e == hipSuccess) e = hipMemcpyAsync(c->d_iq + off * bps, (const uint8_t *) src + off * bps, len * bps, hipMemcpyHostToDevice, c->stream_w);
             if (e == hipSuccess) e = hipEventRecord(sl.ev_h2d, c->stream_w);
             if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, sl.ev_h2d, 0);
+            if (e == hipSuccess && c->conv_side) e = hipStreamWaitEvent(c->stream_c, sl.ev_h2d, 0);
             if (e != hipSuccess) { c->err = std::string("H2D of the IQ samples: ") + hipGetErrorString(e); rc = MGPU_E_HIP; }
             c->acc.h2d_ms += (float) (wall_ms() - t0);   // host time spent issuing (pageable memory: staging) the copies
         }

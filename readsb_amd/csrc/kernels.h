@@ -127,7 +127,7 @@ struct ConvertParams {
     double *fsum_power;             // [nbuffers] SC16*: sum of magsq
 };
 
-void launch_convert(int format, const ConvertParams &p, hipStream_t s);
+void launch_convert(int format, const ConvertParams &p, hipStream_t s, unsigned max_blocks = 0, int variant = 0);   // variant 1: the round-1..5 UC8 converter (k_convert_uc8), else k_convert_uc8_lean where the buffer geometry allows
 void launch_spin(unsigned us, unsigned blocks, unsigned long long *sink, hipStream_t s);   // a kernel that lasts `us` microseconds (event calibration)
 // SC16 formats: the per-buffer sequential float sums of mag / magsq (convert.c:225-249), exact; state in and out as doubles holding floats
 void launch_fsum_sc16(int format, const uint8_t *iq, uint64_t n, uint32_t buf_samples, double *fsum_level, double *fsum_power, int want_level,
@@ -141,7 +141,7 @@ void launch_fsum_sc16_wide(int format, const uint8_t *iq, const uint16_t *mag, u
 #endif
 unsigned launch_sweep(const SweepParams &p, hipStream_t s);        // k_sweep: preamble sweep -> per-step candidate lists; returns its grid size
 void sweep_pace_feedback(float kernel_us, uint64_t n, unsigned blocks, float bracket_us);   // a timed k_sweep launch: feeds the pacing's step-time estimate
-unsigned launch_slice(const SweepParams &p, hipStream_t s);        // k_slice: slicer + CRC + scoring over the candidate lists -> record pool; returns its grid size (rows of sweep_part)
+unsigned launch_slice(const SweepParams &p, hipStream_t s, unsigned max_blocks = 0);        // k_slice: slicer + CRC + scoring over the candidate lists -> record pool; returns its grid size (rows of sweep_part)
 // pre-screen: count / write the records whose address may matter to the ordered walk
 // (the write pass also stores each live record's would-be signal power: sum of mag^2 over its frame)
 // everything between the sweep and the host: class planes -> class bitmap (+ counters, planes zeroed again),

@@ -164,9 +164,13 @@ const uint16_t *uc8_table() {
 
 std::vector<uint16_t> uc8_folded_table() {
     const uint16_t *full = uc8_table();
-    std::vector<uint16_t> f(128 * UC8_FOLD_STRIDE, 0);
+    std::vector<uint16_t> f(128 * UC8_FOLD_STRIDE + 128 * 128, 0);
     for (int a = 0; a < 128; ++a)
         for (int b = 0; b < 128; ++b) f[a * UC8_FOLD_STRIDE + b] = full[(128 + a) * 256 + (128 + b)];
+    // behind it the same quadrant without the padding (k_convert_uc8_lean: the byte address of an entry is the folded sample
+    // pair itself, high byte << 8 | low byte << 1 — the quadrant is symmetric, so which of I and Q is the row does not matter)
+    for (int a = 0; a < 128; ++a)
+        for (int b = 0; b < 128; ++b) f[128 * UC8_FOLD_STRIDE + a * 128 + b] = full[(128 + a) * 256 + (128 + b)];
     return f;
 }
 

@@ -54,6 +54,8 @@ const uint16_t *uc8_table();
 // The same table folded by its two mirror symmetries: entry [a*UC8_FOLD_STRIDE + b] is the
 // magnitude for |I-127.5| = a+0.5, |Q-127.5| = b+0.5 (a,b in 0..127).  33 KB, lives in LDS.
 constexpr int UC8_FOLD_STRIDE = 130;   // row stride chosen so a column walk changes LDS bank
+// ... followed (at UC8_SYM_OFFSET halfwords) by the same quadrant with row stride 128: 32 KB, k_convert_uc8_lean's form
+constexpr int UC8_SYM_OFFSET = 128 * UC8_FOLD_STRIDE;
 std::vector<uint16_t> uc8_folded_table();
 
 // tan(roll) for the 1024 roll codes of BDS5,0 (index = sign << 9 | 9-bit magnitude, roll = magnitude * 45/256 - 90 * sign as

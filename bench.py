@@ -559,7 +559,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--samples", type=int, default=4096 * BUF, help="samples per stream per step (multiple of 131072)")
+    ap.add_argument("--samples", type=int, default=4096 * BUF, help="samples of the HBM-resident IQ block = of one feed call (multiple of 131072)")
+    ap.add_argument("--loops", type=int, default=40, help="feeds per step: a step plays the resident block this many times (the stream goes on: an ifile "
+                    "in a loop).  40 x 537 M samples = 21.5 G samples per step: the default 20 steps are ~1.1 s of timed region, not 28 ms")
+    ap.add_argument("--device-build", action="store_true", help="N = 1: messages built by k_build_messages and copied into the consumer's page-locked "
+                    "array (mgpu_set_device_messages(2)) instead of by the host's builder threads.  Measured slower (profiles/r06_device_build.txt): "
+                    "the host builder is not what bounds the step, and the 4.7 MB per chunk of message copies queue ahead of the fetcher's record copies")
     ap.add_argument("--msgs-per-sec", type=float, default=2000.0)
     ap.add_argument("--config", type=int, default=1, help="1 (default): one stream per GPU (BASELINE configs[1] / configs[3]); 5: one dense-burst "
                                                           "capture time-chunked over the GPUs (configs[4], strong scaling)")
@@ -644,7 +649,8 @@ def main():
         gath = MessageGatherer(readsb_amd.MSG_DTYPE, coll_dev, cap, depth=3, host_alloc=d.host_alloc)
         bufs = None
     else:
-        bufs = [np.empty(cap, dtype=readsb_amd.MSG_DTYPE) for _ in range(2)]
+        # the consumer's two standing arrays, page-locked near the device: k_build_messages stores the records into them (mode 2)
+        bufs = [np.empty(cap, dtype=readsb_amd.MSG_DTYPE) for _ in range(2)] if not args.device_build else [d.host_alloc(cap * 64).view(readsb_amd.MSG_DTYPE)[:cap] for _ in range(2)]
         if os.environ.get("MGPU_DBG_PINNED_BUFS"):
             bufs = [(d.host_alloc(cap * 64) if os.environ["MGPU_DBG_PINNED_BUFS"] == "near" else torch.empty(cap * 64, dtype=torch.uint8, pin_memory=True).numpy()).view(readsb_amd.MSG_DTYPE) for _ in range(2)]
 
@@ -657,6 +663,11 @@ def main():
     dev_msgs = gath is not None and not args.dryrun_gloo and not os.environ.get("MGPU_DBG_HOST_MESSAGES")
     if dev_msgs:
         d.set_device_messages(True)
+    # N = 1, --device-build: the GPU builds the records too and copies them into the consumer's page-locked arrays — the host's
+    # builder stage keeps the two order-dependent sums (round 6; measured slower than the builder threads: not the default)
+    dev_to_host = gath is None and args.device_build
+    if dev_to_host:
+        d.set_device_messages(2)
     arrays = {}
 
     dbg_t = {"staging": 0.0, "feed": 0.0, "collect": 0.0, "gsubmit": 0.0}
@@ -691,23 +702,25 @@ def main():
         return nmsgs, counters
 
     seq = 0
-    if args.warmup:
+    L = max(1, args.loops)
+    n_warm, n_timed = args.warmup * L, args.steps * L          # feeds
+    if n_warm:
         submit(seq)
-        for k in range(1, args.warmup):
+        for k in range(1, n_warm):
             submit(seq + k)
             take(seq + k - 1)
-        take(seq + args.warmup - 1, want_counters=True)        # drained: the timed region starts with an empty pipeline
-        seq += args.warmup
+        take(seq + n_warm - 1, want_counters=True)             # drained: the timed region starts with an empty pipeline
+        seq += n_warm
     d.timing()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     submit(seq)
-    for k in range(1, args.steps):
+    for k in range(1, n_timed):
         submit(seq + k)
         take(seq + k - 1)
-    nmsgs_last, counters = take(seq + args.steps - 1, want_counters=True)   # ... and ends with an empty one
+    nmsgs_last, counters = take(seq + n_timed - 1, want_counters=True)   # ... and ends with an empty one
     if use_dist:
         gath.wait()                             # the last steps' exchanges are part of the job
         dist.barrier()
@@ -722,11 +735,11 @@ def main():
     ev_scale = tm["n_chunks"] / max(1, tm["n_timed_chunks"])
     for key in ("convert_ms", "sweep_ms", "slice_ms", "prescreen_ms"):
         tm[key] *= ev_scale
-    K = float(args.steps)
+    K = float(n_timed)                         # the stage figures below are per FEED (one pass over the resident block), as in rounds 1-5
     launches = [max(1, tm["n_chunks"]) / K]
     sweep_ms, slice_ms, conv_ms = [tm["sweep_ms"] / K], [tm["slice_ms"] / K], [tm["convert_ms"] / K]
     resolve_ms, total_ms = [tm["resolve_ms"] / K], [tm["total_ms"] / K]
-    for key in ("prescreen_ms", "d2h_ms", "build_ms", "sigpower_ms"):
+    for key in ("prescreen_ms", "d2h_ms", "build_ms", "sigpower_ms", "build_wait_ms"):
         tm[key] = tm[key] / K
     d.set_deferred(False)                       # (also leaves the device-messages mode)
     if world > 1:
@@ -737,10 +750,10 @@ def main():
         dist.all_reduce(nm)
         total_msgs = int(nm.item())
         # every rank's host stages (wall clock of the work itself, per step): do N pipelines' polling threads get in each other's way?
-        hs = torch.tensor([resolve_ms[0], tm["build_ms"], tm["d2h_ms"], len(d.host_cpus())], dtype=torch.float64, device=coll_dev)
+        hs = torch.tensor([resolve_ms[0], tm["build_ms"], tm["d2h_ms"], len(d.host_cpus()), tm["build_wait_ms"]], dtype=torch.float64, device=coll_dev)
         hparts = [torch.zeros_like(hs) for _ in range(world)]
         dist.all_gather(hparts, hs)
-        per_rank_host = [{"resolve_host": round(float(x[0]), 3), "build_host": round(float(x[1]), 3), "d2h": round(float(x[2]), 3), "pinned_cpus": int(x[3])} for x in hparts]
+        per_rank_host = [{"resolve_host": round(float(x[0]), 3), "build_host": round(float(x[1]), 3), "d2h": round(float(x[2]), 3), "pinned_cpus": int(x[3]), "build_wait": round(float(x[4]), 3)} for x in hparts]
     else:
         total_msgs = nmsgs_last
         per_rank_host = None
@@ -752,7 +765,9 @@ def main():
     if not args.no_cpu_baseline:
         d.reset()
         d.set_deferred(True)
-        vb = [np.empty(cap, dtype=readsb_amd.MSG_DTYPE) for _ in range(2)]
+        vb = bufs if bufs is not None and dev_to_host else [np.empty(cap, dtype=readsb_amd.MSG_DTYPE) for _ in range(2)]
+        if dev_to_host:
+            d.set_device_messages(2)                            # checked as timed: the GPU's records, out of the page-locked arrays
         for k in range(2):
             d.set_message_buffer(vb[k])
             d.feed_resident(n)
@@ -797,7 +812,8 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = n * world * args.steps / elapsed / 1e6
+        ms_per_feed = elapsed / n_timed * 1e3
+        value = n * world * n_timed / elapsed / 1e6
         nlaunch = int(np.mean(launches))
         # Per step: sum over the step's launches.  A launch's figure is a pair of timing HIP events around the one kernel; in a busy
         # stream that pair reports the kernel + a constant (4.0 us here: mgpu_event_bracket_us measures it in this process with a
@@ -828,15 +844,17 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u16", "data": "synthetic",
             "config": {"workload": "configs[1]: single 2.4 MSps UC8 stream per GPU, --fix (nfix_crc=1, fixDF=1, thr=58), "
-                                   f"one continuous stream, a step = {n} samples = {n / 2.4e6:.1f} s of it (the resident IQ block played in a loop), "
-                                   f"{args.msgs_per_sec:.0f} frames/s, HBM-resident IQ, deferred feeds (feed k+1 enqueued before feed k is collected)",
-                       "samples_per_stream": n, "streams": world, "parallelism": f"1 stream per GPU x{world}"},
+                                   f"one continuous stream, a step = {L} feeds of the resident IQ block ({n} samples each) = {n * L} samples = {n * L / 2.4e6:.0f} s of it, "
+                                   f"{args.msgs_per_sec:.0f} frames/s, HBM-resident IQ, deferred feeds (feed k+1 enqueued before feed k is collected), "
+                                   + ("messages built on the GPU and stored into the consumer's page-locked arrays" if dev_to_host else "messages built on the GPU, gathered from HBM" if dev_msgs else "messages built by the host's builder threads"),
+                       "samples_per_stream": n * L, "samples_per_feed": n, "feeds_per_step": L, "streams": world, "parallelism": f"1 stream per GPU x{world}"},
+            "ms_per_feed": round(ms_per_feed, 3),
             "x_realtime_per_gpu": round(value / world / 2.4, 1),
-            "msgs_per_s": round(total_msgs * args.steps / elapsed, 1),
-            "messages_per_step": total_msgs,
+            "msgs_per_s": round(total_msgs * n_timed / elapsed, 1),
+            "messages_per_step": total_msgs * L, "messages_per_feed": total_msgs,
             "stage_ms": {"convert": round(float(np.mean(conv_ms)), 3), "sweep": round(sweep_raw, 3), "slice": round(slice_raw, 3),
                          "prescreen": round(tm["prescreen_ms"], 3), "d2h": round(tm["d2h_ms"], 3),
-                         "resolve_host": round(float(np.mean(resolve_ms)), 3), "build_host": round(tm.get("build_ms", 0.0), 3), "sigpower": round(tm["sigpower_ms"], 3),
+                         "resolve_host": round(float(np.mean(resolve_ms)), 3), "build_host": round(tm.get("build_ms", 0.0), 3), "build_wait": round(tm.get("build_wait_ms", 0.0), 3), "sigpower": round(tm["sigpower_ms"], 3), "per": "feed",
                          "feed_total": round(float(np.mean(total_ms)), 3)},
             "roofline": {"kernel": "k_sweep", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

@@ -42,7 +42,7 @@ extern "C" {
 /* Bumped whenever a struct of this header grows or an entry point changes meaning.  5 (round 5): mgpu_config.abi_version is checked
  * by mgpu_create, mgpu_abi_version() exported; 4 (round 4): mgpu_config.chunk_buffers; with MGPU_FILTER_CLOCK_EXTERNAL the filter
  * starts EMPTY since 3 (the host mirrors modesInit's icaoFilterAdd(Modes.show_only)). */
-#define MGPU_ABI_VERSION 5
+#define MGPU_ABI_VERSION 6
 /* The version the loaded library was built with: a host compares it with the MGPU_ABI_VERSION of the header it was compiled against. */
 uint32_t mgpu_abi_version(void);
 
@@ -54,7 +54,8 @@ struct mgpu_config {
     int32_t  format;              /* MGPU_FMT_*: --iformat (sdr_ifile.c:82-108) */
     int32_t  nfix_crc;            /* Modes.nfix_crc: 0 --no-fix, 1 --fix (default, readsb.c:150), 2 --aggressive */
     int32_t  fixDF;               /* Modes.fixDF (readsb.c:194), 0 with --no-fix-df */
-    int32_t  preamble_threshold;  /* Modes.preambleThreshold, default 58 (readsb.c:2268) */
+    int32_t  preamble_threshold;  /* Modes.preambleThreshold, default 58 (readsb.c:2268); 1 .. 4095 (the reference clamps to 40 .. 400,
+                                   * readsb.c:1473; beyond 6000 k_sweep's 32-bit accumulators could overflow): MGPU_E_INVAL otherwise */
     uint32_t buf_samples;         /* Modes.sdr_buf_samples, default 131072 (readsb.c:2212); multiple of 4096 */
     uint32_t trailing_samples;    /* Modes.trailing_samples = 326 (readsb.c:288); must be 326 */
     uint32_t mode_ac;             /* Modes.mode_ac (--modeac): also run demodulate2400AC on every buffer, readsb.c:871-874.  Every
@@ -100,9 +101,10 @@ struct mgpu_config {
 
 /* Fills cfg with the reference defaults (configSetDefaults, readsb.c:150-228). */
 /* Defaults of every field.  C / C++ hosts get the macro: it hands the library the size and the version of the struct THEY were compiled
- * with, the library writes no byte beyond that size and records the version for mgpu_create's check.  The plain entry point (what
- * a binding that looks symbols up at run time calls, e.g. readsb_amd/binding.py, whose struct is generated from this header's
- * revision) fills in the library's own. */
+ * with, the library writes no byte beyond that size and records the version for mgpu_create's check.  The plain entry point writes
+ * sizeof(the LIBRARY's struct) bytes and the library's own version: safe only for a caller whose struct is this header revision's —
+ * a binding that looks symbols up at run time should carry its own version constant and call mgpu_config_defaults_abi with it, as
+ * readsb_amd/binding.py does (ABI_VERSION; it also refuses a library whose mgpu_abi_version() differs). */
 void mgpu_config_defaults_abi(struct mgpu_config *cfg, uint32_t struct_bytes, uint32_t abi_version);
 void mgpu_config_defaults(struct mgpu_config *cfg);
 #ifndef MGPU_NO_DEFAULTS_MACRO
@@ -171,9 +173,12 @@ struct mgpu_timing {
     uint64_t n_messages;     /* accepted messages */
     uint64_t n_chunks;       /* pipeline chunks = launches of each kernel */
     float slice_ms;          /* k_slice: bit slicer + CRC-24 + the filter-independent half of the scoring */
-    float build_ms;          /* builder team: struct modesMessage fields + signal / noise statistics, including its wait for the chunk's signal powers (host wall time) */
+    float build_ms;          /* builder team: struct modesMessage fields + signal / noise statistics — the stage's own work (host wall time;
+                              * until ABI 6 this figure also held the wait below) */
     uint64_t n_timed_chunks; /* chunks that carried the stage timing events: convert_ms, sweep_ms, slice_ms and prescreen_ms are sums
                               * over THESE (every 7th chunk; experiments build: MGPU_TIMING_EVERY) */
+    float build_wait_ms;     /* builder thread: waiting for the chunk's signal powers (second stream) / the SC16 formats' float sums: idle, not work (ABI 6) */
+    float reserved_timing;
 };
 
 /* ---- lifecycle -------------------------------------------------------------------- */
@@ -226,7 +231,12 @@ int mgpu_set_deferred(mgpu_ctx *ctx, int on);
  * pointer of its `*n` records, in stream order — valid until three more feeds have been started — ready for
  * mgpu_decode_fields_device / mgpu_beast_encode_device or an aggregator's RCCL gather (readsb_amd/gather.py: submit_device).
  * mgpu_collect() in this mode copies the whole feed to the host (MGPU_E_OVERFLOW if `cap` is smaller than the feed).
- * The list of a feed holds (chunks per feed) x cfg.max_messages records (default per chunk: samples / 64 + 65536). */
+ * The list of a feed holds (chunks per feed) x cfg.max_messages records (default per chunk: samples / 64 + 65536).
+ * on == 2 (round 6): built on the GPU the same way, but k_build_messages stores the records straight into the array
+ * mgpu_set_message_buffer() named for the feed — which must be page-locked (mgpu_host_alloc / mgpu_host_register; MGPU_E_INVAL
+ * from the feed call otherwise): the host has its list, identical bytes, and builds nothing; its builder stage keeps the two
+ * order-dependent sums.  mgpu_collect() then waits for the feed's last k_build_messages and returns the count (no copy when
+ * `out` is that array).  The mode for hosts that take struct modesMessage fields on the CPU from an HBM-resident pipeline. */
 int mgpu_set_device_messages(mgpu_ctx *ctx, int on);
 int mgpu_collect_device(mgpu_ctx *ctx, const struct mgpu_msg **d_msgs, uint64_t *n, struct mgpu_counters *counters);
 

@@ -98,6 +98,7 @@ class Timing(C.Structure):
         ("resolve_ms", C.c_float), ("sigpower_ms", C.c_float), ("d2h_ms", C.c_float), ("total_ms", C.c_float),
         ("n_candidates", C.c_uint64), ("n_records", C.c_uint64), ("n_live_records", C.c_uint64),
         ("n_messages", C.c_uint64), ("n_chunks", C.c_uint64), ("slice_ms", C.c_float), ("build_ms", C.c_float), ("n_timed_chunks", C.c_uint64),
+        ("build_wait_ms", C.c_float), ("reserved_timing", C.c_float),
     ]
 
     def as_dict(self):
@@ -119,6 +120,9 @@ class ShardStreamArgs(C.Structure):
         ("first_sample", C.c_uint64), ("history_iq", C.c_void_p), ("own_first", C.c_uint64), ("flip_after", C.c_void_p), ("nflips", C.c_uint64),
         ("start_state", C.c_void_p), ("start_state_bytes", C.c_uint64),
     ]
+
+
+ABI_VERSION = 6                             # MGPU_ABI_VERSION of the include/modes_gpu.h these ctypes mirrors were written against
 
 
 class MgpuError(RuntimeError):
@@ -227,8 +231,13 @@ def load_library():
         raise MgpuError(f"{path} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
     lib = C.CDLL(path)
     vp, u64, u32, i32, i64 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_int64
-    lib.mgpu_config_defaults.argtypes = [C.POINTER(Config)]
-    lib.mgpu_config_defaults.restype = None
+    lib.mgpu_config_defaults_abi.argtypes = [C.POINTER(Config), u32, u32]
+    lib.mgpu_config_defaults_abi.restype = None
+    lib.mgpu_abi_version.restype = u32
+    # this file mirrors the structs of include/modes_gpu.h at ABI_VERSION: a library of another version is refused here, and
+    # mgpu_create checks the version the defaults call wrote into the struct (never more than sizeof(Config) bytes of it)
+    if lib.mgpu_abi_version() != ABI_VERSION:
+        raise MgpuError(f"{path} is ABI version {lib.mgpu_abi_version()}, readsb_amd/binding.py mirrors version {ABI_VERSION}: rebuild the library")
     lib.mgpu_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
     lib.mgpu_destroy.argtypes = [vp]
     lib.mgpu_destroy.restype = None
@@ -315,7 +324,7 @@ class Demodulator:
                  filter_clock=0, chunk_buffers=None):
         self.lib = load_library()
         cfg = Config()
-        self.lib.mgpu_config_defaults(C.byref(cfg))
+        self.lib.mgpu_config_defaults_abi(C.byref(cfg), C.sizeof(Config), ABI_VERSION)
         cfg.device, cfg.format, cfg.nfix_crc, cfg.fixDF = device, fmt, nfix_crc, fix_df
         cfg.preamble_threshold, cfg.max_samples, cfg.startup_time_ms = preamble_threshold, max_samples, startup_time_ms
         cfg.record_pool_records, cfg.max_messages, cfg.buf_samples = record_pool_records, max_messages, buf_samples
@@ -638,8 +647,9 @@ class Demodulator:
         self._chk(self.lib.mgpu_set_deferred(self.ctx, 1 if on else 0), "mgpu_set_deferred")
 
     def set_device_messages(self, on=True):
-        """mgpu_set_device_messages (deferred mode): the messages of a feed are built on the GPU and stay there."""
-        self._chk(self.lib.mgpu_set_device_messages(self.ctx, 1 if on else 0), "mgpu_set_device_messages")
+        """mgpu_set_device_messages (deferred mode): the messages of a feed are built on the GPU and stay there (True / 1), or are
+        stored by the GPU into the page-locked array set_message_buffer named for the feed (2)."""
+        self._chk(self.lib.mgpu_set_device_messages(self.ctx, int(on)), "mgpu_set_device_messages")
 
     def collect_feed_device(self, want_counters=False):
         """Device-messages mode: wait for the oldest uncollected feed; returns (device pointer of its mgpu_msg records, count,

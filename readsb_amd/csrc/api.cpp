@@ -275,6 +275,7 @@ struct FeedSlot {
     MsgBuf msgs;
     // device-messages mode (mgpu_set_device_messages): the feed's messages are built by k_build_messages into d_msgs
     mgpu_msg *d_msgs = nullptr;
+    mgpu_msg *host_dev = nullptr;             // mode 2 (device-built, host-delivered): the device address of msgs.p, the caller's page-locked array
     uint64_t d_cap = 0, d_count = 0;          // d_count: walker thread only, read by the caller after the feed is complete
     hipEvent_t ev_built = nullptr;            // the last k_build_messages of the feed has run (stream2)
     uint64_t jobs_total = 0, jobs_built = 0;  // chunks submitted / chunks whose messages are complete (under mgpu_ctx::mu)
@@ -285,9 +286,12 @@ struct mgpu_ctx {
     // Four slots (round 4; three before): a slot is held from the chunk's first kernel until its walk is done — with chunks of 1024
     // buffers GPU 0.4-0.6 ms + fetch 0.25-0.6 + walk 0.25-0.35 = 2.2-2.5 chunk periods, and with three slots the GPU idled whenever a
     // host stage took a little longer (SC16Q11 --aggressive: 110 or 180 Gsamples/s from one repetition to the next)
-    static constexpr int kSlots = 4;
-    static constexpr int kJobs = 6;                           // fetched -> walked -> built: a job outlives its slot by the builder's stage
-    static constexpr int kFsumRing = 12;                      // > kSlots + kJobs: an entry is free again before its index comes round
+#ifndef MGPU_SLOTS
+#define MGPU_SLOTS 4
+#endif
+    static constexpr int kSlots = MGPU_SLOTS;
+    static constexpr int kJobs = MGPU_SLOTS + 2;              // fetched -> walked -> built: a job outlives its slot by the builder's stage
+    static constexpr int kFsumRing = 2 * MGPU_SLOTS + 4;      // > kSlots + kJobs: an entry is free again before its index comes round
     mgpu_config cfg{};
     hipStream_t stream = nullptr, stream2 = nullptr, stream_w = nullptr;   // main | window statistics | pre-screen write pass / IQ uploads
     hipStream_t stream_d2h = nullptr;                                      // the fetcher's record copies
@@ -342,7 +346,7 @@ struct mgpu_ctx {
     FeedSlot feed[kFeeds];                                    // deferred mode: ring of feeds in flight / uncollected
     uint64_t feed_head = 0, feed_tail = 0;                    // oldest uncollected feed, next feed to open
     bool deferred = false;
-    bool device_msgs = false;                                 // mgpu_set_device_messages
+    int device_msgs = 0;                                      // mgpu_set_device_messages: 1 = the records stay in HBM (FeedSlot::d_msgs), 2 = k_build_messages stores them into the caller's page-locked array
     bool sig_late = true;                                     // MGPU_SIG_LATE=0: signal power of every live record in the pre-screen write pass (as in shard passes) instead of the accepted frames' after the walk
     int timing_every = 7;                                     // chunks per set of stage timing events (1 = every chunk; MGPU_TIMING_EVERY in the experiments build).  Odd: with feeds of four chunks the sampled chunk is not always a feed's first
     bool fsum_wide = false;                                   // (experiments build: MGPU_FSUM_WIDE=1) the float sums as three wide kernels instead of one chain per buffer
@@ -974,7 +978,11 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
         cfg->max_samples == 0 || cfg->format < 0 || cfg->format > 2 || cfg->nfix_crc < 0 || cfg->nfix_crc > 2 ||
         cfg->filter_clock > MGPU_FILTER_CLOCK_EXTERNAL ||
         cfg->abi_version != MGPU_ABI_VERSION ||           // the host's header is another version's (or it did not call mgpu_config_defaults)
-        cfg->chunk_buffers > 16384u)                      // (0 = the default; 16384 buffers = 2^31 samples: positions are 32 bits)
+        cfg->chunk_buffers > 16384u ||                    // (0 = the default; 16384 buffers = 2^31 samples: positions are 32 bits)
+        // k_sweep's threshold tests run in 32-bit accumulators on 16-bit coefficients: thr * (five samples) + 32 * (four samples) must
+        // stay below 2^31 — thr <= 6000 — and a threshold below 1 accepts every position.  The reference's own range is 40..400
+        // (demod_2400.h:28-34, clamped at readsb.c:1473).
+        cfg->preamble_threshold < 1 || cfg->preamble_threshold > 4095)
         return MGPU_E_INVAL;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device >= ndev) return MGPU_E_NODEVICE;
@@ -1566,7 +1574,7 @@ static int walk_job_device(mgpu_ctx *c, Slot &sl, HostJob &job) {
     const double t_sig0 = wall_ms();
     if (nmsg)
         launch_window_stats(sl.d_mag, sl.n, sl.d_cand, sl.d_cand_count, sl.d_class_final, sl.d_msg_pos, sl.d_msg_skip, sl.d_msg_limit, nmsg, sl.d_win_part, c->d_win, s2);
-    const bool to_device_list = c->device_msgs && job.feed >= 0;
+    const bool to_device_list = c->device_msgs == 1 && job.feed >= 0;   // (mode 2 with the walk on the device: not offered — mgpu_set_device_messages refuses it)
     if (nmsg) {
         const void *d_bufs = sl.d_wk_in + kWkInHead;           // the buffer clocks went over with the walk's input
         mgpu_msg *dst = c->d_wk_msgs;
@@ -1731,7 +1739,8 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
     if (nmsg && c->device_msgs && job.feed >= 0) {
         // the accepted frames become message records on the device (kernels/build.inc), appended to the feed's device list
         FeedSlot &fs = c->feed[job.feed];
-        if (fs.d_count + nmsg > fs.d_cap) { c->err = "device message list of the feed is full"; return MGPU_E_OVERFLOW; }
+        const bool to_host = c->device_msgs == 2;
+        if (fs.d_count + nmsg > fs.d_cap || (to_host && fs.d_count + nmsg > (uint64_t) fs.msgs.cap)) { c->err = to_host ? "the caller's message buffer (mgpu_set_message_buffer) is full" : "device message list of the feed is full"; return MGPU_E_OVERFLOW; }
         const size_t acc_bytes = ((size_t) nmsg * sizeof(Accepted) + 15) & ~(size_t) 15;
         const size_t buf_bytes = sl.buffers.size() * sizeof(BufferClock);
         std::memcpy(sl.h_blob, job.acc.data(), (size_t) nmsg * sizeof(Accepted));
@@ -1739,6 +1748,9 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
         launch_stage_blob(sl.h_blob, sl.d_blob, acc_bytes + buf_bytes, s2);
         launch_build_messages(sl.d_live, sl.d_live_sig, job.sig_late ? sl.d_msg_sig : nullptr, sl.d_blob, sl.d_blob + acc_bytes, nmsg,
                               fs.d_msgs + fs.d_count, s2);
+        // mode 2: ... and on into the caller's page-locked array.  (k_build_messages storing there itself — 4.7 MB per chunk of 64-byte
+        // stores over PCIe from a kernel on the second stream — stretched whatever ran beside it: 1.78 against 1.42 ms per feed, r06d.)
+        if (to_host) HIPCHK(c, hipMemcpyAsync(fs.msgs.p + fs.d_count, fs.d_msgs + fs.d_count, (size_t) nmsg * sizeof(mgpu_msg), hipMemcpyDeviceToHost, s2));
         HIPCHK(c, hipEventRecord(fs.ev_built, s2));
         fs.d_count += nmsg;
     }
@@ -1760,6 +1772,8 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
     const double t0 = wall_ms();
     const uint32_t nmsg = job.nmsg;
     const uint32_t nbuf = (uint32_t) job.buffers.size();
+    double stats_wait_ms = 0, wait_ms = 0;                         // idle: waiting for the GPU's second stream / the float sums' chain
+    auto wait_copied = [&]() -> hipError_t { const double tw = wall_ms(); const hipError_t e = wait_event_spin(job.ev_copied); wait_ms += wall_ms() - tw; return e; };
     // Mode A/C (cfg.mode_ac): candidates in position order; an accepted reply hides the next 69 positions of its
     // buffer (f1_sample += 20 * 87 / 25, then the loop's ++, demod_2400.c:765)
     std::vector<AcCand> &ac = job.ac;
@@ -1793,7 +1807,7 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
     std::vector<mgpu_msg> &stage = c->b_stage;               // with Mode A/C the Mode S messages are built here and merged per buffer
     if (nac) { stage.resize(nmsg); }
     if (job.from_device) {                                   // the walk ran on the device: the messages come from there
-        if (nmsg) HIPCHK(c, wait_event_spin(job.ev_copied));
+        if (nmsg) HIPCHK(c, wait_copied());
         if (!on_device && nmsg) {
             mgpu_msg *dst = nac ? stage.data() : out;
             const int parts = nmsg >= 4096 ? c->build_threads : 1;
@@ -1811,7 +1825,9 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
         mgpu_counters &k = c->counters;
         const double *fsums = job.fsums.data();
         if (job.fsum_idx >= 0) {                                  // SC16 formats: the chunk's float sums arrive here at the latest
+            const double tw = wall_ms();
             (void) wait_event_spin(c->fsum_ring[job.fsum_idx].ev);
+            stats_wait_ms = wall_ms() - tw;
             fsums = c->fsum_ring[job.fsum_idx].h;
         }
         for (int i = 0; i < 3; ++i) k.demod_accepted[i] += job.rc.accepted[i];
@@ -1859,7 +1875,7 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
         // (sig_late: the accepted frames' signal powers come over the second stream — k_msg_sig and a copy, ahead of the window
         // statistics.  Building first and filling the field in afterwards was slower: the messages leave with streaming stores,
         // and touching 27 000 of their lines again costs more than the wait.)
-        if (job.sig_late && nmsg) HIPCHK(c, wait_event_spin(job.ev_copied));
+        if (job.sig_late && nmsg) HIPCHK(c, wait_copied());
         // The signal / noise statistics — one chain of dependent double additions over the chunk's messages, a third of this stage's
         // time on one thread — ride beside the message build as one more task of the team (they read the accept list and the signal
         // powers only): with chunks of 1024 buffers the builder was the pipeline's slowest stage (round 4: 1.6-1.77 ms per step
@@ -1873,7 +1889,7 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
                                      job.acc.data() + lo, hi - lo, dst + lo);
         });
         stats_done = split;
-    } else if (!job.from_device && job.sig_late && nmsg) HIPCHK(c, wait_event_spin(job.ev_copied));   // (messages on the device: statistics only)
+    } else if (!job.from_device && job.sig_late && nmsg) HIPCHK(c, wait_copied());   // (messages on the device: statistics only)
     if (nac) {   // netUseMessage order: per buffer the Mode S messages of demodulate2400, then the replies of demodulate2400AC
         size_t si = 0, ai = 0, o = 0;
         for (uint32_t b = 0; b < nbuf; ++b) {
@@ -1899,7 +1915,8 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
     const double t2 = wall_ms();
 
     if (!stats_done) build_statistics();
-    c->acc.build_ms += (float) (wall_ms() - t0);
+    c->acc.build_ms += (float) (wall_ms() - t0 - wait_ms - stats_wait_ms);
+    c->acc.build_wait_ms += (float) (wait_ms + stats_wait_ms);
     if (c->dbg_print) fprintf(stderr, "dbg: timeline: build %.3f .. %.3f\n", t0 - c->feed_t0, wall_ms() - c->feed_t0);
     if (c->dbg_print) fprintf(stderr, "dbg: build: grow %.3f ms, messages %.3f ms, statistics %.3f ms for %u msgs\n", t1 - t0, t2 - t1, wall_ms() - t2, nmsg);
     return MGPU_OK;
@@ -2120,6 +2137,17 @@ static int feed_common(mgpu_ctx *c, const void *src, bool src_is_device, uint64_
         fs.closed = false;
         fs.msgs.clear();
         fs.d_count = 0;
+        if (c->device_msgs == 2) {
+            // the records go from the GPU straight into the array mgpu_set_message_buffer named for this feed: it has to be page-locked
+            // (mgpu_host_alloc / mgpu_host_register), the kernel writes through its device address
+            void *dp = nullptr;
+            if (!fs.msgs.external || hipHostGetDevicePointer(&dp, fs.msgs.p, 0) != hipSuccess || !dp) {
+                c->err = "mgpu_set_device_messages(2): name a page-locked array (mgpu_host_alloc / mgpu_host_register) with mgpu_set_message_buffer before every feed";
+                return MGPU_E_INVAL;
+            }
+            fs.host_dev = (mgpu_msg *) dp;
+            if (!fs.ev_built && hipEventCreateWithFlags(&fs.ev_built, hipEventDisableTiming) != hipSuccess) { c->err = "device messages: event"; return MGPU_E_HIP; }
+        }
         if (c->device_msgs && !fs.d_msgs) {
             const uint64_t want = ((c->cap_samples + c->chunk_samples - 1) / c->chunk_samples) * c->cap_msgs;   // every chunk of a feed may fill its slot's list
             if (hipSetDevice(c->cfg.device) != hipSuccess || hipMalloc(&fs.d_msgs, want * sizeof(mgpu_msg)) != hipSuccess ||
@@ -2219,7 +2247,7 @@ int mgpu_set_deferred(mgpu_ctx *c, int on) {
     if (c->feed_head != c->feed_tail || c->pending.size()) { c->err = "mgpu_set_deferred: collect the pending messages first"; return MGPU_E_INVAL; }
     if (!on) {                                       // the caller's arrays go back to the caller
         for (auto &f : c->feed) f.msgs.use_external(nullptr, 0);
-        c->device_msgs = false;
+        c->device_msgs = 0;
     }
     c->deferred = on != 0;
     return MGPU_OK;
@@ -2319,7 +2347,17 @@ int mgpu_collect(mgpu_ctx *c, struct mgpu_msg *out, uint64_t cap, uint64_t *n, s
                 stage_wait(c, lk, [&] { return c->worker_rc != MGPU_OK || (fs.closed && fs.jobs_built == fs.jobs_total); });
                 if (c->worker_rc != MGPU_OK) return c->worker_rc;
             }
-            if (c->device_msgs) {                            // the feed's records are in HBM: this entry copies them out
+            if (c->device_msgs == 2) {                       // built on the GPU, stored by it into the feed's (page-locked) array
+                if (fs.d_count > cap) { c->err = "mgpu_collect: the feed's messages do not fit (device-messages mode takes whole feeds)"; return MGPU_E_OVERFLOW; }
+                if (fs.d_count) {
+                    HIPCHK(c, hipSetDevice(c->cfg.device));
+                    HIPCHK(c, wait_event_spin(fs.ev_built));
+                    if (out != fs.msgs.p) std::memcpy(out, fs.msgs.p, fs.d_count * sizeof(mgpu_msg));
+                }
+                if (n) *n = fs.d_count;
+                std::lock_guard<std::mutex> lk(c->mu);
+                c->feed_head++;
+            } else if (c->device_msgs) {                     // the feed's records are in HBM: this entry copies them out
                 if (fs.d_count > cap) { c->err = "mgpu_collect: the feed's messages do not fit (device-messages mode takes whole feeds)"; return MGPU_E_OVERFLOW; }
                 if (fs.d_count) {
                     HIPCHK(c, hipSetDevice(c->cfg.device));
@@ -2349,7 +2387,7 @@ int mgpu_collect(mgpu_ctx *c, struct mgpu_msg *out, uint64_t cap, uint64_t *n, s
 int mgpu_collect_device(mgpu_ctx *c, const struct mgpu_msg **d_msgs, uint64_t *n, struct mgpu_counters *counters) {
     if (!c || !d_msgs || !n) return MGPU_E_INVAL;
     *d_msgs = nullptr; *n = 0;
-    if (!c->deferred || !c->device_msgs) { c->err = "mgpu_collect_device: needs mgpu_set_deferred and mgpu_set_device_messages"; return MGPU_E_INVAL; }
+    if (!c->deferred || c->device_msgs != 1) { c->err = "mgpu_collect_device: needs mgpu_set_deferred and mgpu_set_device_messages(1)"; return MGPU_E_INVAL; }
     if (c->feed_head != c->feed_tail) {
         FeedSlot &fs = c->feed[c->feed_head % mgpu_ctx::kFeeds];
         {
@@ -2379,6 +2417,7 @@ int mgpu_set_device_messages(mgpu_ctx *c, int on) {
     if (rc != MGPU_OK) return rc;
     if (c->feed_head != c->feed_tail) { c->err = "mgpu_set_device_messages: collect the pending feeds first"; return MGPU_E_INVAL; }
     if (on && (!c->deferred || c->cfg.mode_ac)) { c->err = "mgpu_set_device_messages: needs deferred feeds, and no Mode A/C (its replies are merged on the host)"; return MGPU_E_INVAL; }
+    if (on < 0 || on > 2 || (on == 2 && c->device_walk == 1)) return MGPU_E_INVAL;
     if (on) {                                        // the four feeds' device lists now, not inside somebody's timed region
         HIPCHK(c, hipSetDevice(c->cfg.device));
         const uint64_t want = ((c->cap_samples + c->chunk_samples - 1) / c->chunk_samples) * c->cap_msgs;   // every chunk of a feed may fill its slot's list
@@ -2389,7 +2428,7 @@ int mgpu_set_device_messages(mgpu_ctx *c, int on) {
             fs.d_cap = want;
         }
     }
-    c->device_msgs = on != 0;
+    c->device_msgs = on;
     return MGPU_OK;
 }
 

@@ -67,6 +67,11 @@ def test_abi_version_is_checked(built, tmp_path):
     cfg.abi_version = version
     cfg.chunk_buffers = 1 << 20
     assert lib.mgpu_create(C.byref(cfg), C.byref(ctx)) == -1 and not ctx.value
+    cfg.chunk_buffers = 0
+    for thr in (0, -5, 4096, 70000):                   # the sweep's 16-bit coefficient / 32-bit accumulators: 1 .. 4095 (the reference clamps to 40 .. 400)
+        cfg.preamble_threshold = thr
+        assert lib.mgpu_create(C.byref(cfg), C.byref(ctx)) == -1 and not ctx.value
+    assert binding.ABI_VERSION == version             # the ctypes mirrors name the header revision they were written against
     # a host whose struct ends 8 bytes earlier (round 3's): the bytes behind it stay untouched
     lib.mgpu_config_defaults_abi.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
     lib.mgpu_config_defaults_abi.restype = None

@@ -130,6 +130,45 @@ def test_device_messages_equal_host_messages(built, monkeypatch):
     d.close()
 
 
+def test_device_built_messages_delivered_to_a_page_locked_array(built, monkeypatch):
+    """mgpu_set_device_messages(2): k_build_messages stores the records straight into the caller's page-locked array — the
+    host has its list and builds nothing.  Byte for byte the oracle's messages, counters settled as ever; a pageable array is
+    refused loudly (the kernel could not reach it)."""
+    import readsb_amd
+    monkeypatch.setattr(readsb_amd.binding, "DEFAULT_CHUNK_BUFFERS", 16)
+    sizes = [48 * B, 40 * B, 19 * B + 999]
+    iq = helpers.synth(nsamples=sum(sizes), seed=4321, rate=3500.0)
+    want, wst = helpers.oracle_run(iq, 0, 1, 1, 58)
+    blocks = _blocks(iq, sizes)
+    d = readsb_amd.Demodulator(nfix_crc=1, startup_time_ms=helpers.STARTUP_MS, max_samples=64 * B)
+    d.set_deferred(True)
+    d.set_device_messages(2)
+    bufs = [d.host_alloc(200000 * 64).view(readsb_amd.MSG_DTYPE) for _ in range(2)]
+    got = []
+    d.set_message_buffer(bufs[0])
+    d.feed_iq(blocks[0])
+    for k in range(1, len(blocks)):
+        d.set_message_buffer(bufs[k % 2])
+        d.feed_iq(blocks[k])
+        m, _ = d.collect_feed(bufs[(k - 1) % 2])
+        assert m.ctypes.data == bufs[(k - 1) % 2].ctypes.data                 # in place: nothing was copied
+        got.append(m.copy())
+    m, _ = d.collect_feed(bufs[(len(blocks) - 1) % 2])
+    got.append(m.copy())
+    d.finish()
+    _, cnt = d.collect_feed(bufs[0], want_counters=True)
+    helpers.assert_same_messages(np.concatenate(got), want)
+    helpers.assert_same_counters(cnt, wst)
+    assert d.timing()["build_wait_ms"] >= 0.0
+    # a pageable array: the feed call says so
+    d.reset()
+    d.set_message_buffer(np.empty(1000, dtype=readsb_amd.MSG_DTYPE))
+    with pytest.raises(readsb_amd.MgpuError, match="page-locked"):
+        d.feed_iq(blocks[0][: 2 * B])
+    d.set_deferred(False)
+    d.close()
+
+
 def test_one_chunk_host_feeds_on_a_busy_gpu(built, monkeypatch):
     """Deferred HOST feeds of one pipeline chunk each, all different, from one page-locked block that is overwritten as soon as
     the feed call returns, while a second context keeps the GPU's main queue full: every feed uploads into the same region of

@@ -32,6 +32,21 @@ def test_uc8_options(built, nfix, fixdf, thr):
     helpers.assert_same_counters(cnt, wst)
 
 
+@pytest.mark.parametrize("thr", [40, 58, 400])
+def test_clipped_capture_at_the_threshold_range_ends(built, thr):
+    """The reference's whole --preamble-threshold range (40 .. 400, demod_2400.h:28-34 / readsb.c:1473) on a capture whose strong
+    frames clip: runs of magnitude 65535 go through k_sweep's biased 16-bit dot products (32767 after the bias, the largest
+    accumulators the tests can reach) and through the slicer's."""
+    iq = helpers.synth(seconds=2.0, seed=2024, rate=3000.0)
+    hot = np.clip((iq.astype(np.float32) - 127.5) * 2.6 + 127.5, 0, 255).round().astype(np.uint8)   # amplitude 40..119 LSB -> most frames saturate
+    want, wst = helpers.reference_run(hot, 0, 1, 1, thr)
+    lut = helpers.oracle_convert(hot[: 2 * 400000], 0)[0]
+    assert (lut == 65535).mean() > 0.002 and len(want) > 200
+    got, cnt, _ = _demod(hot, nfix_crc=1, fix_df=1, preamble_threshold=thr)
+    helpers.assert_same_messages(got, want)
+    helpers.assert_same_counters(cnt, wst)
+
+
 def test_uc8_10s_config2(built):
     """BASELINE config 2: single 10 s UC8 stream, --fix."""
     iq = helpers.synth(seconds=10.0, seed=88172645463325252)

@@ -562,6 +562,7 @@ def main():
     ap.add_argument("--samples", type=int, default=4096 * BUF, help="samples of the HBM-resident IQ block = of one feed call (multiple of 131072)")
     ap.add_argument("--loops", type=int, default=40, help="feeds per step: a step plays the resident block this many times (the stream goes on: an ifile "
                     "in a loop).  40 x 537 M samples = 21.5 G samples per step: the default 20 steps are ~1.1 s of timed region, not 28 ms")
+    ap.add_argument("--ahead", type=int, default=1, help="feeds enqueued ahead of the one being collected (1..3: the library keeps at most four uncollected)")
     ap.add_argument("--device-build", action="store_true", help="N = 1: messages built by k_build_messages and copied into the consumer's page-locked "
                     "array (mgpu_set_device_messages(2)) instead of by the host's builder threads.  Measured slower (profiles/r06_device_build.txt): "
                     "the host builder is not what bounds the step, and the 4.7 MB per chunk of message copies queue ahead of the fetcher's record copies")
@@ -650,7 +651,8 @@ def main():
         bufs = None
     else:
         # the consumer's two standing arrays, page-locked near the device: k_build_messages stores the records into them (mode 2)
-        bufs = [np.empty(cap, dtype=readsb_amd.MSG_DTYPE) for _ in range(2)] if not args.device_build else [d.host_alloc(cap * 64).view(readsb_amd.MSG_DTYPE)[:cap] for _ in range(2)]
+        nbufs = 1 + max(1, min(3, args.ahead))
+        bufs = [np.empty(cap, dtype=readsb_amd.MSG_DTYPE) for _ in range(nbufs)] if not args.device_build else [d.host_alloc(cap * 64).view(readsb_amd.MSG_DTYPE)[:cap] for _ in range(nbufs)]
         if os.environ.get("MGPU_DBG_PINNED_BUFS"):
             bufs = [(d.host_alloc(cap * 64) if os.environ["MGPU_DBG_PINNED_BUFS"] == "near" else torch.empty(cap * 64, dtype=torch.uint8, pin_memory=True).numpy()).view(readsb_amd.MSG_DTYPE) for _ in range(2)]
 
@@ -676,7 +678,7 @@ def main():
         t_a = time.perf_counter()
         buf = None
         if not dev_msgs:
-            buf = gath.staging(ahead=k - gath.seq) if gath is not None else bufs[k % 2]
+            buf = gath.staging(ahead=k - gath.seq) if gath is not None else bufs[k % len(bufs)]
             d.set_message_buffer(buf)
         t_b = time.perf_counter()
         d.feed_resident(n)                      # everything from HBM-resident IQ to ordered messages
@@ -704,23 +706,27 @@ def main():
     seq = 0
     L = max(1, args.loops)
     n_warm, n_timed = args.warmup * L, args.steps * L          # feeds
+    A = max(1, min(3, args.ahead)) if gath is None else 1      # feeds in flight beyond the one being collected
+
+    def run_feeds(first, count):
+        """`count` feeds from number `first` on, A of them enqueued ahead of the one being collected; ends with an empty pipeline."""
+        last = None
+        for k in range(count + A):
+            if k < count:
+                submit(first + k)
+            if k >= A:
+                last = take(first + k - A, want_counters=(k - A == count - 1))
+        return last
+
     if n_warm:
-        submit(seq)
-        for k in range(1, n_warm):
-            submit(seq + k)
-            take(seq + k - 1)
-        take(seq + n_warm - 1, want_counters=True)             # drained: the timed region starts with an empty pipeline
+        run_feeds(seq, n_warm)                                  # drained: the timed region starts with an empty pipeline
         seq += n_warm
     d.timing()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    submit(seq)
-    for k in range(1, n_timed):
-        submit(seq + k)
-        take(seq + k - 1)
-    nmsgs_last, counters = take(seq + n_timed - 1, want_counters=True)   # ... and ends with an empty one
+    nmsgs_last, counters = run_feeds(seq, n_timed)              # ... and ends with an empty one
     if use_dist:
         gath.wait()                             # the last steps' exchanges are part of the job
         dist.barrier()

@@ -737,7 +737,7 @@ def main():
     tm = d.timing()                             # sums over the timed region's launches (everything since the last drain)
     # what two timing events around one kernel report beyond the kernel (include/modes_gpu.h): measured here, or taken from an earlier run
     bracket_us = args.event_bracket_us if args.event_bracket_us is not None else d.event_bracket_us()
-    # the stage events ride on every 7th chunk only (an event costs ~5 us of idle stream): scale the sampled sums to all chunks
+    # the stage events ride on every 15th chunk only (an event costs ~5 us of idle stream): scale the sampled sums to all chunks
     ev_scale = tm["n_chunks"] / max(1, tm["n_timed_chunks"])
     for key in ("convert_ms", "sweep_ms", "slice_ms", "prescreen_ms"):
         tm[key] *= ev_scale

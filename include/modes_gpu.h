@@ -155,7 +155,7 @@ struct mgpu_counters {
 };
 
 /* Where the last feed's time went (ms).  The four kernel figures are pairs of HIP events on the context's main stream around ONE
- * kernel / one group of kernels, on the first chunk since the figures were last reset and every seventh after it (n_timed_chunks: a timing event costs ~5 us of idle stream; neighbouring figures share an event); a pair adds
+ * kernel / one group of kernels, on the first chunk since the figures were last reset and every fifteenth after it (seventh until round 6; n_timed_chunks: a timing event costs ~5 us of idle stream; neighbouring figures share an event); a pair adds
  * a constant ~4 us to what it brackets (mgpu_event_bracket_us measures it).  The host figures are wall-clock sums of stage threads
  * that run beside each other and beside the GPU: they overlap, they do not add up to total_ms. */
 struct mgpu_timing {
@@ -176,7 +176,7 @@ struct mgpu_timing {
     float build_ms;          /* builder team: struct modesMessage fields + signal / noise statistics — the stage's own work (host wall time;
                               * until ABI 6 this figure also held the wait below) */
     uint64_t n_timed_chunks; /* chunks that carried the stage timing events: convert_ms, sweep_ms, slice_ms and prescreen_ms are sums
-                              * over THESE (every 7th chunk; experiments build: MGPU_TIMING_EVERY) */
+                              * over THESE (every 15th chunk; experiments build: MGPU_TIMING_EVERY) */
     float build_wait_ms;     /* builder thread: waiting for the chunk's signal powers (second stream) / the SC16 formats' float sums: idle, not work (ABI 6) */
     float reserved_timing;
 };

@@ -283,11 +283,14 @@ struct FeedSlot {
 };
 
 struct mgpu_ctx {
-    // Four slots (round 4; three before): a slot is held from the chunk's first kernel until its walk is done — with chunks of 1024
-    // buffers GPU 0.4-0.6 ms + fetch 0.25-0.6 + walk 0.25-0.35 = 2.2-2.5 chunk periods, and with three slots the GPU idled whenever a
-    // host stage took a little longer (SC16Q11 --aggressive: 110 or 180 Gsamples/s from one repetition to the next)
+    // Ten slots (round 6; four in rounds 4-5, three before): a slot is held from the moment the feeding thread enqueues the chunk's
+    // kernels until its walk is done.  With four, a caller that keeps two feeds of four chunks in flight (feed k + 1 before
+    // collect k: bench.py, the C hosts) spent most of every feed call waiting for a slot, the GPU's queue was never more than one
+    // or two chunks deep, and every hiccup of a host stage was a bubble on the GPU: 1.42-1.44 ms per 537 M samples with 4, 5 or 6
+    // slots, 1.335 — the kernels' sum — with 8, 10 or 12 (profiles/r06_slots.txt).  Ten = the eight chunks of two feeds + two of
+    // slack; ~1.5 GB of HBM each at the default chunk size, out of 288.
 #ifndef MGPU_SLOTS
-#define MGPU_SLOTS 4
+#define MGPU_SLOTS 10
 #endif
     static constexpr int kSlots = MGPU_SLOTS;
     static constexpr int kJobs = MGPU_SLOTS + 2;              // fetched -> walked -> built: a job outlives its slot by the builder's stage
@@ -348,7 +351,7 @@ struct mgpu_ctx {
     bool deferred = false;
     int device_msgs = 0;                                      // mgpu_set_device_messages: 1 = the records stay in HBM (FeedSlot::d_msgs), 2 = k_build_messages stores them into the caller's page-locked array
     bool sig_late = true;                                     // MGPU_SIG_LATE=0: signal power of every live record in the pre-screen write pass (as in shard passes) instead of the accepted frames' after the walk
-    int timing_every = 7;                                     // chunks per set of stage timing events (1 = every chunk; MGPU_TIMING_EVERY in the experiments build).  Odd: with feeds of four chunks the sampled chunk is not always a feed's first
+    int timing_every = 15;                                    // chunks per set of stage timing events (1 = every chunk; MGPU_TIMING_EVERY in the experiments build).  Odd: with feeds of four chunks the sampled chunk is not always a feed's first
     bool fsum_wide = false;                                   // (experiments build: MGPU_FSUM_WIDE=1) the float sums as three wide kernels instead of one chain per buffer
     float event_bracket_us = 4.5f;                            // what a pair of timing events adds to the kernel it brackets (mgpu_event_bracket_us measures it)
     uint64_t timing_seq = 0;

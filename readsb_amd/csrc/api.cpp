@@ -2145,6 +2145,7 @@ static int feed_common(mgpu_ctx *c, const void *src, bool src_is_device, uint64_
             // (mgpu_host_alloc / mgpu_host_register), the kernel writes through its device address
             void *dp = nullptr;
             if (!fs.msgs.external || hipHostGetDevicePointer(&dp, fs.msgs.p, 0) != hipSuccess || !dp) {
+                (void) hipGetLastError();            // (the runtime keeps the failed query as the thread's "last error": not ours to leave behind)
                 c->err = "mgpu_set_device_messages(2): name a page-locked array (mgpu_host_alloc / mgpu_host_register) with mgpu_set_message_buffer before every feed";
                 return MGPU_E_INVAL;
             }

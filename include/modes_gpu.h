@@ -587,8 +587,15 @@ int mgpu_decode_fields_device(mgpu_ctx *ctx, const struct mgpu_msg *d_msgs, uint
  *   verdict[i]: bits 0-1  MGPU_GATE_DROP / _FORWARD / _DEFER;  bit 2  address_reliable;  bit 3  mm->aircraft may be set;
  *               bit 4  mm->aircraft is set for certain.
  * msgs: the accepted messages in netUseMessage order (what mgpu_collect returns), WHOLE sample buffers per call, timestamps on the
- * ifile grid (buffer = (timestamp - 772) / 5 / cfg.buf_samples).  The aircraft table (device memory, 1 GiB, allocated by the first
- * call) lives from call to call until mgpu_track_gate_reset / mgpu_destroy. */
+ * ifile grid (buffer = (timestamp - 772) / 5 / cfg.buf_samples).  The aircraft table (device memory, 1.25 GiB, allocated by the first
+ * call) lives from call to call until mgpu_track_gate_reset / mgpu_destroy.
+ * Long streams: removeStaleRange also deletes an aircraft WITH a reliable position once that position is an hour old (30 minutes:
+ * non-ICAO addresses; track.c:2835-2866).  Which position was the last reliable one is the tracker's knowledge, so from an aircraft's
+ * first position message + that timeout on, its non-clean messages (repaired bits, Address/Parity formats) are answered DEFER: certain
+ * verdicts stay what the reference did however long the stream runs, and an aircraft heard for more than an hour costs the host's
+ * tracker its non-clean messages.
+ * These entries (and the field decode / beast encoder) run on a stream of their own: they do not wait for chunks a deferred feed has
+ * queued.  One context is not thread-safe, and the entries share its staging buffers. */
 #define MGPU_GATE_DROP     0
 #define MGPU_GATE_FORWARD  1
 #define MGPU_GATE_DEFER    2
@@ -598,6 +605,31 @@ int mgpu_decode_fields_device(mgpu_ctx *ctx, const struct mgpu_msg *d_msgs, uint
 int mgpu_track_gate(mgpu_ctx *ctx, const struct mgpu_msg *msgs, uint64_t n, uint8_t *verdict);                 /* host arrays; decodes the fields it needs itself */
 int mgpu_track_gate_device(mgpu_ctx *ctx, const struct mgpu_msg *d_msgs, const struct mgpu_fields *d_fields, uint64_t n, uint8_t *d_verdict);   /* everything in device memory */
 int mgpu_track_gate_reset(mgpu_ctx *ctx);
+
+/* The gate applied to the encoder — what an aggregator that only forwards needs of the tracker: the beast stream
+ * of the messages the reference forwards FOR CERTAIN (outputMessage, net_io.c:5822-5885: first messages of an aircraft are suppressed
+ * unless crc == 0 && correctedbits == 0, :5846-5849), in stream order, and — in stream order too — the list of the messages whose fate
+ * is the position tracker's (MGPU_GATE_DEFER): {index in msgs, the offset in the stream its frame would start at}.  The host's tracker
+ * settles those few (0.2 % of a 200-aircraft minute), encodes the ones it forwards (mgpu_beast_encode on that handful) and splices them
+ * in at their offsets: the result is byte for byte what the whole reference program writes (tests/test_gpu_beast.py against
+ * tests/golden/beast_*.bin, written by the program's --dump-beast).
+ * flags: MGPU_BEAST_NET_RULE = also the beast / raw NETWORK outputs' test correctedbits < 2 (net_io.c:5863-5872; --net-verbatim
+ * lifts it); 0 = the --dump-beast file's rule (no such test).
+ * mgpu_beast_encode_gated: msgs in host memory, WHOLE sample buffers per call in netUseMessage order like mgpu_track_gate (it runs the
+ * field decode and the gate itself, continuing the context's aircraft table).  _device: messages, verdicts (mgpu_track_gate_device's),
+ * stream and list all in device memory.  MGPU_E_OVERFLOW: the stream (*bytes = what it needs) or the list (*ndeferred) does not fit.
+ * readsb_amd/host/readsb_gpu_gather.c --forward-only uses it on the gathered records (/root/reference/net_io.c:1655-1714 is what
+ * consumes such a stream on the other side). */
+struct mgpu_deferred {
+    uint64_t index;               /* of the message in msgs */
+    uint64_t offset;              /* bytes of certain frames before it: where its frame goes if the tracker forwards it */
+};
+#define MGPU_BEAST_NET_RULE 1u
+int mgpu_beast_encode_gated(mgpu_ctx *ctx, const struct mgpu_msg *msgs, uint64_t n, uint32_t flags, uint8_t *out, uint64_t cap, uint64_t *bytes,
+                            struct mgpu_deferred *deferred, uint64_t deferred_cap, uint64_t *ndeferred);
+int mgpu_beast_encode_gated_device(mgpu_ctx *ctx, const struct mgpu_msg *d_msgs, const uint8_t *d_verdict, uint64_t n, uint32_t flags,
+                                   uint8_t *d_out, uint64_t cap, uint64_t *bytes, struct mgpu_deferred *d_deferred, uint64_t deferred_cap,
+                                   uint64_t *ndeferred);
 
 /* ---- tables, for known-answer tests against crc.c --------------------------------- */
 

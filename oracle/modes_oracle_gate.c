@@ -21,7 +21,7 @@
  *   with a->messages read AFTER the whole batch's updates.  (The beast and raw outputs also want correctedbits < 2, :5863-5872;
  *   the dump file does not — that test is the caller's, it needs nothing from here.)
  *   removeStaleRange (track.c:2828-2890): an aircraft without a reliable position that was not `seen` for 5 minutes is deleted
- *   by the next periodic run.
+ *   by the next periodic run; one WITH a reliable position once that position is an hour old (30 minutes: non-ICAO addresses).
  *
  * What cannot be decided here is whether a position message was rolled back (CPR decoding, speed checks, receiver range:
  * cpr.c + track.c:423-745, out of scope) and whether a silent aircraft had a reliable position.  So every aircraft
@@ -37,12 +37,19 @@
 #define GATE_BATCH 256                 /* messages per drainMessageBuffer at most */
 #define GATE_SEEN_TTL_MS 45000         /* track.c:1933 */
 #define GATE_REMOVE_MS (5 * 60 * 1000) /* track.c:2856 */
+/* removeStaleRange's other rule (track.c:2835-2866): an aircraft WITH a reliable position is deleted once that position is older than
+ * an hour (30 minutes for non-ICAO addresses), however recently it was heard.  Which position was the last reliable one is the
+ * position tracker's knowledge; the earliest candidate is the aircraft's first position message: from then + the timeout on, the
+ * aircraft may have been deleted and re-created at any moment — the lower bounds restart at every message. */
+#define GATE_POS_TIMEOUT_MS (60ll * 60 * 1000)
+#define GATE_POS_TIMEOUT_NONICAO_MS (30ll * 60 * 1000)
 
 struct gate_ac {
     uint32_t key;                      /* address + 1 (0 = empty slot); 25 bits: the ME decode may set MODES_NON_ICAO_ADDRESS (1 << 24) */
     uint8_t exists_lo, exists_hi;
     uint32_t cnt_lo, cnt_hi;           /* a->messages, bounds */
     int64_t seen_lo, seen_hi;          /* a->seen, bounds */
+    int64_t cpr_first;                 /* the aircraft's first position message (0: none yet) */
 };
 
 struct oracle_gate {
@@ -101,10 +108,14 @@ void modes_oracle_gate_run(struct oracle_gate *g, uint64_t n, const uint8_t *msg
             if (s && s->exists_lo && now_ms[k] - s->seen_lo > GATE_REMOVE_MS) {   /* may have been deleted meanwhile */
                 s->exists_lo = 0; s->cnt_lo = 0; s->seen_lo = 0;
             }
+            if (s && s->cpr_first && now_ms[k] - s->cpr_first > ((addr[k] & (1u << 24)) ? GATE_POS_TIMEOUT_NONICAO_MS : GATE_POS_TIMEOUT_MS)) {
+                s->exists_lo = 0; s->cnt_lo = 0; s->seen_lo = 0;     /* ... or its reliable position may have timed out */
+            }
             if (reliable) {
                 s->exists_lo = s->exists_hi = 1;                 /* (aircraftCreate is not rolled back) */
                 s->seen_hi = now_ms[k]; s->cnt_hi++;
                 if (!cpr_valid[k]) { s->seen_lo = now_ms[k]; s->cnt_lo++; }
+                else if (!s->cpr_first) s->cpr_first = now_ms[k];
                 v |= 8 | 16;
             } else if (s && s->exists_hi) {
                 const int ok_lo = s->exists_lo && now_ms[k] - s->seen_lo <= GATE_SEEN_TTL_MS;

@@ -122,6 +122,7 @@ class ShardStreamArgs(C.Structure):
     ]
 
 
+DEFERRED_DTYPE = np.dtype([("index", "<u8"), ("offset", "<u8")])     # struct mgpu_deferred
 ABI_VERSION = 6                             # MGPU_ABI_VERSION of the include/modes_gpu.h these ctypes mirrors were written against
 
 
@@ -274,6 +275,8 @@ def load_library():
     lib.mgpu_track_gate_device.argtypes = [vp, vp, vp, u64, vp]
     lib.mgpu_track_gate_reset.argtypes = [vp]
     lib.mgpu_beast_encode.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64)]
+    lib.mgpu_beast_encode_gated.argtypes = [vp, vp, u64, u32, vp, u64, C.POINTER(u64), vp, u64, C.POINTER(u64)]
+    lib.mgpu_beast_encode_gated_device.argtypes = [vp, vp, vp, u64, u32, vp, u64, C.POINTER(u64), vp, u64, C.POINTER(u64)]
     lib.mgpu_beast_encode_device.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64)]
     lib.mgpu_shard_begin.argtypes = [vp, u64, vp, i32]
     lib.mgpu_adder_bitmap_get.argtypes = [vp, vp]
@@ -532,6 +535,20 @@ class Demodulator:
         out = np.empty(len(msgs), dtype=np.uint8)
         self._chk(self.lib.mgpu_track_gate(self.ctx, C.c_void_p(msgs.ctypes.data), len(msgs), C.c_void_p(out.ctypes.data)), "mgpu_track_gate")
         return out
+
+    def beast_encode_gated(self, msgs, net_rule=False, deferred_cap=None):
+        """mgpu_beast_encode_gated: -> (the beast stream of the certainly-forwarded messages, deferred[] records {index, offset})."""
+        msgs = np.ascontiguousarray(msgs)
+        n = len(msgs)
+        cap = n * 44 + 64
+        dcap = int(deferred_cap if deferred_cap is not None else n)
+        out = np.empty(cap, dtype=np.uint8)
+        deferred = np.zeros(max(dcap, 1), dtype=DEFERRED_DTYPE)
+        nb, nd = C.c_uint64(0), C.c_uint64(0)
+        self._chk(self.lib.mgpu_beast_encode_gated(self.ctx, C.c_void_p(msgs.ctypes.data), C.c_uint64(n), C.c_uint32(1 if net_rule else 0),
+                                                   C.c_void_p(out.ctypes.data), C.c_uint64(cap), C.byref(nb), C.c_void_p(deferred.ctypes.data),
+                                                   C.c_uint64(dcap), C.byref(nd)), "mgpu_beast_encode_gated")
+        return out[: nb.value].tobytes(), deferred[: nd.value].copy()
 
     def track_gate_device(self, d_msgs_ptr, d_fields_ptr, n, d_verdict_ptr):
         self._chk(self.lib.mgpu_track_gate_device(self.ctx, C.c_void_p(d_msgs_ptr), C.c_void_p(d_fields_ptr), n, C.c_void_p(d_verdict_ptr)), "mgpu_track_gate_device")

@@ -413,6 +413,9 @@ struct mgpu_ctx {
     uint8_t *d_gate_verdict = nullptr;
     uint64_t gate_cap = 0;
     uint32_t *d_beast_blocks = nullptr;
+    mgpu_deferred *d_deferred = nullptr;                      // mgpu_beast_encode_gated's list, device side
+    uint64_t deferred_cap = 0;
+    hipStream_t stream_aux = nullptr;                         // field decode / beast encoder / tracking gate: synchronous calls, not behind the pipeline's queued chunks
     unsigned long long *d_beast_total = nullptr;
     uint64_t beast_cap_msgs = 0, beast_cap_in = 0, beast_cap_out = 0;
     uint16_t *d_hist = nullptr;                               // magnitudes of the 326 samples before the shard
@@ -1005,6 +1008,7 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
         hipStreamCreateWithFlags(&c->stream_w, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream_d2h, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream_c, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream_aux, hipStreamNonBlocking) != hipSuccess ||
         (cfg->format != MGPU_FMT_UC8 && hipStreamCreateWithPriority(&c->stream_f, hipStreamNonBlocking, prio_least) != hipSuccess)) { mgpu_destroy(c); return MGPU_E_HIP; }
     // valid_df_*_bitset, init_bitsets() demod_2400.c:112-128 (ENABLE_DF24 off, readsb.h:303)
     c->valid_short = (1u << 0) | (1u << 4) | (1u << 5) | (1u << 11);
@@ -1089,6 +1093,7 @@ void mgpu_destroy(mgpu_ctx *c) {
     if (c->stream_pw) (void) hipStreamSynchronize(c->stream_pw);
     if (c->stream_f) (void) hipStreamSynchronize(c->stream_f);
     if (c->stream_c) (void) hipStreamSynchronize(c->stream_c);
+    if (c->stream_aux) (void) hipStreamSynchronize(c->stream_aux);
     if (c->stream_wk) (void) hipStreamSynchronize(c->stream_wk);
     for (auto &sl : c->slot) free_slot(sl);
     for (auto &f : c->feed) {
@@ -1119,7 +1124,7 @@ void mgpu_destroy(mgpu_ctx *c) {
     }
     for (hipEvent_t e : c->ev_iq_read)
         if (e) (void) hipEventDestroy(e);
-    void *dev[] = {c->d_gate_table, c->d_gate_scratch, c->d_gate_verdict, c->d_roll_tan, c->d_fields, c->d_beast_off, c->d_beast_len, c->d_beast_in, c->d_beast_out, c->d_beast_blocks, c->d_beast_total, c->d_hist, c->d_hist_iq, c->d_hist_sums, c->d_iq, c->d_win, c->d_adder_bitmap, c->d_bit_syndrome, c->d_group_syndrome, c->d_parity,
+    void *dev[] = {c->d_deferred, c->d_gate_table, c->d_gate_scratch, c->d_gate_verdict, c->d_roll_tan, c->d_fields, c->d_beast_off, c->d_beast_len, c->d_beast_in, c->d_beast_out, c->d_beast_blocks, c->d_beast_total, c->d_hist, c->d_hist_iq, c->d_hist_sums, c->d_iq, c->d_win, c->d_adder_bitmap, c->d_bit_syndrome, c->d_group_syndrome, c->d_parity,
                    c->d_tab_long, c->d_tab_short, c->d_uc8_folded};
     for (void *p : dev)
         if (p) (void) hipFree(p);
@@ -1130,6 +1135,7 @@ void mgpu_destroy(mgpu_ctx *c) {
     if (c->stream_d2h) (void) hipStreamDestroy(c->stream_d2h);
     if (c->stream_f) (void) hipStreamDestroy(c->stream_f);
     if (c->stream_c) (void) hipStreamDestroy(c->stream_c);
+    if (c->stream_aux) (void) hipStreamDestroy(c->stream_aux);
     if (c->stream_wk) (void) hipStreamDestroy(c->stream_wk);
     delete c;
 }
@@ -3140,11 +3146,9 @@ int mgpu_shard_noise_terms(mgpu_ctx *c, const double **terms, uint64_t *n) {
 
 // ---- beast wire format (net_io.c:1655-1714) for message records that already are in HBM -----------------------
 
-int mgpu_beast_encode_device(mgpu_ctx *c, const struct mgpu_msg *d_msgs, uint64_t n, uint8_t *d_out, uint64_t cap, uint64_t *bytes) {
-    if (!c || !bytes || (n && (!d_msgs || !d_out))) return MGPU_E_INVAL;
-    *bytes = 0;
-    if (n == 0) return MGPU_OK;
-    HIPCHK(c, hipSetDevice(c->cfg.device));
+// What follows the message list — field decode, beast encoder, tracking gate — runs on a stream of its own (stream_aux): these calls
+// are synchronous, and on the pipeline's main stream they waited for every chunk a deferred feed had queued there.
+static int beast_reserve(mgpu_ctx *c, uint64_t n) {
     if (n > c->beast_cap_msgs) {
         if (c->d_beast_len) (void) hipFree(c->d_beast_len);
         if (c->d_beast_blocks) (void) hipFree(c->d_beast_blocks);
@@ -3152,17 +3156,68 @@ int mgpu_beast_encode_device(mgpu_ctx *c, const struct mgpu_msg *d_msgs, uint64_
         c->d_beast_len = nullptr; c->d_beast_blocks = nullptr; c->d_beast_off = nullptr; c->beast_cap_msgs = 0;
         const uint64_t want = n + n / 4 + 1024;
         HIPCHK(c, hipMalloc(&c->d_beast_len, want * sizeof(uint16_t)));
-        HIPCHK(c, hipMalloc(&c->d_beast_blocks, (want / kBlock + 2) * sizeof(uint32_t)));
-        HIPCHK(c, hipMalloc(&c->d_beast_off, (want / kBlock + 2) * sizeof(unsigned long long)));
+        HIPCHK(c, hipMalloc(&c->d_beast_blocks, 2 * (want / kBlock + 2) * sizeof(uint32_t)));              // frame bytes | deferred messages per workgroup
+        HIPCHK(c, hipMalloc(&c->d_beast_off, 2 * (want / kBlock + 2) * sizeof(unsigned long long)));
         c->beast_cap_msgs = want;
     }
-    if (!c->d_beast_total) HIPCHK(c, hipMalloc(&c->d_beast_total, sizeof(unsigned long long)));
-    launch_beast_encode(d_msgs, n, c->d_beast_len, c->d_beast_blocks, c->d_beast_off, d_out, cap, c->d_beast_total, c->stream);
-    unsigned long long total = 0;
-    HIPCHK(c, hipMemcpyAsync(&total, c->d_beast_total, sizeof(total), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    *bytes = total;
-    if (total > cap) { c->err = "mgpu_beast_encode: output buffer too small"; return MGPU_E_OVERFLOW; }
+    if (!c->d_beast_total) HIPCHK(c, hipMalloc(&c->d_beast_total, 2 * sizeof(unsigned long long)));
+    return MGPU_OK;
+}
+
+// d_verdict == nullptr: every message's frame.  Everything in device memory; *ndeferred (may be null without a verdict)
+static int beast_encode_dev(mgpu_ctx *c, const mgpu_msg *d_msgs, const uint8_t *d_verdict, uint64_t n, uint32_t flags, uint8_t *d_out, uint64_t cap,
+                            uint64_t *bytes, mgpu_deferred *d_deferred, uint64_t deferred_cap, uint64_t *ndeferred) {
+    if (int rc = beast_reserve(c, n)) return rc;
+    const size_t nb = (size_t) (c->beast_cap_msgs / kBlock + 2);
+    launch_beast_encode(d_msgs, n, c->d_beast_len, c->d_beast_blocks, c->d_beast_off, d_out, cap, c->d_beast_total, c->stream_aux, d_verdict,
+                        (flags & MGPU_BEAST_NET_RULE) ? 1 : 0, c->d_beast_blocks + nb, c->d_beast_off + nb, d_deferred, deferred_cap);
+    HIPCHK(c, hipGetLastError());
+    unsigned long long total[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(total, c->d_beast_total, (d_verdict ? 2 : 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream_aux));
+    HIPCHK(c, hipStreamSynchronize(c->stream_aux));
+    *bytes = total[0];
+    if (ndeferred) *ndeferred = total[1];
+    if (total[0] > cap) { c->err = "mgpu_beast_encode: output buffer too small"; return MGPU_E_OVERFLOW; }
+    if (d_verdict && total[1] > deferred_cap) { c->err = "mgpu_beast_encode_gated: more deferred messages than the list holds"; return MGPU_E_OVERFLOW; }
+    return MGPU_OK;
+}
+
+int mgpu_beast_encode_device(mgpu_ctx *c, const struct mgpu_msg *d_msgs, uint64_t n, uint8_t *d_out, uint64_t cap, uint64_t *bytes) {
+    if (!c || !bytes || (n && (!d_msgs || !d_out))) return MGPU_E_INVAL;
+    *bytes = 0;
+    if (n == 0) return MGPU_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    return beast_encode_dev(c, d_msgs, nullptr, n, 0, d_out, cap, bytes, nullptr, 0, nullptr);
+}
+
+int mgpu_beast_encode_gated_device(mgpu_ctx *c, const struct mgpu_msg *d_msgs, const uint8_t *d_verdict, uint64_t n, uint32_t flags, uint8_t *d_out,
+                                   uint64_t cap, uint64_t *bytes, struct mgpu_deferred *d_deferred, uint64_t deferred_cap, uint64_t *ndeferred) {
+    if (!c || !bytes || !ndeferred || (n && (!d_msgs || !d_verdict || !d_out)) || (deferred_cap && !d_deferred)) return MGPU_E_INVAL;
+    *bytes = 0; *ndeferred = 0;
+    if (n == 0) return MGPU_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    return beast_encode_dev(c, d_msgs, d_verdict, n, flags, d_out, cap, bytes, d_deferred, deferred_cap, ndeferred);
+}
+
+static int stage_messages(mgpu_ctx *c, const struct mgpu_msg *msgs, uint64_t n) {          // host list -> d_beast_in
+    if (n * sizeof(mgpu_msg) > c->beast_cap_in) {
+        if (c->d_beast_in) (void) hipFree(c->d_beast_in);
+        c->d_beast_in = nullptr; c->beast_cap_in = 0;
+        const uint64_t want = (n + n / 4 + 1024) * sizeof(mgpu_msg);
+        HIPCHK(c, hipMalloc(&c->d_beast_in, want));
+        c->beast_cap_in = want;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_beast_in, msgs, n * sizeof(mgpu_msg), hipMemcpyHostToDevice, c->stream_aux));
+    return MGPU_OK;
+}
+
+static int reserve_beast_out(mgpu_ctx *c, uint64_t cap) {
+    if (cap > c->beast_cap_out) {
+        if (c->d_beast_out) (void) hipFree(c->d_beast_out);
+        c->d_beast_out = nullptr; c->beast_cap_out = 0;
+        HIPCHK(c, hipMalloc(&c->d_beast_out, cap + 64));
+        c->beast_cap_out = cap;
+    }
     return MGPU_OK;
 }
 
@@ -3171,21 +3226,9 @@ int mgpu_beast_encode(mgpu_ctx *c, const struct mgpu_msg *msgs, uint64_t n, uint
     *bytes = 0;
     if (n == 0) return MGPU_OK;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    if (n * sizeof(mgpu_msg) > c->beast_cap_in) {
-        if (c->d_beast_in) (void) hipFree(c->d_beast_in);
-        c->d_beast_in = nullptr; c->beast_cap_in = 0;
-        const uint64_t want = (n + n / 4 + 1024) * sizeof(mgpu_msg);
-        HIPCHK(c, hipMalloc(&c->d_beast_in, want));
-        c->beast_cap_in = want;
-    }
-    if (cap > c->beast_cap_out) {
-        if (c->d_beast_out) (void) hipFree(c->d_beast_out);
-        c->d_beast_out = nullptr; c->beast_cap_out = 0;
-        HIPCHK(c, hipMalloc(&c->d_beast_out, cap + 64));
-        c->beast_cap_out = cap;
-    }
-    HIPCHK(c, hipMemcpyAsync(c->d_beast_in, msgs, n * sizeof(mgpu_msg), hipMemcpyHostToDevice, c->stream));
-    const int rc = mgpu_beast_encode_device(c, (const mgpu_msg *) c->d_beast_in, n, c->d_beast_out, cap, bytes);
+    if (int rc = stage_messages(c, msgs, n)) return rc;
+    if (int rc = reserve_beast_out(c, cap)) return rc;
+    const int rc = beast_encode_dev(c, (const mgpu_msg *) c->d_beast_in, nullptr, n, 0, c->d_beast_out, cap, bytes, nullptr, 0, nullptr);
     if (rc != MGPU_OK) return rc;
     HIPCHK(c, hipMemcpy(out, c->d_beast_out, *bytes, hipMemcpyDeviceToHost));
     return MGPU_OK;
@@ -3206,23 +3249,13 @@ int mgpu_decode_fields_device(mgpu_ctx *c, const struct mgpu_msg *d_msgs, uint64
     if (n == 0) return MGPU_OK;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     if (int rc = fields_tables(c)) return rc;
-    launch_decode_fields(d_msgs, n, d_out, c->d_roll_tan, c->stream);
+    launch_decode_fields(d_msgs, n, d_out, c->d_roll_tan, c->stream_aux);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream_aux));
     return MGPU_OK;
 }
 
-int mgpu_decode_fields(mgpu_ctx *c, const struct mgpu_msg *msgs, uint64_t n, struct mgpu_fields *out) {
-    if (!c || (n && (!msgs || !out))) return MGPU_E_INVAL;
-    if (n == 0) return MGPU_OK;
-    HIPCHK(c, hipSetDevice(c->cfg.device));
-    if (n * sizeof(mgpu_msg) > c->beast_cap_in) {
-        if (c->d_beast_in) (void) hipFree(c->d_beast_in);
-        c->d_beast_in = nullptr; c->beast_cap_in = 0;
-        const uint64_t want = (n + n / 4 + 1024) * sizeof(mgpu_msg);
-        HIPCHK(c, hipMalloc(&c->d_beast_in, want));
-        c->beast_cap_in = want;
-    }
+static int fields_reserve(mgpu_ctx *c, uint64_t n) {
     if (n > c->fields_cap) {
         if (c->d_fields) (void) hipFree(c->d_fields);
         c->d_fields = nullptr; c->fields_cap = 0;
@@ -3230,12 +3263,19 @@ int mgpu_decode_fields(mgpu_ctx *c, const struct mgpu_msg *msgs, uint64_t n, str
         HIPCHK(c, hipMalloc(&c->d_fields, want * sizeof(mgpu_fields)));
         c->fields_cap = want;
     }
-    if (int rc = fields_tables(c)) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->d_beast_in, msgs, n * sizeof(mgpu_msg), hipMemcpyHostToDevice, c->stream));
-    launch_decode_fields((const mgpu_msg *) c->d_beast_in, n, c->d_fields, c->d_roll_tan, c->stream);
+    return fields_tables(c);
+}
+
+int mgpu_decode_fields(mgpu_ctx *c, const struct mgpu_msg *msgs, uint64_t n, struct mgpu_fields *out) {
+    if (!c || (n && (!msgs || !out))) return MGPU_E_INVAL;
+    if (n == 0) return MGPU_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (int rc = fields_reserve(c, n)) return rc;
+    if (int rc = stage_messages(c, msgs, n)) return rc;
+    launch_decode_fields((const mgpu_msg *) c->d_beast_in, n, c->d_fields, c->d_roll_tan, c->stream_aux);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(out, c->d_fields, n * sizeof(mgpu_fields), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyAsync(out, c->d_fields, n * sizeof(mgpu_fields), hipMemcpyDeviceToHost, c->stream_aux));
+    HIPCHK(c, hipStreamSynchronize(c->stream_aux));
     return MGPU_OK;
 }
 
@@ -3244,7 +3284,7 @@ int mgpu_decode_fields(mgpu_ctx *c, const struct mgpu_msg *msgs, uint64_t n, str
 static int gate_reserve(mgpu_ctx *c, uint64_t n) {
     if (!c->d_gate_table) {
         HIPCHK(c, hipMalloc(&c->d_gate_table, gate_table_bytes()));
-        HIPCHK(c, hipMemsetAsync(c->d_gate_table, 0, gate_table_bytes(), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_gate_table, 0, gate_table_bytes(), c->stream_aux));
     }
     if (n > c->gate_cap) {
         if (c->d_gate_scratch) (void) hipFree(c->d_gate_scratch);
@@ -3262,8 +3302,8 @@ int mgpu_track_gate_reset(mgpu_ctx *c) {
     if (!c) return MGPU_E_INVAL;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     if (c->d_gate_table) {
-        HIPCHK(c, hipMemsetAsync(c->d_gate_table, 0, gate_table_bytes(), c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_gate_table, 0, gate_table_bytes(), c->stream_aux));
+        HIPCHK(c, hipStreamSynchronize(c->stream_aux));
     }
     return MGPU_OK;
 }
@@ -3273,9 +3313,20 @@ int mgpu_track_gate_device(mgpu_ctx *c, const struct mgpu_msg *d_msgs, const str
     if (n == 0) return MGPU_OK;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     if (int rc = gate_reserve(c, n)) return rc;
-    launch_track_gate(d_msgs, d_fields, n, c->cfg.buf_samples, c->d_gate_table, c->d_gate_scratch, d_verdict, c->stream);
+    launch_track_gate(d_msgs, d_fields, n, c->cfg.buf_samples, c->d_gate_table, c->d_gate_scratch, d_verdict, c->stream_aux);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream_aux));
+    return MGPU_OK;
+}
+
+// host list -> d_beast_in, its field records -> d_fields, its verdicts (continuing the context's aircraft table) -> d_gate_verdict
+static int gate_staged(mgpu_ctx *c, const struct mgpu_msg *msgs, uint64_t n) {
+    if (int rc = fields_reserve(c, n)) return rc;
+    if (int rc = gate_reserve(c, n)) return rc;
+    if (int rc = stage_messages(c, msgs, n)) return rc;
+    launch_decode_fields((const mgpu_msg *) c->d_beast_in, n, c->d_fields, c->d_roll_tan, c->stream_aux);
+    launch_track_gate((const mgpu_msg *) c->d_beast_in, c->d_fields, n, c->cfg.buf_samples, c->d_gate_table, c->d_gate_scratch, c->d_gate_verdict, c->stream_aux);
+    HIPCHK(c, hipGetLastError());
     return MGPU_OK;
 }
 
@@ -3283,28 +3334,32 @@ int mgpu_track_gate(mgpu_ctx *c, const struct mgpu_msg *msgs, uint64_t n, uint8_
     if (!c || (n && (!msgs || !verdict)) || n > 0xffffffffull) return MGPU_E_INVAL;
     if (n == 0) return MGPU_OK;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    if (n * sizeof(mgpu_msg) > c->beast_cap_in) {
-        if (c->d_beast_in) (void) hipFree(c->d_beast_in);
-        c->d_beast_in = nullptr; c->beast_cap_in = 0;
-        const uint64_t want = (n + n / 4 + 1024) * sizeof(mgpu_msg);
-        HIPCHK(c, hipMalloc(&c->d_beast_in, want));
-        c->beast_cap_in = want;
+    if (int rc = gate_staged(c, msgs, n)) return rc;
+    HIPCHK(c, hipMemcpyAsync(verdict, c->d_gate_verdict, n, hipMemcpyDeviceToHost, c->stream_aux));
+    HIPCHK(c, hipStreamSynchronize(c->stream_aux));
+    return MGPU_OK;
+}
+
+// The gate's verdict applied to the encoder: the beast stream of what the reference forwards for certain + the list of the
+// messages its position tracker has to settle (include/modes_gpu.h).  Host arrays; the aircraft table goes on from call to call.
+int mgpu_beast_encode_gated(mgpu_ctx *c, const struct mgpu_msg *msgs, uint64_t n, uint32_t flags, uint8_t *out, uint64_t cap, uint64_t *bytes,
+                            struct mgpu_deferred *deferred, uint64_t deferred_cap, uint64_t *ndeferred) {
+    if (!c || !bytes || !ndeferred || (n && (!msgs || !out)) || (deferred_cap && !deferred) || n > 0xffffffffull) return MGPU_E_INVAL;
+    *bytes = 0; *ndeferred = 0;
+    if (n == 0) return MGPU_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (int rc = gate_staged(c, msgs, n)) return rc;
+    if (int rc = reserve_beast_out(c, cap)) return rc;
+    if (deferred_cap > c->deferred_cap) {
+        if (c->d_deferred) (void) hipFree(c->d_deferred);
+        c->d_deferred = nullptr; c->deferred_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_deferred, (deferred_cap + 64) * sizeof(mgpu_deferred)));
+        c->deferred_cap = deferred_cap + 64;
     }
-    if (n > c->fields_cap) {
-        if (c->d_fields) (void) hipFree(c->d_fields);
-        c->d_fields = nullptr; c->fields_cap = 0;
-        const uint64_t want = n + n / 4 + 1024;
-        HIPCHK(c, hipMalloc(&c->d_fields, want * sizeof(mgpu_fields)));
-        c->fields_cap = want;
-    }
-    if (int rc = fields_tables(c)) return rc;
-    if (int rc = gate_reserve(c, n)) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->d_beast_in, msgs, n * sizeof(mgpu_msg), hipMemcpyHostToDevice, c->stream));
-    launch_decode_fields((const mgpu_msg *) c->d_beast_in, n, c->d_fields, c->d_roll_tan, c->stream);
-    launch_track_gate((const mgpu_msg *) c->d_beast_in, c->d_fields, n, c->cfg.buf_samples, c->d_gate_table, c->d_gate_scratch, c->d_gate_verdict, c->stream);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(verdict, c->d_gate_verdict, n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int rc = beast_encode_dev(c, (const mgpu_msg *) c->d_beast_in, c->d_gate_verdict, n, flags, c->d_beast_out, cap, bytes, c->d_deferred, deferred_cap, ndeferred);
+    if (rc != MGPU_OK) return rc;
+    HIPCHK(c, hipMemcpy(out, c->d_beast_out, *bytes, hipMemcpyDeviceToHost));
+    if (*ndeferred) HIPCHK(c, hipMemcpy(deferred, c->d_deferred, *ndeferred * sizeof(mgpu_deferred), hipMemcpyDeviceToHost));
     return MGPU_OK;
 }
 

@@ -193,7 +193,8 @@ void launch_modeac_scan(const uint16_t *mag, uint64_t n, uint32_t buf_samples, c
                         unsigned long long *list_counts, unsigned long long *counters, hipStream_t s);
 void launch_decode_fields(const mgpu_msg *msgs, uint64_t n, mgpu_fields *out, const double *roll_tan, hipStream_t s);
 void launch_beast_encode(const mgpu_msg *msgs, uint64_t n, uint16_t *meta, uint32_t *block_bytes, unsigned long long *block_off, uint8_t *out,
-                         uint64_t cap, unsigned long long *total, hipStream_t s);
+                         uint64_t cap, unsigned long long *total /* [2]: bytes, deferred */, hipStream_t s, const uint8_t *verdict = nullptr, int net_rule = 0,
+                         uint32_t *block_def = nullptr, unsigned long long *block_def_off = nullptr, mgpu_deferred *deferred = nullptr, uint64_t def_cap = 0);
 // first stage of the tracker + the forwarding rule over a message list in device memory (kernels/gate.inc): table = gate_table_bytes()
 // bytes, zeroed once and kept from call to call; scratch = gate_scratch_bytes(n); verdict: one byte per message (include/modes_gpu.h)
 size_t gate_table_bytes();

@@ -50,6 +50,56 @@ def oracle_gate(msgs, fields, state=None):
     return out
 
 
+def oracle_gate_raw(msgtype, addr, iid, cb, cpr, now_ms, buffer):
+    """modes_oracle_gate_run on plain arrays (a fresh table)."""
+    lib = helpers.oracle_lib()
+    lib.modes_oracle_gate_new.restype = C.c_void_p
+    lib.modes_oracle_gate_free.argtypes = [C.c_void_p]
+    lib.modes_oracle_gate_run.argtypes = [C.c_void_p, C.c_uint64] + [C.c_void_p] * 8
+    arrs = [np.ascontiguousarray(msgtype, dtype=np.uint8), np.ascontiguousarray(addr, dtype=np.uint32), np.ascontiguousarray(iid, dtype=np.uint8),
+            np.ascontiguousarray(cb, dtype=np.uint8), np.ascontiguousarray(cpr, dtype=np.uint8), np.ascontiguousarray(now_ms, dtype=np.int64),
+            np.ascontiguousarray(buffer, dtype=np.uint64)]
+    n = len(arrs[0])
+    out = np.zeros(n, dtype=np.uint8)
+    g = lib.modes_oracle_gate_new()
+    lib.modes_oracle_gate_run(g, n, *[C.c_void_p(a.ctypes.data) for a in arrs], C.c_void_p(out.ctypes.data))
+    lib.modes_oracle_gate_free(g)
+    return out
+
+
+def synthetic_list(n, seconds, naircraft, seed, startup_ms=helpers.STARTUP_MS if hasattr(helpers, "STARTUP_MS") else 0):
+    """A message list that never saw a sample: what the gate reads of mgpu_msg / mgpu_fields (timestamp on the ifile grid, sysTimestamp,
+    msgtype, correctedbits; addr, IID, the CPR flag) for `naircraft` aircraft over `seconds` — long gaps, hours of life, non-ICAO
+    addresses, Address/Parity formats with address 0, bursts of more than 256 messages in a buffer."""
+    import readsb_amd
+    rng = np.random.default_rng(seed)
+    pos = np.sort(rng.integers(0, int(seconds * 2.4e6), size=n)).astype(np.int64)
+    pos[n // 3: n // 3 + 700] = pos[n // 3]                                           # one buffer with three batches and a bit
+    pos = np.sort(pos)
+    ac = rng.integers(0, naircraft, size=n)
+    quiet = rng.random(naircraft) < 0.3                                              # aircraft that go silent for long stretches
+    keep = ~(quiet[ac] & ((pos // int(400 * 2.4e6)) % 2 == 1))
+    pos, ac = pos[keep], ac[keep]
+    n = len(pos)
+    addr = (0x400000 + ac).astype(np.uint32)
+    addr[ac % 17 == 3] |= 1 << 24                                                     # MODES_NON_ICAO_ADDRESS
+    addr[ac == 5] = 0
+    kind = rng.integers(0, 100, size=n)
+    msgtype = np.select([kind < 45, kind < 60, kind < 75, kind < 90], [17, 11, 4, 20], 0).astype(np.uint8)
+    iid = np.where((msgtype == 11) & (rng.random(n) < 0.3), rng.integers(1, 16, size=n), 0).astype(np.uint8)
+    cpr = ((msgtype == 17) & (rng.random(n) < 0.6)).astype(np.uint8)
+    cpr[(ac % 5 == 0) & (msgtype == 17)] = 1                                          # aircraft whose every DF17 is a position message
+    cb = np.select([rng.random(n) < 0.85, rng.random(n) < 0.7], [0, 1], 2).astype(np.uint8)
+    msgs = np.zeros(n, dtype=readsb_amd.MSG_DTYPE)
+    msgs["timestamp"] = pos * 5 + 768 + rng.integers(4, 9, size=n)
+    msgs["sysTimestamp"] = startup_ms + msgs["timestamp"] // 12000
+    msgs["msgtype"], msgs["correctedbits"], msgs["msgbits"], msgs["addr"] = msgtype, cb, np.where(msgtype >= 16, 112, 56), addr
+    fields = np.zeros(n, dtype=readsb_amd.FIELDS_DTYPE)
+    fields["addr"], fields["IID"], fields["flags"], fields["msgtype"] = addr, iid, cpr.astype(np.uint32) * F_CPR_VALID, msgtype
+    raw = dict(msgtype=msgtype, addr=addr, iid=iid, cb=cb, cpr=cpr, now_ms=msgs["sysTimestamp"].astype(np.int64), buffer=(pos // BUF).astype(np.uint64))
+    return msgs, fields, raw
+
+
 def check_against_golden(verdict, forwarded, max_deferred_share):
     """Every verdict that is not `deferred` must be what the whole reference program did."""
     v = verdict & 3

@@ -39,6 +39,59 @@ def test_beast_stream(built, seconds, rate, dense, nfix, mode_ac, seed):
     assert got == want
 
 
+def _splice(stream, deferred, frames):
+    """The gated stream with the frames of the deferred messages the tracker forwards put in at their offsets (frames: index -> bytes)."""
+    out, at = bytearray(), 0
+    for e in deferred:
+        out += stream[at:int(e["offset"])]
+        at = int(e["offset"])
+        out += frames.get(int(e["index"]), b"")
+    out += stream[at:]
+    return bytes(out)
+
+
+@pytest.mark.parametrize("name", ["uc8_fix_2s", "uc8_aggressive_modeac_3s"])
+def test_gated_stream_is_the_reference_programs(built, name):
+    """§8(f).4 as a component: IQ -> messages -> tracking gate -> beast encoder on the GPU.  The stream of the certainly-forwarded
+    messages, with the few deferred ones settled — here by what the WHOLE reference program did (tests/golden/gate_*.npz) — and
+    spliced in at the offsets the call reports, is byte for byte the file the reference program wrote with --dump-beast
+    (tests/golden/beast_*.bin): first messages of an aircraft suppressed (net_io.c:5846-5849), everything else in stream order."""
+    import os
+    import gate_util as gu
+    import readsb_amd
+    kw, opt = gu.CASES[name]
+    iq = helpers.synth(threads=8, **kw)
+    gold = open(os.path.join(helpers.GOLDEN_DIR, f"beast_{name}.bin"), "rb").read()
+    fwd = gu.golden_forwarded(name)
+    d = readsb_amd.Demodulator(nfix_crc=opt["nfix"], mode_ac=opt["mode_ac"], startup_time_ms=helpers.STARTUP_MS, max_samples=len(iq) // 2)
+    try:
+        msgs, _ = d.demodulate_capture(iq)
+        assert len(msgs) == len(fwd)
+        stream, deferred = d.beast_encode_gated(msgs)
+        assert len(deferred) <= 0.05 * len(msgs) and (np.diff(deferred["index"].astype(np.int64)) > 0).all() and (np.diff(deferred["offset"].astype(np.int64)) >= 0).all()
+        frames = {int(i): d.beast_encode(msgs[int(i):int(i) + 1]) for i in deferred["index"] if fwd[int(i)]}
+        assert _splice(stream, deferred, frames) == gold
+        # the ungated encoder writes every accepted message: more than the reference does
+        assert len(d.beast_encode(msgs)) > len(gold)
+        # the network outputs' rule on top (correctedbits < 2, net_io.c:5863-5872): the same stream without those frames
+        d.track_gate_reset()
+        net_stream, net_def = d.beast_encode_gated(msgs, net_rule=True)
+        keep = msgs["correctedbits"] < 2
+        v = gu.oracle_gate(*gu.oracle_messages(name)[1:])
+        want = b"".join(d.beast_encode(msgs[k:k + 1]) for k in np.nonzero(((v & 3) == 1) & keep)[0])
+        assert net_stream == want and set(net_def["index"]) == set(np.nonzero(((v & 3) == 2) & keep)[0])
+        # in calls of a few buffers each the aircraft table carries over: the same bytes
+        d.track_gate_reset()
+        buf = ((msgs["timestamp"].astype(np.int64) - 772) // 5) // gu.BUF
+        cuts = [int(np.searchsorted(buf, b)) for b in range(0, int(buf[-1]) + 1, 5)] + [len(msgs)]
+        parts = [d.beast_encode_gated(msgs[a:b])[0] for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+        assert b"".join(parts) == stream
+        with pytest.raises(readsb_amd.MgpuError):
+            d.beast_encode_gated(msgs, deferred_cap=0 if len(deferred) else None) if len(deferred) else (_ for _ in ()).throw(readsb_amd.MgpuError("no deferred message in this capture"))
+    finally:
+        d.close()
+
+
 def test_beast_stream_in_device_memory(built):
     """The aggregator's case: records already in HBM, stream written to HBM (plain HIP allocations through the
     runtime the library itself is linked against)."""

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("name,max_deferred", [("uc8_fix_2s", 0.05), ("uc8_aggressive_modeac_3s", 0.05), ("uc8_fix_200ac_60s", 0.005),
-                                               ("uc8_fix_30000ac_130s", 0.12)])
+                                               ("uc8_fix_30000ac_130s", 0.12)])   # (tightened to the measured shares + 10 % once they are known: see DEFERRED_MEASURED)
 def test_gate_against_the_reference_program(built, name, max_deferred):
     import readsb_amd
     kw, opt = gu.CASES[name]
@@ -69,6 +69,83 @@ def test_gate_in_device_memory(built):
         d.close()
     assert np.array_equal(v, gu.oracle_gate(want_msgs, want_fields))
     gu.check_against_golden(v, gu.golden_forwarded(name), 0.05)
+
+
+def _gate_in_hbm(d, msgs, fields):
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    n = len(msgs)
+    d_msgs, d_fields, d_v = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    try:
+        assert hip.hipMalloc(C.byref(d_msgs), msgs.nbytes) == 0 and hip.hipMalloc(C.byref(d_fields), fields.nbytes) == 0 and hip.hipMalloc(C.byref(d_v), n) == 0
+        assert hip.hipMemcpy(d_msgs, msgs.ctypes.data, msgs.nbytes, 1) == 0 and hip.hipMemcpy(d_fields, fields.ctypes.data, fields.nbytes, 1) == 0
+        d.track_gate_device(d_msgs.value, d_fields.value, n, d_v.value)
+        v = np.empty(n, dtype=np.uint8)
+        assert hip.hipMemcpy(v.ctypes.data, d_v, n, 2) == 0
+        return v
+    finally:
+        for p in (d_msgs, d_fields, d_v):
+            if p.value:
+                hip.hipFree(p)
+
+
+@pytest.mark.parametrize("n,seconds,naircraft,seed", [(300000, 3 * 3600.0, 40, 1), (400000, 2.2 * 3600.0, 3000, 2), (200000, 900.0, 7, 3), (1000, 5.0, 2000, 4)])
+def test_gate_scans_equal_the_message_by_message_machine(built, n, seconds, naircraft, seed):
+    """k_gate_walk computes the tracker's first stage as wave scans over an address's run; the CPU restatement steps it message by
+    message.  Lists that never saw a sample: hours of life (the position timeout of removeStaleRange, track.c:2835-2866 — an hour,
+    30 minutes for non-ICAO addresses), aircraft that fall silent for 400 s at a time (the 5-minute rule), runs from one message to
+    tens of thousands, more than three drainMessageBuffer batches in one buffer."""
+    import readsb_amd
+    msgs, fields, raw = gu.synthetic_list(n, seconds, naircraft, seed)
+    want = gu.oracle_gate_raw(**raw)
+    d = readsb_amd.Demodulator(startup_time_ms=helpers.STARTUP_MS, max_samples=1 << 20)
+    try:
+        got = _gate_in_hbm(d, msgs, fields)
+    finally:
+        d.close()
+    bad = np.nonzero(got != want)[0]
+    assert len(bad) == 0, f"{len(bad)} of {len(got)} verdicts differ, first at {bad[:5]}: got {got[bad[:5]]} want {want[bad[:5]]}"
+    assert ((want & 3) == 2).sum() > 0 and ((want & 3) == 1).sum() > 0 and ((want & 3) == 0).sum() > 0
+
+
+def test_position_timeout_defers(built):
+    """removeStaleRange deletes an aircraft with a reliable position once that position is an hour old, however recently it was
+    heard (track.c:2835-2866): behind it a->messages restarts at 1 and the next corrected-bit message is NOT forwarded.  Whether and
+    when a position was reliable is the tracker's knowledge, so from the first position message + 60 min on (30: non-ICAO
+    addresses) the gate must not call such a message certain any more."""
+    import readsb_amd
+    rows = []                                                        # (seconds, msgtype, cpr, correctedbits)
+    for t in range(0, 4000, 10):
+        rows.append((t, 17, 1 if t == 0 else 0, 0))                  # one position message at t = 0, identification messages every 10 s
+        rows.append((t + 5, 4, 0, 0))                                # an Address/Parity reply in between: needs the aircraft and messages > 1
+    n = len(rows)
+    pos = np.array([int(r[0] * 2.4e6) + 1000 for r in rows], dtype=np.int64)
+    for addr, limit in ((0x4840D6, 3600), (0x4840D6 | (1 << 24), 1800)):
+        msgs = np.zeros(n, dtype=readsb_amd.MSG_DTYPE)
+        msgs["timestamp"] = pos * 5 + 768 + 4
+        msgs["sysTimestamp"] = helpers.STARTUP_MS + msgs["timestamp"] // 12000
+        msgs["msgtype"] = [r[1] for r in rows]
+        msgs["correctedbits"] = [r[3] for r in rows]
+        msgs["msgbits"], msgs["addr"] = 56, addr
+        fields = np.zeros(n, dtype=readsb_amd.FIELDS_DTYPE)
+        fields["addr"], fields["msgtype"] = addr, msgs["msgtype"]
+        fields["flags"] = np.array([r[2] for r in rows], dtype=np.uint32) * gu.F_CPR_VALID
+        want = gu.oracle_gate_raw(msgs["msgtype"], fields["addr"], fields["IID"], msgs["correctedbits"], [r[2] for r in rows],
+                                  msgs["sysTimestamp"], pos // gu.BUF)
+        d = readsb_amd.Demodulator(startup_time_ms=helpers.STARTUP_MS, max_samples=1 << 20)
+        try:
+            got = _gate_in_hbm(d, msgs, fields)
+        finally:
+            d.close()
+        assert np.array_equal(got, want)
+        t = np.array([r[0] for r in rows])
+        ap = msgs["msgtype"] == 4
+        early, late = ap & (t > 20) & (t < limit - 10), ap & (t > limit + 10)
+        assert ((got[early] & 3) == 1).all(), "a known aircraft's replies are forwarded while its position cannot have timed out"
+        assert ((got[late] & 3) == 2).all(), "behind the position timeout the tracker decides"
 
 
 def test_gate_edge_cases(built):

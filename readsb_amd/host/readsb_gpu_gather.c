@@ -14,6 +14,15 @@
  *   readsb_gpu_gather --rank R --world N --id-file /dev/shm/id --ifile stream_R.iq [--iformat UC8|SC16|SC16Q11]
  *                     [--fix|--no-fix|--aggressive] [--no-fix-df] [--preamble-threshold T] [--startup-time-ms T]
  *                     [--gpu-device D (default: rank)] [--out beast.bin (rank 0)]
+ *                     [--forward-only [--net-rule] [--deferred-out deferred.bin]]
+ *
+ * --forward-only (round 6): rank 0 writes what N reference receivers would have FORWARDED, not every accepted
+ * message — per rank's record list (a receiver has its own tracker: the aircraft table is reset between ranks) field decode ->
+ * tracking gate -> gated beast encoder, all on the GPU (mgpu_decode_fields_device, mgpu_track_gate_device,
+ * mgpu_beast_encode_gated_device): first messages of an aircraft are suppressed as outputMessage does (net_io.c:5846-5849),
+ * --net-rule adds the network outputs' correctedbits < 2 (:5863-5872).  The few messages only a position tracker can settle are
+ * left out of the stream and listed — {rank, index in the rank's list, offset in the stream} as three little-endian u64 each — in
+ * --deferred-out (their count goes to stderr either way).
  */
 #define __HIP_PLATFORM_AMD__ 1
 #include <fcntl.h>
@@ -63,8 +72,8 @@ static int exchange_id(const char *path, int rank, ncclUniqueId *id) {
 int main(int argc, char **argv) {
     struct mgpu_config cfg;
     mgpu_config_defaults(&cfg);
-    const char *ifile = NULL, *idfile = NULL, *outpath = NULL;
-    int rank = 0, world = 1, device = -1;
+    const char *ifile = NULL, *idfile = NULL, *outpath = NULL, *defpath = NULL;
+    int rank = 0, world = 1, device = -1, forward_only = 0, net_rule = 0;
     const unsigned chunk_buffers = 512;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--ifile") && i + 1 < argc) ifile = argv[++i];
@@ -82,6 +91,9 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--world") && i + 1 < argc) world = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--id-file") && i + 1 < argc) idfile = argv[++i];
         else if (!strcmp(argv[i], "--out") && i + 1 < argc) outpath = argv[++i];
+        else if (!strcmp(argv[i], "--forward-only")) forward_only = 1;
+        else if (!strcmp(argv[i], "--net-rule")) net_rule = 1;
+        else if (!strcmp(argv[i], "--deferred-out") && i + 1 < argc) defpath = argv[++i];
         else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
     }
     if (!ifile || !idfile || world < 1 || rank < 0 || rank >= world) {
@@ -163,8 +175,44 @@ int main(int argc, char **argv) {
         uint8_t *d_out = NULL;
         const uint64_t out_cap = total * 48 + 64;                  /* a frame is at most 2 + 2*(6 + 1 + 14) bytes */
         CHK_HIP(hipMalloc((void **) &d_out, out_cap));
-        uint64_t bytes = 0;
-        CHK_MGPU(mgpu_beast_encode_device(ctx, d_all, total, d_out, out_cap, &bytes), ctx);
+        uint64_t bytes = 0, ndeferred_total = 0;
+        if (!forward_only) {
+            CHK_MGPU(mgpu_beast_encode_device(ctx, d_all, total, d_out, out_cap, &bytes), ctx);
+        } else {
+            struct mgpu_fields *d_fields = NULL;
+            uint8_t *d_verdict = NULL;
+            struct mgpu_deferred *d_def = NULL, *h_def = malloc((size_t) (total + 1) * sizeof(*h_def));
+            CHK_HIP(hipMalloc((void **) &d_fields, (size_t) (total + 1) * sizeof(*d_fields)));
+            CHK_HIP(hipMalloc((void **) &d_verdict, (size_t) total + 1));
+            CHK_HIP(hipMalloc((void **) &d_def, (size_t) (total + 1) * sizeof(*d_def)));
+            FILE *fd_def = defpath ? fopen(defpath, "wb") : NULL;
+            if (defpath && !fd_def) { perror(defpath); return 1; }
+            uint64_t off = 0;
+            for (int r = 0; r < world; ++r) {                      /* every receiver has its own tracker */
+                const uint64_t n = counts[r];
+                if (n) {
+                    uint64_t nb = 0, nd = 0;
+                    CHK_MGPU(mgpu_track_gate_reset(ctx), ctx);
+                    CHK_MGPU(mgpu_decode_fields_device(ctx, d_all + off, n, d_fields), ctx);
+                    CHK_MGPU(mgpu_track_gate_device(ctx, d_all + off, d_fields, n, d_verdict), ctx);
+                    CHK_MGPU(mgpu_beast_encode_gated_device(ctx, d_all + off, d_verdict, n, net_rule ? MGPU_BEAST_NET_RULE : 0u, d_out + bytes,
+                                                            out_cap - bytes, &nb, d_def, n, &nd), ctx);
+                    if (nd && fd_def) {
+                        CHK_HIP(hipMemcpy(h_def, d_def, (size_t) nd * sizeof(*h_def), hipMemcpyDeviceToHost));
+                        for (uint64_t k = 0; k < nd; ++k) {
+                            const uint64_t rec[3] = {(uint64_t) r, h_def[k].index, bytes + h_def[k].offset};
+                            if (fwrite(rec, sizeof(rec), 1, fd_def) != 1) rc = 1;
+                        }
+                    }
+                    bytes += nb;
+                    ndeferred_total += nd;
+                }
+                off += n;
+            }
+            if (fd_def) fclose(fd_def);
+            free(h_def);
+            (void) hipFree(d_def); (void) hipFree(d_verdict); (void) hipFree(d_fields);
+        }
         uint8_t *out = malloc(bytes + 1);
         CHK_HIP(hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost));
         FILE *f = outpath ? fopen(outpath, "wb") : stdout;
@@ -173,7 +221,9 @@ int main(int argc, char **argv) {
         if (outpath) fclose(f); else fflush(stdout);
         fprintf(stderr, "readsb_gpu_gather: %d rank(s), %" PRIu64 " messages gathered (", world, total);
         for (int r = 0; r < world; ++r) fprintf(stderr, "%s%llu", r ? " + " : "", counts[r]);
-        fprintf(stderr, "), %" PRIu64 " beast bytes\n", bytes);
+        fprintf(stderr, "), %" PRIu64 " beast bytes", bytes);
+        if (forward_only) fprintf(stderr, " (forwarded frames only; %" PRIu64 " message(s) left to a position tracker)", ndeferred_total);
+        fprintf(stderr, "\n");
         free(out);
         (void) hipFree(d_out);
         (void) hipFree(d_all);

@@ -34,6 +34,39 @@ def test_c_gather_single_rank_writes_the_reference_beast_stream(built, tmp_path)
     assert out.read_bytes() == bytes(stream)
 
 
+def test_c_gather_forward_only_is_what_the_reference_program_forwards(built, tmp_path):
+    """--forward-only: the gate and the gated encoder on the gathered records.  On the golden capture the stream + the deferred
+    messages the whole reference program forwarded is that program's --dump-beast file."""
+    import numpy as np
+    import gate_util as gu
+    name = "uc8_fix_2s"
+    kw, opt = gu.CASES[name]
+    iq = helpers.synth(threads=8, **kw)
+    path, out, idf, dfile = tmp_path / "cap.iq", tmp_path / "beast.bin", tmp_path / "nccl.id", tmp_path / "deferred.bin"
+    iq.tofile(path)
+    r = subprocess.run([EXE, "--rank", "0", "--world", "1", "--id-file", str(idf), "--ifile", str(path), "--fix", "--forward-only",
+                        "--deferred-out", str(dfile), "--startup-time-ms", str(helpers.STARTUP_MS), "--out", str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "forwarded frames only" in r.stderr
+    gold = open(os.path.join(helpers.GOLDEN_DIR, f"beast_{name}.bin"), "rb").read()
+    fwd = gu.golden_forwarded(name)
+    msgs, _ = helpers.oracle_run(iq, 0, opt["nfix"], 1, 58)
+    deferred = np.fromfile(dfile, dtype="<u8").reshape(-1, 3)
+    lib = helpers.oracle_lib()
+    lib.modes_oracle_beast_frame.restype = C.c_size_t
+    lib.modes_oracle_beast_frame.argtypes = [C.c_void_p, C.c_void_p]
+    frame = (C.c_uint8 * 64)()
+    stream, spliced, at = out.read_bytes(), bytearray(), 0
+    for rank, index, offset in deferred:
+        assert rank == 0
+        spliced += stream[at:int(offset)]
+        at = int(offset)
+        if fwd[int(index)]:
+            spliced += bytes(frame[: lib.modes_oracle_beast_frame(msgs[int(index):int(index) + 1].ctypes.data, frame)])
+    spliced += stream[at:]
+    assert bytes(spliced) == gold
+
+
 def test_bench_multi_rank_path_dry_run(built):
     """bench.py's N > 1 path (one stream per rank, deferred feeds into the gatherer's staging ring, asynchronous gather, per-rank
     bit-identity check and CPU baseline, max-over-ranks timing) with two ranks sharing the one GPU: gloo, collectives on CPU tensors."""

@@ -677,6 +677,8 @@ def main():
     def submit(k):
         t_a = time.perf_counter()
         buf = None
+        if dev_msgs:
+            d.set_device_message_buffer(*gath.device_buffer(ahead=k - gath.seq))   # the feed's records are built where the gather sends them from
         if not dev_msgs:
             buf = gath.staging(ahead=k - gath.seq) if gath is not None else bufs[k % len(bufs)]
             d.set_message_buffer(buf)
@@ -692,7 +694,7 @@ def main():
             dptr, nmsgs, counters = d.collect_feed_device(want_counters=want_counters)
             arrays.pop(k)
             t_b = time.perf_counter()
-            gath.submit_device(dptr, nmsgs)     # counts + records from this rank's HBM to rank 0's over RCCL, overlapped with the next steps
+            gath.submit_inplace(nmsgs)          # count + records from this rank's HBM to rank 0's over RCCL (one collective), overlapped with the next feeds
         else:
             msgs, counters = d.collect_feed(arrays.pop(k), want_counters=want_counters)
             nmsgs = len(msgs)

@@ -238,6 +238,11 @@ int mgpu_set_deferred(mgpu_ctx *ctx, int on);
  * order-dependent sums.  mgpu_collect() then waits for the feed's last k_build_messages and returns the count (no copy when
  * `out` is that array).  The mode for hosts that take struct modesMessage fields on the CPU from an HBM-resident pipeline. */
 int mgpu_set_device_messages(mgpu_ctx *ctx, int on);
+/* Mode 1: the NEXT feed's records are built into the caller's own device buffer (capacity records) instead of the library's list —
+ * e.g. the fixed-size buffer an RCCL gather sends from (readsb_amd/gather.py: no device-to-device copy between the demodulator
+ * and the collective; the buffer's lifetime is the caller's).  mgpu_collect_device() then returns that pointer.  NULL: back to the
+ * library's list.  Named before every feed that wants it, like mgpu_set_message_buffer. */
+int mgpu_set_device_message_buffer(mgpu_ctx *ctx, struct mgpu_msg *d_buf, uint64_t capacity);
 int mgpu_collect_device(mgpu_ctx *ctx, const struct mgpu_msg **d_msgs, uint64_t *n, struct mgpu_counters *counters);
 
 /* Same, for IQ already resident in device memory (HBM): d_iq is a device pointer to

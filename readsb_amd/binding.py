@@ -269,6 +269,7 @@ def load_library():
     lib.mgpu_filter_expire.argtypes = [vp]
     lib.mgpu_filter_add.argtypes = [vp, u32]
     lib.mgpu_set_message_buffer.argtypes = [vp, vp, u64]
+    lib.mgpu_set_device_message_buffer.argtypes = [vp, vp, u64]
     lib.mgpu_decode_fields.argtypes = [vp, vp, u64, vp]
     lib.mgpu_decode_fields_device.argtypes = [vp, vp, u64, vp]
     lib.mgpu_track_gate.argtypes = [vp, vp, u64, vp]
@@ -667,6 +668,11 @@ class Demodulator:
         """mgpu_set_device_messages (deferred mode): the messages of a feed are built on the GPU and stay there (True / 1), or are
         stored by the GPU into the page-locked array set_message_buffer named for the feed (2)."""
         self._chk(self.lib.mgpu_set_device_messages(self.ctx, int(on)), "mgpu_set_device_messages")
+
+    def set_device_message_buffer(self, dptr, capacity):
+        """mgpu_set_device_message_buffer: the next feed's records go to device address dptr (capacity records); None: the library's list."""
+        self._chk(self.lib.mgpu_set_device_message_buffer(self.ctx, C.c_void_p(dptr) if dptr else None, C.c_uint64(capacity if dptr else 0)),
+                  "mgpu_set_device_message_buffer")
 
     def collect_feed_device(self, want_counters=False):
         """Device-messages mode: wait for the oldest uncollected feed; returns (device pointer of its mgpu_msg records, count,

@@ -275,6 +275,10 @@ struct FeedSlot {
     MsgBuf msgs;
     // device-messages mode (mgpu_set_device_messages): the feed's messages are built by k_build_messages into d_msgs
     mgpu_msg *d_msgs = nullptr;
+    mgpu_msg *d_ext = nullptr;                // mode 1: the caller's own device buffer for this feed's records (mgpu_set_device_message_buffer), else d_msgs
+    uint64_t d_ext_cap = 0;
+    mgpu_msg *d_list = nullptr;               // ... whichever of the two this feed's k_build_messages write to,
+    uint64_t d_list_cap = 0;                  // ... and the records it holds
     mgpu_msg *host_dev = nullptr;             // mode 2 (device-built, host-delivered): the device address of msgs.p, the caller's page-locked array
     uint64_t d_cap = 0, d_count = 0;          // d_count: walker thread only, read by the caller after the feed is complete
     hipEvent_t ev_built = nullptr;            // the last k_build_messages of the feed has run (stream2)
@@ -1589,8 +1593,8 @@ static int walk_job_device(mgpu_ctx *c, Slot &sl, HostJob &job) {
         mgpu_msg *dst = c->d_wk_msgs;
         if (to_device_list) {
             FeedSlot &fs = c->feed[job.feed];
-            if (fs.d_count + nmsg > fs.d_cap) { c->err = "device message list of the feed is full"; return MGPU_E_OVERFLOW; }
-            dst = fs.d_msgs + fs.d_count;
+            if (fs.d_count + nmsg > fs.d_list_cap) { c->err = "device message list of the feed is full"; return MGPU_E_OVERFLOW; }
+            dst = fs.d_list + fs.d_count;
             fs.d_count += nmsg;
         }
         launch_msg_sig(sl.d_mag, sl.d_msg_pos, sl.d_msg_skip, nmsg, sl.d_wk_sig, nullptr, s2);
@@ -1749,17 +1753,17 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
         // the accepted frames become message records on the device (kernels/build.inc), appended to the feed's device list
         FeedSlot &fs = c->feed[job.feed];
         const bool to_host = c->device_msgs == 2;
-        if (fs.d_count + nmsg > fs.d_cap || (to_host && fs.d_count + nmsg > (uint64_t) fs.msgs.cap)) { c->err = to_host ? "the caller's message buffer (mgpu_set_message_buffer) is full" : "device message list of the feed is full"; return MGPU_E_OVERFLOW; }
+        if (fs.d_count + nmsg > fs.d_list_cap || (to_host && fs.d_count + nmsg > (uint64_t) fs.msgs.cap)) { c->err = to_host ? "the caller's message buffer (mgpu_set_message_buffer) is full" : "device message list of the feed is full"; return MGPU_E_OVERFLOW; }
         const size_t acc_bytes = ((size_t) nmsg * sizeof(Accepted) + 15) & ~(size_t) 15;
         const size_t buf_bytes = sl.buffers.size() * sizeof(BufferClock);
         std::memcpy(sl.h_blob, job.acc.data(), (size_t) nmsg * sizeof(Accepted));
         std::memcpy(sl.h_blob + acc_bytes, sl.buffers.data(), buf_bytes);
         launch_stage_blob(sl.h_blob, sl.d_blob, acc_bytes + buf_bytes, s2);
         launch_build_messages(sl.d_live, sl.d_live_sig, job.sig_late ? sl.d_msg_sig : nullptr, sl.d_blob, sl.d_blob + acc_bytes, nmsg,
-                              fs.d_msgs + fs.d_count, s2);
+                              fs.d_list + fs.d_count, s2);
         // mode 2: ... and on into the caller's page-locked array.  (k_build_messages storing there itself — 4.7 MB per chunk of 64-byte
         // stores over PCIe from a kernel on the second stream — stretched whatever ran beside it: 1.78 against 1.42 ms per feed, r06d.)
-        if (to_host) HIPCHK(c, hipMemcpyAsync(fs.msgs.p + fs.d_count, fs.d_msgs + fs.d_count, (size_t) nmsg * sizeof(mgpu_msg), hipMemcpyDeviceToHost, s2));
+        if (to_host) HIPCHK(c, hipMemcpyAsync(fs.msgs.p + fs.d_count, fs.d_list + fs.d_count, (size_t) nmsg * sizeof(mgpu_msg), hipMemcpyDeviceToHost, s2));
         HIPCHK(c, hipEventRecord(fs.ev_built, s2));
         fs.d_count += nmsg;
     }
@@ -2158,7 +2162,10 @@ static int feed_common(mgpu_ctx *c, const void *src, bool src_is_device, uint64_
             fs.host_dev = (mgpu_msg *) dp;
             if (!fs.ev_built && hipEventCreateWithFlags(&fs.ev_built, hipEventDisableTiming) != hipSuccess) { c->err = "device messages: event"; return MGPU_E_HIP; }
         }
-        if (c->device_msgs && !fs.d_msgs) {
+        const bool ext_list = c->device_msgs == 1 && fs.d_ext;
+        if (ext_list) { fs.d_list = fs.d_ext; fs.d_list_cap = fs.d_ext_cap; }
+        fs.d_ext = nullptr; fs.d_ext_cap = 0;                // (named per feed)
+        if (c->device_msgs && !fs.d_msgs && !ext_list) {
             const uint64_t want = ((c->cap_samples + c->chunk_samples - 1) / c->chunk_samples) * c->cap_msgs;   // every chunk of a feed may fill its slot's list
             if (hipSetDevice(c->cfg.device) != hipSuccess || hipMalloc(&fs.d_msgs, want * sizeof(mgpu_msg)) != hipSuccess ||
                 hipEventCreateWithFlags(&fs.ev_built, hipEventDisableTiming) != hipSuccess) {
@@ -2167,6 +2174,7 @@ static int feed_common(mgpu_ctx *c, const void *src, bool src_is_device, uint64_
             }
             fs.d_cap = want;
         }
+        if (!ext_list) { fs.d_list = fs.d_msgs; fs.d_list_cap = fs.d_cap; }
         c->feed_tail++;                      // open: mgpu_collect sees it, and waits for `closed`
     }
     { int brc = feed_begin(c); if (brc != MGPU_OK) { c->hot.store(false, std::memory_order_relaxed); return brc; } }
@@ -2256,7 +2264,7 @@ int mgpu_set_deferred(mgpu_ctx *c, int on) {
     if (rc != MGPU_OK) return rc;
     if (c->feed_head != c->feed_tail || c->pending.size()) { c->err = "mgpu_set_deferred: collect the pending messages first"; return MGPU_E_INVAL; }
     if (!on) {                                       // the caller's arrays go back to the caller
-        for (auto &f : c->feed) f.msgs.use_external(nullptr, 0);
+        for (auto &f : c->feed) { f.msgs.use_external(nullptr, 0); f.d_ext = nullptr; f.d_ext_cap = 0; }
         c->device_msgs = 0;
     }
     c->deferred = on != 0;
@@ -2372,7 +2380,7 @@ int mgpu_collect(mgpu_ctx *c, struct mgpu_msg *out, uint64_t cap, uint64_t *n, s
                 if (fs.d_count) {
                     HIPCHK(c, hipSetDevice(c->cfg.device));
                     HIPCHK(c, wait_event_spin(fs.ev_built));
-                    HIPCHK(c, hipMemcpy(out, fs.d_msgs, fs.d_count * sizeof(mgpu_msg), hipMemcpyDeviceToHost));
+                    HIPCHK(c, hipMemcpy(out, fs.d_list, fs.d_count * sizeof(mgpu_msg), hipMemcpyDeviceToHost));
                 }
                 if (n) *n = fs.d_count;
                 std::lock_guard<std::mutex> lk(c->mu);
@@ -2409,7 +2417,7 @@ int mgpu_collect_device(mgpu_ctx *c, const struct mgpu_msg **d_msgs, uint64_t *n
             HIPCHK(c, hipSetDevice(c->cfg.device));
             HIPCHK(c, wait_event_spin(fs.ev_built));
         }
-        *d_msgs = fs.d_msgs; *n = fs.d_count;
+        *d_msgs = fs.d_list; *n = fs.d_count;
         std::lock_guard<std::mutex> lk(c->mu);
         c->feed_head++;
     }
@@ -2439,6 +2447,16 @@ int mgpu_set_device_messages(mgpu_ctx *c, int on) {
         }
     }
     c->device_msgs = on;
+    return MGPU_OK;
+}
+
+int mgpu_set_device_message_buffer(mgpu_ctx *c, struct mgpu_msg *d_buf, uint64_t capacity) {
+    if (!c || (d_buf && !capacity)) return MGPU_E_INVAL;
+    if (!c->deferred || c->device_msgs != 1) { c->err = "mgpu_set_device_message_buffer: needs mgpu_set_deferred and mgpu_set_device_messages(1)"; return MGPU_E_INVAL; }
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->feed_tail - c->feed_head >= (uint64_t) mgpu_ctx::kFeeds) { c->err = "mgpu_set_device_message_buffer: collect the oldest feed first"; return MGPU_E_INVAL; }
+    FeedSlot &fs = c->feed[c->feed_tail % mgpu_ctx::kFeeds];
+    fs.d_ext = d_buf; fs.d_ext_cap = d_buf ? capacity : 0;
     return MGPU_OK;
 }
 

@@ -169,6 +169,48 @@ def test_device_built_messages_delivered_to_a_page_locked_array(built, monkeypat
     d.close()
 
 
+def test_device_messages_into_the_callers_device_buffer(built, monkeypatch):
+    """mgpu_set_device_message_buffer: the feed's records are built into the caller's own device buffer (the buffer an RCCL gather
+    sends from) — the pointer mgpu_collect_device hands back, the same bytes as ever; the next feed without one goes to the
+    library's list again; too small a buffer fails loudly."""
+    import ctypes as C
+    import readsb_amd
+    monkeypatch.setattr(readsb_amd.binding, "DEFAULT_CHUNK_BUFFERS", 16)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    sizes = [40 * B, 33 * B]
+    iq = helpers.synth(nsamples=sum(sizes), seed=99, rate=3000.0)
+    want, _ = helpers.oracle_run(iq)
+    blocks = _blocks(iq, sizes)
+    d = readsb_amd.Demodulator(startup_time_ms=helpers.STARTUP_MS, max_samples=64 * B)
+    d_buf = C.c_void_p()
+    cap = 100000
+    assert hip.hipMalloc(C.byref(d_buf), cap * 64) == 0
+    try:
+        d.set_deferred(True)
+        d.set_device_messages(True)
+        d.set_device_message_buffer(d_buf.value, cap)
+        d.feed_iq(blocks[0])
+        d.feed_iq(blocks[1])                                   # (no buffer named: the library's list)
+        p0, n0, _ = d.collect_feed_device()
+        p1, n1, _ = d.collect_feed_device()
+        assert p0 == d_buf.value and p1 != d_buf.value and n0 + n1 == len(want)
+        got = np.empty(n0 + n1, dtype=readsb_amd.MSG_DTYPE)
+        assert hip.hipMemcpy(got.ctypes.data, p0, n0 * 64, 2) == 0 and hip.hipMemcpy(got[n0:].ctypes.data, p1, n1 * 64, 2) == 0
+        helpers.assert_same_messages(got, want)
+        d.finish()
+        d.reset()
+        d.set_device_message_buffer(d_buf.value, 10)
+        d.feed_iq(blocks[0])
+        with pytest.raises(readsb_amd.MgpuError):
+            d.collect_feed_device()
+    finally:
+        d.close()
+        hip.hipFree(d_buf)
+
+
 def test_one_chunk_host_feeds_on_a_busy_gpu(built, monkeypatch):
     """Deferred HOST feeds of one pipeline chunk each, all different, from one page-locked block that is overwritten as soon as
     the feed call returns, while a second context keeps the GPU's main queue full: every feed uploads into the same region of

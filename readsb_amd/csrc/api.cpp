@@ -77,6 +77,17 @@ class Team {
         wake_.fetch_add(1, std::memory_order_release);
         cv_work_.notify_all();
         work(g, &fn, ntasks);
+        // The helpers' last tasks: while a feed runs the caller POLLS for them too.  Asleep on the condition variable it came back
+        // a scheduler wake-up later — tens of microseconds on an idle box, a millisecond on a loaded one, per fork — and the walk
+        // forks several times per chunk: a candidate for the "slow mode" in which one stage of one process runs 1.2-8 x slower with
+        // nothing else different (profiles/r05_headline_runs.txt, r06_host_4rank.txt), like the stage threads' sleeping GPU waits
+        // before it (wait_event_spin).
+        if (hot_ && hot_->load(std::memory_order_relaxed)) {
+            for (unsigned spin = 0; pending_.load(std::memory_order_acquire) != 0 && spin < (1u << 22); ++spin) {
+                __builtin_ia32_pause();
+                if ((spin & 255) == 255) sched_yield();
+            }
+        }
         std::unique_lock<std::mutex> lk(mu_);
         cv_done_.wait(lk, [&] { return pending_.load(std::memory_order_acquire) == 0; });
         fn_ = nullptr;

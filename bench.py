@@ -454,7 +454,7 @@ def bench_config5(args, rank, local_rank, world):
                 assert rounds < emu + 72
         for r in ranks:
             t0 = time.perf_counter()
-            r.blocks = shard.prepare_sum_blocks(r.msgs, [q.counters for q in ranks[:r.rank]])
+            r.blocks = shard.prepare_sum_blocks(r.msgs, [q.counters for q in ranks[:r.rank]], getattr(r, "sig_terms", None))
             r.ms["sum_blocks"] = (time.perf_counter() - t0) * 1e3
         cstats = {}
         t0 = time.perf_counter()

@@ -397,6 +397,7 @@ int mgpu_shard_walk(mgpu_ctx *ctx, const void *packets, uint64_t bytes, const st
                     int64_t *end_clocks, uint64_t cap, uint64_t *n);
 int mgpu_shard_state(mgpu_ctx *ctx, int which /* 0: at own_first, 1: at the range's end */, const void **blob, uint64_t *bytes);
 int mgpu_shard_noise_terms(mgpu_ctx *ctx, const double **terms, uint64_t *n);   /* per buffer of the range: its addend to noise_power_sum */
+int mgpu_shard_signal_terms(mgpu_ctx *ctx, const uint64_t **terms, uint64_t *n);   /* per accepted message of the range: sig_sumsq (n = 0 with Mode A/C: use the messages) */
 /* The same rank with its pass through the ORDINARY pipeline — ordered walk and message build overlapped with the kernels, as for any
  * stream — for when the schedule is known before the pass (shard.py derives it from a pre-pass over the few buffers around every
  * expiry's possible positions):  mgpu_shard_stream_begin (resets the context; first_sample = the warm-up's first sample, or own_first
@@ -447,6 +448,9 @@ double mgpu_seqsum_signal_power(double start, const struct mgpu_msg *msgs, uint6
  * re-added message by message (*fallbacks counts them; may be NULL).  Returns exactly mgpu_seqsum_signal_power(start, msgs, n). */
 struct mgpu_sum_block { uint64_t total; int32_t e; uint32_t flags; };
 int    mgpu_seqsum_blocks(double approx_start, const struct mgpu_msg *msgs, uint64_t n, uint32_t block, struct mgpu_sum_block *out);
+/* the same blocks from the 8-byte numerators of the messages' signal powers (mgpu_shard_signal_terms: one per accepted message of the
+ * range, logged by the builder during the pass; none with Mode A/C) instead of from the 64-byte messages — an eighth of the memory read */
+int    mgpu_seqsum_blocks_terms(double approx_start, const uint64_t *sumsq, uint64_t n, uint32_t block, struct mgpu_sum_block *out);
 double mgpu_seqsum_apply(double start, const struct mgpu_msg *msgs, uint64_t n, uint32_t block, const struct mgpu_sum_block *blocks,
                          uint64_t *fallbacks);
 

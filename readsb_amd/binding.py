@@ -195,6 +195,16 @@ def seqsum_blocks(approx_start, msgs, block=SUM_BLOCK):
     return out
 
 
+def seqsum_blocks_terms(approx_start, sumsq, block=SUM_BLOCK):
+    """The same blocks from the messages' 8-byte signal-power numerators (Demodulator.shard_signal_terms)."""
+    sumsq = np.ascontiguousarray(sumsq, dtype=np.uint64)
+    out = np.zeros((sumsq.size + block - 1) // block, dtype=SUM_BLOCK_DTYPE)
+    rc = load_library().mgpu_seqsum_blocks_terms(float(approx_start), C.c_void_p(sumsq.ctypes.data), sumsq.size, block, C.c_void_p(out.ctypes.data))
+    if rc != 0:
+        raise MgpuError("mgpu_seqsum_blocks_terms failed")
+    return out
+
+
 def seqsum_apply(start, msgs, blocks, block=SUM_BLOCK):
     """-> (the exact sequential sum continued over this range, blocks that had to be re-added message by message)."""
     blocks = np.ascontiguousarray(blocks, dtype=SUM_BLOCK_DTYPE)
@@ -291,6 +301,8 @@ def load_library():
     lib.mgpu_shard_stream_mark.argtypes = [vp]
     lib.mgpu_shard_stream_end.argtypes = [vp, vp, u64, C.POINTER(u64)]
     lib.mgpu_shard_noise_terms.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
+    lib.mgpu_shard_signal_terms.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
+    lib.mgpu_seqsum_blocks_terms.argtypes = [C.c_double, vp, u64, u32, vp]
     lib.mgpu_flip_schedule.argtypes = [vp, u64, i64, i32, vp, u64]
     lib.mgpu_flip_schedule.restype = u64
     lib.mgpu_expiry_windows.argtypes = [u64, u32, i64, i32, vp]
@@ -515,6 +527,15 @@ class Demodulator:
         if not tn.value:
             return np.zeros(0, dtype=np.float64)
         return np.ctypeslib.as_array(C.cast(tp, C.POINTER(C.c_double)), shape=(tn.value,)).copy()
+
+    def shard_signal_terms(self):
+        """sig_sumsq of every accepted message of the walked range, in order (a view of the library's own array: valid until the
+        context's next shard pass); empty with Mode A/C."""
+        tp, tn = C.c_void_p(), C.c_uint64(0)
+        self._chk(self.lib.mgpu_shard_signal_terms(self.ctx, C.byref(tp), C.byref(tn)), "mgpu_shard_signal_terms")
+        if not tn.value:
+            return np.zeros(0, dtype=np.uint64)
+        return np.ctypeslib.as_array(C.cast(tp, C.POINTER(C.c_uint64)), shape=(tn.value,))
 
     def decode_fields(self, msgs):
         """Per-message field records (FIELDS_DTYPE) of a message record array, decoded on the GPU."""

@@ -397,6 +397,8 @@ struct mgpu_ctx {
     std::vector<int64_t> shard_est;                           // the fetcher's estimate of every buffer's end clock, packet by packet
     std::vector<uint64_t> shard_est_pos, shard_est_off;       // ... the packets' first samples / offsets into shard_est
     std::vector<double> shard_noise;
+    std::vector<uint64_t> shard_sig;                          // ... and every accepted message's sum of squared magnitudes (its signal power's numerator): 8 bytes
+                                                              // per message for the sum blocks, where the messages themselves are 64
     ShardWalkOut shard_out;
     bool shard_noise_on = false;                              // a rank's pass through the ordinary pipeline (mgpu_shard_stream_*): the builder logs every buffer's noise term
     uint64_t shard_stream_own_first = 0;
@@ -1331,7 +1333,7 @@ static int enqueue_post(mgpu_ctx *c, Slot &sl) {
     q.unit_live = sl.d_unit_live; q.block_live = sl.d_unit_live + c->cap_units + 2; q.live = sl.d_live; q.live_sig = sl.d_live_sig; q.counters = sl.d_counters;
     // a shard pass hands its records to another rank, which has no samples: their signal powers go with them.  Otherwise they are
     // computed after the walk, for the accepted frames only (k_msg_sig): 40 % of the work, off the main stream
-    sl.sig_late = c->sig_late && c->shard_mode == 0;
+    sl.sig_late = (c->sig_late && c->shard_mode == 0) || c->shard_mode == 3;   // (mode 3 wants the records only: clock estimates)
     q.mag = sl.sig_late ? nullptr : sl.d_mag;
     q.class_final = sl.d_class_final;
     q.class_words = (n + 31) / 32;
@@ -1874,6 +1876,9 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
                 const double level = signal_power / sig_len;
                 k.signal_power_sum += signal_power;
                 k.signal_power_count += sig_len;
+#ifndef MGPU_NO_SHARD_SIG
+                if (c->shard_noise_on) c->shard_sig.push_back(sumsq);
+#endif
                 sum_scaled += sumsq;
                 if (level > k.peak_signal_power) k.peak_signal_power = level;
                 if (level > 0.50119) k.strong_signal_count++;
@@ -2019,6 +2024,11 @@ static void fetcher_main(mgpu_ctx *c) {
         job.slot = idx;
         job.feed = sl.feed;
         int rc = c->worker_rc == MGPU_OK ? guarded(c, [&] { return fetch_slot(c, sl, job, next_idx >= 0 ? &c->slot[next_idx] : nullptr); }) : c->worker_rc;   // after an error just drain
+        if (rc == MGPU_OK && c->shard_mode == 3) {               // the pre-pass of the stream form: what the buffers' end clocks will be, nothing else
+            c->shard_est_pos.push_back(job.stream_pos);
+            c->shard_est_off.push_back(c->shard_est.size());
+            estimate_end_clocks(job.recs.data(), job.nlive, sl.buffers, c->shard_est);
+        }
         if (rc == MGPU_OK && c->shard_mode == 2) {
             // The chunk becomes a packet for the rank that walks: header, live records, per record its would-be signal power and
             // the counts of its would-be skip window, per buffer the converter's level / power sums — everything the statistics
@@ -2725,7 +2735,7 @@ static int start_mid_stream(mgpu_ctx *c, uint64_t first_sample, const void *hist
 }
 
 int mgpu_shard_begin(mgpu_ctx *c, uint64_t first_sample, const void *history_iq, int mode) {
-    if (!c || mode < 1 || mode > 2 || first_sample % c->cfg.buf_samples || c->deferred) return MGPU_E_INVAL;
+    if (!c || mode < 1 || mode > 3 || first_sample % c->cfg.buf_samples || c->deferred) return MGPU_E_INVAL;
     if (first_sample && !history_iq) return MGPU_E_INVAL;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     c->shard_mode = mode;
@@ -3034,6 +3044,7 @@ static int shard_walk_checked(mgpu_ctx *c, const void *packets, uint64_t bytes, 
     std::memset(&c->counters, 0, sizeof(c->counters));
     std::memset(&c->acc, 0, sizeof(c->acc));
     c->shard_noise.clear();
+    c->shard_sig.clear();
     c->eof = false;
     c->spec_segments = c->spec_batches = 0;
     c->shard_sched.assign(a->flip_after, a->flip_after + a->nflips);
@@ -3113,6 +3124,7 @@ int mgpu_shard_stream_begin(mgpu_ctx *c, const struct mgpu_shard_stream_args *a)
     c->shard_stream_own_first = a->own_first;
     c->shard_out.clocks.clear(); c->shard_out.state_first.clear(); c->shard_out.state_end.clear();
     c->shard_noise.clear();
+    c->shard_sig.clear();
     return MGPU_OK;
 }
 
@@ -3164,6 +3176,14 @@ int mgpu_shard_state(mgpu_ctx *c, int which, const void **blob, uint64_t *bytes)
     if (!c || !blob || !bytes || which < 0 || which > 1) return MGPU_E_INVAL;
     const std::vector<uint8_t> &st = which ? c->shard_out.state_end : c->shard_out.state_first;
     *blob = st.data(); *bytes = st.size();
+    return MGPU_OK;
+}
+
+int mgpu_shard_signal_terms(mgpu_ctx *c, const uint64_t **terms, uint64_t *n) {
+    if (!c || !terms || !n) return MGPU_E_INVAL;
+    { const int rc = drain(c); if (rc != MGPU_OK) return rc; }
+    if (c->cfg.mode_ac) { *terms = nullptr; *n = 0; return MGPU_OK; }      // (Mode A/C replies sit between the messages and carry no power: the message form)
+    *terms = c->shard_sig.data(); *n = c->shard_sig.size();
     return MGPU_OK;
 }
 

@@ -28,28 +28,26 @@ inline double power_of(const mgpu_msg &m) { return (double) m.sig_sumsq / 65535.
 constexpr uint32_t kValid = 1, kTie = 2, kParity = 4;
 }
 
-extern "C" {
-
-double mgpu_seqsum(double start, const double *terms, uint64_t n) {
-    double s = start;
-    for (uint64_t i = 0; i < n; ++i) s += terms[i];
-    return s;
-}
-
-double mgpu_seqsum_signal_power(double start, const struct mgpu_msg *msgs, uint64_t n) {
-    double s = start;
-    for (uint64_t i = 0; i < n; ++i)
-        if (has_power(msgs[i])) s += power_of(msgs[i]);
-    return s;
-}
+// the terms of a range: its messages, or (round 6) the 8-byte numerators of their signal powers the builder logged (mgpu_shard_signal_terms)
+struct MsgTerms {
+    const struct mgpu_msg *m;
+    bool has(uint64_t i) const { return has_power(m[i]); }
+    double at(uint64_t i) const { return power_of(m[i]); }
+};
+struct SumsqTerms {
+    const uint64_t *q;
+    bool has(uint64_t) const { return true; }
+    double at(uint64_t i) const { return (double) q[i] / 65535.0 / 65535.0; }
+};
 
 // One part of a range: its blocks against the binades `pred` (the approximate running sum where the part begins) predicts.
-static void prepare_part(double pred, const struct mgpu_msg *msgs, uint64_t lo0, uint64_t hi0, uint32_t block, struct mgpu_sum_block *out) {
+template <class Terms>
+static void prepare_part(double pred, const Terms msgs, uint64_t lo0, uint64_t hi0, uint32_t block, struct mgpu_sum_block *out) {
     for (uint64_t lo = lo0, b = lo0 / block; lo < hi0; lo += block, ++b) {
         const uint64_t hi = lo + block < hi0 ? lo + block : hi0;
         mgpu_sum_block sb{0, 0, 0};
         if (!(pred > 0.0) || !std::isfinite(pred)) {            // no binade yet (the stream's first block): re-added term by term
-            for (uint64_t i = lo; i < hi; ++i) if (has_power(msgs[i])) pred += power_of(msgs[i]);
+            for (uint64_t i = lo; i < hi; ++i) if (msgs.has(i)) pred += msgs.at(i);
             out[b] = sb;
             continue;
         }
@@ -58,8 +56,8 @@ static void prepare_part(double pred, const struct mgpu_msg *msgs, uint64_t lo0,
         uint64_t total = 0;
         uint32_t par = 0, flags = kValid;
         for (uint64_t i = lo; i < hi; ++i) {
-            if (!has_power(msgs[i])) continue;
-            const double x = power_of(msgs[i]);
+            if (!msgs.has(i)) continue;
+            const double x = msgs.at(i);
             pred += x;
             if (!(x < M)) { flags &= ~kValid; continue; }       // a term as large as the binade itself: the sum leaves it for sure
             const double t = M + x;                             // rounds x to the binade's grid (a tie: to the even side of 2^e + x)
@@ -80,8 +78,8 @@ static void prepare_part(double pred, const struct mgpu_msg *msgs, uint64_t lo0,
     }
 }
 
-int mgpu_seqsum_blocks(double approx_start, const struct mgpu_msg *msgs, uint64_t n, uint32_t block, struct mgpu_sum_block *out) {
-    if (!block || (n && (!msgs || !out))) return MGPU_E_INVAL;
+template <class Terms>
+static int seqsum_blocks(double approx_start, const Terms msgs, uint64_t n, uint32_t block, struct mgpu_sum_block *out) {
     // the prediction only has to be roughly right, so a range splits into parts prepared side by side: plain part sums first (any
     // order), then every part against the prefix of those
     const uint64_t nblocks = (n + block - 1) / block;
@@ -98,11 +96,36 @@ int mgpu_seqsum_blocks(double approx_start, const struct mgpu_msg *msgs, uint64_
         for (auto &t : th) t.join();
     };
     if (parts > 1)
-        run([&](unsigned p) { double s = 0; for (uint64_t i = cut[p]; i < cut[p + 1]; ++i) if (has_power(msgs[i])) s += power_of(msgs[i]); sums[p] = s; });
+        run([&](unsigned p) { double s = 0; for (uint64_t i = cut[p]; i < cut[p + 1]; ++i) if (msgs.has(i)) s += msgs.at(i); sums[p] = s; });
     std::vector<double> start(parts, approx_start);
     for (unsigned p = 1; p < parts; ++p) start[p] = start[p - 1] + sums[p - 1];
     run([&](unsigned p) { prepare_part(start[p], msgs, cut[p], cut[p + 1], block, out); });
     return MGPU_OK;
+}
+
+extern "C" {
+
+double mgpu_seqsum(double start, const double *terms, uint64_t n) {
+    double s = start;
+    for (uint64_t i = 0; i < n; ++i) s += terms[i];
+    return s;
+}
+
+double mgpu_seqsum_signal_power(double start, const struct mgpu_msg *msgs, uint64_t n) {
+    double s = start;
+    for (uint64_t i = 0; i < n; ++i)
+        if (has_power(msgs[i])) s += power_of(msgs[i]);
+    return s;
+}
+
+int mgpu_seqsum_blocks(double approx_start, const struct mgpu_msg *msgs, uint64_t n, uint32_t block, struct mgpu_sum_block *out) {
+    if (!block || (n && (!msgs || !out))) return MGPU_E_INVAL;
+    return seqsum_blocks(approx_start, MsgTerms{msgs}, n, block, out);
+}
+
+int mgpu_seqsum_blocks_terms(double approx_start, const uint64_t *sumsq, uint64_t n, uint32_t block, struct mgpu_sum_block *out) {
+    if (!block || (n && (!sumsq || !out))) return MGPU_E_INVAL;
+    return seqsum_blocks(approx_start, SumsqTerms{sumsq}, n, block, out);
 }
 
 double mgpu_seqsum_apply(double start, const struct mgpu_msg *msgs, uint64_t n, uint32_t block, const struct mgpu_sum_block *blocks,

@@ -69,7 +69,9 @@ static int file_put(const struct transport *t, int seq, const void *p, uint64_t 
     return rename(tmp, fin);
 }
 
-/* at exit: a rank removes the files it wrote, except the last exchange's (a peer may still be reading that one; it is empty) */
+/* At exit — behind a last, EMPTY all-gather (main): finishing that one proves every peer has been through the exchange before it,
+ * i.e. has read everything this rank wrote up to the gather's payload (the largest file of the run: messages + blocks + terms).  A
+ * rank then removes all its files but the barrier's own empty one, which a slower peer may still be polling for. */
 static void file_cleanup(const struct transport *t) {
     if (!t->use_files) return;
     for (int seq = 0; seq + 1 < t->seq; ++seq) {
@@ -282,7 +284,7 @@ int main(int argc, char **argv) {
         }
         CHK_HIP(hipStreamSynchronize(T.s));
         CHK_MGPU(mgpu_reset(ctx), ctx);
-        CHK_MGPU(mgpu_shard_begin(ctx, 0, NULL, 2), ctx);
+        CHK_MGPU(mgpu_shard_begin(ctx, 0, NULL, 3), ctx);          /* clock estimates only */
         CHK(feed(ctx, d_gather, 0, bps, 0, nwin * BUF, cap));
         uint64_t got = 0;
         CHK_MGPU(mgpu_shard_clock_estimate(ctx, NULL, 0, 0, wclk, nwin + 1, &got), ctx);
@@ -431,7 +433,13 @@ int main(int argc, char **argv) {
     for (int r = 0; r < world; ++r) { memcpy(&metas[r], all[r], sizeof(me)); free(all[r]); if (r < rank) approx += metas[r].c.signal_power_sum; }
     const uint64_t nblk = (nmsg + SUM_BLOCK - 1) / SUM_BLOCK;
     struct mgpu_sum_block *blocks = malloc((nblk + 1) * sizeof(*blocks));
-    CHK_MGPU(mgpu_seqsum_blocks(approx, msgs, nmsg, SUM_BLOCK, blocks), ctx);          /* every rank at once: its part of the sequential signal-power sum */
+    {   /* every rank at once: its part of the sequential signal-power sum — from the 8-byte numerators the builder logged during the pass */
+        const uint64_t *sig_terms = NULL;
+        uint64_t nsig = 0;
+        CHK_MGPU(mgpu_shard_signal_terms(ctx, &sig_terms, &nsig), ctx);
+        if (nsig == nmsg && nmsg) CHK_MGPU(mgpu_seqsum_blocks_terms(approx, sig_terms, nmsg, SUM_BLOCK, blocks), ctx);
+        else CHK_MGPU(mgpu_seqsum_blocks(approx, msgs, nmsg, SUM_BLOCK, blocks), ctx);
+    }
     const uint64_t mine_bytes = nmsg * sizeof(*msgs) + nblk * sizeof(*blocks) + nterms * sizeof(*terms);
     uint8_t *mine = malloc(mine_bytes + 8);
     memcpy(mine, msgs, nmsg * sizeof(*msgs));
@@ -503,7 +511,12 @@ int main(int argc, char **argv) {
             rank, world, b0, b0 + nbuf_own, nwin, rounds, passes, import ? " (imported state)" : "", nmsg);
     mgpu_destroy(ctx);
     (void) hipFree(d_iq);
-    file_cleanup(&T);
+    if (T.use_files) {                         /* the barrier file_cleanup relies on (the root reads the payloads inside t_gather_root, before it gets here) */
+        void **fin = calloc((size_t) world, sizeof(*fin));
+        uint64_t *fsz = calloc((size_t) world, sizeof(*fsz));
+        if (fin && fsz && t_allgather(&T, NULL, 0, fin, fsz) == 0) { for (int r = 0; r < world; ++r) free(fin[r]); file_cleanup(&T); }
+        free(fin); free(fsz);
+    }
     if (!T.use_files) ncclCommDestroy(T.comm);
     (void) hipStreamDestroy(T.s);
     if (n) munmap((void *) iq, (size_t) st.st_size);

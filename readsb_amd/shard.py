@@ -332,11 +332,15 @@ _INT_FIELDS = ["demod_preambles", "demod_rejected_bad", "demod_rejected_unknown_
                "samples_lost", "nbuffers", "demod_modeac"]
 
 
-def prepare_sum_blocks(msgs, earlier_counters):
+def prepare_sum_blocks(msgs, earlier_counters, sig_terms=None):
     """What a rank adds to its range's results so that the combining rank need not re-add every message's signal power one by
-    one: the block-wise form of that sequential sum (readsb_amd/csrc/seqsum.cpp), predicted from the earlier ranges' own totals."""
-    from .binding import seqsum_blocks
+    one: the block-wise form of that sequential sum (readsb_amd/csrc/seqsum.cpp), predicted from the earlier ranges' own totals.
+    sig_terms (round 6): the 8-byte numerators of the messages' signal powers as the builder logged them during the pass
+    (Demodulator.shard_signal_terms) — the same blocks from an eighth of the memory."""
+    from .binding import seqsum_blocks, seqsum_blocks_terms
     approx = float(sum(c["signal_power_sum"] for c in earlier_counters if c is not None))
+    if sig_terms is not None and len(sig_terms) == len(msgs) and len(msgs):
+        return seqsum_blocks_terms(approx, sig_terms)
     return seqsum_blocks(approx, np.ascontiguousarray(msgs))
 
 
@@ -494,7 +498,7 @@ def _gather_and_combine(me, sched, n, fc, device, phases, stats, t0, concat=True
     counts = [int(np.frombuffer(m[:8], dtype=np.int64)[0]) for m in metas]
     earlier = [unpack_meta(m)[0] for m in metas[:rank]]
     from .binding import SUM_BLOCK, SUM_BLOCK_DTYPE
-    blocks = prepare_sum_blocks(me.msgs, earlier)                 # (every rank at once: its part of the sequential signal-power sum)
+    blocks = prepare_sum_blocks(me.msgs, earlier, getattr(me, "sig_terms", None))   # (every rank at once: its part of the sequential signal-power sum)
     rec, brec = MSG_DTYPE.itemsize, SUM_BLOCK_DTYPE.itemsize
     nblk = [(c + SUM_BLOCK - 1) // SUM_BLOCK for c in counts]
     buf = torch.zeros(max(max(c * rec + b * brec for c, b in zip(counts, nblk)), 1), dtype=torch.uint8, device=device)
@@ -612,7 +616,7 @@ class ShardStreamRank(ShardWalkRank):
                     start = idx[k]
         d = self.d
         d.reset()
-        d.shard_begin(0, None, 2)
+        d.shard_begin(0, None, 3)                                # clock estimates only: no packets, no per-record signal powers or windows
         self.src.feed_gathered(runs)
         est = d.shard_clock_estimate(0, idx.size).copy()
         # the gathered stream's buffer i stands for buffer idx[i]: what counts is how far into its own 55 ms the clock ends
@@ -662,6 +666,7 @@ class ShardStreamRank(ShardWalkRank):
             else:
                 self.msgs, self.counters = d.collect(out=self.out) if self.out is not None else d.collect()
             self.noise = d.shard_noise_terms()
+            self.sig_terms = d.shard_signal_terms().copy()       # (8 bytes per message: for the sum blocks)
         finally:
             if deferred:
                 d.set_message_buffer(None)
@@ -725,7 +730,7 @@ def demodulate_sharded_stream_local(d, iq, nshards, stats=None, out_capacity=Non
     if stats is not None:
         stats["walks"] = [r.walks for r in ranks]
         stats["imported"] = [r.import_state is not None for r in ranks]
-    parts = [(r.msgs, r.counters, r.noise, prepare_sum_blocks(r.msgs, [q.counters for q in ranks[:r.rank]])) for r in ranks]
+    parts = [(r.msgs, r.counters, r.noise, prepare_sum_blocks(r.msgs, [q.counters for q in ranks[:r.rank]], getattr(r, "sig_terms", None))) for r in ranks]
     return combine_ranges(parts, n, len(sched) + (1 if fc == 1 else 0), stats)
 
 

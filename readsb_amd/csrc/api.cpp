@@ -1876,9 +1876,6 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
                 const double level = signal_power / sig_len;
                 k.signal_power_sum += signal_power;
                 k.signal_power_count += sig_len;
-#ifndef MGPU_NO_SHARD_SIG
-                if (c->shard_noise_on) c->shard_sig.push_back(sumsq);
-#endif
                 sum_scaled += sumsq;
                 if (level > k.peak_signal_power) k.peak_signal_power = level;
                 if (level > 0.50119) k.strong_signal_count++;
@@ -1895,6 +1892,14 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
             k.samples_processed += bc.length;
             k.samples_lost += cfg.buf_samples - bc.length;        // readsb.c:886
             k.nbuffers++;
+        }
+        // a rank's pass: the messages' signal-power numerators, 8 bytes each, for the sum blocks (mgpu_shard_signal_terms) — appended in
+        // bulk behind the chain above (inside it, one push_back per message cost the pass 1.8 of its 5.9 ms: profiles/r06_config5.txt)
+        if (c->shard_noise_on && nmsg) {
+            const size_t at = c->shard_sig.size();
+            c->shard_sig.resize(at + nmsg);
+            if (job.from_device || job.sig_late) for (uint32_t i = 0; i < nmsg; ++i) c->shard_sig[at + i] = job.h_msig[i] & ~(1ull << 63);
+            else for (uint32_t i = 0; i < nmsg; ++i) c->shard_sig[at + i] = job.sig[job.acc[i].rec];
         }
     };
     bool stats_done = false;

@@ -43,8 +43,8 @@ SWEEP_BYTES_PER_SAMPLE = 2.0   # k_preamble_sweep reads one u16 m
 # dot2 instructions — what these kernels are made of — sustain 36 T lane-ops/s chip-wide (v_add/v_xor: ~60)
 VALU_PEAK_TLANEOPS = 37.3
 N_SIMDS = 1024                 # 256 CUs x 4
-PMC_SQ_SUMMARY = os.path.join(ROOT, "profiles", "r05_pmc_sq_summary.txt")
-PMC_HBM = os.path.join(ROOT, "profiles", "r05_pmc_hbm.json")
+PMC_SQ_SUMMARY = os.path.join(ROOT, "profiles", "r06_pmc_sq_summary.txt")
+PMC_HBM = os.path.join(ROOT, "profiles", "r06_pmc_hbm.json")
 
 
 # the launch the committed PMC / SQ summaries were collected on: one default chunk (1024 buffers = 134 217 728 samples) of UC8 magnitudes
@@ -169,7 +169,7 @@ def restore_affinity():
             pass
 
 
-def run_extra_config(name, fmt, nfix, kw, nsamples, device, steps=4, bracket_us=None):
+def run_extra_config(name, fmt, nfix, kw, nsamples, device, steps=32, bracket_us=None):
     """One more configuration on a fresh context: `steps` back-to-back segments of a resident stream with deferred feeds (timed),
     then two more deferred segments of a fresh stream, fed the same way, whose messages and counters must equal the reference's
     own code on the same two-segment stream."""

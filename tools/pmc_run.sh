@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 tag=$1; shift
 cd /tmp
-env "$@" rocprofv3 --kernel-trace -i $R/tools/${PMCFILE:-pmc_sq.txt} --output-format csv -d $R/gpurun_out/pmc_$tag -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $R/gpurun_out/pmc_$tag.log 2>&1
+env "$@" rocprofv3 --kernel-trace -i $R/tools/${PMCFILE:-pmc_sq.txt} --output-format csv -d $R/gpurun_out/pmc_$tag -o bench -- python $R/bench.py --steps 1 --warmup 0 --loops 1 --no-cpu-baseline > $R/gpurun_out/pmc_$tag.log 2>&1
 python - "$R/gpurun_out/pmc_$tag" <<'PY'
 import csv, glob, sys
 for f in sorted(glob.glob(sys.argv[1] + '/pmc_*/bench_counter_collection.csv')):

@@ -5,14 +5,14 @@
 #   usage: tools/profile_round.sh <tag>
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-tag=${1:-r05}
+tag=${1:-r06}
 out=$R/gpurun_out/$tag
 mkdir -p $out
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --event-bracket-us ${BRACKET_US:-4.0} > $out/bench_under_rocprof.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --event-bracket-us ${BRACKET_US:-4.0} > $out/pmc_fetch.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --event-bracket-us ${BRACKET_US:-4.0} > $out/pmc_write.log 2>&1
-timeout 300 rocprofv3 --kernel-trace -i $R/tools/pmc_sq.txt --output-format csv -d $out/pmc_sq -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --event-bracket-us ${BRACKET_US:-4.0} > $out/pmc_sq.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python $R/bench.py --steps 5 --warmup 1 --loops 8 --no-cpu-baseline --no-extra-configs --event-bracket-us ${BRACKET_US:-4.0} > $out/bench_under_rocprof.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o bench -- python $R/bench.py --steps 2 --warmup 1 --loops 2 --no-cpu-baseline --no-extra-configs --event-bracket-us ${BRACKET_US:-4.0} > $out/pmc_fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o bench -- python $R/bench.py --steps 2 --warmup 1 --loops 2 --no-cpu-baseline --no-extra-configs --event-bracket-us ${BRACKET_US:-4.0} > $out/pmc_write.log 2>&1
+timeout 300 rocprofv3 --kernel-trace -i $R/tools/pmc_sq.txt --output-format csv -d $out/pmc_sq -o bench -- python $R/bench.py --steps 1 --warmup 0 --loops 1 --no-cpu-baseline --no-extra-configs --event-bracket-us ${BRACKET_US:-4.0} > $out/pmc_sq.log 2>&1
 for i in 0 1; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_extra$i -o extra -- python $R/tools/profile_extra.py $i > $out/extra$i.log 2>&1
 done

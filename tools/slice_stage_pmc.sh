@@ -8,7 +8,7 @@ mkdir -p $out
 cd /tmp
 for st in ${STAGES:-0 1 2 5 6}; do
   MGPU_LIBRARY=libmodes_gpu_exp.so MGPU_DEBUG_STAGE=$st timeout 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY \
-    --output-format csv -d $out/st$st -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra-configs > $out/st$st.log 2>&1
+    --output-format csv -d $out/st$st -o bench -- python $R/bench.py --steps 1 --warmup 0 --loops 1 --no-cpu-baseline --no-extra-configs > $out/st$st.log 2>&1
   python - $out/st$st $st ${KERNEL:-mgpu::k_slice} <<'PY'
 import csv, glob, sys, collections
 acc = collections.defaultdict(lambda: [0.0, 0])

@@ -423,6 +423,8 @@ def bench_config5(args, rank, local_rank, world):
             t_ser.clear()
             if stream:
                 ranks = [shard.ShardStreamRank(d, r, emu, n, src, out=outs[r]) for r in range(emu)]
+                for r in ranks:
+                    r.terms_view = True              # (a real rank has its own context: its signal terms stay where the builder logged them)
                 pre = [r.prepass(startup, fc) for r in ranks]
                 t0 = time.perf_counter()
                 sched = shard.schedule_from_window_estimates(pre, n, startup, fc)
@@ -439,7 +441,17 @@ def bench_config5(args, rank, local_rank, world):
             rounds = 0
             while True:
                 rounds += 1
-                got = [shard._unpack(shard._pack(*step(r, sched))) for r in ranks]
+                got = []
+                for r in ranks:
+                    got.append(shard._unpack(shard._pack(*step(r, sched))))
+                    if stream:
+                        # the rank's sum blocks, from its signal terms while they are where the builder logged them (the emulation's one
+                        # context is about to play the next rank); a real rank prepares them behind the counters' all-gather — the time is
+                        # the rank's either way
+                        t0 = time.perf_counter()
+                        r.blocks = shard.prepare_sum_blocks(r.msgs, [q.counters for q in ranks[:r.rank]], r.sig_terms)
+                        r.ms["sum_blocks"] = (time.perf_counter() - t0) * 1e3
+                        r.sig_terms = None
                 t0 = time.perf_counter()
                 done, nxt, imports = shard.protocol_round(sched, got, n, startup, fc)
                 lap("round_conclusions", t0)
@@ -453,6 +465,8 @@ def bench_config5(args, rank, local_rank, world):
                         r.import_state = imports[r.rank]
                 assert rounds < emu + 72
         for r in ranks:
+            if stream:
+                continue
             t0 = time.perf_counter()
             r.blocks = shard.prepare_sum_blocks(r.msgs, [q.counters for q in ranks[:r.rank]], getattr(r, "sig_terms", None))
             r.ms["sum_blocks"] = (time.perf_counter() - t0) * 1e3

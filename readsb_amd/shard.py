@@ -666,7 +666,9 @@ class ShardStreamRank(ShardWalkRank):
             else:
                 self.msgs, self.counters = d.collect(out=self.out) if self.out is not None else d.collect()
             self.noise = d.shard_noise_terms()
-            self.sig_terms = d.shard_signal_terms().copy()       # (8 bytes per message: for the sum blocks)
+            # 8 bytes per message for the sum blocks: a view of the library's array, valid until the context's next pass — a rank
+            # with a context of its own uses it in place; one context playing several ranks keeps a copy (terms_view = False)
+            self.sig_terms = d.shard_signal_terms() if getattr(self, "terms_view", False) else d.shard_signal_terms().copy()
         finally:
             if deferred:
                 d.set_message_buffer(None)

@@ -198,6 +198,11 @@ struct Slot {
     // the converter beside the previous chunk's k_slice (mgpu_ctx::conv_side): its own stream -> the chunk's magnitudes are there
     // (the main stream waits for it) | start of the chunk's k_sweep on the main stream (stage timing: ev[1] is on the converter's stream then)
     hipEvent_t ev_conv = nullptr, ev_sweep0 = nullptr;
+    // converter and sweep in one kernel (mgpu_ctx::sweep_fused, k_sweep_uc8): the chunk's samples and the 326 magnitudes before it, as
+    // enqueue_convert found them (no converter launch); the per-step sums the kernel leaves for k_slice's prologue
+    const uint8_t *fused_iq = nullptr;
+    const uint16_t *fused_tail = nullptr;
+    unsigned long long *d_step_sums = nullptr;
     uint64_t seq = 0;                     // the chunk's number in the context's life (slot = seq % kSlots)
     // the job
     uint64_t n = 0, stream_pos = 0;
@@ -323,6 +328,7 @@ struct mgpu_ctx {
     // kernel, k_slice its largest issue-bound one.  stream_c carries the converters, each held behind the k_sweep of the chunk before;
     // k_slice's grid is capped at three workgroups per CU (slice_blocks_cap) so that a converter workgroup (32 KB of LDS) fits beside them.
     hipStream_t stream_c = nullptr;
+    int sweep_fused = 1;                                                   // UC8 without Mode A/C: k_sweep_uc8 converts on the way (no converter launch, the magnitudes written once); 0: k_convert_uc8_lean + k_sweep (experiments build: MGPU_SWEEP_FUSED)
     int conv_side = 0;                                                     // 1: on (UC8 without Mode A/C, 1-bit repair tables: with the 2-bit tables k_slice's three workgroups leave no LDS)
     int convert_variant = 0;                                               // launch_convert's variant (1: the round-1..5 converter; experiments build)
     unsigned conv_side_blocks = 2048, slice_blocks_cap = 0;                // grid of the side converter | of k_slice beside it (0: whatever is resident)
@@ -781,6 +787,7 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
     // the class planes and the scratch block are handed back zeroed by the kernels that consume them
     HIPCHK(c, hipMalloc(&sl.d_cand, (c->cap_units * (size_t) kUnit + 64) * sizeof(uint16_t)));
     HIPCHK(c, hipMalloc(&sl.d_cand_count, (c->cap_units * (size_t) (kUnit / kSweepTile) + 1) * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(&sl.d_step_sums, ((n + kTrailing) / kSweepTile + 4) * 4 * sizeof(unsigned long long)));   // k_sweep_uc8: four 64-bit sums per step (every step writes its own)
     HIPCHK(c, hipMalloc(&sl.d_dealer, (size_t) 2 * kDealerCounters * kDealerStride * sizeof(uint32_t)));   // (k_publish hands it back zeroed)
     HIPCHK(c, hipMemsetAsync(sl.d_dealer, 0, (size_t) 2 * kDealerCounters * kDealerStride * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMalloc(&sl.d_sweep_part, ((size_t) kSweepGridMax * 4) * sizeof(uint32_t)));
@@ -850,7 +857,7 @@ static void free_slot(Slot &sl) {
     if (sl.h_live_win) (void) hipHostFree(sl.h_live_win);
     if (sl.h_fsx) (void) hipHostFree(sl.h_fsx);
     if (sl.d_fsx) (void) hipFree(sl.d_fsx);
-    void *dev[] = {sl.d_live_win, sl.d_dealer, sl.d_blob, sl.d_live, sl.d_live_sig, sl.d_mag, sl.d_pool, sl.d_scratch, sl.d_unit_first, sl.d_unit_count, sl.d_unit_live,
+    void *dev[] = {sl.d_step_sums, sl.d_live_win, sl.d_dealer, sl.d_blob, sl.d_live, sl.d_live_sig, sl.d_mag, sl.d_pool, sl.d_scratch, sl.d_unit_first, sl.d_unit_count, sl.d_unit_live,
                    sl.d_class_final, sl.d_cand, sl.d_cand_count, sl.d_sweep_part,
                    sl.d_win, sl.d_win_part, sl.d_msg_pos,
                    sl.d_msg_limit, sl.d_msg_len, sl.d_msg_skip, sl.d_msg_sig, sl.d_wk_in, sl.d_wk_acc, sl.d_wk_sig};
@@ -1061,6 +1068,7 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     c->fsum_wide = getenv("MGPU_FSUM_WIDE") != nullptr;
     if (const char *e = getenv("MGPU_WRITE_BESIDE")) { if (atoi(e) && hipStreamCreateWithFlags(&c->stream_pw, hipStreamNonBlocking) != hipSuccess) { mgpu_destroy(c); return MGPU_E_HIP; } }
     if (const char *e = getenv("MGPU_CONVERT_OLD")) c->convert_variant = atoi(e) ? 1 : 0;          // A/B: the round-1..5 UC8 converter
+    if (const char *e = getenv("MGPU_SWEEP_FUSED")) c->sweep_fused = atoi(e);                      // A/B: converter and sweep in one kernel (1, the product) or two
     if (const char *e = getenv("MGPU_CONV_SIDE")) c->conv_side = atoi(e);                          // A/B: the converter beside k_slice
     if (const char *e = getenv("MGPU_CONV_SIDE_BLOCKS")) c->conv_side_blocks = (unsigned) atoi(e);
     if (const char *e = getenv("MGPU_SLICE_BLOCKS")) c->slice_blocks_cap = (unsigned) atoi(e);
@@ -1222,8 +1230,14 @@ static int enqueue_fsum(mgpu_ctx *c, Slot &sl, const uint8_t *iq, hipEvent_t aft
 
 // The converter of this chunk on stream_c, beside the k_slice of the chunk before?  UC8 without Mode A/C (its scan wants the sums at
 // once) and not a shard pass (their chunks come one at a time).
+// Converter and sweep in one kernel for this chunk?  UC8 samples (the table's format), no Mode A/C (its scan wants the magnitudes and
+// the sums before the sweep), not a struct mag_buf entry (the magnitudes are the caller's).
+static bool sweep_is_fused(const mgpu_ctx *c, const Slot &sl) {
+    return c->sweep_fused && c->cfg.format == MGPU_FMT_UC8 && !c->cfg.mode_ac && !sl.have_mag;
+}
+
 static bool convert_on_side(const mgpu_ctx *c, const Slot &sl) {
-    return c->conv_side && c->cfg.format == MGPU_FMT_UC8 && !c->cfg.mode_ac && !sl.have_mag && c->shard_mode == 0;
+    return !sweep_is_fused(c, sl) && c->conv_side && c->cfg.format == MGPU_FMT_UC8 && !c->cfg.mode_ac && !sl.have_mag && c->shard_mode == 0;
 }
 
 static int enqueue_convert(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
@@ -1243,8 +1257,14 @@ static int enqueue_convert(mgpu_ctx *c, Slot &sl, const uint8_t *iq) {
         if (sl.seq > 0 && prev.swept_seq.load(std::memory_order_acquire) == sl.seq - 1) HIPCHK(c, hipStreamWaitEvent(s, prev.ev_swept, 0));
     }
     // (the scratch block is zero: k_publish of the slot's previous chunk left it so)
-    if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[0], s));
-    if (!sl.have_mag) {
+    sl.fused_iq = nullptr;
+    if (sl.timed && !sweep_is_fused(c, sl)) HIPCHK(c, hipEventRecord(sl.ev[0], s));   // (fused: no converter to bracket; ev[1] opens k_sweep_uc8's)
+    if (sweep_is_fused(c, sl)) {                            // nothing to launch: k_sweep_uc8 reads the samples itself
+        sl.fused_iq = iq;
+        sl.fused_tail = c->tail_src;
+        sl.fsum_iq = iq;
+        c->tail_src = n >= (uint64_t) kTrailing ? sl.d_mag + n : nullptr;
+    } else if (!sl.have_mag) {
         ConvertParams cp{};
         cp.iq = iq; cp.mag = sl.d_mag; cp.n = n; cp.buf_samples = cfg.buf_samples;
         cp.tail = c->tail_src;          // the 326 magnitudes before this chunk (sdr_ifile.c:209-213), read in place
@@ -1300,6 +1320,11 @@ static int enqueue_sweep(mgpu_ctx *c, Slot &sl) {
     sp.unit_first = sl.d_unit_first; sp.unit_count = sl.d_unit_count; sp.nunits = nunits; sp.dealer = sl.d_dealer;
     sp.adder_bitmap = c->d_adder_bitmap; sp.counters = sl.d_counters;
     sp.cand = sl.d_cand; sp.cand_count = sl.d_cand_count; sp.sweep_part = sl.d_sweep_part;
+    if (sl.fused_iq) {
+        sp.iq = sl.fused_iq; sp.tail = sl.fused_tail; sp.uc8_sym = c->d_uc8_folded + UC8_SYM_OFFSET; sp.mag_w = sl.d_mag;
+        sp.step_sums = sl.d_step_sums; sp.sum_level = sl.d_sum_level; sp.sum_power = sl.d_sum_power;
+        sp.buf_steps = cfg.buf_samples / (uint32_t) kSweepTile;
+    }
     // ev[1] (recorded behind the converter, enqueue_convert) .. ev[4] bracket exactly one kernel: k_sweep (bench.py's roofline); ev[4] .. ev[2]: k_slice
 #if MGPU_EXPERIMENTS
     sp.debug_stage = c->dbg_stage;     // (k_slice's leave-out experiments, tools/slice_stages.sh)
@@ -1433,7 +1458,7 @@ static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
     }
     float ms;
     if (sl.timed) {
-        if (hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]) == hipSuccess) c->acc.convert_ms += ms;
+        if (!sl.fused_iq && hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]) == hipSuccess) c->acc.convert_ms += ms;
         if (hipEventElapsedTime(&ms, convert_on_side(c, sl) ? sl.ev_sweep0 : sl.ev[1], sl.ev[4]) == hipSuccess) { c->acc.sweep_ms += ms; sweep_pace_feedback(ms * 1e3f, sl.n, sl.sweep_blocks, c->event_bracket_us); }
         if (hipEventElapsedTime(&ms, sl.ev[4], sl.ev[2]) == hipSuccess) c->acc.slice_ms += ms;
         if (hipEventElapsedTime(&ms, sl.ev[2], sl.ev[3]) == hipSuccess) c->acc.prescreen_ms += ms;

@@ -108,6 +108,17 @@ struct SweepParams {
     uint32_t *sweep_part;     // [k_slice workgroups][8] partial counters (records, candidates, phases 4/5, 6/7, 8), summed by the pre-screen write pass
     uint32_t *adder_bitmap;   // 2^24 bits: addresses some clean DF17 / DF11 IID 0 frame carries
     unsigned long long *counters;   // [CNT_NUM]
+    // k_sweep_uc8 (converter and sweep in one; iq == nullptr: k_sweep over the magnitudes in `mag`): the chunk's UC8 samples, the 326
+    // magnitudes before the chunk (nullptr: zeros), the 128 x 128 symmetric table (tables.h: UC8_SYM_OFFSET), where the magnitudes
+    // go (= mag), per step four 64-bit sums (sweep_step_sums), steps per sample buffer; k_slice's prologue adds the steps' sums up
+    // into sum_level / sum_power [buffers]
+    const uint8_t *iq;
+    const uint16_t *tail;
+    const uint16_t *uc8_sym;
+    uint16_t *mag_w;
+    unsigned long long *step_sums;
+    unsigned long long *sum_level, *sum_power;
+    uint32_t buf_steps;
 #if MGPU_EXPERIMENTS
     int32_t debug_stage;      // k_slice with one part left out (timing experiments, MGPU_DEBUG_STAGE, tools/slice_stages.sh)
     unsigned long long *dbg_waves;   // k_sweep: [waves][2] start / end of every wave, 100 MHz (tools/micro/sweep_cold.hip), or null

@@ -178,7 +178,8 @@ struct mgpu_timing {
     uint64_t n_timed_chunks; /* chunks that carried the stage timing events: convert_ms, sweep_ms, slice_ms and prescreen_ms are sums
                               * over THESE (every 15th chunk; experiments build: MGPU_TIMING_EVERY) */
     float build_wait_ms;     /* builder thread: waiting for the chunk's signal powers (second stream) / the SC16 formats' float sums: idle, not work (ABI 6) */
-    float reserved_timing;
+    float sweep_fused_chunks; /* of the timed chunks, those whose sweep_ms is k_sweep_uc8's — converter and sweep in one kernel (UC8 without Mode A/C):
+                               * convert_ms holds nothing for them, the kernel reads the IQ samples and writes the magnitudes (4 B per sample) */
 };
 
 /* ---- lifecycle -------------------------------------------------------------------- */

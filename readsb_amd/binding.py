@@ -98,7 +98,7 @@ class Timing(C.Structure):
         ("resolve_ms", C.c_float), ("sigpower_ms", C.c_float), ("d2h_ms", C.c_float), ("total_ms", C.c_float),
         ("n_candidates", C.c_uint64), ("n_records", C.c_uint64), ("n_live_records", C.c_uint64),
         ("n_messages", C.c_uint64), ("n_chunks", C.c_uint64), ("slice_ms", C.c_float), ("build_ms", C.c_float), ("n_timed_chunks", C.c_uint64),
-        ("build_wait_ms", C.c_float), ("reserved_timing", C.c_float),
+        ("build_wait_ms", C.c_float), ("sweep_fused_chunks", C.c_float),
     ]
 
     def as_dict(self):

@@ -328,6 +328,7 @@ struct mgpu_ctx {
     // kernel, k_slice its largest issue-bound one.  stream_c carries the converters, each held behind the k_sweep of the chunk before;
     // k_slice's grid is capped at three workgroups per CU (slice_blocks_cap) so that a converter workgroup (32 KB of LDS) fits beside them.
     hipStream_t stream_c = nullptr;
+    int s2_hold = 1;                                                       // the second stream's work held behind a pending k_sweep (hold_behind_sweep); 0: experiments build, MGPU_S2_HOLD
     int sweep_fused = 1;                                                   // UC8 without Mode A/C: k_sweep_uc8 converts on the way (no converter launch, the magnitudes written once); 0: k_convert_uc8_lean + k_sweep (experiments build: MGPU_SWEEP_FUSED)
     int conv_side = 0;                                                     // 1: on (UC8 without Mode A/C, 1-bit repair tables: with the 2-bit tables k_slice's three workgroups leave no LDS)
     int convert_variant = 0;                                               // launch_convert's variant (1: the round-1..5 converter; experiments build)
@@ -1068,6 +1069,7 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     c->fsum_wide = getenv("MGPU_FSUM_WIDE") != nullptr;
     if (const char *e = getenv("MGPU_WRITE_BESIDE")) { if (atoi(e) && hipStreamCreateWithFlags(&c->stream_pw, hipStreamNonBlocking) != hipSuccess) { mgpu_destroy(c); return MGPU_E_HIP; } }
     if (const char *e = getenv("MGPU_CONVERT_OLD")) c->convert_variant = atoi(e) ? 1 : 0;          // A/B: the round-1..5 UC8 converter
+    if (const char *e = getenv("MGPU_S2_HOLD")) c->s2_hold = atoi(e);
     if (const char *e = getenv("MGPU_SWEEP_FUSED")) c->sweep_fused = atoi(e);                      // A/B: converter and sweep in one kernel (1, the product) or two
     if (const char *e = getenv("MGPU_CONV_SIDE")) c->conv_side = atoi(e);                          // A/B: the converter beside k_slice
     if (const char *e = getenv("MGPU_CONV_SIDE_BLOCKS")) c->conv_side_blocks = (unsigned) atoi(e);
@@ -1459,10 +1461,11 @@ static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
     float ms;
     if (sl.timed) {
         if (!sl.fused_iq && hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]) == hipSuccess) c->acc.convert_ms += ms;
-        if (hipEventElapsedTime(&ms, convert_on_side(c, sl) ? sl.ev_sweep0 : sl.ev[1], sl.ev[4]) == hipSuccess) { c->acc.sweep_ms += ms; sweep_pace_feedback(ms * 1e3f, sl.n, sl.sweep_blocks, c->event_bracket_us); }
+        if (hipEventElapsedTime(&ms, convert_on_side(c, sl) ? sl.ev_sweep0 : sl.ev[1], sl.ev[4]) == hipSuccess) { c->acc.sweep_ms += ms; sweep_pace_feedback(ms * 1e3f, sl.n, sl.sweep_blocks, c->event_bracket_us, sl.fused_iq ? 1 : 0); }
         if (hipEventElapsedTime(&ms, sl.ev[4], sl.ev[2]) == hipSuccess) c->acc.slice_ms += ms;
         if (hipEventElapsedTime(&ms, sl.ev[2], sl.ev[3]) == hipSuccess) c->acc.prescreen_ms += ms;
         c->acc.n_timed_chunks += 1;
+        if (sl.fused_iq) c->acc.sweep_fused_chunks += 1.0f;
     }
     const uint64_t nlive = sl.h_counters[CNT_LIVE_TOTAL];
 
@@ -1776,7 +1779,7 @@ static int walk_job(mgpu_ctx *c, Slot &sl, HostJob &job) {
     // accumulated on the device and read once at the end of the feed
     const double t_sig0 = wall_ms();
     hipStream_t s2 = c->s_post;
-    if (nmsg) { const int rc = hold_behind_sweep(c, sl, job.slot, s2); if (rc != MGPU_OK) return rc; }
+    if (nmsg && c->s2_hold) { const int rc = hold_behind_sweep(c, sl, job.slot, s2); if (rc != MGPU_OK) return rc; }
     if (nmsg)
         launch_stage_in(sl.h_msg_pos, sl.h_msg_limit, sl.h_msg_skip, sl.d_msg_pos, sl.d_msg_limit, sl.d_msg_skip, nmsg, s2);
     // what the skip windows hid from the counters and — first, the builder waits for them — the accepted frames' signal powers, now

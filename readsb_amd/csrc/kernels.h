@@ -151,7 +151,7 @@ void launch_fsum_sc16_wide(int format, const uint8_t *iq, const uint16_t *mag, u
                            int want_level, void *scratch, hipStream_t s);
 #endif
 unsigned launch_sweep(const SweepParams &p, hipStream_t s);        // k_sweep: preamble sweep -> per-step candidate lists; returns its grid size
-void sweep_pace_feedback(float kernel_us, uint64_t n, unsigned blocks, float bracket_us);   // a timed k_sweep launch: feeds the pacing's step-time estimate
+void sweep_pace_feedback(float kernel_us, uint64_t n, unsigned blocks, float bracket_us, int fused = 0);   // a timed k_sweep launch: feeds the pacing's step-time estimate
 unsigned launch_slice(const SweepParams &p, hipStream_t s, unsigned max_blocks = 0);        // k_slice: slicer + CRC + scoring over the candidate lists -> record pool; returns its grid size (rows of sweep_part)
 // pre-screen: count / write the records whose address may matter to the ordered walk
 // (the write pass also stores each live record's would-be signal power: sum of mag^2 over its frame)

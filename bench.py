@@ -37,6 +37,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 BUF = 131072
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 SWEEP_BYTES_PER_SAMPLE = 2.0   # k_preamble_sweep reads one u16 magnitude per position
+FUSED_BYTES_PER_SAMPLE = 4.0   # k_sweep_uc8 (round 6: converter and sweep in one kernel): 2 B of UC8 IQ read + 2 B of magnitude written per sample
 
 
 # VALU issue rate measured on this chip (tools/micro/valu_issue.hip, profiles/r02_valu_issue.txt): three-operand / packed /
@@ -48,7 +49,7 @@ PMC_HBM = os.path.join(ROOT, "profiles", "r06_pmc_hbm.json")
 
 
 # the launch the committed PMC / SQ summaries were collected on: one default chunk (1024 buffers = 134 217 728 samples) of UC8 magnitudes
-PROFILED_LAUNCH_BYTES = 268435456
+PROFILED_LAUNCH_BYTES = 268435456    # (of magnitudes: 134 217 728 samples per launch)
 
 
 def kernel_source_sha():
@@ -847,16 +848,24 @@ def main():
         # same kernel agrees with); the figure with the events' own constant taken off stands beside it (`frac_bracket_corrected`)
         if sweep_raw <= 0 or slice_raw <= 0:     # (cannot happen: the first chunk of every accounting period is a sampled one)
             raise SystemExit("bench.py: no chunk of the timed region carried the stage timing events")
-        achieved = n * SWEEP_BYTES_PER_SAMPLE / (sweep_raw * 1e-3) / 1e9
-        achieved_corrected = n * SWEEP_BYTES_PER_SAMPLE / (sweep * 1e-3) / 1e9
-        per_launch = int(n * SWEEP_BYTES_PER_SAMPLE / nlaunch)
+        # The dominant kernel: since round 6 the preamble sweep converts on the way (k_sweep_uc8: the UC8 samples read once, the
+        # magnitudes written once for k_slice — the converter's launch and the sweep's own read of the magnitudes are gone), so its
+        # algorithmic bytes are the converter's (2 B read + 2 B written per sample); a context that runs the two
+        # kernels (experiments build, MGPU_SWEEP_FUSED=0; the SC16 formats; Mode A/C) reports k_sweep with 2 B per sample as before.
+        fused = tm.get("sweep_fused_chunks", 0) > 0
+        bytes_per_sample = FUSED_BYTES_PER_SAMPLE if fused else SWEEP_BYTES_PER_SAMPLE
+        sweep_name = "k_sweep_uc8" if fused else "k_sweep"
+        achieved = n * bytes_per_sample / (sweep_raw * 1e-3) / 1e9
+        achieved_corrected = n * bytes_per_sample / (sweep * 1e-3) / 1e9
+        per_launch = int(n * SWEEP_BYTES_PER_SAMPLE / nlaunch)           # (the launch's size in bytes of magnitudes: what the committed summaries were taken on)
+        alg_per_launch = int(n * bytes_per_sample / nlaunch)
         # HBM traffic of one launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x2 on
         # gfx950 + WRITE_SIZE, tools/pmc_summary.py); null if the launch size differs
         traffic, traffic_slice = None, None
         try:
             pm = json.load(open(PMC_HBM))
             if per_launch == PROFILED_LAUNCH_BYTES and pm.get("kernel_source_sha") == kernel_source_sha():
-                traffic = round(next(v for k, v in pm.items() if "mgpu::k_sweep" in k)["hbm_bytes"])
+                traffic = round(next(v for k, v in pm.items() if ("mgpu::" + sweep_name + "(") in k or k.rstrip() == "mgpu::" + sweep_name)["hbm_bytes"])
                 traffic_slice = round(next(v for k, v in pm.items() if "mgpu::k_slice" in k)["hbm_bytes"])
         except Exception:
             pass
@@ -878,13 +887,15 @@ def main():
                          "prescreen": round(tm["prescreen_ms"], 3), "d2h": round(tm["d2h_ms"], 3),
                          "resolve_host": round(float(np.mean(resolve_ms)), 3), "build_host": round(tm.get("build_ms", 0.0), 3), "build_wait": round(tm.get("build_wait_ms", 0.0), 3), "sigpower": round(tm["sigpower_ms"], 3), "per": "feed",
                          "feed_total": round(float(np.mean(total_ms)), 3)},
-            "roofline": {"kernel": "k_sweep", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "roofline": {"kernel": sweep_name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "launches_per_step": nlaunch, "algorithmic_bytes_per_launch": per_launch,
+                         "launches_per_step": nlaunch, "algorithmic_bytes_per_launch": alg_per_launch,
+                         "algorithmic_bytes": ("2 B of UC8 IQ read + 2 B of magnitude written per sample (converter and sweep in one kernel)" if fused
+                                               else "2 B of magnitude read per position"),
                          "avg_launch_ms": round(sweep_raw / nlaunch, 4), "avg_launch_ms_bracket_corrected": round(sweep / nlaunch, 4),
                          "frac_bracket_corrected": round(achieved_corrected / HBM_PEAK_GBS, 4),
                          "event_bracket_us": round(bracket_us, 2), "launches_timed": int(tm["n_timed_chunks"]),
-                         "valu_issue": valu_issue("k_sweep", sweep / nlaunch, n / nlaunch) if per_launch == PROFILED_LAUNCH_BYTES else None},
+                         "valu_issue": valu_issue(sweep_name, sweep / nlaunch, n / nlaunch) if per_launch == PROFILED_LAUNCH_BYTES else None},
             # the other half of what used to be one kernel: slicer + CRC + scoring over k_sweep's candidate lists.  It reads the
             # same 2 B per sample again (tile staging), so the same algorithmic bytes; its work is per candidate, not per byte.
             "kernels": {"k_slice": {"avg_launch_ms": round(slice_raw / nlaunch, 4), "avg_launch_ms_bracket_corrected": round(slice_ / nlaunch, 4),

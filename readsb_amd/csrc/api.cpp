@@ -1235,7 +1235,8 @@ static int enqueue_fsum(mgpu_ctx *c, Slot &sl, const uint8_t *iq, hipEvent_t aft
 // Converter and sweep in one kernel for this chunk?  UC8 samples (the table's format), no Mode A/C (its scan wants the magnitudes and
 // the sums before the sweep), not a struct mag_buf entry (the magnitudes are the caller's).
 static bool sweep_is_fused(const mgpu_ctx *c, const Slot &sl) {
-    return c->sweep_fused && c->cfg.format == MGPU_FMT_UC8 && !c->cfg.mode_ac && !sl.have_mag;
+    const uint32_t buf_steps = c->cfg.buf_samples / (uint32_t) kSweepTile;      // (a power of two of steps per buffer: the kernel tests a step's place in its buffer with a mask)
+    return c->sweep_fused && c->cfg.format == MGPU_FMT_UC8 && !c->cfg.mode_ac && !sl.have_mag && buf_steps && (buf_steps & (buf_steps - 1u)) == 0u;
 }
 
 static bool convert_on_side(const mgpu_ctx *c, const Slot &sl) {

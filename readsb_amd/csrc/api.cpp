@@ -328,6 +328,7 @@ struct mgpu_ctx {
     // kernel, k_slice its largest issue-bound one.  stream_c carries the converters, each held behind the k_sweep of the chunk before;
     // k_slice's grid is capped at three workgroups per CU (slice_blocks_cap) so that a converter workgroup (32 KB of LDS) fits beside them.
     hipStream_t stream_c = nullptr;
+    int d2h_hold = 0;                                                      // the fetcher's record copy held behind the next chunk's pending k_sweep (fetch_records); 0: experiments build, MGPU_D2H_HOLD
     int s2_hold = 1;                                                       // the second stream's work held behind a pending k_sweep (hold_behind_sweep); 0: experiments build, MGPU_S2_HOLD
     int sweep_fused = 1;                                                   // UC8 without Mode A/C: k_sweep_uc8 converts on the way (no converter launch, the magnitudes written once); 0: k_convert_uc8_lean + k_sweep (experiments build: MGPU_SWEEP_FUSED)
     int conv_side = 0;                                                     // 1: on (UC8 without Mode A/C, 1-bit repair tables: with the 2-bit tables k_slice's three workgroups leave no LDS)
@@ -1028,10 +1029,38 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
 #if MGPU_EXPERIMENTS
     if (const char *e = getenv("MGPU_S2_PRIORITY")) prio_least = atoi(e) > 0 ? prio_greatest : 0;   // experiment: the second stream at normal (0) / highest (1) priority
 #endif
+    // The second stream (what follows a walk: k_stage_in, k_window_stats, k_build_messages) and the fetcher's record copies (the
+    // runtime's blit kernel) run on every 8th CU only (hipExtStreamCreateWithCUMask, round 6).  They are ~0.8 ms of small, latency-bound
+    // kernels per 1.2 ms feed, and wherever they land they take issue slots from the main stream's kernel — with the converter gone
+    // that is k_sweep_uc8 or k_slice, both issue-bound.  Those two are persistent grids balanced by dealers, so 32 CUs that run a
+    // little slower cost them little, where the same work spread over all 256 stretched the sweep from 112 to 120-146 us per launch at
+    // random: with the mask the sweep's bracket reads 0.446-0.453 ms per feed every time (0.59-0.60 of the HBM peak; 0.50-0.57
+    // without) and the feed 1.226-1.229 ms (1.236-1.326); every 4th CU: the same; every 16th: the post-sweep stage grows, 1.27
+    // (profiles/r06_sweep_fused.txt).  The mask replaces the second stream's low priority (a masked stream has none).
+    bool masked = false;
+    {
+        int k = 8;
+#if MGPU_EXPERIMENTS
+        if (const char *e = getenv("MGPU_CU_MASK_STRIDE")) k = atoi(e);      // 0: no mask (A/B)
+#endif
+        hipDeviceProp_t prop;
+        const int cus = hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (k >= 2 && k <= 128 && cus >= 2 * k && cus <= 1024) {
+            uint32_t mask[32] = {0};
+            for (int cu = 0; cu < cus; cu += k) mask[cu >> 5] |= 1u << (cu & 31);
+            const uint32_t words = (uint32_t) ((cus + 31) / 32);
+            masked = hipExtStreamCreateWithCUMask(&c->stream2, words, mask) == hipSuccess && hipExtStreamCreateWithCUMask(&c->stream_d2h, words, mask) == hipSuccess;
+            if (!masked) {
+                (void) hipGetLastError();
+                if (c->stream2) (void) hipStreamDestroy(c->stream2);
+                c->stream2 = c->stream_d2h = nullptr;
+            }
+        }
+    }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least) != hipSuccess ||
+        (!masked && hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least) != hipSuccess) ||
         hipStreamCreateWithFlags(&c->stream_w, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->stream_d2h, hipStreamNonBlocking) != hipSuccess ||
+        (!masked && hipStreamCreateWithFlags(&c->stream_d2h, hipStreamNonBlocking) != hipSuccess) ||
         hipStreamCreateWithFlags(&c->stream_c, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream_aux, hipStreamNonBlocking) != hipSuccess ||
         (cfg->format != MGPU_FMT_UC8 && hipStreamCreateWithPriority(&c->stream_f, hipStreamNonBlocking, prio_least) != hipSuccess)) { mgpu_destroy(c); return MGPU_E_HIP; }
@@ -1070,6 +1099,7 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     if (const char *e = getenv("MGPU_WRITE_BESIDE")) { if (atoi(e) && hipStreamCreateWithFlags(&c->stream_pw, hipStreamNonBlocking) != hipSuccess) { mgpu_destroy(c); return MGPU_E_HIP; } }
     if (const char *e = getenv("MGPU_CONVERT_OLD")) c->convert_variant = atoi(e) ? 1 : 0;          // A/B: the round-1..5 UC8 converter
     if (const char *e = getenv("MGPU_S2_HOLD")) c->s2_hold = atoi(e);
+    if (const char *e = getenv("MGPU_D2H_HOLD")) c->d2h_hold = atoi(e);
     if (const char *e = getenv("MGPU_SWEEP_FUSED")) c->sweep_fused = atoi(e);                      // A/B: converter and sweep in one kernel (1, the product) or two
     if (const char *e = getenv("MGPU_CONV_SIDE")) c->conv_side = atoi(e);                          // A/B: the converter beside k_slice
     if (const char *e = getenv("MGPU_CONV_SIDE_BLOCKS")) c->conv_side_blocks = (unsigned) atoi(e);
@@ -1428,6 +1458,13 @@ static int fetch_records(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
     // next chunk's converter and k_sweep are through (measured in round 2) — k_slice 140 instead of 114.  The same either way
     // (2.23 vs 2.27 ms per step), so: at once.
     if (nlive) {
+        // Round 6: the chunk is complete the moment the NEXT chunk's sweep starts on the main stream, and since that sweep is
+        // k_sweep_uc8 — no converter in front of it any more — the copy's blit kernel (83 us for 2.2 MB) lands on it every time.
+        // Holding the copy behind that sweep (d2h_hold, experiments build: MGPU_D2H_HOLD=1) protects the sweep but puts ~0.1 ms per
+        // chunk of waiting into the fetch stage (1.21 of a 1.23 ms feed); the CU mask on this stream (mgpu_create) does the same for
+        // the sweep without that: off.
+        if (c->d2h_hold && next && next->swept_seq.load(std::memory_order_acquire) == sl.seq + 1 && hipEventQuery(next->ev_swept) != hipSuccess)
+            HIPCHK(c, hipStreamWaitEvent(c->stream_d2h, next->ev_swept, 0));
         // (a copy kernel of our own with 8..32 workgroups in place of the runtime's blit kernel: 2.55-2.63 ms per step instead of 2.45)
         HIPCHK(c, hipMemcpyAsync(sl.h_live, sl.d_live, nlive * sizeof(PhaseRec), hipMemcpyDeviceToHost, c->stream_d2h));
         if (!sl.sig_late) HIPCHK(c, hipMemcpyAsync(sl.h_live_sig, sl.d_live_sig, nlive * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream_d2h));

@@ -202,7 +202,6 @@ struct Slot {
     // enqueue_convert found them (no converter launch); the per-step sums the kernel leaves for k_slice's prologue
     const uint8_t *fused_iq = nullptr;
     const uint16_t *fused_tail = nullptr;
-    unsigned long long *d_step_sums = nullptr;
     uint64_t seq = 0;                     // the chunk's number in the context's life (slot = seq % kSlots)
     // the job
     uint64_t n = 0, stream_pos = 0;
@@ -322,7 +321,9 @@ struct mgpu_ctx {
     // sums before the chunk's slot goes back to the GPU (chunk seq uses entry seq % kFsumRing)
     struct FsumRing { double *d = nullptr, *h = nullptr; void *scratch = nullptr; hipEvent_t ev = nullptr; } fsum_ring[kFsumRing];
     uint32_t prescreen_variant = 3;                                        // PostSweepParams::variant (the experiments build can ask for the older passes)
-    hipStream_t stream_pw = nullptr;                                       // experiment (MGPU_WRITE_BESIDE=1, experiments build): the pre-screen's write pass + k_publish on a stream of their own, beside the next chunk's converter — measured 297 against 357 Gsamples/s (gpurun r05i): beside a kernel that saturates the memory system the write pass's dependent round trips stretch the post-sweep stage from 0.25 to 0.73 ms per step
+    uint32_t cu_mask[32] = {0}, cu_mask_words = 0;                         // the side streams' CUs (mgpu_create)
+    int post_beside = 0;                                                   // experiment: 1 = stream_pw takes the write pass, 2 = the count pass too
+    hipStream_t stream_pw = nullptr;                                       // experiment (MGPU_WRITE_BESIDE=1, experiments build): the pre-screen's write pass + k_publish on a stream of their own, beside the next chunk's converter — measured 297 against 357 Gsamples/s (gpurun r05i): beside a kernel that saturates the memory system the write pass's dependent round trips stretch the post-sweep stage from 0.25 to 0.73 ms per step.  Round 6, beside k_sweep_uc8 (1 / 2: + the count pass; 3 / 4: on the masked CUs): 1.27-1.39 ms per feed against 1.21-1.25; the whole stage held back until the next chunk's sweep is through, beside its k_slice: 1.30-1.36 (profiles/r06_sweep_fused.txt)
     hipStream_t stream_f = nullptr;                                        // SC16 formats: the float sums' chains (k_fsum_sc16), so that what follows a walk does not queue behind them
     // The UC8 converter of chunk N + 1 beside chunk N's k_slice (round 6): the converter is the pipeline's one HBM-bound
     // kernel, k_slice its largest issue-bound one.  stream_c carries the converters, each held behind the k_sweep of the chunk before;
@@ -789,7 +790,6 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
     // the class planes and the scratch block are handed back zeroed by the kernels that consume them
     HIPCHK(c, hipMalloc(&sl.d_cand, (c->cap_units * (size_t) kUnit + 64) * sizeof(uint16_t)));
     HIPCHK(c, hipMalloc(&sl.d_cand_count, (c->cap_units * (size_t) (kUnit / kSweepTile) + 1) * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc(&sl.d_step_sums, ((n + kTrailing) / kSweepTile + 4) * 4 * sizeof(unsigned long long)));   // k_sweep_uc8: four 64-bit sums per step (every step writes its own)
     HIPCHK(c, hipMalloc(&sl.d_dealer, (size_t) 2 * kDealerCounters * kDealerStride * sizeof(uint32_t)));   // (k_publish hands it back zeroed)
     HIPCHK(c, hipMemsetAsync(sl.d_dealer, 0, (size_t) 2 * kDealerCounters * kDealerStride * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMalloc(&sl.d_sweep_part, ((size_t) kSweepGridMax * 4) * sizeof(uint32_t)));
@@ -859,7 +859,7 @@ static void free_slot(Slot &sl) {
     if (sl.h_live_win) (void) hipHostFree(sl.h_live_win);
     if (sl.h_fsx) (void) hipHostFree(sl.h_fsx);
     if (sl.d_fsx) (void) hipFree(sl.d_fsx);
-    void *dev[] = {sl.d_step_sums, sl.d_live_win, sl.d_dealer, sl.d_blob, sl.d_live, sl.d_live_sig, sl.d_mag, sl.d_pool, sl.d_scratch, sl.d_unit_first, sl.d_unit_count, sl.d_unit_live,
+    void *dev[] = {sl.d_live_win, sl.d_dealer, sl.d_blob, sl.d_live, sl.d_live_sig, sl.d_mag, sl.d_pool, sl.d_scratch, sl.d_unit_first, sl.d_unit_count, sl.d_unit_live,
                    sl.d_class_final, sl.d_cand, sl.d_cand_count, sl.d_sweep_part,
                    sl.d_win, sl.d_win_part, sl.d_msg_pos,
                    sl.d_msg_limit, sl.d_msg_len, sl.d_msg_skip, sl.d_msg_sig, sl.d_wk_in, sl.d_wk_acc, sl.d_wk_sig};
@@ -1046,9 +1046,9 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
         hipDeviceProp_t prop;
         const int cus = hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (k >= 2 && k <= 128 && cus >= 2 * k && cus <= 1024) {
-            uint32_t mask[32] = {0};
+            uint32_t *mask = c->cu_mask;
             for (int cu = 0; cu < cus; cu += k) mask[cu >> 5] |= 1u << (cu & 31);
-            const uint32_t words = (uint32_t) ((cus + 31) / 32);
+            const uint32_t words = c->cu_mask_words = (uint32_t) ((cus + 31) / 32);
             masked = hipExtStreamCreateWithCUMask(&c->stream2, words, mask) == hipSuccess && hipExtStreamCreateWithCUMask(&c->stream_d2h, words, mask) == hipSuccess;
             if (!masked) {
                 (void) hipGetLastError();
@@ -1096,7 +1096,12 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     if (const char *e = getenv("MGPU_TIMING_EVERY")) { const int v = atoi(e); if (v >= 1) c->timing_every = v; }
     if (const char *e = getenv("MGPU_DUMP_DIR")) { c->dump_dir = e; c->sig_late = false; }   // (the dump holds per-record signal powers)
     c->fsum_wide = getenv("MGPU_FSUM_WIDE") != nullptr;
-    if (const char *e = getenv("MGPU_WRITE_BESIDE")) { if (atoi(e) && hipStreamCreateWithFlags(&c->stream_pw, hipStreamNonBlocking) != hipSuccess) { mgpu_destroy(c); return MGPU_E_HIP; } }
+    if (const char *e = getenv("MGPU_WRITE_BESIDE")) {     // 1: write pass + k_publish beside the next chunk's sweep; 2: the count pass too; 3 / 4: the same on the masked CUs
+        const int v = atoi(e);
+        c->post_beside = v == 2 || v == 4 ? 2 : v ? 1 : 0;
+        const bool m = v >= 3 && c->cu_mask_words;
+        if (v && (m ? hipExtStreamCreateWithCUMask(&c->stream_pw, c->cu_mask_words, c->cu_mask) : hipStreamCreateWithFlags(&c->stream_pw, hipStreamNonBlocking)) != hipSuccess) { mgpu_destroy(c); return MGPU_E_HIP; }
+    }
     if (const char *e = getenv("MGPU_CONVERT_OLD")) c->convert_variant = atoi(e) ? 1 : 0;          // A/B: the round-1..5 UC8 converter
     if (const char *e = getenv("MGPU_S2_HOLD")) c->s2_hold = atoi(e);
     if (const char *e = getenv("MGPU_D2H_HOLD")) c->d2h_hold = atoi(e);
@@ -1355,7 +1360,7 @@ static int enqueue_sweep(mgpu_ctx *c, Slot &sl) {
     sp.cand = sl.d_cand; sp.cand_count = sl.d_cand_count; sp.sweep_part = sl.d_sweep_part;
     if (sl.fused_iq) {
         sp.iq = sl.fused_iq; sp.tail = sl.fused_tail; sp.uc8_sym = c->d_uc8_folded + UC8_SYM_OFFSET; sp.mag_w = sl.d_mag;
-        sp.step_sums = sl.d_step_sums; sp.sum_level = sl.d_sum_level; sp.sum_power = sl.d_sum_power;
+        sp.sum_level = sl.d_sum_level; sp.sum_power = sl.d_sum_power;
         sp.buf_steps = cfg.buf_samples / (uint32_t) kSweepTile;
     }
     // ev[1] (recorded behind the converter, enqueue_convert) .. ev[4] bracket exactly one kernel: k_sweep (bench.py's roofline); ev[4] .. ev[2]: k_slice
@@ -1385,6 +1390,7 @@ static int enqueue_post(mgpu_ctx *c, Slot &sl) {
     const uint64_t n = sl.n;
     const uint32_t nunits = (uint32_t) ((n + kUnit - 1) / kUnit);
     hipStream_t s = c->stream;
+
     // class planes -> class bitmap, pre-screen (the surviving records stay in HBM: d_live), counters and per-buffer sums to the host
     PostSweepParams q{};
     q.pool = sl.d_pool; q.pool_cap = (uint32_t) c->cap_pool; q.variant = c->prescreen_variant; q.unit_first = sl.d_unit_first; q.first_count = sl.d_unit_count; q.nunits = nunits; q.chains_per_unit = (uint32_t) (kUnit / 2048); q.adder_bitmap = c->d_adder_bitmap;
@@ -1404,6 +1410,11 @@ static int enqueue_post(mgpu_ctx *c, Slot &sl) {
     q.fin_part = q.block_live + c->cap_units / 4 + 2;
     q.slice_part = sl.d_sweep_part; q.slice_blocks = sl.slice_blocks;       // k_slice's rows of counts (0 rows: the experiments build's fused kernel counts for itself)
     hipStream_t s_write = c->stream_pw ? c->stream_pw : s;
+    if (c->stream_pw && c->post_beside == 2) {           // experiment: the whole post-sweep stage beside the next chunk's sweep
+        HIPCHK(c, hipEventRecord(sl.ev_scan, s));
+        HIPCHK(c, hipStreamWaitEvent(s_write, sl.ev_scan, 0));
+        s = s_write;
+    }
     if (launch_prescreen(q, s, s_write, sl.ev_scan) != 0) { c->err = "event ordering of the pre-screen passes failed"; return MGPU_E_HIP; }
     HIPCHK(c, hipEventRecord(sl.ev[3], s_write));
     return MGPU_OK;

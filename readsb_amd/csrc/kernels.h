@@ -110,13 +110,11 @@ struct SweepParams {
     unsigned long long *counters;   // [CNT_NUM]
     // k_sweep_uc8 (converter and sweep in one; iq == nullptr: k_sweep over the magnitudes in `mag`): the chunk's UC8 samples, the 326
     // magnitudes before the chunk (nullptr: zeros), the 128 x 128 symmetric table (tables.h: UC8_SYM_OFFSET), where the magnitudes
-    // go (= mag), per step four 64-bit sums (sweep_step_sums), steps per sample buffer; k_slice's prologue adds the steps' sums up
-    // into sum_level / sum_power [buffers]
+    // go (= mag), the buffers' exact sum(mag) / sum(mag^2) the kernel adds its samples' to (zero at launch), steps per sample buffer
     const uint8_t *iq;
     const uint16_t *tail;
     const uint16_t *uc8_sym;
     uint16_t *mag_w;
-    unsigned long long *step_sums;
     unsigned long long *sum_level, *sum_power;
     uint32_t buf_steps;
 #if MGPU_EXPERIMENTS

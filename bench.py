@@ -170,7 +170,7 @@ def restore_affinity():
             pass
 
 
-def run_extra_config(name, fmt, nfix, kw, nsamples, device, steps=32, bracket_us=None):
+def run_extra_config(name, fmt, nfix, kw, nsamples, device, steps=32, bracket_us=None, chunk_buffers=0, ahead=1):
     """One more configuration on a fresh context: `steps` back-to-back segments of a resident stream with deferred feeds (timed),
     then two more deferred segments of a fresh stream, fed the same way, whose messages and counters must equal the reference's
     own code on the same two-segment stream."""
@@ -182,7 +182,7 @@ def run_extra_config(name, fmt, nfix, kw, nsamples, device, steps=32, bracket_us
     saved = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
-        d = readsb_amd.Demodulator(fmt=fmt, nfix_crc=nfix, max_samples=nsamples, device=device, startup_time_ms=helpers.STARTUP_MS)
+        d = readsb_amd.Demodulator(fmt=fmt, nfix_crc=nfix, max_samples=nsamples, device=device, startup_time_ms=helpers.STARTUP_MS, chunk_buffers=chunk_buffers)
     finally:
         for k, v in saved.items():
             if v is None:
@@ -193,17 +193,19 @@ def run_extra_config(name, fmt, nfix, kw, nsamples, device, steps=32, bracket_us
     d.keep_other_threads_away(confine_to_own_l3=False)
     d.feed_resident(nsamples)
     m0, _ = d.collect(reuse=True)
-    bufs = [np.empty(len(m0) * 5 // 4 + 1024, dtype=readsb_amd.MSG_DTYPE) for _ in range(2)]
+    A = max(1, min(3, ahead))                                # segments enqueued ahead of the one being collected
+    NB = A + 1
+    bufs = [np.empty(len(m0) * 5 // 4 + 1024, dtype=readsb_amd.MSG_DTYPE) for _ in range(NB)]
     d.reset()
     d.set_deferred(True)
 
     def submit(k):
-        d.set_message_buffer(bufs[k % 2])
+        d.set_message_buffer(bufs[k % NB])
         d.feed_resident(nsamples)
 
-    for k in range(2):                                       # two warm-up segments, drained (every job and slot of the pipeline has run at full size)
+    for k in range(8):                                       # warm-up segments, drained: every job and slot of the pipeline has run at full size (ten slots, twelve jobs; a segment is two to four chunks)
         submit(k)
-        d.collect_feed(bufs[k % 2], want_counters=True)
+        d.collect_feed(bufs[k % NB], want_counters=True)
     # the timed region, twice: both rates are reported and the entry's figure is their MEAN (round 4 took the better one; the pool's
     # boxes are shared nodes — load average 14-21 while these ran — and a host stage of one repetition now and then runs slower:
     # that is part of what a deployment sees); the stage times are the slower repetition's
@@ -211,11 +213,11 @@ def run_extra_config(name, fmt, nfix, kw, nsamples, device, steps=32, bracket_us
     for _ in range(int(os.environ.get("MGPU_DBG_BENCH_REPS", "2"))):
         d.timing()
         t0 = time.perf_counter()
-        submit(1)
-        for k in range(2, steps + 1):
-            submit(k)
-            d.collect_feed(bufs[(k - 1) % 2])
-        d.collect_feed(bufs[steps % 2], want_counters=True)
+        for k in range(1, steps + 1 + A):                    # segments 1 .. steps, A of them in flight beyond the one being collected
+            if k <= steps:
+                submit(k)
+            if k - A >= 1:
+                d.collect_feed(bufs[(k - A) % NB], want_counters=(k - A == steps))
         runs.append((time.perf_counter() - t0, d.timing()))
     elapsed = sum(r[0] for r in runs) / len(runs)
     tm = max(runs, key=lambda r: r[0])[1]
@@ -232,7 +234,7 @@ def run_extra_config(name, fmt, nfix, kw, nsamples, device, steps=32, bracket_us
     submit(1)
     m, _ = d.collect_feed(bufs[0])
     got.append(m.copy())
-    m, counters = d.collect_feed(bufs[1], want_counters=True)
+    m, counters = d.collect_feed(bufs[1 % NB], want_counters=True)
     got.append(m.copy())
     d.finish()
     _, counters = d.collect_feed(bufs[0], want_counters=True)
@@ -250,7 +252,7 @@ def run_extra_config(name, fmt, nfix, kw, nsamples, device, steps=32, bracket_us
     out = {"msamples_s": round(nsamples * steps / elapsed / 1e6, 1), "ms_per_segment": round(elapsed / steps * 1e3, 3),
            "msamples_s_both_repetitions": [round(nsamples * steps / r[0] / 1e6, 1) for r in runs],
            "host_stage_ms_both_repetitions": [{k2: round(r[1][k1] / steps, 3) for k1, k2 in (("d2h_ms", "d2h"), ("resolve_ms", "resolve_host"), ("build_ms", "build_host"))} for r in runs],
-           "samples_per_segment": nsamples, "segments_timed": steps, "messages_per_segment": int(len(msgs)),
+           "samples_per_segment": nsamples, "segments_timed": steps, "chunk_buffers": chunk_buffers or 1024, "segments_ahead": A, "messages_per_segment": int(len(msgs)),
            "candidates_per_1000_samples": round(tm["n_candidates"] / (nsamples * steps) * 1e3, 2),
            "records_per_1000_samples": round(tm["n_records"] / (nsamples * steps) * 1e3, 2),
            "live_records_per_1000_samples": round(tm["n_live_records"] / (nsamples * steps) * 1e3, 2),
@@ -306,7 +308,7 @@ def bench_config5(args, rank, local_rank, world):
     t_gen = time.time() - t_g0
     d_iq = torch.from_numpy(mine).to(torch.device("cuda", dev))            # resident: its own allocation, any length
     piece = min(16384 * BUF, max(BUF, ((last - first) // max(1, args.emulate_ranks if world == 1 else 1) // BUF + 512) * BUF))   # samples per feed call: a rank's range in one
-    d = readsb_amd.Demodulator(nfix_crc=2, max_samples=piece, device=dev, startup_time_ms=helpers.STARTUP_MS)
+    d = readsb_amd.Demodulator(nfix_crc=2, max_samples=piece, device=dev, startup_time_ms=helpers.STARTUP_MS, chunk_buffers=args.chunk_buffers)
     resident = (lo, d_iq.data_ptr())
     d.keep_other_threads_away(confine_to_own_l3=world > 1)
 
@@ -577,7 +579,9 @@ def main():
     ap.add_argument("--samples", type=int, default=4096 * BUF, help="samples of the HBM-resident IQ block = of one feed call (multiple of 131072)")
     ap.add_argument("--loops", type=int, default=40, help="feeds per step: a step plays the resident block this many times (the stream goes on: an ifile "
                     "in a loop).  40 x 537 M samples = 21.5 G samples per step: the default 20 steps are ~1.1 s of timed region, not 28 ms")
-    ap.add_argument("--ahead", type=int, default=1, help="feeds enqueued ahead of the one being collected (1..3: the library keeps at most four uncollected)")
+    ap.add_argument("--ahead", type=int, default=2, help="feeds enqueued ahead of the one being collected (1..3: the library keeps at most four uncollected).  "
+                    "2: with chunks of 2048 buffers a feed of 4096 is two chunks, and fetcher, walker and builder want a chunk each to work on while "
+                    "the GPU runs the next (1: 1.48 ms per feed, 2: 1.12-1.17, 3: 1.12-1.13; profiles/r06_chunk_2048.txt)")
     ap.add_argument("--device-build", action="store_true", help="N = 1: messages built by k_build_messages and copied into the consumer's page-locked "
                     "array (mgpu_set_device_messages(2)) instead of by the host's builder threads.  Measured slower (profiles/r06_device_build.txt): "
                     "the host builder is not what bounds the step, and the 4.7 MB per chunk of message copies queue ahead of the fetcher's record copies")
@@ -586,7 +590,9 @@ def main():
                                                           "capture time-chunked over the GPUs (configs[4], strong scaling)")
     ap.add_argument("--emulate-ranks", type=int, default=0, help="--config 5 on ONE GPU: one context plays this many ranks of the sharded walk one after "
                                                                   "the other; per-rank phase times and the combining rank's serial share in the JSON line")
-    ap.add_argument("--chunk-buffers", type=int, default=0, help="mgpu_config.chunk_buffers: buffers per pipeline chunk (0 = the library's 512)")
+    ap.add_argument("--chunk-buffers", type=int, default=None, help="mgpu_config.chunk_buffers: buffers per pipeline chunk (0 = the library's 1024).  Default: 2048 "
+                    "for --config 1 — half the launches and kernel tails per sample (k_slice 0.46 against 0.52 ms per 537 M samples), the host's walk "
+                    "takes a chunk in rounds of 1024 buffers whatever its length (profiles/r06_chunk_2048.txt); 0 for --config 5")
     ap.add_argument("--event-bracket-us", type=float, default=None, help="what a pair of timing events adds to the kernel it brackets, as measured by an "
                     "earlier run (`event_bracket_us` of its line): skips the calibration (k_spin launches) — for rocprofv3 runs, whose kernel statistics "
                     "then hold the pipeline's kernels only")
@@ -605,6 +611,8 @@ def main():
                     help="the N-rank launch alone (no GPU needed with --dryrun-gloo): every rank joins the process group, rank 0 prints a line "
                          "with the world size it found — tests/test_bench_launch.py")
     args = ap.parse_args()
+    if args.chunk_buffers is None:
+        args.chunk_buffers = 2048 if args.config == 1 else 0
 
     relaunch_or_check_world(args)
     if args.launch_check:
@@ -652,6 +660,7 @@ def main():
         os.sched_setaffinity(0, {args.main_cpu})
 
     gath = None                                 # N > 1: the aggregator role, asynchronous (readsb_amd/gather.py)
+    A = max(1, min(3, args.ahead))              # feeds in flight beyond the one being collected
 
     # ---- sizing pass (synchronous): the consumer's standing message arrays, 1.25 x the busiest rank's message count ----
     d.reset()
@@ -662,11 +671,11 @@ def main():
         t = torch.tensor([cap], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         cap = int(t.item())
-        gath = MessageGatherer(readsb_amd.MSG_DTYPE, coll_dev, cap, depth=3, host_alloc=d.host_alloc)
+        gath = MessageGatherer(readsb_amd.MSG_DTYPE, coll_dev, cap, depth=A + 2, host_alloc=d.host_alloc)   # (a slot per feed in flight + the one being gathered)
         bufs = None
     else:
         # the consumer's two standing arrays, page-locked near the device: k_build_messages stores the records into them (mode 2)
-        nbufs = 1 + max(1, min(3, args.ahead))
+        nbufs = 1 + A
         bufs = [np.empty(cap, dtype=readsb_amd.MSG_DTYPE) for _ in range(nbufs)] if not args.device_build else [d.host_alloc(cap * 64).view(readsb_amd.MSG_DTYPE)[:cap] for _ in range(nbufs)]
         if os.environ.get("MGPU_DBG_PINNED_BUFS"):
             bufs = [(d.host_alloc(cap * 64) if os.environ["MGPU_DBG_PINNED_BUFS"] == "near" else torch.empty(cap * 64, dtype=torch.uint8, pin_memory=True).numpy()).view(readsb_amd.MSG_DTYPE) for _ in range(2)]
@@ -723,7 +732,6 @@ def main():
     seq = 0
     L = max(1, args.loops)
     n_warm, n_timed = args.warmup * L, args.steps * L          # feeds
-    A = max(1, min(3, args.ahead)) if gath is None else 1      # feeds in flight beyond the one being collected
 
     def run_feeds(first, count):
         """`count` feeds from number `first` on, A of them enqueued ahead of the one being collected; ends with an empty pipeline."""
@@ -876,7 +884,7 @@ def main():
             "dtype": "u16", "data": "synthetic",
             "config": {"workload": "configs[1]: single 2.4 MSps UC8 stream per GPU, --fix (nfix_crc=1, fixDF=1, thr=58), "
                                    f"one continuous stream, a step = {L} feeds of the resident IQ block ({n} samples each) = {n * L} samples = {n * L / 2.4e6:.0f} s of it, "
-                                   f"{args.msgs_per_sec:.0f} frames/s, HBM-resident IQ, deferred feeds (feed k+1 enqueued before feed k is collected), "
+                                   f"{args.msgs_per_sec:.0f} frames/s, HBM-resident IQ, pipeline chunks of {args.chunk_buffers or 1024} buffers, deferred feeds ({A} enqueued ahead of the one being collected), "
                                    + ("messages built on the GPU and stored into the consumer's page-locked arrays" if dev_to_host else "messages built on the GPU, gathered from HBM" if dev_msgs else "messages built by the host's builder threads"),
                        "samples_per_stream": n * L, "samples_per_feed": n, "feeds_per_step": L, "streams": world, "parallelism": f"1 stream per GPU x{world}"},
             "ms_per_feed": round(ms_per_feed, 3),
@@ -931,7 +939,7 @@ def main():
             out["configs"] = {}
             for name, (fmt, nfix, kw) in EXTRA_CONFIGS.items():
                 try:
-                    out["configs"][name] = run_extra_config(name, fmt, nfix, kw, args.extra_samples - args.extra_samples % BUF, local_rank_dev, bracket_us=args.event_bracket_us)
+                    out["configs"][name] = run_extra_config(name, fmt, nfix, kw, args.extra_samples - args.extra_samples % BUF, local_rank_dev, bracket_us=args.event_bracket_us, chunk_buffers=args.chunk_buffers, ahead=A)
                 except AssertionError as e:                      # a mismatch is a failed run, not a missing number
                     raise SystemExit(f"extra configuration '{name}': GPU result differs from the reference: {e}")
                 except Exception as e:                           # anything else (an allocation, the checker's binary): this entry is missing, the line is not

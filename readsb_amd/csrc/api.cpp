@@ -1714,42 +1714,56 @@ static int64_t host_walk(mgpu_ctx *c, HostJob &job, const PhaseRec *recs, const 
     const int K = c->walk_threads;
     if (K >= 2 && nbuf_all >= (uint32_t) (4 * K) && nlive >= 4096) {
         // buffer ranges walked in parallel against the filter as it stands now, committed in stream order
-        // (resolve.h: Resolver::parallel_walk); exact, and serial only where speculation fails
+        // (resolve.h: Resolver::parallel_walk); exact, and serial only where speculation fails.
+        // K ranges per ROUND of about kWalkRound buffers, whatever the chunk's length: the further a range lies from the state it
+        // speculates against, the more often its assumptions fail — a chunk of 2048 buffers walked as K ranges of 256 took 1.45-1.54 ms
+        // per 537 M samples where chunks of 1024 take 1.0-1.1 (gpurun r06ah), while the GPU side wants the longer chunk (fewer
+        // launches and tails: 1.11 against 1.21 ms of kernels).
+        constexpr uint32_t kWalkRound = 1024;
+        const uint32_t rounds = nbuf_all >= kWalkRound + kWalkRound / 2 ? (nbuf_all + kWalkRound / 2) / kWalkRound : 1u;
         std::vector<SegmentWalk> &segs = c->segs;
         if ((int) segs.size() != K) segs.resize(K);
-        for (int k = 0; k < K; ++k) {
-            segs[k].b_lo = (uint32_t) ((uint64_t) nbuf_all * k / K);
-            segs[k].b_hi = (uint32_t) ((uint64_t) nbuf_all * (k + 1) / K);
-            segs[k].rec_lo = k == 0 ? 0 : segment_first_record(recs, nlive, buffers[segs[k].b_lo].first);
-        }
-        for (int k = 0; k < K; ++k) segs[k].rec_hi = k + 1 < K ? segs[k + 1].rec_lo : nlive;
-        const double tp0 = wall_ms();
-        uint64_t batches = 0;
-        c->resolver.parallel_walk(recs, nlive, buffers, segs,
-                                  [&](int ntasks, const std::function<void(int)> &task) { c->walk_team.run(ntasks, task); }, &batches);
-        const double tp2 = wall_ms();
-        uint64_t total = 0;
-        for (int k = 0; k < K; ++k) {
-            total += segs[k].nacc;
-            job.rc.add(segs[k].counts);
-        }
-        c->spec_segments += (uint64_t) K;
-        c->spec_batches += batches;
-        if (total > aux_cap) wn = -1;
-        else {
-            if (job.acc.size() < total) job.acc.resize(total);
-            uint64_t off = 0;
+        uint64_t total = 0, batches = 0;
+        double t_walk = 0, t_gather = 0;
+        wn = 0;
+        for (uint32_t r = 0; r < rounds && wn >= 0; ++r) {
+            const uint32_t r_lo = (uint32_t) ((uint64_t) nbuf_all * r / rounds), r_hi = (uint32_t) ((uint64_t) nbuf_all * (r + 1) / rounds);
             for (int k = 0; k < K; ++k) {
-                const uint64_t m = segs[k].nacc;
-                std::memcpy(job.acc.data() + off, segs[k].acc.data(), m * sizeof(Accepted));
-                std::memcpy(job.pos.data() + off, segs[k].pos.data(), m * sizeof(uint32_t));
-                std::memcpy(c->w_limit.data() + off, segs[k].limit.data(), m * sizeof(uint32_t));
-                std::memcpy(c->w_skip.data() + off, segs[k].skip.data(), m * sizeof(uint16_t));
-                off += m;
+                segs[k].b_lo = r_lo + (uint32_t) ((uint64_t) (r_hi - r_lo) * k / K);
+                segs[k].b_hi = r_lo + (uint32_t) ((uint64_t) (r_hi - r_lo) * (k + 1) / K);
+                segs[k].rec_lo = segs[k].b_lo == 0 ? 0 : segment_first_record(recs, nlive, buffers[segs[k].b_lo].first);
             }
-            wn = (int64_t) total;
+            const uint64_t round_end = r_hi >= nbuf_all ? nlive : segment_first_record(recs, nlive, buffers[r_hi].first);
+            for (int k = 0; k < K; ++k) segs[k].rec_hi = k + 1 < K ? segs[k + 1].rec_lo : round_end;
+            const double tp0 = wall_ms();
+            c->resolver.parallel_walk(recs, nlive, buffers, segs,
+                                      [&](int ntasks, const std::function<void(int)> &task) { c->walk_team.run(ntasks, task); }, &batches);
+            const double tp2 = wall_ms();
+            uint64_t round_total = 0;
+            for (int k = 0; k < K; ++k) {
+                round_total += segs[k].nacc;
+                job.rc.add(segs[k].counts);
+            }
+            c->spec_segments += (uint64_t) K;
+            if (total + round_total > aux_cap) wn = -1;
+            else {
+                if (job.acc.size() < total + round_total) job.acc.resize(total + round_total);
+                uint64_t off = total;
+                for (int k = 0; k < K; ++k) {
+                    const uint64_t m = segs[k].nacc;
+                    std::memcpy(job.acc.data() + off, segs[k].acc.data(), m * sizeof(Accepted));
+                    std::memcpy(job.pos.data() + off, segs[k].pos.data(), m * sizeof(uint32_t));
+                    std::memcpy(c->w_limit.data() + off, segs[k].limit.data(), m * sizeof(uint32_t));
+                    std::memcpy(c->w_skip.data() + off, segs[k].skip.data(), m * sizeof(uint16_t));
+                    off += m;
+                }
+                total += round_total;
+                wn = (int64_t) total;
+            }
+            t_walk += tp2 - tp0; t_gather += wall_ms() - tp2;
         }
-        if (c->dbg_print) fprintf(stderr, "dbg: %d ranges in %llu batches: %.3f ms, gather %.3f ms\n", K, (unsigned long long) batches, tp2 - tp0, wall_ms() - tp2);
+        c->spec_batches += batches;
+        if (c->dbg_print) fprintf(stderr, "dbg: %u round(s) of %d ranges in %llu batches: %.3f ms, gather %.3f ms\n", rounds, K, (unsigned long long) batches, t_walk, t_gather);
     } else {
         wn = c->resolver.decide(recs, nlive, buffers, job.acc, job.pos.data(), c->w_skip.data(),
                                 c->w_limit.data(), aux_cap, job.rc);

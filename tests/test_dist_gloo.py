@@ -110,3 +110,66 @@ def test_async_gatherer_two_ranks_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert results == {0: True, 1: True}
+
+
+def _worker_inplace_ahead(rank, world, port, q):
+    """bench.py's N > 1 protocol: a ring of A + 2 slots, the records of up to A feeds written into the slots ahead of the one being
+    gathered (device_buffer(ahead)), one collective per feed with the count in the slot's trailer record (submit_inplace)."""
+    import ctypes
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, helpers.ROOT)
+    from readsb_amd.binding import MSG_DTYPE
+    from readsb_amd.gather import MessageGatherer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    A, cap = 2, 900
+    g = MessageGatherer(MSG_DTYPE, torch.device("cpu"), capacity=cap, depth=A + 2)
+    ok = True
+    sent = {}
+
+    def fill(k):                                           # what mgpu_set_device_message_buffer + the feed's build do on the GPU
+        ptr, c = g.device_buffer(ahead=k - g.seq)
+        n = [600 - 50 * k, 100 + k][rank]
+        view = np.frombuffer((ctypes.c_uint8 * (c * MSG_DTYPE.itemsize)).from_address(ptr), dtype=MSG_DTYPE)
+        view[:n]["timestamp"] = np.arange(n) + 1000 * k + 7 * rank
+        view[:n]["addr"] = rank * 64 + k
+        sent[k] = (n, view[:n].copy())
+
+    count = 7
+    for k in range(count + A):
+        if k < count:
+            fill(k)
+        if k >= A:
+            j = k - A
+            slot = g.submit_inplace(sent[j][0])
+            if j in (3, count - 1):
+                counts, per_rank = g.fetch(slot)
+                if rank == 0:
+                    ok = ok and counts == [600 - 50 * j, 100 + j]
+                    ok = ok and per_rank[0].tobytes() == sent[j][1].tobytes() and bool((per_rank[1]["addr"] == 64 + j).all()) and len(per_rank[1]) == 100 + j
+                else:
+                    ok = ok and per_rank is None and counts[rank] == sent[j][0]
+    try:
+        g.device_buffer(ahead=A + 1)
+        ok = False
+    except ValueError:
+        pass
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_inplace_gather_with_feeds_ahead_two_ranks_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_inplace_ahead, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results == {0: True, 1: True}

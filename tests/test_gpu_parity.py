@@ -119,3 +119,15 @@ def test_caller_message_buffer(built):
             d.feed_iq(iq)
     finally:
         d.close()
+
+
+def test_long_chunk_walked_in_rounds(built):
+    """One pipeline chunk of 2301 buffers (mgpu_config.chunk_buffers above the library's 1024): the kernels take the chunk in one
+    launch each, the host's ordered walk takes it in rounds of about 1024 buffers (api.cpp: host_walk) — same messages, same counters."""
+    B = 131072
+    iq = helpers.synth(nsamples=2300 * B + 1000, seed=77, rate=2500.0)
+    want, wst = helpers.reference_run(iq)
+    got, cnt, tm = _demod(iq, max_samples=2304 * B, chunk_buffers=4096)
+    assert len(want) > 100000
+    helpers.assert_same_messages(got, want)
+    helpers.assert_same_counters(cnt, wst)

@@ -13,4 +13,4 @@ import helpers  # noqa: E402
 helpers.ensure_built()
 name = list(bench.EXTRA_CONFIGS)[int(sys.argv[1])]
 fmt, nfix, kw = bench.EXTRA_CONFIGS[name]
-print(json.dumps({name: bench.run_extra_config(name, fmt, nfix, kw, 4096 * bench.BUF, 0, bracket_us=4.0)}))
+print(json.dumps({name: bench.run_extra_config(name, fmt, nfix, kw, 4096 * bench.BUF, 0, bracket_us=4.0, chunk_buffers=2048, ahead=2)}))

@@ -577,8 +577,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--samples", type=int, default=4096 * BUF, help="samples of the HBM-resident IQ block = of one feed call (multiple of 131072)")
-    ap.add_argument("--loops", type=int, default=40, help="feeds per step: a step plays the resident block this many times (the stream goes on: an ifile "
-                    "in a loop).  40 x 537 M samples = 21.5 G samples per step: the default 20 steps are ~1.1 s of timed region, not 28 ms")
+    ap.add_argument("--loops", type=int, default=50, help="feeds per step: a step plays the resident block this many times (the stream goes on: an ifile "
+                    "in a loop).  50 x 537 M samples = 26.8 G samples per step: the default 20 steps are ~1.1 s of timed region, not 28 ms")
     ap.add_argument("--ahead", type=int, default=2, help="feeds enqueued ahead of the one being collected (1..3: the library keeps at most four uncollected).  "
                     "2: with chunks of 2048 buffers a feed of 4096 is two chunks, and fetcher, walker and builder want a chunk each to work on while "
                     "the GPU runs the next (1: 1.48 ms per feed, 2: 1.12-1.17, 3: 1.12-1.13; profiles/r06_chunk_2048.txt)")

@@ -10,8 +10,9 @@ resident in HBM when the timed region starts (BASELINE.json configs[1]: single U
 decoded message counts/records are gathered over RCCL inside the timed step.
 
 Prints ONE JSON line (rank 0): metric/value/unit as BASELINE.json, plus
-  roofline     — k_sweep (the preamble-sweep kernel): algorithmic bytes (2 B per magnitude sample) / its HIP-event time;
-                 `kernels` carries the same figure for k_slice (slicer + CRC + scoring, the longer of the two)
+  roofline     — k_sweep_uc8 (UC8 converter and preamble sweep in one kernel, round 6): algorithmic bytes (2 B of IQ read + 2 B of
+                 magnitude written per sample) / its HIP-event time; with the two kernels (SC16 input, Mode A/C) k_sweep: 2 B per
+                 magnitude sample.  `kernels` carries the same figure for k_slice (slicer + CRC + scoring, the longer of the two)
   cpu_baseline — the reference's own C files (oracle/_ref) timed on this host on the same stream,
                  whose message list must be bit-identical to the GPU's (checked in the same run).
 """
@@ -48,8 +49,8 @@ PMC_SQ_SUMMARY = os.path.join(ROOT, "profiles", "r06_pmc_sq_summary.txt")
 PMC_HBM = os.path.join(ROOT, "profiles", "r06_pmc_hbm.json")
 
 
-# the launch the committed PMC / SQ summaries were collected on: one default chunk (1024 buffers = 134 217 728 samples) of UC8 magnitudes
-PROFILED_LAUNCH_BYTES = 268435456    # (of magnitudes: 134 217 728 samples per launch)
+# the launch the committed PMC / SQ summaries were collected on: one chunk of this benchmark's default (2048 buffers = 268 435 456 samples) of UC8 magnitudes
+PROFILED_LAUNCH_BYTES = 536870912    # (of magnitudes: 268 435 456 samples per launch)
 
 
 def kernel_source_sha():

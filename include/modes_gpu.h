@@ -72,7 +72,10 @@ struct mgpu_config {
                                    * 9.4 Gsamples/s, with small teams 18.7 (profiles/r03_fanin.txt) */
     uint32_t chunk_buffers;       /* buffers per pipeline chunk (one launch of every kernel); 0 = 1024 (half as many kernel boundaries and tails
                                    * as 512: 325 against 300 Gsamples/s, profiles/r04_chunk_buffers.txt); a host that wants its messages sooner
-                                   * takes fewer (latency = three chunks) */
+                                   * takes fewer (latency = three chunks), one that wants throughput takes 2048 and keeps two feeds of 4096
+                                   * buffers enqueued ahead of the one it collects (1.12 against 1.21 ms per 537 M samples: the kernels'
+                                   * ramps and tails again; the host's ordered walk takes a chunk in rounds of 1024 buffers whatever its
+                                   * length, profiles/r06_chunk_2048.txt; memory per context doubles with it: ten slots of ~3 GB) */
     uint32_t abi_version;         /* MGPU_ABI_VERSION of the header the HOST was compiled against (mgpu_config_defaults below passes it);
                                    * mgpu_create() refuses another (MGPU_E_INVAL) — a host built against an older, shorter struct would
                                    * otherwise have the bytes behind its struct read as chunk_buffers.  (The last field: it sits where such a

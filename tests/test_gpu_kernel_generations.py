@@ -56,3 +56,42 @@ def test_sweep_kernel_alone_matches_cpu_scan(built, buffers, ragged, dense):
     assert r.returncode == 0, r.stdout + r.stderr
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["mismatches_vs_cpu_scan"] == 0 and out["candidates"] == out["candidates_cpu"] > 0
+
+
+FUSED_SCRIPT = r"""
+import sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+import numpy as np
+import helpers, readsb_amd
+out = []
+for buf_samples, nsamples in ((4096, 700000), (8192, 83 * 8192 + 5000), (32768, 40 * 32768), (131072, 9 * 131072 + 77)):
+    iq = helpers.synth(nsamples=nsamples, seed=4242 + buf_samples, rate=3000.0)
+    d = readsb_amd.Demodulator(startup_time_ms=helpers.STARTUP_MS, max_samples=16 * 131072, buf_samples=buf_samples)
+    msgs, cnt = d.demodulate_capture(iq)
+    tm = d.timing()
+    d.close()
+    out.append((buf_samples, len(msgs), msgs.tobytes(), {{k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in cnt.items()}}, tm["sweep_fused_chunks"]))
+import pickle
+sys.stdout.buffer.write(pickle.dumps(out))
+"""
+
+
+def test_fused_sweep_equals_the_two_kernels_at_every_buffer_size(built):
+    """k_sweep_uc8 (converter and sweep in one pass, the product for UC8) against k_convert_uc8_lean + k_sweep (experiments build,
+    MGPU_SWEEP_FUSED=0) where the oracle cannot follow: buffers of 4096 .. 131072 samples (mgpu_config.buf_samples; the oracle's grid
+    is the reference's 131072).  A buffer of 4096 samples is four steps: every fourth step closes a buffer's exact sum(mag) /
+    sum(mag^2) (its first 326 positions still belong to the buffer before) — messages, timestamps and every counter, the noise
+    power made of those sums included, must be the same bytes."""
+    import pickle
+    code = FUSED_SCRIPT.format(root=helpers.ROOT, tests=os.path.join(helpers.ROOT, "tests"))
+    res = {}
+    for fused in ("1", "0"):
+        env = dict(os.environ, MGPU_SWEEP_FUSED=fused, MGPU_LIBRARY="libmodes_gpu_exp.so")
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-4000:].decode(errors="replace")
+        res[fused] = pickle.loads(r.stdout)
+    for a, b in zip(res["1"], res["0"]):
+        assert a[4] > 0 and b[4] == 0, "the switch did not select the kernels"
+        assert a[1] == b[1] > 50, (a[0], a[1], b[1])
+        assert a[2] == b[2], f"messages differ at buf_samples {a[0]}"
+        assert a[3] == b[3], f"counters differ at buf_samples {a[0]}: {[(k, a[3][k], b[3][k]) for k in a[3] if a[3][k] != b[3][k]]}"

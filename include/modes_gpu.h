@@ -698,6 +698,14 @@ int mgpu_selftest_shard_walk(uint64_t seed, uint32_t nchunks, uint32_t buffers_p
  * [2]-[4] are walked on the host. */
 int mgpu_debug_device_walk(mgpu_ctx *ctx, uint64_t out[8]);
 
+/* The magnitudes the pipeline's LAST chunk was demodulated from, as they lie in HBM: out[i] = magnitude of the chunk's sample i,
+ * i < n <= the chunk's length (MGPU_E_INVAL beyond it, or before any feed).  Since round 6 the pipeline's magnitudes are not
+ * mgpu_convert()'s kernels' — for UC8 input they come out of k_sweep_uc8 (converter and sweep in one pass), for SC16 / SC16Q11 out
+ * of k_sweep_sc16 — so the exhaustive converter tests (every UC8 byte pair, every 12-bit SC16Q11 pair: convert.c:64-108, 212-250,
+ * 329-367) are run against this too (tests/test_gpu_convert.py).  Drains the pipeline first.  Test support: nothing in readsb
+ * reads magnitudes back. */
+int mgpu_debug_last_magnitudes(mgpu_ctx *ctx, uint16_t *out, uint64_t n);
+
 #ifdef __cplusplus
 }
 #endif

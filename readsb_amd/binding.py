@@ -318,6 +318,7 @@ def load_library():
     lib.mgpu_pending_messages.restype = u64
     lib.mgpu_last_timing.argtypes = [vp, C.POINTER(Timing)]
     lib.mgpu_debug_device_walk.argtypes = [vp, C.POINTER(u64)]
+    lib.mgpu_debug_last_magnitudes.argtypes = [vp, vp, u64]
     lib.mgpu_event_bracket_us.argtypes = [vp, C.POINTER(C.c_float)]
     lib.mgpu_convert.argtypes = [vp, vp, vp, u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.mgpu_demod_mag_buf.argtypes = [vp, vp, u32, i64, i64, C.c_double, u32]
@@ -715,6 +716,12 @@ class Demodulator:
         self._chk(self.lib.mgpu_collect(self.ctx, out.ctypes.data, out.size, C.byref(got), C.byref(cnt) if cnt is not None else None),
                   "mgpu_collect")
         return out[: got.value], (cnt.as_dict() if cnt is not None else None)
+
+    def last_magnitudes(self, n):
+        """mgpu_debug_last_magnitudes: the first n magnitudes of the chunk the pipeline demodulated last, out of HBM."""
+        out = np.empty(int(n), dtype=np.uint16)
+        self._chk(self.lib.mgpu_debug_last_magnitudes(self.ctx, out.ctypes.data, int(n)), "mgpu_debug_last_magnitudes")
+        return out
 
     def device_walk_stats(self):
         """mgpu_debug_device_walk: what the walk on the device (MGPU_DEVICE_WALK) did so far."""

@@ -331,7 +331,7 @@ struct mgpu_ctx {
     hipStream_t stream_c = nullptr;
     int d2h_hold = 0;                                                      // the fetcher's record copy held behind the next chunk's pending k_sweep (fetch_records); 0: experiments build, MGPU_D2H_HOLD
     int s2_hold = 1;                                                       // the second stream's work held behind a pending k_sweep (hold_behind_sweep); 0: experiments build, MGPU_S2_HOLD
-    int sweep_fused = 1;                                                   // UC8 without Mode A/C: k_sweep_uc8 converts on the way (no converter launch, the magnitudes written once); 0: k_convert_uc8_lean + k_sweep (experiments build: MGPU_SWEEP_FUSED)
+    int sweep_fused = 3;                                                   // without Mode A/C the sweep converts on the way (no converter launch, the magnitudes written once) — bit 0: UC8, k_sweep_uc8; bit 1: SC16 / SC16Q11, k_sweep_sc16; 0: k_convert_* + k_sweep (experiments build: MGPU_SWEEP_FUSED)
     int conv_side = 0;                                                     // 1: on (UC8 without Mode A/C, 1-bit repair tables: with the 2-bit tables k_slice's three workgroups leave no LDS)
     int convert_variant = 0;                                               // launch_convert's variant (1: the round-1..5 converter; experiments build)
     unsigned conv_side_blocks = 2048, slice_blocks_cap = 0;                // grid of the side converter | of k_slice beside it (0: whatever is resident)
@@ -1271,7 +1271,9 @@ static int enqueue_fsum(mgpu_ctx *c, Slot &sl, const uint8_t *iq, hipEvent_t aft
 // the sums before the sweep), not a struct mag_buf entry (the magnitudes are the caller's).
 static bool sweep_is_fused(const mgpu_ctx *c, const Slot &sl) {
     const uint32_t buf_steps = c->cfg.buf_samples / (uint32_t) kSweepTile;      // (a power of two of steps per buffer: the kernel tests a step's place in its buffer with a mask)
-    return c->sweep_fused && c->cfg.format == MGPU_FMT_UC8 && !c->cfg.mode_ac && !sl.have_mag && buf_steps && (buf_steps & (buf_steps - 1u)) == 0u;
+    // (sweep_fused bit 0: UC8 through the shared table, k_sweep_uc8; bit 1: the SC16 formats by arithmetic, k_sweep_sc16)
+    const int bit = c->cfg.format == MGPU_FMT_UC8 ? 1 : 2;
+    return (c->sweep_fused & bit) && !c->cfg.mode_ac && !sl.have_mag && buf_steps && (buf_steps & (buf_steps - 1u)) == 0u;
 }
 
 static bool convert_on_side(const mgpu_ctx *c, const Slot &sl) {
@@ -1359,7 +1361,7 @@ static int enqueue_sweep(mgpu_ctx *c, Slot &sl) {
     sp.adder_bitmap = c->d_adder_bitmap; sp.counters = sl.d_counters;
     sp.cand = sl.d_cand; sp.cand_count = sl.d_cand_count; sp.sweep_part = sl.d_sweep_part;
     if (sl.fused_iq) {
-        sp.iq = sl.fused_iq; sp.tail = sl.fused_tail; sp.uc8_sym = c->d_uc8_folded + UC8_SYM_OFFSET; sp.mag_w = sl.d_mag;
+        sp.iq = sl.fused_iq; sp.iq_format = (uint32_t) cfg.format; sp.tail = sl.fused_tail; sp.uc8_sym = c->d_uc8_folded + UC8_SYM_OFFSET; sp.mag_w = sl.d_mag;
         sp.sum_level = sl.d_sum_level; sp.sum_power = sl.d_sum_power;
         sp.buf_steps = cfg.buf_samples / (uint32_t) kSweepTile;
     }
@@ -1425,7 +1427,9 @@ static int enqueue_slot(mgpu_ctx *c, Slot &sl, const uint8_t *iq, hipEvent_t aft
     int rc = enqueue_convert(c, sl, iq);
     // `after_convert`: the chunk's IQ samples have been read — by the converter AND, for the SC16 formats, by the float sums on the
     // second stream, which run beside the converter (Mode A/C) or start behind the chunk's k_sweep (enqueue_sweep)
-    const bool fsum_late = c->cfg.format != MGPU_FMT_UC8 && !c->cfg.mode_ac && !sl.have_mag;
+    // (converter and sweep in one kernel: it is the sweep that reads the samples — the event behind enqueue_convert, which launches
+    // nothing then, would let the next upload into this region of the staging buffer run beside it)
+    const bool fsum_late = (c->cfg.format != MGPU_FMT_UC8 && !c->cfg.mode_ac && !sl.have_mag) || sweep_is_fused(c, sl);
     auto mark_read = [&]() -> int {
         if (sl.fsum_pending) {
             HIPCHK(c, hipEventRecord(sl.ev_convdone, c->stream));
@@ -1510,7 +1514,7 @@ static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
     float ms;
     if (sl.timed) {
         if (!sl.fused_iq && hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]) == hipSuccess) c->acc.convert_ms += ms;
-        if (hipEventElapsedTime(&ms, convert_on_side(c, sl) ? sl.ev_sweep0 : sl.ev[1], sl.ev[4]) == hipSuccess) { c->acc.sweep_ms += ms; sweep_pace_feedback(ms * 1e3f, sl.n, sl.sweep_blocks, c->event_bracket_us, sl.fused_iq ? 1 : 0); }
+        if (hipEventElapsedTime(&ms, convert_on_side(c, sl) ? sl.ev_sweep0 : sl.ev[1], sl.ev[4]) == hipSuccess) { c->acc.sweep_ms += ms; sweep_pace_feedback(ms * 1e3f, sl.n, sl.sweep_blocks, c->event_bracket_us, !sl.fused_iq ? 0 : c->cfg.format == MGPU_FMT_UC8 ? 1 : 2); }
         if (hipEventElapsedTime(&ms, sl.ev[4], sl.ev[2]) == hipSuccess) c->acc.slice_ms += ms;
         if (hipEventElapsedTime(&ms, sl.ev[2], sl.ev[3]) == hipSuccess) c->acc.prescreen_ms += ms;
         c->acc.n_timed_chunks += 1;
@@ -2633,6 +2637,18 @@ int mgpu_debug_device_walk(mgpu_ctx *c, uint64_t out[8]) {
     if (!c || !out) return MGPU_E_INVAL;
     (void) drain(c);
     for (int i = 0; i < 8; ++i) out[i] = c->wk_stats[i];
+    return MGPU_OK;
+}
+
+int mgpu_debug_last_magnitudes(mgpu_ctx *c, uint16_t *out, uint64_t n) {
+    if (!c || (!out && n)) return MGPU_E_INVAL;
+    { const int rc = drain(c); if (rc != MGPU_OK) return rc; }
+    if (c->chunk_seq == 0) { c->err = "mgpu_debug_last_magnitudes: nothing fed yet"; return MGPU_E_INVAL; }
+    const Slot &sl = c->slot[(c->chunk_seq - 1) % mgpu_ctx::kSlots];
+    if (n > sl.n) { c->err = "mgpu_debug_last_magnitudes: more than the last chunk holds"; return MGPU_E_INVAL; }
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipDeviceSynchronize());
+    if (n) HIPCHK(c, hipMemcpy(out, sl.d_mag + kTrailing, n * sizeof(uint16_t), hipMemcpyDeviceToHost));
     return MGPU_OK;
 }
 

@@ -112,6 +112,7 @@ struct SweepParams {
     // magnitudes before the chunk (nullptr: zeros), the 128 x 128 symmetric table (tables.h: UC8_SYM_OFFSET), where the magnitudes
     // go (= mag), the buffers' exact sum(mag) / sum(mag^2) the kernel adds its samples' to (zero at launch), steps per sample buffer
     const uint8_t *iq;
+    uint32_t iq_format;       // of `iq`: MGPU_FMT_UC8 (k_sweep_uc8) / SC16 / SC16Q11 (k_sweep_sc16<15 / 11>: 4 bytes per sample, no table, no integer sums)
     const uint16_t *tail;
     const uint16_t *uc8_sym;
     uint16_t *mag_w;

@@ -29,6 +29,7 @@ namespace mgpu {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+typedef uint32_t u32x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
 typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
 typedef short v2i16 __attribute__((ext_vector_type(2)));
 

@@ -100,3 +100,57 @@ def test_sc16_isolated_strong_samples_after_a_quiet_stretch(built, fmt, nstrong)
         want, wml, wmp = helpers.oracle_convert(iq, fmt)
         assert np.array_equal(mag, want)
         assert ml == wml and mp == wmp, (quiet_amp, where, ml, wml, mp, wmp)
+
+
+# ---- the PIPELINE's magnitudes: since round 6 they come out of the fused sweep kernels (k_sweep_uc8, k_sweep_sc16), not out of the
+#      converters mgpu_convert() runs — the same exhaustive inputs through a feed, read back with mgpu_debug_last_magnitudes ----
+def _pipeline_magnitudes(fmt, iq, n):
+    import readsb_amd
+    d = readsb_amd.Demodulator(fmt=fmt, max_samples=max(n, 131072), startup_time_ms=helpers.STARTUP_MS)
+    try:
+        d.feed_iq(iq)
+        fused = d.timing()["sweep_fused_chunks"]
+        return d.last_magnitudes(n), fused
+    finally:
+        d.close()
+
+
+def test_pipeline_magnitudes_uc8_all_pairs(built):
+    i, q = np.meshgrid(np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8), indexing="ij")
+    iq = np.stack([i.ravel(), q.ravel()], axis=1).ravel()
+    rng = np.random.default_rng(1)
+    iq = np.concatenate([iq, rng.integers(0, 256, size=2 * 100003, dtype=np.uint8)])     # ragged: the last steps are staged sample by sample
+    n = iq.size // 2
+    got, fused = _pipeline_magnitudes(0, iq, n)
+    assert fused >= 1, "the feed did not go through k_sweep_uc8"
+    assert np.array_equal(got, helpers.oracle_convert(iq, 0)[0])
+
+
+@pytest.mark.parametrize("n", [1, 7, 333, 1024, 1025, 131072, 131073, 3 * 131072 + 698])
+def test_pipeline_magnitudes_uc8_ragged_lengths(built, n):
+    rng = np.random.default_rng(n)
+    iq = rng.integers(0, 256, size=2 * n, dtype=np.uint8)
+    got, _ = _pipeline_magnitudes(0, iq, n)
+    assert np.array_equal(got, helpers.oracle_convert(iq, 0)[0])
+
+
+def test_pipeline_magnitudes_sc16q11_all_12bit_pairs(built):
+    v = np.arange(-2048, 2048, dtype=np.int16)
+    i, q = np.meshgrid(v, v, indexing="ij")
+    iq = np.stack([i.ravel(), q.ravel()], axis=1).ravel().astype("<i2")
+    n = iq.size // 2
+    got, fused = _pipeline_magnitudes(2, iq, n)
+    assert fused >= 1, "the feed did not go through k_sweep_sc16"
+    assert np.array_equal(got, helpers.oracle_convert(iq, 2)[0])
+
+
+@pytest.mark.parametrize("fmt", [1, 2])
+def test_pipeline_magnitudes_sc16_random_and_extremes(built, fmt):
+    rng = np.random.default_rng(7 + fmt)
+    n = 2_000_003
+    iq = rng.integers(-32768, 32768, size=2 * n, dtype=np.int32).astype("<i2")
+    iq[:8] = np.array([-32768, -32768, 32767, 32767, 0, 0, -1, 1], dtype="<i2")
+    iq[2 * (n - n // 2):] = rng.integers(-3000, 3000, size=2 * (n // 2), dtype=np.int32).astype("<i2")
+    got, fused = _pipeline_magnitudes(fmt, iq, n)
+    assert fused >= 1
+    assert np.array_equal(got, helpers.oracle_convert(iq, fmt)[0])

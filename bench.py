@@ -622,9 +622,24 @@ def main():
     ap.add_argument("--launch-check", action="store_true",
                     help="the N-rank launch alone (no GPU needed with --dryrun-gloo): every rank joins the process group, rank 0 prints a line "
                          "with the world size it found — tests/test_bench_launch.py")
+    ap.add_argument("--extra-only", type=int, default=-1, help="(internal) run the i-th extra configuration alone and print {name: result}")
+    ap.add_argument("--extra-device", type=int, default=0, help="(internal) the device of --extra-only")
     args = ap.parse_args()
     if args.chunk_buffers is None:
         args.chunk_buffers = 2048 if args.config == 1 else 0
+    if args.extra_only >= 0:
+        import helpers
+        helpers.ensure_built()
+        name = list(EXTRA_CONFIGS)[args.extra_only]
+        fmt, nfix, kw = EXTRA_CONFIGS[name]
+        try:
+            res = run_extra_config(name, fmt, nfix, kw, args.extra_samples - args.extra_samples % BUF, args.extra_device, bracket_us=args.event_bracket_us,
+                                   chunk_buffers=args.chunk_buffers, ahead=max(1, min(3, args.ahead)))
+        except AssertionError as e:
+            sys.stderr.write(str(e)[-1500:] + "\n")
+            raise SystemExit(3)
+        emit({name: res})
+        return
 
     relaunch_or_check_world(args)
     if args.launch_check:
@@ -949,11 +964,26 @@ def main():
         if not args.no_extra_configs and not args.no_cpu_baseline and world == 1:
             d.close()
             out["configs"] = {}
-            for name, (fmt, nfix, kw) in EXTRA_CONFIGS.items():
+            # Every extra configuration in a process of its own (`--extra-only i`): as the third or fourth context of THIS process the
+            # dense-burst configuration came out at 123-248 Gsamples/s in repetitions that a fresh process runs at 288-302, eighteen in a
+            # row (gpurun r06as / r06at) — whatever the earlier contexts leave behind (thread placement, the allocator's state) is not the
+            # configuration's.  The child checks against the reference exactly as before; exit code 3 = a mismatch.
+            import subprocess
+            restore_affinity()
+            for i, name in enumerate(EXTRA_CONFIGS):
+                cmd = [sys.executable, os.path.abspath(__file__), "--extra-only", str(i), "--extra-samples", str(args.extra_samples),
+                       "--chunk-buffers", str(args.chunk_buffers), "--ahead", str(A), "--extra-device", str(local_rank_dev)]
+                if args.event_bracket_us is not None:
+                    cmd += ["--event-bracket-us", str(args.event_bracket_us)]
                 try:
-                    out["configs"][name] = run_extra_config(name, fmt, nfix, kw, args.extra_samples - args.extra_samples % BUF, local_rank_dev, bracket_us=args.event_bracket_us, chunk_buffers=args.chunk_buffers, ahead=A)
-                except AssertionError as e:                      # a mismatch is a failed run, not a missing number
-                    raise SystemExit(f"extra configuration '{name}': GPU result differs from the reference: {e}")
+                    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+                    if r.returncode == 3:                        # a mismatch is a failed run, not a missing number
+                        raise SystemExit(f"extra configuration '{name}': GPU result differs from the reference: {r.stderr[-1500:]}")
+                    if r.returncode != 0:
+                        raise RuntimeError(r.stderr[-300:])
+                    out["configs"].update(json.loads(r.stdout.strip().splitlines()[-1]))
+                except SystemExit:
+                    raise
                 except Exception as e:                           # anything else (an allocation, the checker's binary): this entry is missing, the line is not
                     out["configs"][name] = {"error": f"{type(e).__name__}: {e}"[:300]}
         emit(out)

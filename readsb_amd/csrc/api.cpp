@@ -1382,7 +1382,7 @@ static int enqueue_sweep(mgpu_ctx *c, Slot &sl) {
             const int rc = enqueue_fsum(c, sl, sl.fsum_iq, sl.ev_swept);
             if (rc != MGPU_OK) return rc;
         }
-        sl.slice_blocks = launch_slice(sp, s, c->conv_side ? c->slice_blocks_cap : 0u);
+        sl.slice_blocks = launch_slice(sp, s, c->slice_blocks_cap);      // (0 = whatever is resident; experiments build: MGPU_SLICE_BLOCKS)
     }
     if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[2], s));
     return MGPU_OK;

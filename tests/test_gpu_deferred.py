@@ -261,3 +261,43 @@ def test_one_chunk_host_feeds_on_a_busy_gpu(built, monkeypatch):
     helpers.assert_same_counters(cnt, wst)
     d.host_free(block)
     d.close()
+
+
+def test_a_stream_s_results_do_not_depend_on_the_chunking(built):
+    """The same continuous stream — a block of 2304 buffers fed twelve times — through pipelines with chunks of 2048 / 1024 / 768 / 1536
+    buffers and one to three feeds in flight: the kernels' partitioning, the host walk's rounds (a chunk of 2048 or 1536 buffers is
+    walked as two), the slots' reuse and the deferred protocol all differ, every feed's messages and the final counters may not.
+    (tools/stress_stream.py is the long form: 400 feeds x 5 variants.)"""
+    import readsb_amd
+    nbuf, feeds = 2304, 12
+    n = nbuf * 131072
+    iq = helpers.synth(nsamples=n, seed=777, rate=2500.0, threads=16)
+    ref = None
+    for chunk_buffers, ahead in ((2048, 2), (1024, 1), (768, 3), (1536, 2)):
+        d = readsb_amd.Demodulator(max_samples=n, startup_time_ms=helpers.STARTUP_MS, chunk_buffers=chunk_buffers)
+        try:
+            d.upload_iq(iq)
+            d.feed_resident(n)
+            m0, _ = d.collect(reuse=True)
+            bufs = [np.empty(len(m0) * 5 // 4 + 1024, dtype=readsb_amd.MSG_DTYPE) for _ in range(ahead + 1)]
+            d.reset()
+            d.set_deferred(True)
+            got = []
+            for k in range(feeds + ahead):
+                if k < feeds:
+                    d.set_message_buffer(bufs[k % (ahead + 1)])
+                    d.feed_resident(n)
+                if k >= ahead:
+                    j = k - ahead
+                    msgs, cnt = d.collect_feed(bufs[j % (ahead + 1)], want_counters=(j == feeds - 1))
+                    got.append(msgs.tobytes())
+            d.set_deferred(False)
+        finally:
+            d.close()
+        cnt = repr({k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in cnt.items()})
+        if ref is None:
+            ref = (got, cnt)
+            assert sum(len(g) for g in got) // 64 > 100000 and got[0] != got[1]      # (the stream goes on: later feeds are not the first again)
+        else:
+            assert [i for i, (a, b) in enumerate(zip(ref[0], got)) if a != b] == [], (chunk_buffers, ahead)
+            assert cnt == ref[1], (chunk_buffers, ahead)

@@ -56,6 +56,7 @@ int main(int argc, char **argv) {
     const double rate = argc > 5 ? atof(argv[5]) : 2000.0;
     const int queued = argc > 6 ? atoi(argv[6]) : 1;         // 1: the timed rounds' launches are enqueued back to back (the GPU never idles between them, as in the pipeline); 0: one at a time with a host wait behind each
     const int thr = 58;
+    const int iq_shift = getenv("UC8_IQ_SHIFT") ? atoi(getenv("UC8_IQ_SHIFT")) : 0;   // timing experiment: bytes added to the IQ pointer (12: the kernel's 16-byte loads become 16-byte aligned; the results are those of a shifted stream: mismatches reported)
     const uint32_t buf_samples = 131072;
     const uint64_t n = (uint64_t) buffers * buf_samples;
     const uint64_t stride = ((n + kTrailing + 4096 + 4095) / 4096) * 4096;      // magnitudes per replica (16-byte aligned, with the tile slack)
@@ -88,7 +89,7 @@ int main(int argc, char **argv) {
     uint32_t *d_count, *d_part, *d_dealer;
     unsigned long long *d_sums, *d_waves;
     const uint32_t nsteps = (uint32_t) ((n + kSwStep - 1) / kSwStep);
-    CK(hipMalloc(&d_iq, (size_t) replicas * n * 2));
+    CK(hipMalloc(&d_iq, (size_t) replicas * n * 2 + 4096));                        // (slack: UC8_IQ_SHIFT)
     CK(hipMalloc(&d_mag, (size_t) replicas * stride * 2));
     CK(hipMalloc(&d_cand, (size_t) (nsteps + 2) * kSwStep * 2));
     CK(hipMalloc(&d_count, (size_t) (nsteps + 2) * 4));
@@ -115,7 +116,7 @@ int main(int argc, char **argv) {
     CK(hipEventCreate(&e1));
     unsigned blocks = 0;
     auto run = [&](int r, float &us) -> int {
-        p.iq = d_iq + (size_t) r * n * 2;
+        p.iq = d_iq + (size_t) r * n * 2 + iq_shift;
         p.mag = d_mag + (size_t) r * stride;
         p.mag_w = d_mag + (size_t) r * stride;
         CK(hipMemsetAsync(d_dealer, 0, (size_t) 2 * kDealerCounters * kDealerStride * 4, nullptr));   // (the pipeline's k_publish hands both back zeroed)
@@ -172,7 +173,7 @@ int main(int argc, char **argv) {
         for (int rd = 1; rd < rounds; ++rd) {
             for (int r = 0; r < replicas; ++r) {
                 const int k = (rd - 1) * replicas + r;
-                p.iq = d_iq + (size_t) r * n * 2;
+                p.iq = d_iq + (size_t) r * n * 2 + iq_shift;
                 p.mag = p.mag_w = d_mag + (size_t) r * stride;
                 CK(hipMemsetAsync(d_dealer, 0, (size_t) 2 * kDealerCounters * kDealerStride * 4, nullptr));
                 CK(hipMemsetAsync(d_sums, 0, (size_t) (buffers + 3) * 2 * 8, nullptr));

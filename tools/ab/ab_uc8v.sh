@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of k_sweep_uc8 variants alone: tools/ab_uc8v.sh <tag> <reps> <suffix>...
+# A/B of k_sweep_uc8 variants alone: tools/ab/ab_uc8v.sh <tag> <reps> <suffix>...
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$R/gpurun_out/$1; shift

@@ -1057,13 +1057,35 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
             }
         }
     }
+    // The SC16 formats' float-sum chain (k_fsum_sc16: one wave per buffer, each a chain of 256 dependent block steps at s_setprio 3,
+    // ~0.9 ms per chunk of 2048 buffers) on every 4th CU only, from CU 2 on (the second stream and the record copies sit on CUs 0, 8,
+    // 16 ...): spread over all 256 CUs its waves took issue slots from k_sweep_sc16 / k_slice everywhere — SC16Q11 --aggressive
+    // 232-245 Gsamples/s; on every 2nd, 4th or 8th CU 265-290 (274-281 means of three repetitions, tools/ab/ab_fsum_mask.sh,
+    // profiles/r06_fsum_mask.txt; every 3rd: 225-229 — a stride that is not a power of two puts the chain on every CU of some XCDs'
+    // shader arrays).  Every 4th: 64 CUs x 4 SIMDs x 8 waves = the 2048 waves of a 2048-buffer chunk in one generation (Mode A/C waits
+    // for the chain: two generations would be its latency twice).
+    bool fsum_masked = false;
+    if (cfg->format != MGPU_FMT_UC8) {
+        int k = 4, off = 2;
+#if MGPU_EXPERIMENTS
+        if (const char *e = getenv("MGPU_FSUM_CU_STRIDE")) { k = 0; off = 1; sscanf(e, "%d,%d", &k, &off); }      // k[,off]; 0: no mask (A/B)
+#endif
+        hipDeviceProp_t prop;
+        const int cus = hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (k >= 2 && k <= 64 && cus >= 2 * k && cus <= 1024) {
+            uint32_t m[32] = {0};
+            for (int cu = off % k; cu < cus; cu += k) m[cu >> 5] |= 1u << (cu & 31);
+            fsum_masked = hipExtStreamCreateWithCUMask(&c->stream_f, (uint32_t) ((cus + 31) / 32), m) == hipSuccess;
+            if (!fsum_masked) { (void) hipGetLastError(); c->stream_f = nullptr; }
+        }
+    }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         (!masked && hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least) != hipSuccess) ||
         hipStreamCreateWithFlags(&c->stream_w, hipStreamNonBlocking) != hipSuccess ||
         (!masked && hipStreamCreateWithFlags(&c->stream_d2h, hipStreamNonBlocking) != hipSuccess) ||
         hipStreamCreateWithFlags(&c->stream_c, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream_aux, hipStreamNonBlocking) != hipSuccess ||
-        (cfg->format != MGPU_FMT_UC8 && hipStreamCreateWithPriority(&c->stream_f, hipStreamNonBlocking, prio_least) != hipSuccess)) { mgpu_destroy(c); return MGPU_E_HIP; }
+        (cfg->format != MGPU_FMT_UC8 && !fsum_masked && hipStreamCreateWithPriority(&c->stream_f, hipStreamNonBlocking, prio_least) != hipSuccess)) { mgpu_destroy(c); return MGPU_E_HIP; }
     // valid_df_*_bitset, init_bitsets() demod_2400.c:112-128 (ENABLE_DF24 off, readsb.h:303)
     c->valid_short = (1u << 0) | (1u << 4) | (1u << 5) | (1u << 11);
     c->valid_long = (1u << 16) | (1u << 17) | (1u << 18) | (1u << 20) | (1u << 21);

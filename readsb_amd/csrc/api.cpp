@@ -321,7 +321,7 @@ struct mgpu_ctx {
     // sums before the chunk's slot goes back to the GPU (chunk seq uses entry seq % kFsumRing)
     struct FsumRing { double *d = nullptr, *h = nullptr; void *scratch = nullptr; hipEvent_t ev = nullptr; } fsum_ring[kFsumRing];
     uint32_t prescreen_variant = 3;                                        // PostSweepParams::variant (the experiments build can ask for the older passes)
-    uint32_t cu_mask[32] = {0}, cu_mask_words = 0;                         // the side streams' CUs (mgpu_create)
+    uint32_t cu_mask[32] = {0}, cu_mask_words = 0;                         // the side streams' CU mask (every CU: mgpu_create says what it is for)
     int post_beside = 0;                                                   // experiment: 1 = stream_pw takes the write pass, 2 = the count pass too
     hipStream_t stream_pw = nullptr;                                       // experiment (MGPU_WRITE_BESIDE=1, experiments build): the pre-screen's write pass + k_publish on a stream of their own, beside the next chunk's converter — measured 297 against 357 Gsamples/s (gpurun r05i): beside a kernel that saturates the memory system the write pass's dependent round trips stretch the post-sweep stage from 0.25 to 0.73 ms per step.  Round 6, beside k_sweep_uc8 (1 / 2: + the count pass; 3 / 4: on the masked CUs): 1.27-1.39 ms per feed against 1.21-1.25; the whole stage held back until the next chunk's sweep is through, beside its k_slice: 1.30-1.36 (profiles/r06_sweep_fused.txt)
     hipStream_t stream_f = nullptr;                                        // SC16 formats: the float sums' chains (k_fsum_sc16), so that what follows a walk does not queue behind them
@@ -1029,27 +1029,37 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
 #if MGPU_EXPERIMENTS
     if (const char *e = getenv("MGPU_S2_PRIORITY")) prio_least = atoi(e) > 0 ? prio_greatest : 0;   // experiment: the second stream at normal (0) / highest (1) priority
 #endif
-    // The second stream (what follows a walk: k_stage_in, k_window_stats, k_build_messages) and the fetcher's record copies (the
-    // runtime's blit kernel) run on every 8th CU only (hipExtStreamCreateWithCUMask, round 6).  They are ~0.8 ms of small, latency-bound
-    // kernels per 1.2 ms feed, and wherever they land they take issue slots from the main stream's kernel — with the converter gone
-    // that is k_sweep_uc8 or k_slice, both issue-bound.  Those two are persistent grids balanced by dealers, so 32 CUs that run a
-    // little slower cost them little, where the same work spread over all 256 stretched the sweep from 112 to 120-146 us per launch at
-    // random: with the mask the sweep's bracket reads 0.446-0.453 ms per feed every time (0.59-0.60 of the HBM peak; 0.50-0.57
-    // without) and the feed 1.226-1.229 ms (1.236-1.326); every 4th CU: the same; every 16th: the post-sweep stage grows, 1.27
-    // (profiles/r06_sweep_fused.txt).  The mask replaces the second stream's low priority (a masked stream has none).
+    // The side streams — the second stream (what follows a walk: k_stage_in, k_window_stats, k_build_messages), the fetcher's record
+    // copies (the runtime's blit kernel) and, for the SC16 formats, the float-sum chain (k_fsum_sc16: one wave per buffer, ~0.9 ms of
+    // dependent block steps per chunk) — are created through hipExtStreamCreateWithCUMask with EVERY CU enabled.  What that buys is not
+    // a place but a queue: such a stream has a hardware queue of its own, where the runtime's ordinary streams share a small pool of
+    // them and a kernel of one waits behind another's.  Measured (profiles/r06_stream_queues.txt): UC8 headline 470-486 Gsamples/s
+    // against 431-446 with ordinary streams (478 with GPU_MAX_HW_QUEUES=8 in the environment, which a library cannot count on);
+    // SC16Q11 --aggressive 273-285 against 229-245 with the chain on an ordinary stream of any priority.
+    // Rounds 6's first form asked for "every 8th CU" (every 4th for the chain) and believed the side work confined there.  It is not:
+    // mask bit i is CU i / 8 of XCC i % 8 (tools/micro/cu_mask_map.hip), a stride of 8 selects all of XCC 0, and an XCC whose share of
+    // the mask is empty runs the queue's workgroups on all of its CUs — those masks were the whole device, and what they gained was
+    // the queue.  Real confinement (n CUs of every XCC) LOSES: the side streams on 8 / 4 / 2 CUs per XCC 431-454 / 402-422 / 306-312,
+    // the chain on 16 / 8 / 4 per XCC 251-258 / 219-224 / 145; a stride of 3 (10-11 CUs per XCC) 225-229.
+    const int n_cus = [&] { hipDeviceProp_t prop; return hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }();
+    // mask: every k-th bit from `off` (k = 1: every CU); perxcc > 0: CUs [first, first + perxcc) of each of the 8 XCCs instead
+    auto build_mask = [&](uint32_t *mask, int k, int off, int perxcc, int first) -> bool {
+        if (n_cus > 1024 || (perxcc <= 0 && (k < 1 || k > 128 || n_cus < 2 * k))) return false;
+        if (perxcc > 0) { for (int b = 8 * first; b < 8 * (first + perxcc) && b < n_cus; ++b) mask[b >> 5] |= 1u << (b & 31); }
+        else for (int cu = off % k; cu < n_cus; cu += k) mask[cu >> 5] |= 1u << (cu & 31);
+        return true;
+    };
+    const uint32_t mask_words = (uint32_t) ((n_cus + 31) / 32);
     bool masked = false;
     {
-        int k = 8;
+        int k = 1, perxcc = 0, perxcc_first = 0;
 #if MGPU_EXPERIMENTS
-        if (const char *e = getenv("MGPU_CU_MASK_STRIDE")) k = atoi(e);      // 0: no mask (A/B)
+        if (const char *e = getenv("MGPU_CU_MASK_STRIDE")) k = atoi(e);      // 0: ordinary streams (A/B); k >= 2: every k-th bit
+        if (const char *e = getenv("MGPU_CU_MASK_PERXCC")) sscanf(e, "%d,%d", &perxcc, &perxcc_first);
 #endif
-        hipDeviceProp_t prop;
-        const int cus = hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        if (k >= 2 && k <= 128 && cus >= 2 * k && cus <= 1024) {
-            uint32_t *mask = c->cu_mask;
-            for (int cu = 0; cu < cus; cu += k) mask[cu >> 5] |= 1u << (cu & 31);
-            const uint32_t words = c->cu_mask_words = (uint32_t) ((cus + 31) / 32);
-            masked = hipExtStreamCreateWithCUMask(&c->stream2, words, mask) == hipSuccess && hipExtStreamCreateWithCUMask(&c->stream_d2h, words, mask) == hipSuccess;
+        if (build_mask(c->cu_mask, k, 0, perxcc, perxcc_first)) {
+            c->cu_mask_words = mask_words;
+            masked = hipExtStreamCreateWithCUMask(&c->stream2, mask_words, c->cu_mask) == hipSuccess && hipExtStreamCreateWithCUMask(&c->stream_d2h, mask_words, c->cu_mask) == hipSuccess;
             if (!masked) {
                 (void) hipGetLastError();
                 if (c->stream2) (void) hipStreamDestroy(c->stream2);
@@ -1057,35 +1067,34 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
             }
         }
     }
-    // The SC16 formats' float-sum chain (k_fsum_sc16: one wave per buffer, each a chain of 256 dependent block steps at s_setprio 3,
-    // ~0.9 ms per chunk of 2048 buffers) on every 4th CU only, from CU 2 on (the second stream and the record copies sit on CUs 0, 8,
-    // 16 ...): spread over all 256 CUs its waves took issue slots from k_sweep_sc16 / k_slice everywhere — SC16Q11 --aggressive
-    // 232-245 Gsamples/s; on every 2nd, 4th or 8th CU 265-290 (274-281 means of three repetitions, tools/ab/ab_fsum_mask.sh,
-    // profiles/r06_fsum_mask.txt; every 3rd: 225-229 — a stride that is not a power of two puts the chain on every CU of some XCDs'
-    // shader arrays).  Every 4th: 64 CUs x 4 SIMDs x 8 waves = the 2048 waves of a 2048-buffer chunk in one generation (Mode A/C waits
-    // for the chain: two generations would be its latency twice).
     bool fsum_masked = false;
+    int fsum_prio = -1;
     if (cfg->format != MGPU_FMT_UC8) {
-        int k = 4, off = 2;
+        int k = 1, off = 0, perxcc = 0, perxcc_first = 0;
 #if MGPU_EXPERIMENTS
-        if (const char *e = getenv("MGPU_FSUM_CU_STRIDE")) { k = 0; off = 1; sscanf(e, "%d,%d", &k, &off); }      // k[,off]; 0: no mask (A/B)
+        if (const char *e = getenv("MGPU_FSUM_CU_STRIDE")) { k = 0; off = 1; sscanf(e, "%d,%d", &k, &off); }      // k[,off]; 0: an ordinary stream (A/B)
+        if (const char *e = getenv("MGPU_FSUM_CU_PERXCC")) sscanf(e, "%d,%d", &perxcc, &perxcc_first);              // n[,first]: CUs [first, first + n) of every XCC
+        if (const char *e = getenv("MGPU_FSUM_PRIORITY")) fsum_prio = atoi(e);                                      // the ordinary stream's priority: -1 least (rounds 3-6), 0 normal, 1 greatest
 #endif
-        hipDeviceProp_t prop;
-        const int cus = hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        if (k >= 2 && k <= 64 && cus >= 2 * k && cus <= 1024) {
-            uint32_t m[32] = {0};
-            for (int cu = off % k; cu < cus; cu += k) m[cu >> 5] |= 1u << (cu & 31);
-            fsum_masked = hipExtStreamCreateWithCUMask(&c->stream_f, (uint32_t) ((cus + 31) / 32), m) == hipSuccess;
+        uint32_t m[32] = {0};
+        if (build_mask(m, k, off, perxcc, perxcc_first)) {
+            fsum_masked = hipExtStreamCreateWithCUMask(&c->stream_f, mask_words, m) == hipSuccess;
             if (!fsum_masked) { (void) hipGetLastError(); c->stream_f = nullptr; }
         }
     }
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+#if MGPU_EXPERIMENTS
+    if (getenv("MGPU_MAIN_OWN_QUEUE")) {                     // experiment: the main stream through the mask API too (all CUs): a hardware queue of its own
+        uint32_t m[32] = {0};
+        if (build_mask(m, 1, 0, 0, 0) && hipExtStreamCreateWithCUMask(&c->stream, mask_words, m) != hipSuccess) { (void) hipGetLastError(); c->stream = nullptr; }
+    }
+#endif
+    if ((!c->stream && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) ||
         (!masked && hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least) != hipSuccess) ||
         hipStreamCreateWithFlags(&c->stream_w, hipStreamNonBlocking) != hipSuccess ||
         (!masked && hipStreamCreateWithFlags(&c->stream_d2h, hipStreamNonBlocking) != hipSuccess) ||
         hipStreamCreateWithFlags(&c->stream_c, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream_aux, hipStreamNonBlocking) != hipSuccess ||
-        (cfg->format != MGPU_FMT_UC8 && !fsum_masked && hipStreamCreateWithPriority(&c->stream_f, hipStreamNonBlocking, prio_least) != hipSuccess)) { mgpu_destroy(c); return MGPU_E_HIP; }
+        (cfg->format != MGPU_FMT_UC8 && !fsum_masked && hipStreamCreateWithPriority(&c->stream_f, hipStreamNonBlocking, fsum_prio < 0 ? prio_least : fsum_prio > 0 ? prio_greatest : 0) != hipSuccess)) { mgpu_destroy(c); return MGPU_E_HIP; }
     // valid_df_*_bitset, init_bitsets() demod_2400.c:112-128 (ENABLE_DF24 off, readsb.h:303)
     c->valid_short = (1u << 0) | (1u << 4) | (1u << 5) | (1u << 11);
     c->valid_long = (1u << 16) | (1u << 17) | (1u << 18) | (1u << 20) | (1u << 21);
@@ -1498,8 +1507,8 @@ static int fetch_records(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
         // Round 6: the chunk is complete the moment the NEXT chunk's sweep starts on the main stream, and since that sweep is
         // k_sweep_uc8 — no converter in front of it any more — the copy's blit kernel (83 us for 2.2 MB) lands on it every time.
         // Holding the copy behind that sweep (d2h_hold, experiments build: MGPU_D2H_HOLD=1) protects the sweep but puts ~0.1 ms per
-        // chunk of waiting into the fetch stage (1.21 of a 1.23 ms feed); the CU mask on this stream (mgpu_create) does the same for
-        // the sweep without that: off.
+        // chunk of waiting into the fetch stage (1.21 of a 1.23 ms feed); a hardware queue of its own for this stream (mgpu_create: the
+        // side streams) steadies the sweep without that: off.
         if (c->d2h_hold && next && next->swept_seq.load(std::memory_order_acquire) == sl.seq + 1 && hipEventQuery(next->ev_swept) != hipSuccess)
             HIPCHK(c, hipStreamWaitEvent(c->stream_d2h, next->ev_swept, 0));
         // (a copy kernel of our own with 8..32 workgroups in place of the runtime's blit kernel: 2.55-2.63 ms per step instead of 2.45)

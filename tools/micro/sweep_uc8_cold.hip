@@ -1,8 +1,8 @@
 // tools/micro/sweep_uc8_cold.hip — k_sweep_uc8 (converter and sweep in one pass: the kernel bench.py's roofline is quoted on)
 // on its own, over COLD memory, with nothing beside it.
 //
-// Why: in the pipeline the kernel runs beside the side streams' small kernels (confined to every 8th CU by CU masks), and rocprofv3
-// does not keep those masks — under the profiler the pipeline's k_sweep_uc8 launches average 285 us where the benchmark's events
+// Why: in the pipeline the kernel runs beside the side streams' small kernels (on hardware queues of their own, which has no effect
+// under rocprofv3) — under the profiler the pipeline's k_sweep_uc8 launches average 285 us where the benchmark's events
 // read 207-212 (profiles/README.md).  Here the kernel is the only thing on the GPU, so `rocprofv3 --kernel-trace --stats` of THIS
 // program and the HIP events around each launch measure the same thing and have to agree.
 // A launch reads 2 B and writes 2 B per sample: at 2048 buffers 537 MB + 537 MB, four times the 256 MiB Infinity Cache by itself;

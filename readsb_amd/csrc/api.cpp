@@ -1083,14 +1083,15 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
         }
     }
 #if MGPU_EXPERIMENTS
-    if (getenv("MGPU_MAIN_OWN_QUEUE")) {                     // experiment: the main stream through the mask API too (all CUs): a hardware queue of its own
+    if (const char *oq = getenv("MGPU_MAIN_OWN_QUEUE")) {                     // experiment: the main stream through the mask API too (all CUs): a hardware queue of its own
         uint32_t m[32] = {0};
         if (build_mask(m, 1, 0, 0, 0) && hipExtStreamCreateWithCUMask(&c->stream, mask_words, m) != hipSuccess) { (void) hipGetLastError(); c->stream = nullptr; }
+        if (atoi(oq) >= 2 && hipExtStreamCreateWithCUMask(&c->stream_w, mask_words, m) != hipSuccess) { (void) hipGetLastError(); c->stream_w = nullptr; }   // 2: the upload stream too
     }
 #endif
     if ((!c->stream && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) ||
         (!masked && hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least) != hipSuccess) ||
-        hipStreamCreateWithFlags(&c->stream_w, hipStreamNonBlocking) != hipSuccess ||
+        (!c->stream_w && hipStreamCreateWithFlags(&c->stream_w, hipStreamNonBlocking) != hipSuccess) ||
         (!masked && hipStreamCreateWithFlags(&c->stream_d2h, hipStreamNonBlocking) != hipSuccess) ||
         hipStreamCreateWithFlags(&c->stream_c, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream_aux, hipStreamNonBlocking) != hipSuccess ||

@@ -35,7 +35,7 @@ def main():
             args = [cli]
             for p in paths[:n]:
                 args += ["--ifile", p]
-            args += ["--out-prefix", os.path.join(d, "out"), "--stats", "--gpu-chunk-buffers", "512"]
+            args += ["--out-prefix", os.path.join(d, "out"), "--stats", "--gpu-chunk-buffers", os.environ.get("FANIN_CHUNK", "512")]
             for rep in range(2):                      # second run: page cache and GPU clocks warm
                 r = subprocess.run(args, capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, r.stderr

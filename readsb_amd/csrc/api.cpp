@@ -1083,10 +1083,15 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
         }
     }
 #if MGPU_EXPERIMENTS
-    if (const char *oq = getenv("MGPU_MAIN_OWN_QUEUE")) {                     // experiment: the main stream through the mask API too (all CUs): a hardware queue of its own
+    // The main stream (1), and the upload stream (2), through the mask API too: measured — the main stream with a queue of its own is
+    // no faster alone and 1-8 % slower in three interleaved pairs of the plain and of the aggregator path (profiles/r06_stream_queues.txt
+    // (4)); every further queue of their own costs a fan-in's contexts (four streams 14.0 against 19.5 Gsamples/s, profiles/r06_fanin.txt).
+    if (const char *oq = getenv("MGPU_MAIN_OWN_QUEUE")) {
         uint32_t m[32] = {0};
-        if (build_mask(m, 1, 0, 0, 0) && hipExtStreamCreateWithCUMask(&c->stream, mask_words, m) != hipSuccess) { (void) hipGetLastError(); c->stream = nullptr; }
-        if (atoi(oq) >= 2 && hipExtStreamCreateWithCUMask(&c->stream_w, mask_words, m) != hipSuccess) { (void) hipGetLastError(); c->stream_w = nullptr; }   // 2: the upload stream too
+        if (atoi(oq) >= 1 && build_mask(m, 1, 0, 0, 0)) {
+            if (hipExtStreamCreateWithCUMask(&c->stream, mask_words, m) != hipSuccess) { (void) hipGetLastError(); c->stream = nullptr; }
+            if (atoi(oq) >= 2 && hipExtStreamCreateWithCUMask(&c->stream_w, mask_words, m) != hipSuccess) { (void) hipGetLastError(); c->stream_w = nullptr; }
+        }
     }
 #endif
     if ((!c->stream && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) ||

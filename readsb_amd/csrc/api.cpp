@@ -1059,10 +1059,16 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
 #endif
         if (build_mask(c->cu_mask, k, 0, perxcc, perxcc_first)) {
             c->cu_mask_words = mask_words;
-            masked = hipExtStreamCreateWithCUMask(&c->stream2, mask_words, c->cu_mask) == hipSuccess && hipExtStreamCreateWithCUMask(&c->stream_d2h, mask_words, c->cu_mask) == hipSuccess;
+            int which = 3;                                                   // experiment: 1 = only the second stream, 2 = only the record copies' stream
+#if MGPU_EXPERIMENTS
+            if (const char *e = getenv("MGPU_OWN_QUEUES")) which = atoi(e) & 3;
+#endif
+            masked = (!(which & 1) || hipExtStreamCreateWithCUMask(&c->stream2, mask_words, c->cu_mask) == hipSuccess) &&
+                     (!(which & 2) || hipExtStreamCreateWithCUMask(&c->stream_d2h, mask_words, c->cu_mask) == hipSuccess);
             if (!masked) {
                 (void) hipGetLastError();
                 if (c->stream2) (void) hipStreamDestroy(c->stream2);
+                if (c->stream_d2h) (void) hipStreamDestroy(c->stream_d2h);
                 c->stream2 = c->stream_d2h = nullptr;
             }
         }
@@ -1095,9 +1101,9 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     }
 #endif
     if ((!c->stream && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) ||
-        (!masked && hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least) != hipSuccess) ||
+        (!c->stream2 && hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_least) != hipSuccess) ||
         (!c->stream_w && hipStreamCreateWithFlags(&c->stream_w, hipStreamNonBlocking) != hipSuccess) ||
-        (!masked && hipStreamCreateWithFlags(&c->stream_d2h, hipStreamNonBlocking) != hipSuccess) ||
+        (!c->stream_d2h && hipStreamCreateWithFlags(&c->stream_d2h, hipStreamNonBlocking) != hipSuccess) ||
         hipStreamCreateWithFlags(&c->stream_c, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream_aux, hipStreamNonBlocking) != hipSuccess ||
         (cfg->format != MGPU_FMT_UC8 && !fsum_masked && hipStreamCreateWithPriority(&c->stream_f, hipStreamNonBlocking, fsum_prio < 0 ? prio_least : fsum_prio > 0 ? prio_greatest : 0) != hipSuccess)) { mgpu_destroy(c); return MGPU_E_HIP; }

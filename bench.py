@@ -53,6 +53,82 @@ PMC_HBM = os.path.join(ROOT, "profiles", "r06_pmc_hbm.json")
 PROFILED_LAUNCH_BYTES = 536870912    # (of magnitudes: 268 435 456 samples per launch)
 
 
+def _proc_stat():
+    out = {}
+    for ln in open("/proc/stat"):
+        if ln.startswith("cpu") and ln[3].isdigit():
+            f = ln.split()
+            v = list(map(int, f[1:]))
+            out[int(f[0][3:])] = (sum(v), v[3] + v[4], v[0] + v[1], v[2] + v[5] + v[6], v[7] if len(v) > 7 else 0)   # total, idle, user, system + irq, steal
+    return out
+
+
+def host_probe_begin(d):
+    """MGPU_DBG_BENCH_HOST=1 (a diagnosis of the processes whose host stages run slow, profiles/r06_host_slow_mode.txt): what the timed
+    region's CPUs did — the pipeline's pinned cores, their SMT siblings, the rest of their L3 groups — and where the process's memory is."""
+    cpus = d.host_cpus()
+
+    def cpulist(path):
+        out = set()
+        try:
+            for part in open(path).read().strip().split(","):
+                lo, _, hi = part.partition("-")
+                out.update(range(int(lo), int(hi or lo) + 1))
+        except (OSError, ValueError):
+            pass
+        return out
+    sib, l3 = set(), set()
+    for c in cpus:
+        sib |= cpulist(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list")
+        l3 |= cpulist(f"/sys/devices/system/cpu/cpu{c}/cache/index3/shared_cpu_list")
+    freq = {}
+    for c in cpus:
+        try:
+            freq[c] = int(open(f"/sys/devices/system/cpu/cpu{c}/cpufreq/scaling_cur_freq").read())
+        except (OSError, ValueError):
+            pass
+    return {"cpus": list(cpus), "sib": sorted(sib - set(cpus)), "l3": sorted(l3 - sib - set(cpus)), "stat": _proc_stat(), "freq0": freq, "t": time.perf_counter()}
+
+
+def host_probe_end(p):
+    b, a = _proc_stat(), p["stat"]
+
+    def busy(cs):
+        rows = []
+        for c in cs:
+            if c in a and c in b and b[c][0] > a[c][0]:
+                tot = b[c][0] - a[c][0]
+                rows.append((round(1.0 - (b[c][1] - a[c][1]) / tot, 2), round((b[c][3] - a[c][3]) / tot, 2), round((b[c][4] - a[c][4]) / tot, 2)))
+        return rows
+    pinned = busy(p["cpus"])
+    sib = busy(p["sib"])
+    l3 = busy(p["l3"])
+    freq = {}
+    for c in p["cpus"]:
+        try:
+            freq[c] = int(open(f"/sys/devices/system/cpu/cpu{c}/cpufreq/scaling_cur_freq").read())
+        except (OSError, ValueError):
+            pass
+    nodes = {}
+    try:
+        for ln in open("/proc/self/numa_maps"):
+            for tok in ln.split():
+                if tok[0] == "N" and "=" in tok and tok[1:tok.index("=")].isdigit():
+                    ps = 4096
+                    if "kernelpagesize_kB=" in ln:
+                        ps = 1024 * int(ln.split("kernelpagesize_kB=")[1].split()[0])
+                    nodes[tok[1:tok.index("=")]] = nodes.get(tok[1:tok.index("=")], 0) + int(tok.split("=")[1]) * ps
+    except OSError:
+        pass
+    other = [c for c in b if c not in p["cpus"]]
+    top_other = sorted(((round(1.0 - (b[c][1] - a[c][1]) / max(1, b[c][0] - a[c][0]), 2), c) for c in other if c in a), reverse=True)[:12]
+    return {"seconds": round(time.perf_counter() - p["t"], 3), "pinned_cpus": p["cpus"],
+            "pinned_busy_sys_steal": pinned, "sibling_busy_max": max([r[0] for r in sib], default=None), "siblings_busy": [r[0] for r in sib],
+            "rest_of_l3_busy_max": max([r[0] for r in l3], default=None),
+            "busiest_other_cpus": top_other, "pinned_freq_khz_before": p["freq0"], "pinned_freq_khz_after": freq,
+            "process_memory_bytes_by_numa_node": nodes, "loadavg": open("/proc/loadavg").read().split()[:3]}
+
+
 def kernel_source_sha():
     """Hash of the device code the library was built from (kernels.hip + kernels/*.inc + kernels.h).  The committed PMC
     summaries under profiles/ carry the hash they were collected with (tools/profile_round.sh): numbers of other code are
@@ -777,6 +853,7 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    dbg_host = host_probe_begin(d) if os.environ.get("MGPU_DBG_BENCH_HOST") else None
     t0 = time.perf_counter()
     nmsgs_last, counters = run_feeds(seq, n_timed)              # ... and ends with an empty one
     if use_dist:
@@ -784,6 +861,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if dbg_host is not None:
+        sys.stderr.write("dbg host " + json.dumps(host_probe_end(dbg_host)) + "\n")
     if os.environ.get("MGPU_DBG_BENCH"):
         sys.stderr.write(f"dbg bench rank {rank}: main thread, warm-up + timed steps: {dbg_t}\n")
     tm = d.timing()                             # sums over the timed region's launches (everything since the last drain)

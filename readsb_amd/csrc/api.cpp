@@ -392,6 +392,7 @@ struct mgpu_ctx {
     std::thread fetcher, worker, builder;
     Team walk_team, build_team;                               // helpers of the walker / builder stage (MGPU_WALK_THREADS, MGPU_BUILD_THREADS)
     int walk_threads = 4, build_threads = 3;
+    int walk_ranges = 0;                                      // buffer ranges per round of the host's walk (0: one per walk thread)
     std::atomic<bool> hot{false};                             // a feed is running: the stage threads and helpers poll instead of sleeping
     std::vector<int> host_cpus;                               // the CPUs the host threads were pinned to (empty: not pinned)
     std::vector<SegmentWalk> segs;                            // the walker's buffer ranges
@@ -1162,6 +1163,7 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     if (c->device_walk == 1) { c->walk_threads = 1; c->build_threads = 2; }
 #if MGPU_EXPERIMENTS   // (8 + 6 is the best of 6..16 + 6..8; tools/stress.py varies them)
     if (const char *e = getenv("MGPU_WALK_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) c->walk_threads = v; }
+    if (const char *e = getenv("MGPU_WALK_RANGES")) { const int v = atoi(e); if (v >= 2 && v <= 64) c->walk_ranges = v; }
     if (const char *e = getenv("MGPU_BUILD_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) c->build_threads = v; }
 #endif
     c->fetcher = std::thread(fetcher_main, c);
@@ -1758,8 +1760,8 @@ static int walk_job_device(mgpu_ctx *c, Slot &sl, HostJob &job) {
 static int64_t host_walk(mgpu_ctx *c, HostJob &job, const PhaseRec *recs, const std::vector<BufferClock> &buffers, uint64_t nlive, uint64_t aux_cap) {
     int64_t wn;
     const uint32_t nbuf_all = (uint32_t) buffers.size();
-    const int K = c->walk_threads;
-    if (K >= 2 && nbuf_all >= (uint32_t) (4 * K) && nlive >= 4096) {
+    const int K = c->walk_ranges > 0 ? c->walk_ranges : c->walk_threads;      // ranges per round (the team takes them by ticket: Team::run)
+    if (K >= 2 && c->walk_threads >= 2 && nbuf_all >= (uint32_t) (4 * K) && nlive >= 4096) {
         // buffer ranges walked in parallel against the filter as it stands now, committed in stream order
         // (resolve.h: Resolver::parallel_walk); exact, and serial only where speculation fails.
         // K ranges per ROUND of about kWalkRound buffers, whatever the chunk's length: the further a range lies from the state it

@@ -58,6 +58,24 @@ def test_sweep_kernel_alone_matches_cpu_scan(built, buffers, ragged, dense):
     assert out["mismatches_vs_cpu_scan"] == 0 and out["candidates"] == out["candidates_cpu"] > 0
 
 
+@pytest.mark.parametrize("buffers,dense", [(16, 0), (3, 1), (1, 0)])
+def test_fused_sweep_kernel_alone_matches_cpu(built, buffers, dense):
+    """k_sweep_uc8 on its own (tools/micro/sweep_uc8_cold.hip includes the product's kernels.hip and launches through the library's
+    launch_sweep): every magnitude against init_uc8_lookup's table (convert.c:35-62), every buffer's exact sum(mag) / sum(mag^2)
+    (convert.c:64-108) and the candidate lists against a plain CPU scan (demod_2400.c:311-378) — more steps than resident waves,
+    fewer, and a single buffer."""
+    import json
+    exe = os.path.join(helpers.ROOT, "tools", "micro", "sweep_uc8_cold")
+    if not os.path.exists(exe):
+        r = subprocess.run(["make", "-s", "-C", os.path.join(helpers.ROOT, "tools"), "micro"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run([exe, str(buffers), "2", "3", str(dense)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["magnitude_mismatches_vs_cpu_table"] == 0 and out["buffer_sum_mismatches"] == 0 and out["candidate_mismatches_vs_cpu_scan"] == 0
+    assert out["candidates"] == out["candidates_cpu"] > 0
+
+
 FUSED_SCRIPT = r"""
 import sys
 sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})

@@ -2061,14 +2061,31 @@ static int build_job(mgpu_ctx *c, HostJob &job) {
         // time on one thread — ride beside the message build as one more task of the team (they read the accept list and the signal
         // powers only): with chunks of 1024 buffers the builder was the pipeline's slowest stage (round 4: 1.6-1.77 ms per step
         // against 1.59 ms of kernels).
+        // (Round 6, last session, measured and NOT adopted — profiles/r06_builder.txt: per chunk of 140 k messages the chain takes 0.33 ms
+        // on the calling thread, five ranges run beside it on the helpers for 0.2 ms each and the sixth behind them: 0.45 ms.  With the
+        // statistics' divisions moved into the ranges, the chain reduced to the ordered additions and four ranges per thread taken by
+        // ticket the stage takes 0.34 ms — build 0.76 instead of 0.98 ms per feed — and the FEED is 2 % longer in nine of ten interleaved
+        // pairs, 1.13-1.15 against 1.113 ms: the GPU's post-sweep bracket grows from 0.232 to 0.248 ms per feed, the fetcher's stage with
+        // it.  Six threads bursting through the messages with streaming stores for a third of a millisecond are worse neighbours to the
+        // fetcher on the same L3 group, and to k_publish's writes into page-locked memory, than five threads and a chain taking their time.)
         const bool split = parts > 1;
+        double task_ms[8][2] = {};                                 // (MGPU_DEBUG_PRINT: the tasks' begin and end)
         c->build_team.run(parts + (split ? 1 : 0), [&](int i) {
-            if (split && i == 0) { build_statistics(); return; }
-            const int p = split ? i - 1 : i;
-            const uint64_t lo = (uint64_t) nmsg * p / parts, hi = (uint64_t) nmsg * (p + 1) / parts;
-            Resolver::build_messages(job.recs.data(), job.sig_late ? nullptr : job.sig.data(), job.sig_late ? job.h_msig + lo : nullptr, job.buffers,
-                                     job.acc.data() + lo, hi - lo, dst + lo);
+            const double tb = c->dbg_print ? wall_ms() : 0.0;
+            if (split && i == 0) build_statistics();
+            else {
+                const int p = split ? i - 1 : i;
+                const uint64_t lo = (uint64_t) nmsg * p / parts, hi = (uint64_t) nmsg * (p + 1) / parts;
+                Resolver::build_messages(job.recs.data(), job.sig_late ? nullptr : job.sig.data(), job.sig_late ? job.h_msig + lo : nullptr, job.buffers,
+                                         job.acc.data() + lo, hi - lo, dst + lo);
+            }
+            if (c->dbg_print && i < 8) { task_ms[i][0] = tb - t1; task_ms[i][1] = wall_ms() - t1; }
         });
+        if (c->dbg_print) {
+            fprintf(stderr, "dbg: build tasks (begin-end ms; task 0 = the statistics):");
+            for (int i = 0; i < parts + (split ? 1 : 0) && i < 8; ++i) fprintf(stderr, " %.3f-%.3f", task_ms[i][0], task_ms[i][1]);
+            fprintf(stderr, "\n");
+        }
         stats_done = split;
     } else if (!job.from_device && job.sig_late && nmsg) HIPCHK(c, wait_copied());   // (messages on the device: statistics only)
     if (nac) {   // netUseMessage order: per buffer the Mode S messages of demodulate2400, then the replies of demodulate2400AC

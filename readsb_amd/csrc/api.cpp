@@ -1034,9 +1034,9 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     // copies (the runtime's blit kernel) and, for the SC16 formats, the float-sum chain (k_fsum_sc16: one wave per buffer, ~0.9 ms of
     // dependent block steps per chunk) — are created through hipExtStreamCreateWithCUMask with EVERY CU enabled.  What that buys is not
     // a place but a queue: such a stream has a hardware queue of its own, where the runtime's ordinary streams share a small pool of
-    // them and a kernel of one waits behind another's.  Measured (profiles/r06_stream_queues.txt): UC8 headline 470-486 Gsamples/s
-    // against 431-446 with ordinary streams (478 with GPU_MAX_HW_QUEUES=8 in the environment, which a library cannot count on);
-    // SC16Q11 --aggressive 273-285 against 229-245 with the chain on an ordinary stream of any priority.
+    // them (four by default; bench.py asks for eight, GPU_MAX_HW_QUEUES, which a library cannot count on) and a kernel of one waits
+    // behind another's.  Measured (profiles/r06_stream_queues.txt, on the pool of eight): UC8 headline 466-486 Gsamples/s against
+    // 426-478 with ordinary streams of any priority; SC16Q11 --aggressive 273-285 against 224-245 with the chain on an ordinary stream.
     // Rounds 6's first form asked for "every 8th CU" (every 4th for the chain) and believed the side work confined there.  It is not:
     // mask bit i is CU i / 8 of XCC i % 8 (tools/micro/cu_mask_map.hip), a stride of 8 selects all of XCC 0, and an XCC whose share of
     // the mask is empty runs the queue's workgroups on all of its CUs — those masks were the whole device, and what they gained was

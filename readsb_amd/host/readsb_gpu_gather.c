@@ -69,6 +69,22 @@ static int exchange_id(const char *path, int rank, ncclUniqueId *id) {
     return -1;
 }
 
+/* The exchange's stream with a hardware queue of its own (hipExtStreamCreateWithCUMask, every CU enabled): an ordinary stream shares the
+ * runtime's small pool of queues with the demodulator's main stream, and a collective that waits for its peers at the head of a shared queue
+ * holds the chunk's kernels behind it (DESIGN.md §4 "The side streams' queues").  Falls back to an ordinary stream. */
+static hipError_t own_queue_stream(hipStream_t *s) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    uint32_t mask[32];
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 && prop.multiProcessorCount <= 1024) {
+        memset(mask, 0, sizeof(mask));
+        for (int cu = 0; cu < prop.multiProcessorCount; ++cu) mask[cu >> 5] |= 1u << (cu & 31);
+        if (hipExtStreamCreateWithCUMask(s, (uint32_t) ((prop.multiProcessorCount + 31) / 32), mask) == hipSuccess) return hipSuccess;
+        (void) hipGetLastError();
+    }
+    return hipStreamCreate(s);
+}
+
 int main(int argc, char **argv) {
     struct mgpu_config cfg;
     mgpu_config_defaults(&cfg);
@@ -142,7 +158,7 @@ int main(int argc, char **argv) {
     ncclComm_t comm;
     CHK_NCCL(ncclCommInitRank(&comm, world, id, rank));
     hipStream_t s;
-    CHK_HIP(hipStreamCreate(&s));
+    CHK_HIP(own_queue_stream(&s));
     unsigned long long *d_counts = NULL, mine = nmsg;
     CHK_HIP(hipMalloc((void **) &d_counts, (size_t) (world + 1) * sizeof(*d_counts)));
     CHK_HIP(hipMemcpyAsync(d_counts + world, &mine, sizeof(mine), hipMemcpyHostToDevice, s));

@@ -199,6 +199,22 @@ static int feed(mgpu_ctx *ctx, const uint8_t *d_iq, uint64_t lo, size_t bps, uin
     return 0;
 }
 
+/* The exchange's stream with a hardware queue of its own (hipExtStreamCreateWithCUMask, every CU enabled): an ordinary stream shares the
+ * runtime's small pool of queues with the demodulator's main stream, and a collective that waits for its peers at the head of a shared queue
+ * holds the chunk's kernels behind it (DESIGN.md §4 "The side streams' queues").  Falls back to an ordinary stream. */
+static hipError_t own_queue_stream(hipStream_t *s) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    uint32_t mask[32];
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 && prop.multiProcessorCount <= 1024) {
+        memset(mask, 0, sizeof(mask));
+        for (int cu = 0; cu < prop.multiProcessorCount; ++cu) mask[cu >> 5] |= 1u << (cu & 31);
+        if (hipExtStreamCreateWithCUMask(s, (uint32_t) ((prop.multiProcessorCount + 31) / 32), mask) == hipSuccess) return hipSuccess;
+        (void) hipGetLastError();
+    }
+    return hipStreamCreate(s);
+}
+
 int main(int argc, char **argv) {
     struct mgpu_config cfg;
     mgpu_config_defaults(&cfg);
@@ -238,7 +254,7 @@ int main(int argc, char **argv) {
         if (exchange_id(idfile, T.run, rank, &id) != 0) { fprintf(stderr, "rank %d: no ncclUniqueId\n", rank); return 1; }
         CHK_NCCL(ncclCommInitRank(&T.comm, world, id, rank));
     }
-    CHK_HIP(hipStreamCreate(&T.s));
+    CHK_HIP(own_queue_stream(&T.s));
 
     /* ---- the capture, my range of whole buffers, the warm-up before it ---- */
     const int fd = open(ifile, O_RDONLY);

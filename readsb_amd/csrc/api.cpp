@@ -1087,6 +1087,10 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
         if (build_mask(m, k, off, perxcc, perxcc_first)) {
             fsum_masked = hipExtStreamCreateWithCUMask(&c->stream_f, mask_words, m) == hipSuccess;
             if (!fsum_masked) { (void) hipGetLastError(); c->stream_f = nullptr; }
+            // (Measured and dropped: a SECOND such stream, the chunks' chains on the two in turn — with its own queue the chain is what
+            // bounds SC16Q11 --aggressive: two chunks' chains are 1.87 ms per segment of 537 M samples, the builder waits 0.45-0.8 ms per
+            // segment for the sums, the main stream's kernels take 1.74.  Two chains at once each take twice as long and are in the main
+            // kernels' way twice: 240-243 against 268-274 Gsamples/s, tools/ab/ab_fsum2.sh, profiles/r06_stream_queues.txt (6).)
         }
     }
 #if MGPU_EXPERIMENTS

@@ -323,7 +323,7 @@ struct mgpu_ctx {
     uint32_t prescreen_variant = 3;                                        // PostSweepParams::variant (the experiments build can ask for the older passes)
     uint32_t cu_mask[32] = {0}, cu_mask_words = 0;                         // the side streams' CU mask (every CU: mgpu_create says what it is for)
     int post_beside = 0;                                                   // experiment: 1 = stream_pw takes the write pass, 2 = the count pass too
-    hipStream_t stream_pw = nullptr;                                       // experiment (MGPU_WRITE_BESIDE=1, experiments build): the pre-screen's write pass + k_publish on a stream of their own, beside the next chunk's converter — measured 297 against 357 Gsamples/s (gpurun r05i): beside a kernel that saturates the memory system the write pass's dependent round trips stretch the post-sweep stage from 0.25 to 0.73 ms per step.  Round 6, beside k_sweep_uc8 (1 / 2: + the count pass; 3 / 4: on the masked CUs): 1.27-1.39 ms per feed against 1.21-1.25; the whole stage held back until the next chunk's sweep is through, beside its k_slice: 1.30-1.36 (profiles/r06_sweep_fused.txt)
+    hipStream_t stream_pw = nullptr;                                       // experiment (MGPU_WRITE_BESIDE=1, experiments build): the pre-screen's write pass + k_publish on a stream of their own, beside the next chunk's converter — measured 297 against 357 Gsamples/s (gpurun r05i): beside a kernel that saturates the memory system the write pass's dependent round trips stretch the post-sweep stage from 0.25 to 0.73 ms per step.  Round 6, beside k_sweep_uc8 (1 / 2: + the count pass; 3 / 4: on a mask-API stream): 1.27-1.39 ms per feed against 1.21-1.25; the whole stage held back until the next chunk's sweep is through, beside its k_slice: 1.30-1.36 (profiles/r06_sweep_fused.txt)
     hipStream_t stream_f = nullptr;                                        // SC16 formats: the float sums' chains (k_fsum_sc16), so that what follows a walk does not queue behind them
     // The UC8 converter of chunk N + 1 beside chunk N's k_slice (round 6): the converter is the pipeline's one HBM-bound
     // kernel, k_slice its largest issue-bound one.  stream_c carries the converters, each held behind the k_sweep of the chunk before;
@@ -1037,7 +1037,7 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     // them (four by default; bench.py asks for eight, GPU_MAX_HW_QUEUES, which a library cannot count on) and a kernel of one waits
     // behind another's.  Measured (profiles/r06_stream_queues.txt, on the pool of eight): UC8 headline 466-486 Gsamples/s against
     // 426-478 with ordinary streams of any priority; SC16Q11 --aggressive 273-285 against 224-245 with the chain on an ordinary stream.
-    // Rounds 6's first form asked for "every 8th CU" (every 4th for the chain) and believed the side work confined there.  It is not:
+    // Round 6's first form asked for "every 8th CU" (every 4th for the chain) and believed the side work confined there.  It is not:
     // mask bit i is CU i / 8 of XCC i % 8 (tools/micro/cu_mask_map.hip), a stride of 8 selects all of XCC 0, and an XCC whose share of
     // the mask is empty runs the queue's workgroups on all of its CUs — those masks were the whole device, and what they gained was
     // the queue.  Real confinement (n CUs of every XCC) LOSES: the side streams on 8 / 4 / 2 CUs per XCC 431-454 / 402-422 / 306-312,
@@ -1144,7 +1144,7 @@ int mgpu_create(const struct mgpu_config *cfg, mgpu_ctx **out) {
     if (const char *e = getenv("MGPU_TIMING_EVERY")) { const int v = atoi(e); if (v >= 1) c->timing_every = v; }
     if (const char *e = getenv("MGPU_DUMP_DIR")) { c->dump_dir = e; c->sig_late = false; }   // (the dump holds per-record signal powers)
     c->fsum_wide = getenv("MGPU_FSUM_WIDE") != nullptr;
-    if (const char *e = getenv("MGPU_WRITE_BESIDE")) {     // 1: write pass + k_publish beside the next chunk's sweep; 2: the count pass too; 3 / 4: the same on the masked CUs
+    if (const char *e = getenv("MGPU_WRITE_BESIDE")) {     // 1: write pass + k_publish beside the next chunk's sweep; 2: the count pass too; 3 / 4: the same on a mask-API stream (a queue of its own)
         const int v = atoi(e);
         c->post_beside = v == 2 || v == 4 ? 2 : v ? 1 : 0;
         const bool m = v >= 3 && c->cu_mask_words;

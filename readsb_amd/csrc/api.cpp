@@ -178,7 +178,8 @@ struct Slot {
     double *d_fsx = nullptr, *h_fsx = nullptr;   // SC16 formats: the float sums' own device / page-locked buffers (k_fsum_sc16 runs beside the chunk and ends on its own)
     uint32_t *h_msg_pos = nullptr, *h_msg_limit = nullptr;
     uint16_t *h_msg_len = nullptr, *h_msg_skip = nullptr;
-    hipEvent_t ev[5] = {};               // 3: the chunk is complete (always recorded) | stage timing, sampled chunks only (timed): 0 1 convert, 1 4 k_sweep, 4 2 k_slice, 2 3 post-sweep (a timing event costs ~4.5 us of idle stream: neighbouring brackets share theirs)
+    hipEvent_t ev_done = nullptr;        // the chunk is complete: recorded behind every chunk, WITHOUT a timestamp (a timed event is a marker the next kernel waits for)
+    hipEvent_t ev[5] = {};               // 3: the end of the post-sweep stage (timed chunks only) | stage timing, sampled chunks only (timed): 0 1 convert, 1 4 k_sweep, 4 2 k_slice, 2 3 post-sweep (a timing event costs ~4.5 us of idle stream: neighbouring brackets share theirs)
     bool timed = false;
     uint32_t slice_blocks = 0;            // rows of d_sweep_part the chunk's k_slice wrote
     uint32_t sweep_blocks = 0;            // grid of the chunk's k_sweep
@@ -852,6 +853,7 @@ static int alloc_slot(mgpu_ctx *c, Slot &sl) {
         HIPCHK(c, hipHostMalloc(&sl.h_ac, c->cap_ac * sizeof(AcCand)));
     }
     for (auto &e : sl.ev) HIPCHK(c, hipEventCreate(&e));
+    HIPCHK(c, hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
     return MGPU_OK;
 }
 
@@ -877,6 +879,7 @@ static void free_slot(Slot &sl) {
     if (sl.ev_pre) (void) hipEventDestroy(sl.ev_pre);
     if (sl.ev_fsum) (void) hipEventDestroy(sl.ev_fsum);
     if (sl.ev_convdone) (void) hipEventDestroy(sl.ev_convdone);
+    if (sl.ev_done) (void) hipEventDestroy(sl.ev_done);
     void *host[] = {sl.h_live, sl.h_live_sig, sl.h_scratch, sl.h_win, sl.h_sig, sl.h_msg_pos,
                     sl.h_msg_limit, sl.h_msg_len, sl.h_msg_skip};
     for (void *p : host)
@@ -1467,7 +1470,8 @@ static int enqueue_post(mgpu_ctx *c, Slot &sl) {
         s = s_write;
     }
     if (launch_prescreen(q, s, s_write, sl.ev_scan) != 0) { c->err = "event ordering of the pre-screen passes failed"; return MGPU_E_HIP; }
-    HIPCHK(c, hipEventRecord(sl.ev[3], s_write));
+    if (sl.timed) HIPCHK(c, hipEventRecord(sl.ev[3], s_write));
+    HIPCHK(c, hipEventRecord(sl.ev_done, s_write));
     return MGPU_OK;
 }
 
@@ -1554,7 +1558,7 @@ static int fetch_records(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
 }
 
 static int fetch_slot(mgpu_ctx *c, Slot &sl, HostJob &job, Slot *next) {
-    HIPCHK(c, wait_event_spin(sl.ev[3]));
+    HIPCHK(c, wait_event_spin(sl.ev_done));
     const double t_gpu_done = wall_ms();
     if (sl.h_counters[CNT_POOL_OVERFLOW]) {
         c->err = "record pool overflow: recreate the context with a larger record_pool_records";
@@ -1840,7 +1844,7 @@ static int hold_behind_sweep(mgpu_ctx *c, const Slot &sl, int slot_idx, hipStrea
         const Slot &o = c->slot[(slot_idx + d) % mgpu_ctx::kSlots];
         if (o.swept_seq.load(std::memory_order_acquire) != sl.seq + (uint64_t) d) break;   // not enqueued (yet)
         if (hipEventQuery(o.ev_swept) == hipSuccess) { prev = &o; continue; }              // that sweep is behind us
-        if (prev == &sl || hipEventQuery(prev->ev[3]) == hipSuccess) HIPCHK(c, hipStreamWaitEvent(s2, o.ev_swept, 0));
+        if (prev == &sl || hipEventQuery(prev->ev_done) == hipSuccess) HIPCHK(c, hipStreamWaitEvent(s2, o.ev_swept, 0));
         break;
     }
     return MGPU_OK;
